@@ -1,0 +1,84 @@
+"""ctypes binding of libcqs_hip.so — the C ABI declared in include/cqs_hip.h.
+
+The product path has no CPU fallback: if the HIP library is missing this module
+raises (callers on a GPU box must fail loudly, never fall back to the oracle).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcqs_hip.so")
+
+OK = 0
+ERR_INVALID = -1
+ERR_DEVICE = -2
+ERR_NOMEM = -3
+ERR_POISONED = -4
+ERR_NO_DEVICE = -5
+
+METRIC_COSINE = 0
+METRIC_DOT = 1
+MODE_RAW = 0
+MODE_PIPELINE = 1
+MAX_K = 1024
+
+_c_idx = C.c_void_p
+_pp = C.POINTER
+
+# (name, restype, argtypes) — one row per symbol include/cqs_hip.h declares.
+SIGNATURES = [
+    ("cqs_hip_version", C.c_char_p, []),
+    ("cqs_hip_device_count", C.c_int32, []),
+    ("cqs_hip_device_mem", C.c_int32, [C.c_int32, _pp(C.c_uint64), _pp(C.c_uint64)]),
+    ("cqs_hip_index_create", C.c_int32,
+     [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int32, C.c_uint64, _pp(_c_idx)]),
+    ("cqs_hip_index_create_device", C.c_int32,
+     [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int32, C.c_uint64, C.c_int32, _pp(_c_idx)]),
+    ("cqs_hip_index_extend", C.c_int32, [_c_idx, C.c_void_p, C.c_uint64]),
+    ("cqs_hip_index_destroy", None, [_c_idx]),
+    ("cqs_hip_index_len", C.c_uint64, [_c_idx]),
+    ("cqs_hip_index_dim", C.c_uint32, [_c_idx]),
+    ("cqs_hip_index_metric", C.c_uint32, [_c_idx]),
+    ("cqs_hip_index_max_k", C.c_uint32, [_c_idx]),
+    ("cqs_hip_index_poisoned", C.c_int32, [_c_idx]),
+    ("cqs_hip_index_device", C.c_int32, [_c_idx]),
+    ("cqs_hip_index_row_base", C.c_uint64, [_c_idx]),
+    ("cqs_hip_index_last_error", C.c_size_t, [_c_idx, C.c_char_p, C.c_size_t]),
+    ("cqs_hip_index_search", C.c_int32,
+     [_c_idx, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_float,
+      C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("cqs_hip_index_search_device", C.c_int32,
+     [_c_idx, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_float,
+      C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("cqs_hip_unpack_keys", None, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    ("cqs_hip_merge_keys", C.c_size_t,
+     [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p]),
+    ("cqs_hip_index_set_timing", None, [_c_idx, C.c_int32]),
+    ("cqs_hip_index_scan_time", C.c_int32, [_c_idx, _pp(C.c_uint32), _pp(C.c_double)]),
+]
+
+_lib = None
+
+
+class HipLibraryMissing(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load libcqs_hip.so (built in-tree by __graft_entry__.build / `make -C cqs_amd/csrc`)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryMissing(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C cqs_amd/csrc`. There is no CPU fallback for the cqs_amd product path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, res, args in SIGNATURES:
+        fn = getattr(lib, name)  # AttributeError if the header and the library disagree
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib

@@ -1,0 +1,474 @@
+// index.hip — host side of libcqs_hip.so: the exact GPU index behind the C ABI
+// of include/cqs_hip.h.  Shape follows the reference's GPU backend exemplar
+// `CagraIndex` (src/cagra.rs:255-277): a flat [n, dim] f32 dataset resident on
+// the device, device work serialised behind one mutex (src/cagra.rs:263), a
+// poisoned flag instead of panics (src/cagra.rs:472-489), stream sync before
+// teardown (src/cagra.rs:289-302).  The id_map (row -> chunk id) stays with
+// the caller (the Rust shim), as rows are addressed by integer here.
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/cqs_hip.h"
+#include "scan_kernels.h"
+
+using cqs::kCandCap;
+using cqs::kMaxK;
+using cqs::kRowsPerBlock;
+using cqs::kSelWords;
+
+struct cqs_hip_index {
+    int device = 0;
+    uint64_t n = 0;         // rows
+    uint64_t cap_rows = 0;  // allocated rows (owning index)
+    uint32_t dim = 0;
+    uint32_t metric = 0;
+    uint64_t row_base = 0;
+    bool borrow = false;
+    float* d_rows = nullptr;
+    hipStream_t stream = nullptr;
+
+    // scratch, grown on demand (never inside an enqueue-only path once warm)
+    uint32_t q_cap = 0;        // queries the scratch can hold
+    uint64_t scr_n_pad = 0;    // score-row stride the scratch was sized for
+    uint32_t k_cap = 0;
+    float* d_q = nullptr;
+    float* d_scores = nullptr;
+    uint32_t* d_sel = nullptr;
+    uint64_t* d_cand = nullptr;
+    uint64_t* d_out_keys = nullptr;
+    uint32_t* d_out_counts = nullptr;
+    uint32_t* d_keep = nullptr;
+    uint64_t keep_words_cap = 0;
+    // pinned host staging
+    float* h_q = nullptr;
+    uint64_t* h_out_keys = nullptr;
+    uint32_t* h_out_counts = nullptr;
+
+    bool timing = false;
+    std::vector<hipEvent_t> ev;  // pairs: [2i] before, [2i+1] after the scan launches
+    size_t ev_used = 0;          // events recorded since the last read
+
+    mutable std::mutex mu;
+    std::atomic<bool> poisoned{false};
+    std::string last_error;
+};
+
+namespace {
+
+constexpr size_t kMaxTimingEvents = 8192;
+constexpr uint64_t kNtBytes = 200ull << 20;  // corpus larger than this streams past L2/MALL
+
+uint64_t pad_rows(uint64_t n) { return (n + kRowsPerBlock - 1) / kRowsPerBlock * kRowsPerBlock; }
+
+int32_t fail(cqs_hip_index* idx, int32_t code, const char* what, hipError_t e = hipSuccess) {
+    char buf[512];
+    if (e != hipSuccess)
+        snprintf(buf, sizeof buf, "%s: %s (%s)", what, hipGetErrorString(e), hipGetErrorName(e));
+    else
+        snprintf(buf, sizeof buf, "%s", what);
+    if (idx) {
+        idx->last_error = buf;
+        if (code == CQS_HIP_ERR_DEVICE) idx->poisoned.store(true, std::memory_order_release);
+    }
+    return code;
+}
+
+#define HIP_TRY(idx, expr)                                                        \
+    do {                                                                          \
+        hipError_t _e = (expr);                                                   \
+        if (_e != hipSuccess)                                                     \
+            return fail((idx), _e == hipErrorOutOfMemory ? CQS_HIP_ERR_NOMEM : CQS_HIP_ERR_DEVICE, #expr, _e); \
+    } while (0)
+
+void free_scratch(cqs_hip_index* x) {
+    hipFree(x->d_q); hipFree(x->d_scores); hipFree(x->d_sel); hipFree(x->d_cand);
+    hipFree(x->d_out_keys); hipFree(x->d_out_counts);
+    hipHostFree(x->h_q); hipHostFree(x->h_out_keys); hipHostFree(x->h_out_counts);
+    x->d_q = x->d_scores = nullptr; x->d_sel = nullptr; x->d_cand = nullptr;
+    x->d_out_keys = nullptr; x->d_out_counts = nullptr;
+    x->h_q = nullptr; x->h_out_keys = nullptr; x->h_out_counts = nullptr;
+    x->q_cap = 0; x->k_cap = 0; x->scr_n_pad = 0;
+}
+
+// Make the scratch hold `b` queries at top-`k` for the current n.
+int32_t ensure_scratch(cqs_hip_index* x, uint32_t b, uint32_t k) {
+    const uint64_t n_pad = pad_rows(x->n);
+    if (b <= x->q_cap && k <= x->k_cap && n_pad == x->scr_n_pad) return CQS_HIP_OK;
+    HIP_TRY(x, hipDeviceSynchronize());  // searches may be in flight on caller streams
+    uint32_t qc = x->q_cap > b ? x->q_cap : b;
+    uint32_t kc = x->k_cap > k ? x->k_cap : k;
+    free_scratch(x);
+    HIP_TRY(x, hipMalloc(&x->d_q, (size_t)qc * x->dim * sizeof(float)));
+    HIP_TRY(x, hipMalloc(&x->d_scores, (size_t)qc * n_pad * sizeof(float)));
+    HIP_TRY(x, hipMalloc(&x->d_sel, (size_t)qc * kSelWords * sizeof(uint32_t)));
+    HIP_TRY(x, hipMalloc(&x->d_cand, (size_t)qc * kCandCap * sizeof(uint64_t)));
+    HIP_TRY(x, hipMalloc(&x->d_out_keys, (size_t)qc * kc * sizeof(uint64_t)));
+    HIP_TRY(x, hipMalloc(&x->d_out_counts, (size_t)qc * sizeof(uint32_t)));
+    HIP_TRY(x, hipHostMalloc(&x->h_q, (size_t)qc * x->dim * sizeof(float), hipHostMallocDefault));
+    HIP_TRY(x, hipHostMalloc(&x->h_out_keys, (size_t)qc * kc * sizeof(uint64_t), hipHostMallocDefault));
+    HIP_TRY(x, hipHostMalloc(&x->h_out_counts, (size_t)qc * sizeof(uint32_t), hipHostMallocDefault));
+    x->q_cap = qc; x->k_cap = kc; x->scr_n_pad = n_pad;
+    return CQS_HIP_OK;
+}
+
+// Largest query block whose score rows fit the scratch budget (score matrix
+// is b * n_pad f32).  16 GiB default: 256 queries x 10M rows fit in one pass.
+uint32_t max_query_block(const cqs_hip_index* x) {
+    const uint64_t budget = 16ull << 30;
+    const uint64_t per_q = pad_rows(x->n) * sizeof(float);
+    uint64_t q = per_q ? budget / per_q : 1024;
+    if (q < 1) q = 1;
+    if (q > 1024) q = 1024;
+    return (uint32_t)q;
+}
+
+// Enqueue scan + select for queries already on the device.  Caller holds mu.
+int32_t enqueue_search(cqs_hip_index* x, const float* d_q, uint32_t b, uint32_t k, const uint32_t* d_keep,
+                       uint32_t mode, float thr, uint64_t* d_out_keys, uint32_t* d_out_counts, hipStream_t st) {
+    cqs::ScanArgs a;
+    a.rows = x->d_rows;
+    a.n = (uint32_t)x->n;
+    a.n_pad = (uint32_t)pad_rows(x->n);
+    a.dim = x->dim;
+    a.q = d_q;
+    a.b = b;
+    a.scores = x->d_scores;
+    a.keep = d_keep;
+    a.mode = mode;
+    a.threshold = thr;
+    a.nontemporal = x->n * x->dim * sizeof(float) > kNtBytes;
+    const bool timed = x->timing && x->ev_used + 2 <= kMaxTimingEvents;
+    if (timed) {
+        while (x->ev.size() < x->ev_used + 2) {
+            hipEvent_t e = nullptr;
+            HIP_TRY(x, hipEventCreate(&e));
+            x->ev.push_back(e);
+        }
+        HIP_TRY(x, hipEventRecord(x->ev[x->ev_used], st));
+    }
+    HIP_TRY(x, cqs::launch_scan(a, st));
+    if (timed) {
+        HIP_TRY(x, hipEventRecord(x->ev[x->ev_used + 1], st));
+        x->ev_used += 2;
+    }
+    HIP_TRY(x, cqs::launch_select(x->d_scores, a.n, a.n_pad, b, k, (uint32_t)x->row_base, x->d_sel, x->d_cand,
+                                  d_out_keys, d_out_counts, st));
+    return CQS_HIP_OK;
+}
+
+int32_t create_common(uint64_t n, uint32_t dim, uint32_t metric, int32_t device, uint64_t row_base,
+                      cqs_hip_index** out, cqs_hip_index** made) {
+    if (!out) return CQS_HIP_ERR_INVALID;
+    *out = nullptr;
+    if (!cqs::scan_dim_supported(dim) || metric > CQS_HIP_METRIC_DOT) return CQS_HIP_ERR_INVALID;
+    if (n + row_base > 0xFFFFFFFEull) return CQS_HIP_ERR_INVALID;  // row ids are packed in 32 bits
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0) return CQS_HIP_ERR_NO_DEVICE;
+    if (device < 0 || device >= cnt) return CQS_HIP_ERR_INVALID;
+    cqs_hip_index* x = new (std::nothrow) cqs_hip_index();
+    if (!x) return CQS_HIP_ERR_NOMEM;
+    x->device = device; x->n = n; x->dim = dim; x->metric = metric; x->row_base = row_base;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&x->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete x;
+        return CQS_HIP_ERR_DEVICE;
+    }
+    *made = x;
+    return CQS_HIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* cqs_hip_version(void) { return "cqs-hip 0.1.0 (gfx950)"; }
+
+int32_t cqs_hip_device_count(void) {
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess) return 0;
+    return cnt;
+}
+
+int32_t cqs_hip_device_mem(int32_t device, uint64_t* free_bytes, uint64_t* total_bytes) {
+    if (hipSetDevice(device) != hipSuccess) return CQS_HIP_ERR_NO_DEVICE;
+    size_t f = 0, t = 0;
+    if (hipMemGetInfo(&f, &t) != hipSuccess) return CQS_HIP_ERR_DEVICE;
+    if (free_bytes) *free_bytes = f;
+    if (total_bytes) *total_bytes = t;
+    return CQS_HIP_OK;
+}
+
+int32_t cqs_hip_index_create(const float* rows, uint64_t n, uint32_t dim, uint32_t metric, int32_t device,
+                             uint64_t row_base, cqs_hip_index** out) {
+    if (n > 0 && !rows) return CQS_HIP_ERR_INVALID;
+    cqs_hip_index* x = nullptr;
+    int32_t rc = create_common(n, dim, metric, device, row_base, out, &x);
+    if (rc != CQS_HIP_OK) return rc;
+    x->cap_rows = n ? n : 1;
+    hipError_t e = hipMalloc(&x->d_rows, (size_t)x->cap_rows * dim * sizeof(float));
+    if (e == hipSuccess && n)
+        e = hipMemcpyAsync(x->d_rows, rows, (size_t)n * dim * sizeof(float), hipMemcpyHostToDevice, x->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(x->stream);
+    if (e != hipSuccess) {
+        cqs_hip_index_destroy(x);
+        return e == hipErrorOutOfMemory ? CQS_HIP_ERR_NOMEM : CQS_HIP_ERR_DEVICE;
+    }
+    *out = x;
+    return CQS_HIP_OK;
+}
+
+int32_t cqs_hip_index_create_device(const void* d_rows, uint64_t n, uint32_t dim, uint32_t metric, int32_t device,
+                                    uint64_t row_base, int32_t borrow, cqs_hip_index** out) {
+    if (n > 0 && !d_rows) return CQS_HIP_ERR_INVALID;
+    if (((uintptr_t)d_rows & 15u) != 0) return CQS_HIP_ERR_INVALID;  // 16-B row loads
+    cqs_hip_index* x = nullptr;
+    int32_t rc = create_common(n, dim, metric, device, row_base, out, &x);
+    if (rc != CQS_HIP_OK) return rc;
+    if (borrow) {
+        x->borrow = true;
+        x->d_rows = (float*)d_rows;
+        x->cap_rows = n;
+    } else {
+        x->cap_rows = n ? n : 1;
+        hipError_t e = hipMalloc(&x->d_rows, (size_t)x->cap_rows * dim * sizeof(float));
+        if (e == hipSuccess && n)
+            e = hipMemcpyAsync(x->d_rows, d_rows, (size_t)n * dim * sizeof(float), hipMemcpyDeviceToDevice, x->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(x->stream);
+        if (e != hipSuccess) {
+            cqs_hip_index_destroy(x);
+            return e == hipErrorOutOfMemory ? CQS_HIP_ERR_NOMEM : CQS_HIP_ERR_DEVICE;
+        }
+    }
+    *out = x;
+    return CQS_HIP_OK;
+}
+
+int32_t cqs_hip_index_extend(cqs_hip_index* x, const float* rows, uint64_t n_new) {
+    if (!x) return CQS_HIP_ERR_INVALID;
+    std::lock_guard<std::mutex> g(x->mu);
+    if (x->poisoned.load(std::memory_order_acquire)) return CQS_HIP_ERR_POISONED;
+    if (x->borrow) return fail(x, CQS_HIP_ERR_INVALID, "extend: index borrows its rows");
+    if (n_new == 0) return CQS_HIP_OK;
+    if (!rows) return fail(x, CQS_HIP_ERR_INVALID, "extend: null rows");
+    if (x->n + n_new + x->row_base > 0xFFFFFFFEull) return fail(x, CQS_HIP_ERR_INVALID, "extend: row id overflow");
+    HIP_TRY(x, hipSetDevice(x->device));
+    HIP_TRY(x, hipStreamSynchronize(x->stream));
+    const size_t row_bytes = (size_t)x->dim * sizeof(float);
+    if (x->n + n_new > x->cap_rows) {  // grow geometrically, copy device-to-device
+        uint64_t cap = x->cap_rows * 2;
+        if (cap < x->n + n_new) cap = x->n + n_new;
+        float* nd = nullptr;
+        HIP_TRY(x, hipMalloc(&nd, cap * row_bytes));
+        hipError_t e = hipMemcpyAsync(nd, x->d_rows, x->n * row_bytes, hipMemcpyDeviceToDevice, x->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(x->stream);
+        if (e != hipSuccess) {
+            hipFree(nd);
+            return fail(x, CQS_HIP_ERR_DEVICE, "extend: copy", e);
+        }
+        hipFree(x->d_rows);
+        x->d_rows = nd;
+        x->cap_rows = cap;
+    }
+    HIP_TRY(x, hipMemcpyAsync(x->d_rows + x->n * x->dim, rows, n_new * row_bytes, hipMemcpyHostToDevice, x->stream));
+    HIP_TRY(x, hipStreamSynchronize(x->stream));
+    x->n += n_new;
+    return CQS_HIP_OK;
+}
+
+void cqs_hip_index_destroy(cqs_hip_index* x) {
+    if (!x) return;
+    hipSetDevice(x->device);
+    if (x->stream) hipStreamSynchronize(x->stream);  // src/cagra.rs:289-302
+    free_scratch(x);
+    hipFree(x->d_keep);
+    if (!x->borrow) hipFree(x->d_rows);
+    for (hipEvent_t e : x->ev) hipEventDestroy(e);
+    if (x->stream) hipStreamDestroy(x->stream);
+    delete x;
+}
+
+uint64_t cqs_hip_index_len(const cqs_hip_index* x) { return x ? x->n : 0; }
+uint32_t cqs_hip_index_dim(const cqs_hip_index* x) { return x ? x->dim : 0; }
+uint32_t cqs_hip_index_metric(const cqs_hip_index* x) { return x ? x->metric : 0; }
+uint32_t cqs_hip_index_max_k(const cqs_hip_index* x) { (void)x; return kMaxK; }
+int32_t cqs_hip_index_poisoned(const cqs_hip_index* x) { return x && x->poisoned.load(std::memory_order_acquire) ? 1 : 0; }
+int32_t cqs_hip_index_device(const cqs_hip_index* x) { return x ? x->device : -1; }
+uint64_t cqs_hip_index_row_base(const cqs_hip_index* x) { return x ? x->row_base : 0; }
+
+size_t cqs_hip_index_last_error(const cqs_hip_index* x, char* buf, size_t cap) {
+    if (!x || !buf || cap == 0) return 0;
+    std::lock_guard<std::mutex> g(x->mu);
+    size_t m = x->last_error.size() < cap - 1 ? x->last_error.size() : cap - 1;
+    memcpy(buf, x->last_error.data(), m);
+    buf[m] = 0;
+    return m;
+}
+
+void cqs_hip_unpack_keys(const uint64_t* keys, size_t count, uint64_t* rows, float* scores) {
+    for (size_t i = 0; i < count; ++i) {
+        const uint32_t ok = (uint32_t)(keys[i] >> 32);
+        const uint32_t bits = (ok & 0x80000000u) ? (ok ^ 0x80000000u) : ~ok;
+        float f;
+        memcpy(&f, &bits, 4);
+        if (scores) scores[i] = f;
+        if (rows) rows[i] = (uint64_t)(0xFFFFFFFFu - (uint32_t)keys[i]);
+    }
+}
+
+size_t cqs_hip_merge_keys(const uint64_t* lists, const uint32_t* counts, size_t n_lists, size_t stride, size_t k,
+                          uint64_t* out_keys) {
+    // k-way merge of descending lists; n_lists is small (<= #GPUs), so a
+    // linear scan over the list heads is cheaper than a heap.
+    std::vector<size_t> pos(n_lists, 0);
+    size_t outc = 0;
+    while (outc < k) {
+        size_t best = n_lists;
+        uint64_t bk = 0;
+        for (size_t l = 0; l < n_lists; ++l) {
+            if (pos[l] < counts[l]) {
+                const uint64_t v = lists[l * stride + pos[l]];
+                if (best == n_lists || v > bk) { best = l; bk = v; }
+            }
+        }
+        if (best == n_lists) break;
+        out_keys[outc++] = bk;
+        pos[best]++;
+    }
+    return outc;
+}
+
+int32_t cqs_hip_index_search_device(cqs_hip_index* x, const float* d_queries, uint32_t b, uint32_t k,
+                                    const uint32_t* d_keep_bitset, uint32_t mode, float threshold,
+                                    uint64_t* d_out_keys, uint32_t* d_out_counts, void* stream) {
+    if (!x) return CQS_HIP_ERR_INVALID;
+    std::lock_guard<std::mutex> g(x->mu);
+    if (x->poisoned.load(std::memory_order_acquire)) return CQS_HIP_ERR_POISONED;
+    if (b == 0) return CQS_HIP_OK;
+    if (!d_queries || !d_out_keys || !d_out_counts) return fail(x, CQS_HIP_ERR_INVALID, "search_device: null buffer");
+    if (k == 0 || k > kMaxK) return fail(x, CQS_HIP_ERR_INVALID, "search_device: k out of range");
+    if (mode > CQS_HIP_MODE_PIPELINE) return fail(x, CQS_HIP_ERR_INVALID, "search_device: bad mode");
+    if (b > max_query_block(x)) return fail(x, CQS_HIP_ERR_INVALID, "search_device: batch exceeds scratch budget");
+    HIP_TRY(x, hipSetDevice(x->device));
+    hipStream_t st = stream ? (hipStream_t)stream : x->stream;
+    if (x->n == 0) {
+        HIP_TRY(x, hipMemsetAsync(d_out_counts, 0, (size_t)b * sizeof(uint32_t), st));
+        return CQS_HIP_OK;
+    }
+    int32_t rc = ensure_scratch(x, b, k);
+    if (rc != CQS_HIP_OK) return rc;
+    return enqueue_search(x, d_queries, b, k, d_keep_bitset, mode, threshold, d_out_keys, d_out_counts, st);
+}
+
+int32_t cqs_hip_index_search(cqs_hip_index* x, const float* queries, uint32_t b, uint32_t query_dim, uint32_t k,
+                             const uint32_t* keep_bitset, uint32_t mode, float threshold, uint64_t* out_rows,
+                             float* out_scores, uint32_t* out_counts) {
+    if (!x) return CQS_HIP_ERR_INVALID;
+    std::lock_guard<std::mutex> g(x->mu);
+    if (x->poisoned.load(std::memory_order_acquire)) return CQS_HIP_ERR_POISONED;  // src/cagra.rs:486-490
+    if (b == 0) return CQS_HIP_OK;
+    if (!queries || !out_counts) return fail(x, CQS_HIP_ERR_INVALID, "search: null buffer");
+    for (uint32_t i = 0; i < b; ++i) out_counts[i] = 0;
+    if (x->n == 0 || k == 0) return CQS_HIP_OK;               // src/cagra.rs:445-447
+    if (query_dim != x->dim) {                                  // src/cagra.rs:449-456
+        x->last_error = "search: query dimension mismatch (empty result)";
+        return CQS_HIP_OK;
+    }
+    if (k > kMaxK) return fail(x, CQS_HIP_ERR_INVALID, "search: k > max_k");
+    if (mode > CQS_HIP_MODE_PIPELINE) return fail(x, CQS_HIP_ERR_INVALID, "search: bad mode");
+    if (!out_rows || !out_scores) return fail(x, CQS_HIP_ERR_INVALID, "search: null output buffer");
+
+    HIP_TRY(x, hipSetDevice(x->device));
+    // bitset: count kept rows on the host (src/cagra.rs:747-775)
+    const uint32_t* d_keep = nullptr;
+    uint32_t k_eff = k;
+    if (keep_bitset) {
+        const uint64_t words = (x->n + 31) / 32;
+        uint64_t included = 0;
+        for (uint64_t w = 0; w < words; ++w) {
+            uint32_t v = keep_bitset[w];
+            if (w == words - 1 && (x->n % 32)) v &= (1u << (x->n % 32)) - 1u;
+            included += (uint64_t)__builtin_popcount(v);
+        }
+        if (included == 0) return CQS_HIP_OK;                   // src/cagra.rs:765-767
+        if (included < x->n) {                                  // all-pass == unfiltered, :760-762
+            if (included < k_eff) k_eff = (uint32_t)included;   // :775
+            if (words > x->keep_words_cap) {
+                HIP_TRY(x, hipStreamSynchronize(x->stream));
+                hipFree(x->d_keep);
+                x->d_keep = nullptr;
+                x->keep_words_cap = 0;
+                HIP_TRY(x, hipMalloc(&x->d_keep, words * sizeof(uint32_t)));
+                x->keep_words_cap = words;
+            }
+            HIP_TRY(x, hipMemcpyAsync(x->d_keep, keep_bitset, words * sizeof(uint32_t), hipMemcpyHostToDevice, x->stream));
+            d_keep = x->d_keep;
+        }
+    }
+
+    const uint32_t blk = max_query_block(x);
+    std::vector<uint8_t> bad(b, 0);
+    for (uint32_t done = 0; done < b;) {
+        const uint32_t nb = (b - done) < blk ? (b - done) : blk;
+        int32_t rc = ensure_scratch(x, nb, k_eff);
+        if (rc != CQS_HIP_OK) return rc;
+        // stage queries; a non-finite query yields an empty result (src/cagra.rs:464-470)
+        for (uint32_t i = 0; i < nb; ++i) {
+            const float* src = queries + (size_t)(done + i) * x->dim;
+            float* dst = x->h_q + (size_t)i * x->dim;
+            bool ok = true;
+            for (uint32_t d = 0; d < x->dim; ++d) ok &= std::isfinite(src[d]);
+            bad[done + i] = !ok;
+            if (ok) memcpy(dst, src, (size_t)x->dim * sizeof(float));
+            else memset(dst, 0, (size_t)x->dim * sizeof(float));
+        }
+        HIP_TRY(x, hipMemcpyAsync(x->d_q, x->h_q, (size_t)nb * x->dim * sizeof(float), hipMemcpyHostToDevice, x->stream));
+        rc = enqueue_search(x, x->d_q, nb, k_eff, d_keep, mode, threshold, x->d_out_keys, x->d_out_counts, x->stream);
+        if (rc != CQS_HIP_OK) return rc;
+        HIP_TRY(x, hipMemcpyAsync(x->h_out_keys, x->d_out_keys, (size_t)nb * k_eff * sizeof(uint64_t), hipMemcpyDeviceToHost, x->stream));
+        HIP_TRY(x, hipMemcpyAsync(x->h_out_counts, x->d_out_counts, (size_t)nb * sizeof(uint32_t), hipMemcpyDeviceToHost, x->stream));
+        HIP_TRY(x, hipStreamSynchronize(x->stream));
+        for (uint32_t i = 0; i < nb; ++i) {
+            const uint32_t qi = done + i;
+            if (bad[qi]) continue;
+            uint32_t c = x->h_out_counts[i];
+            if (c > k_eff) c = k_eff;
+            cqs_hip_unpack_keys(x->h_out_keys + (size_t)i * k_eff, c, out_rows + (size_t)qi * k, out_scores + (size_t)qi * k);
+            out_counts[qi] = c;
+        }
+        done += nb;
+    }
+    return CQS_HIP_OK;
+}
+
+void cqs_hip_index_set_timing(cqs_hip_index* x, int32_t enable) {
+    if (!x) return;
+    std::lock_guard<std::mutex> g(x->mu);
+    x->timing = enable != 0;
+    x->ev_used = 0;
+}
+
+int32_t cqs_hip_index_scan_time(cqs_hip_index* x, uint32_t* launches, double* total_ms) {
+    if (!x || !launches || !total_ms) return CQS_HIP_ERR_INVALID;
+    std::lock_guard<std::mutex> g(x->mu);
+    *launches = 0;
+    *total_ms = 0.0;
+    HIP_TRY(x, hipSetDevice(x->device));
+    for (size_t i = 0; i + 1 < x->ev_used; i += 2) {
+        HIP_TRY(x, hipEventSynchronize(x->ev[i + 1]));
+        float ms = 0.f;
+        HIP_TRY(x, hipEventElapsedTime(&ms, x->ev[i], x->ev[i + 1]));
+        *total_ms += ms;
+        *launches += 1;
+    }
+    x->ev_used = 0;
+    return CQS_HIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,166 @@
+/*
+ * cqs_hip.h — C ABI of libcqs_hip.so, the MI355X (gfx950) implementation of the
+ * cqs semantic-search hot path: exact brute-force dot/cosine scan + top-k over
+ * an HBM-resident [n, dim] f32 corpus, and (embed section) the embedding
+ * forward.  This is the drop-in boundary: plain pointers and sizes, opaque
+ * handles, int32 status codes, no exceptions, no callbacks, no torch types.
+ *
+ * The reference (jamie8johnson/cqs, Rust) has no FFI for this path today; the
+ * seams it would bind this library behind are cited per entry point
+ * (file:line relative to the cqs repo root, v1.51.0).  INTEGRATION.md shows
+ * the Rust `extern "C"` block + `impl VectorIndex` a maintainer would add.
+ *
+ * Threading: every entry point is safe to call concurrently on one handle
+ * (the handle serialises device work behind an internal mutex, like
+ * `CagraIndex.gpu: Mutex<GpuState>`, src/cagra.rs:263).  Device failures never
+ * abort: they return a negative status, set the handle's poisoned flag
+ * (src/index.rs:203-205, src/cagra.rs:472-489) and leave a message for
+ * cqs_hip_index_last_error.
+ */
+#ifndef CQS_HIP_H
+#define CQS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes --------------------------------------------------------- */
+#define CQS_HIP_OK              0
+#define CQS_HIP_ERR_INVALID    (-1)  /* bad argument (null, k > max_k, dim unsupported, ...) */
+#define CQS_HIP_ERR_DEVICE     (-2)  /* HIP runtime error; handle is poisoned */
+#define CQS_HIP_ERR_NOMEM      (-3)  /* device or host allocation failed */
+#define CQS_HIP_ERR_POISONED   (-4)  /* handle was poisoned by an earlier device error */
+#define CQS_HIP_ERR_NO_DEVICE  (-5)  /* no usable gfx950 device */
+
+/* DistanceMetric (src/index.rs:45-56).  Both rank by the raw inner product;
+ * COSINE additionally promises unit-norm rows so that score == cosine and
+ * `index_scores_are_cosine()` (src/index.rs:236-238) may return true. */
+#define CQS_HIP_METRIC_COSINE 0u
+#define CQS_HIP_METRIC_DOT    1u
+
+/* Score mode of a search.
+ * RAW     : rank and return the raw dot product — the `VectorIndex::search`
+ *           contract (src/index.rs:139-146; CAGRA's score at src/cagra.rs:656-662).
+ * PIPELINE: rank on clamp(score,0,1) and drop scores < threshold — what the
+ *           reference's brute-force scan ranks on with a default SearchFilter
+ *           (src/search/scoring/candidate.rs:550 clamp, :513-519 ThresholdGate,
+ *           loop at src/search/query.rs:469-481). */
+#define CQS_HIP_MODE_RAW      0u
+#define CQS_HIP_MODE_PIPELINE 1u
+
+/* Largest k one search call serves (`VectorIndex::max_k`, src/index.rs:219-221;
+ * production asks for candidate_count_for(limit) = max(5*limit, 500),
+ * src/limits.rs:315-320). */
+#define CQS_HIP_MAX_K 1024u
+
+typedef struct cqs_hip_index cqs_hip_index;
+
+/* ---- library / device ------------------------------------------------------ */
+const char* cqs_hip_version(void);
+/* Number of visible HIP devices (0 if none / runtime unusable).  Mirrors
+ * `CagraIndex::gpu_available` (src/cagra.rs:336-376) for backend selection. */
+int32_t cqs_hip_device_count(void);
+/* Free + total HBM bytes of `device` (gpu_available_for sizing, src/cagra.rs:336-376). */
+int32_t cqs_hip_device_mem(int32_t device, uint64_t* free_bytes, uint64_t* total_bytes);
+
+/* ---- index lifetime -------------------------------------------------------- */
+/* Build an exact index over `n` rows of `dim` f32 (host, row-major, rows in
+ * rowid order = id_map order; replaces `CagraIndex::build_from_flat`,
+ * src/cagra.rs:922-960).  The rows are copied to HBM.  Nothing is skipped:
+ * the caller pre-filters zero / non-finite rows exactly like
+ * `prepare_index_data` (src/hnsw/mod.rs:688-746) so len() and row->id agree.
+ * `row_base` is added to every emitted row id (0 for a whole corpus; the shard
+ * offset when the corpus is row-sharded over several GPUs/processes).
+ * dim must be a multiple of 4 and <= 2048. */
+int32_t cqs_hip_index_create(const float* rows, uint64_t n, uint32_t dim, uint32_t metric,
+                             int32_t device, uint64_t row_base, cqs_hip_index** out);
+/* Same, from rows already resident in `device`'s HBM.  borrow != 0: the index
+ * uses the caller's buffer in place (caller keeps it alive and unmodified);
+ * borrow == 0: the rows are copied device-to-device. */
+int32_t cqs_hip_index_create_device(const void* d_rows, uint64_t n, uint32_t dim, uint32_t metric,
+                                    int32_t device, uint64_t row_base, int32_t borrow,
+                                    cqs_hip_index** out);
+/* Append rows (host) to an owning index — incremental add, the contract the
+ * tiered backend's extend() exposes (src/tiered.rs:1-43).  Not valid on a
+ * borrowing index. */
+int32_t cqs_hip_index_extend(cqs_hip_index* idx, const float* rows, uint64_t n_new);
+/* Synchronises the index's streams, then frees everything (src/cagra.rs:289-302). */
+void cqs_hip_index_destroy(cqs_hip_index* idx);
+
+/* ---- index properties (VectorIndex, src/index.rs:139-239) ------------------ */
+uint64_t cqs_hip_index_len(const cqs_hip_index* idx);       /* len()  :149 */
+uint32_t cqs_hip_index_dim(const cqs_hip_index* idx);       /* dim()  :160 */
+uint32_t cqs_hip_index_metric(const cqs_hip_index* idx);
+uint32_t cqs_hip_index_max_k(const cqs_hip_index* idx);     /* max_k() :219 */
+int32_t  cqs_hip_index_poisoned(const cqs_hip_index* idx);  /* is_poisoned() :203 */
+int32_t  cqs_hip_index_device(const cqs_hip_index* idx);
+uint64_t cqs_hip_index_row_base(const cqs_hip_index* idx);
+/* Copies the last error / warning text (NUL-terminated, truncated to cap). */
+size_t cqs_hip_index_last_error(const cqs_hip_index* idx, char* buf, size_t cap);
+
+/* ---- search: host buffers --------------------------------------------------
+ * `VectorIndex::search` / `search_with_filter` for a block of `b` queries
+ * (src/index.rs:146,167; the CAGRA exemplar src/cagra.rs:443-672,727-820).
+ *
+ * queries   [b * query_dim] f32, host.
+ * query_dim must equal dim(); a mismatch yields out_counts[*] = 0 and
+ *           CQS_HIP_OK (reference: warn + empty Vec, src/cagra.rs:449-456).
+ * k         0 -> counts 0; k > max_k -> CQS_HIP_ERR_INVALID (callers trim
+ *           with cap_k_to_backend, src/search/query.rs:232-245).
+ * keep_bitset nullable, host, ceil(len/32) words, bit (i%32) of word i/32 = keep
+ *           local row i (src/cagra.rs:747-757).  All-pass == unfiltered, none ->
+ *           counts 0, k is capped at the number of kept rows (src/cagra.rs:760-775).
+ * mode/threshold: see CQS_HIP_MODE_*.
+ * A query with a non-finite component yields count 0 (src/cagra.rs:464-470).
+ *
+ * Result per query q: out_rows[q*k .. q*k+out_counts[q]) (row_base + local row)
+ * and out_scores likewise, ordered by (score desc under f32 total order, row
+ * asc) — the reference's order (candidate.rs:327, neighbors.rs:131) with
+ * integer ids.  Non-finite scores are never emitted (src/cagra.rs:649-651).
+ * Slots past out_counts[q] are untouched. */
+int32_t cqs_hip_index_search(cqs_hip_index* idx, const float* queries, uint32_t b, uint32_t query_dim,
+                             uint32_t k, const uint32_t* keep_bitset, uint32_t mode, float threshold,
+                             uint64_t* out_rows, float* out_scores, uint32_t* out_counts);
+
+/* ---- search: device buffers, asynchronous ----------------------------------
+ * Same computation with every buffer in the index's device memory space and
+ * no host synchronisation: work is enqueued on `stream` (a hipStream_t; NULL =
+ * the index's own stream) and the call returns.  Used by the bench (inputs
+ * resident in HBM) and by the sharded multi-GPU path, whose per-shard
+ * candidates feed an RCCL all-gather straight from HBM.
+ * d_queries [b*dim] f32 must hold finite values (the caller checks; the host
+ * entry point above does it for host queries).  d_keep_bitset nullable.
+ * d_out_keys [b*k] u64 receives the packed candidates
+ *     key = (ordered_u32(score) << 32) | (0xFFFFFFFF - global_row)
+ * sorted descending (i.e. score desc, row asc), unused slots = 0.
+ * d_out_counts [b] u32.  cqs_hip_unpack_keys decodes keys on the host. */
+int32_t cqs_hip_index_search_device(cqs_hip_index* idx, const float* d_queries, uint32_t b, uint32_t k,
+                                    const uint32_t* d_keep_bitset, uint32_t mode, float threshold,
+                                    uint64_t* d_out_keys, uint32_t* d_out_counts, void* stream);
+
+/* Host helpers for packed candidate keys (see above). */
+void cqs_hip_unpack_keys(const uint64_t* keys, size_t count, uint64_t* rows, float* scores);
+/* Final host-side k-way merge of per-shard candidate lists for one query
+ * (north_star: "RCCL all-gather of per-shard (score,id) candidates before the
+ * final host-side merge").  lists = n_lists blocks of `stride` keys, of which
+ * the first counts[i] are valid and sorted descending.  Writes the top
+ * min(k, total) keys, sorted descending; returns that count. */
+size_t cqs_hip_merge_keys(const uint64_t* lists, const uint32_t* counts, size_t n_lists, size_t stride,
+                          size_t k, uint64_t* out_keys);
+
+/* ---- profiling aid ---------------------------------------------------------
+ * With timing enabled every search brackets its dominant scan kernel launch(es)
+ * with a HIP event pair on the launch stream (up to 4096 pairs between reads).
+ * cqs_hip_index_scan_time synchronises those events, returns how many searches
+ * were bracketed and their summed scan time in milliseconds, and resets the
+ * pool.  bench.py derives roofline.achieved from it. */
+void    cqs_hip_index_set_timing(cqs_hip_index* idx, int32_t enable);
+int32_t cqs_hip_index_scan_time(cqs_hip_index* idx, uint32_t* launches, double* total_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CQS_HIP_H */

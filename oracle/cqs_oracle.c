@@ -1,0 +1,502 @@
+/*
+ * cqs_oracle.c — CPU restatement of the cqs semantic-search hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY (see cqs_oracle.h).  Build: `make -C oracle`
+ * (gcc -O2 -ffp-contract=off: only the explicit fmaf() calls below fuse, so
+ * the arithmetic order is exactly what each function documents).
+ *
+ * Every function cites the reference file:line (relative to the cqs repo
+ * root, v1.51.0) whose behaviour it restates.
+ */
+#include "cqs_oracle.h"
+
+#include <math.h>
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------ */
+/* f32::total_cmp (Rust std): IEEE-754 totalOrder on the bit pattern.        */
+static inline int32_t total_key(float x) {
+    int32_t i;
+    memcpy(&i, &x, 4);
+    i ^= (int32_t)(((uint32_t)(i >> 31)) >> 1);
+    return i;
+}
+static inline int total_cmp(float a, float b) {
+    int32_t ka = total_key(a), kb = total_key(b);
+    return (ka > kb) - (ka < kb);
+}
+/* Rust f32::clamp(min,max): `if self < min {min} else if self > max {max} else {self}`
+ * (NaN and -0.0 pass through unchanged). */
+static inline float rust_clamp(float x, float lo, float hi) {
+    if (x < lo) return lo;
+    if (x > hi) return hi;
+    return x;
+}
+
+/* ---- A1 ------------------------------------------------------------------ */
+/* simsimd 6.5.16 simsimd_dot_f32_haswell (published algorithm): ab_vec (8 f32
+ * lanes) = fmadd(a_vec, b_vec, ab_vec) per 8 elements; a partial tail is loaded
+ * zero-filled; the 8 lanes are reduced after widening to f64: lanes i and i+4
+ * are added first (low/high 128-bit halves), then the 4 f64 sums pairwise.
+ * Called from src/math.rs:15-16. */
+__attribute__((target_clones("arch=haswell", "default")))
+double cqs_oracle_dot_simsimd(const float* a, const float* b, size_t n) {
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    size_t i = 0;
+    for (; i + 8 <= n; i += 8)
+        for (int l = 0; l < 8; ++l) acc[l] = fmaf(a[i + l], b[i + l], acc[l]);
+    if (i < n) {
+        for (int l = 0; l < 8; ++l) {
+            float av = (i + l < n) ? a[i + l] : 0.0f;
+            float bv = (i + l < n) ? b[i + l] : 0.0f;
+            acc[l] = fmaf(av, bv, acc[l]);
+        }
+    }
+    double s[4];
+    for (int l = 0; l < 4; ++l) s[l] = (double)acc[l] + (double)acc[l + 4];
+    double lo = s[0] + s[2], hi = s[1] + s[3];
+    return lo + hi;
+}
+
+/* src/math.rs:18-22: `.map(|(&x,&y)| (x as f64)*(y as f64)).sum::<f64>()`. */
+double cqs_oracle_dot_f64(const float* a, const float* b, size_t n) {
+    double s = 0.0;
+    for (size_t i = 0; i < n; ++i) s += (double)a[i] * (double)b[i];
+    return s;
+}
+
+/* neighbors.rs:82 `a.iter().zip(b).map(|(x,y)| x*y).sum()` and
+ * hnsw/mod.rs:291: f32 product then f32 add, strictly left to right. */
+float cqs_oracle_dot_seq_f32(const float* a, const float* b, size_t n) {
+    float s = 0.0f;
+    for (size_t i = 0; i < n; ++i) {
+        float p = a[i] * b[i];
+        s = s + p;
+    }
+    return s;
+}
+
+static double dot_by_kind(const float* a, const float* b, size_t n, int kind) {
+    switch (kind) {
+        case 1: return cqs_oracle_dot_f64(a, b, n);
+        case 2: return (double)cqs_oracle_dot_seq_f32(a, b, n);
+        default: return cqs_oracle_dot_simsimd(a, b, n);
+    }
+}
+
+/* src/math.rs:11-28 */
+static int cosine_kind(const float* a, size_t na, const float* b, size_t nb, int kind, float* out) {
+    if (na != nb || na == 0) return 0;            /* math.rs:12-14 */
+    float score = (float)dot_by_kind(a, b, na, kind); /* math.rs:16-22 `as f32` */
+    if (isfinite(score)) {                         /* math.rs:23-27 */
+        *out = score;
+        return 1;
+    }
+    return 0;
+}
+int cqs_oracle_cosine_similarity(const float* a, size_t na, const float* b, size_t nb, float* out) {
+    return cosine_kind(a, na, b, nb, 0, out);
+}
+
+/* src/math.rs:35-67 */
+int cqs_oracle_full_cosine_similarity(const float* a, size_t na, const float* b, size_t nb, float* out) {
+    if (na != nb || na == 0) return 0;
+    double dot = 0.0, norm_a = 0.0, norm_b = 0.0;
+    for (size_t i = 0; i < na; ++i) {
+        double xd = a[i], yd = b[i];
+        dot += xd * yd;
+        norm_a += xd * xd;
+        norm_b += yd * yd;
+    }
+    double denom = sqrt(norm_a) * sqrt(norm_b);
+    if (denom == 0.0) return 0;
+    float r = (float)(dot / denom);
+    if (!isfinite(r)) return 0;
+    *out = r;
+    return 1;
+}
+
+/* ---- A17 ----------------------------------------------------------------- */
+/* src/embedder/pooling.rs:60-67: norm_sq = fold(0.0, acc + x*x) in f32;
+ * if norm_sq > 0 { inv = 1.0/sqrt(norm_sq); x *= inv }. */
+void cqs_oracle_normalize_l2(float* v, size_t n) {
+    float norm_sq = 0.0f;
+    for (size_t i = 0; i < n; ++i) {
+        float p = v[i] * v[i];
+        norm_sq = norm_sq + p;
+    }
+    if (norm_sq > 0.0f) {
+        float inv_norm = 1.0f / sqrtf(norm_sq);
+        for (size_t i = 0; i < n; ++i) v[i] *= inv_norm;
+    }
+}
+
+/* ---- A2 ------------------------------------------------------------------ */
+/* src/store/helpers/embeddings.rs:31-57: length must equal dim*4 else
+ * EmbeddingBlobMismatch; bytes are native little-endian f32; NaN/Inf pass. */
+int cqs_oracle_bytes_to_embedding(const uint8_t* bytes, size_t len, size_t dim, float* out) {
+    if (len != dim * 4) return -1;
+    memcpy(out, bytes, len);
+    return 0;
+}
+
+/* ---- A3 ------------------------------------------------------------------ */
+/* candidate.rs:550 `embedding_score.clamp(0.0,1.0)`; with the default
+ * SearchFilter and no notes every signal but ThresholdGate is disabled or the
+ * identity, and ThresholdGate is `current >= threshold` (candidate.rs:513-519). */
+int cqs_oracle_apply_scoring_default(float embedding_score, float threshold, float* out) {
+    float base = rust_clamp(embedding_score, 0.0f, 1.0f);
+    if (base >= threshold) {
+        *out = base;
+        return 1;
+    }
+    return 0;
+}
+
+/* ---- A4 ------------------------------------------------------------------ */
+typedef struct {
+    float score;
+    uint64_t id;     /* u64 id, or push index for string heaps */
+    char* sid;       /* NULL for u64 heaps */
+    size_t slen;
+} heap_ent;
+
+struct cqs_oracle_heap {
+    heap_ent* e;
+    size_t len, capacity, pushes;
+};
+
+static int id_cmp(const heap_ent* a, const heap_ent* b) {
+    if (a->sid || b->sid) { /* Rust String Ord: lexicographic bytes */
+        size_t m = a->slen < b->slen ? a->slen : b->slen;
+        int c = m ? memcmp(a->sid, b->sid, m) : 0;
+        if (c) return c < 0 ? -1 : 1;
+        return (a->slen > b->slen) - (a->slen < b->slen);
+    }
+    return (a->id > b->id) - (a->id < b->id);
+}
+/* Key order of `(OrderedFloat, Reverse<id>)` (candidate.rs:163): score by
+ * total_cmp, then id reversed.  "worse" = smaller key = min-heap top. */
+static int key_cmp(const heap_ent* a, const heap_ent* b) {
+    int c = total_cmp(a->score, b->score);
+    if (c) return c;
+    return -id_cmp(a, b);
+}
+static void sift_up(heap_ent* e, size_t i) {
+    while (i > 0) {
+        size_t p = (i - 1) / 2;
+        if (key_cmp(&e[i], &e[p]) >= 0) break;
+        heap_ent t = e[i]; e[i] = e[p]; e[p] = t;
+        i = p;
+    }
+}
+static void sift_down(heap_ent* e, size_t n, size_t i) {
+    for (;;) {
+        size_t l = 2 * i + 1, r = l + 1, m = i;
+        if (l < n && key_cmp(&e[l], &e[m]) < 0) m = l;
+        if (r < n && key_cmp(&e[r], &e[m]) < 0) m = r;
+        if (m == i) break;
+        heap_ent t = e[i]; e[i] = e[m]; e[m] = t;
+        i = m;
+    }
+}
+
+cqs_oracle_heap* cqs_oracle_heap_new(size_t capacity) {
+    cqs_oracle_heap* h = (cqs_oracle_heap*)calloc(1, sizeof(*h));
+    h->capacity = capacity;
+    h->e = (heap_ent*)calloc(capacity + 1, sizeof(heap_ent)); /* candidate.rs:219 */
+    return h;
+}
+void cqs_oracle_heap_free(cqs_oracle_heap* h) {
+    if (!h) return;
+    for (size_t i = 0; i < h->len; ++i) free(h->e[i].sid);
+    free(h->e);
+    free(h);
+}
+size_t cqs_oracle_heap_len(const cqs_oracle_heap* h) { return h->len; }
+
+/* candidate.rs:246-279 */
+int cqs_oracle_heap_would_accept(const cqs_oracle_heap* h, float score) {
+    if (!isfinite(score)) return 0;
+    if (h->capacity == 0) return 0;
+    if (h->len < h->capacity) return 1;
+    return !(total_cmp(score, h->e[0].score) < 0);
+}
+
+/* candidate.rs:281-323 */
+static void heap_push_ent(cqs_oracle_heap* h, heap_ent in) {
+    h->pushes++;
+    if (!isfinite(in.score)) { free(in.sid); return; }     /* :282-285 */
+    if (h->len < h->capacity) {                            /* :288-291 */
+        h->e[h->len] = in;
+        sift_up(h->e, h->len);
+        h->len++;
+        return;
+    }
+    if (h->len == 0) { free(in.sid); return; }             /* capacity 0: peek() is None */
+    heap_ent* worst = &h->e[0];                            /* :299 */
+    int c = total_cmp(in.score, worst->score);
+    int better = c > 0 || (c == 0 && id_cmp(&in, worst) < 0); /* :311-315 */
+    if (better) {                                          /* :316-319 */
+        free(worst->sid);
+        h->e[0] = in;
+        sift_down(h->e, h->len, 0);
+    } else {
+        free(in.sid);
+    }
+}
+void cqs_oracle_heap_push_u64(cqs_oracle_heap* h, uint64_t id, float score) {
+    heap_ent in = {score, id, NULL, 0};
+    heap_push_ent(h, in);
+}
+void cqs_oracle_heap_push_str(cqs_oracle_heap* h, const char* id, float score) {
+    heap_ent in;
+    in.score = score;
+    in.id = h->pushes;
+    in.slen = strlen(id);
+    in.sid = (char*)malloc(in.slen + 1);
+    memcpy(in.sid, id, in.slen + 1);
+    heap_push_ent(h, in);
+}
+
+/* candidate.rs:325-334: sort_by(|a,b| b.1.total_cmp(&a.1).then(a.0.cmp(&b.0))) */
+static int sorted_cmp(const void* pa, const void* pb) {
+    const heap_ent* a = (const heap_ent*)pa;
+    const heap_ent* b = (const heap_ent*)pb;
+    int c = total_cmp(b->score, a->score);
+    if (c) return c;
+    return id_cmp(a, b);
+}
+size_t cqs_oracle_heap_into_sorted(cqs_oracle_heap* h, uint64_t* ids_out, float* scores_out, size_t cap) {
+    qsort(h->e, h->len, sizeof(heap_ent), sorted_cmp);
+    size_t n = h->len < cap ? h->len : cap;
+    for (size_t i = 0; i < n; ++i) {
+        ids_out[i] = h->e[i].id;
+        scores_out[i] = h->e[i].score;
+    }
+    return n;
+}
+
+/* ---- A5 ------------------------------------------------------------------ */
+/* search/query.rs:453-484: for each row (rowid order): embedding_slice ->
+ * score_candidate (cosine -> pipeline) -> score_heap.push; then
+ * into_sorted_vec.  check_query_dim (query.rs:263): a query whose length
+ * differs from the store dim is an error -> here 0 results. */
+size_t cqs_oracle_brute_force(const float* rows, size_t n, size_t dim, const float* query, size_t qdim,
+                              size_t limit, float threshold, int dot_kind,
+                              uint64_t* ids_out, float* scores_out) {
+    if (qdim != dim) return 0;
+    cqs_oracle_heap* h = cqs_oracle_heap_new(limit);
+    for (size_t r = 0; r < n; ++r) {
+        float base, score;
+        if (!cosine_kind(query, qdim, rows + r * dim, dim, dot_kind, &base)) continue; /* query.rs:476 */
+        if (!cqs_oracle_apply_scoring_default(base, threshold, &score)) continue;
+        cqs_oracle_heap_push_u64(h, (uint64_t)r, score);                              /* query.rs:479 */
+    }
+    size_t c = cqs_oracle_heap_into_sorted(h, ids_out, scores_out, limit);
+    cqs_oracle_heap_free(h);
+    return c;
+}
+
+/* ---- A6 ------------------------------------------------------------------ */
+typedef struct { float score; uint64_t id; } scored;
+static int scored_cmp(const void* pa, const void* pb) {
+    const scored* a = (const scored*)pa;
+    const scored* b = (const scored*)pb;
+    int c = total_cmp(b->score, a->score);
+    if (c) return c;
+    return (a->id > b->id) - (a->id < b->id);
+}
+/* neighbors.rs:86-132 (limit.clamp(1, SIMILAR_LIMIT_MAX=100), cli/limits.rs:40) */
+size_t cqs_oracle_find_neighbors(const float* rows, size_t n, size_t dim, size_t target_row,
+                                 size_t limit, uint64_t* ids_out, float* scores_out) {
+    if (limit < 1) limit = 1;
+    if (limit > 100) limit = 100;
+    if (target_row >= n) return 0;
+    scored* s = (scored*)malloc(sizeof(scored) * (n ? n : 1));
+    size_t m = 0;
+    const float* t = rows + target_row * dim;
+    for (size_t r = 0; r < n; ++r) {
+        if (r == target_row) continue;                      /* neighbors.rs:116-118 */
+        s[m].score = cqs_oracle_dot_seq_f32(t, rows + r * dim, dim);
+        s[m].id = r;
+        ++m;
+    }
+    qsort(s, m, sizeof(scored), scored_cmp);               /* neighbors.rs:131 */
+    if (m > limit) m = limit;                              /* neighbors.rs:132 */
+    for (size_t i = 0; i < m; ++i) { ids_out[i] = s[i].id; scores_out[i] = s[i].score; }
+    free(s);
+    return m;
+}
+
+/* ---- A7/A9 --------------------------------------------------------------- */
+size_t cqs_oracle_index_search(const float* rows, size_t n, size_t dim, const float* query, size_t qdim,
+                               size_t k, const uint32_t* keep_bitset, int mode, float threshold,
+                               int dot_kind, uint64_t* ids_out, float* scores_out) {
+    if (n == 0 || k == 0) return 0;                        /* cagra.rs:445-447 */
+    if (qdim != dim) return 0;                             /* cagra.rs:449-456 */
+    for (size_t i = 0; i < qdim; ++i)
+        if (!isfinite(query[i])) return 0;                 /* cagra.rs:464-470 */
+    size_t included = n;
+    if (keep_bitset) {                                     /* cagra.rs:747-757 */
+        included = 0;
+        for (size_t i = 0; i < n; ++i)
+            if (keep_bitset[i / 32] & (1u << (i % 32))) ++included;
+        if (included == n) keep_bitset = NULL;             /* cagra.rs:760-762 */
+        if (included == 0) return 0;                       /* cagra.rs:765-767 */
+        if (k > included) k = included;                    /* cagra.rs:775 */
+    }
+    scored* s = (scored*)malloc(sizeof(scored) * n);
+    size_t m = 0;
+    for (size_t r = 0; r < n; ++r) {
+        if (keep_bitset && !(keep_bitset[r / 32] & (1u << (r % 32)))) continue;
+        float sc = (float)dot_by_kind(query, rows + r * dim, dim, dot_kind);
+        if (!isfinite(sc)) continue;                       /* cagra.rs:649-651 */
+        if (mode == 1 && !cqs_oracle_apply_scoring_default(sc, threshold, &sc)) continue;
+        s[m].score = sc;
+        s[m].id = r;
+        ++m;
+    }
+    qsort(s, m, sizeof(scored), scored_cmp);
+    if (m > k) m = k;
+    for (size_t i = 0; i < m; ++i) { ids_out[i] = s[i].id; scores_out[i] = s[i].score; }
+    free(s);
+    return m;
+}
+
+/* cagra.rs:656-661 */
+float cqs_oracle_cagra_cosine_from_l2sq(float d) {
+    float v = 1.0f - d / 2.0f;
+    return v < 1.0f ? v : 1.0f; /* f32::min(1.0); NaN.min(1.0) = 1.0 */
+}
+/* hnsw/mod.rs:287-299: `1.0 - dot.min(1.0)` */
+float cqs_oracle_dist_dot_clamped(const float* a, const float* b, size_t n) {
+    float dot = cqs_oracle_dot_seq_f32(a, b, n);
+    float m = dot < 1.0f ? dot : 1.0f; /* NaN.min(1.0) = 1.0 */
+    return 1.0f - m;
+}
+
+/* hnsw/mod.rs:717-731 */
+size_t cqs_oracle_prepare_index_keep(const float* rows, size_t n, size_t dim, uint8_t* keep) {
+    size_t kept = 0;
+    for (size_t r = 0; r < n; ++r) {
+        const float* v = rows + r * dim;
+        int any_nonzero = 0, any_nonfinite = 0;
+        for (size_t i = 0; i < dim; ++i) {
+            if (v[i] != 0.0f) any_nonzero = 1;   /* NaN != 0.0 is true */
+            if (!isfinite(v[i])) any_nonfinite = 1;
+        }
+        keep[r] = (uint8_t)(any_nonzero && !any_nonfinite);
+        kept += keep[r];
+    }
+    return kept;
+}
+
+/* ---- limits -------------------------------------------------------------- */
+static size_t sat_mul(size_t a, size_t b) {
+    if (a != 0 && b > SIZE_MAX / a) return SIZE_MAX;
+    return a * b;
+}
+static size_t clamp_sz(size_t v, size_t lo, size_t hi) { return v < lo ? lo : (v > hi ? hi : v); }
+/* limits.rs:292-300 */
+size_t cqs_oracle_dim_scaled_batch(size_t baseline, size_t dim, size_t min, size_t max) {
+    if (dim == 0) return clamp_sz(baseline, min, max);
+    size_t scaled = sat_mul(baseline, 1024) / dim;
+    return clamp_sz(scaled, min, max);
+}
+/* limits.rs:315-320 (floor = CQS_SEARCH_CANDIDATE_FLOOR, default 500) */
+size_t cqs_oracle_candidate_count_for(size_t limit, size_t floor) {
+    size_t v = sat_mul(limit, 5);
+    return v > floor ? v : floor;
+}
+/* models.rs:802-817 */
+size_t cqs_oracle_embed_batch_size(size_t dim, size_t max_seq_length) {
+    double d = (double)(dim > 1 ? dim : 1);
+    double s = (double)(max_seq_length > 1 ? max_seq_length : 1);
+    double dim_factor = 1024.0 / d;
+    double seq_factor = 512.0 / s;
+    if (seq_factor < 0.25) seq_factor = 0.25;
+    double v = 64.0 * dim_factor * seq_factor;
+    if (v < 1.0) v = 1.0;
+    size_t scaled = (size_t)v;
+    size_t p = 1;
+    while (p < scaled) p <<= 1; /* next_power_of_two */
+    return clamp_sz(p, 2, 256);
+}
+
+/* ---- poolers ------------------------------------------------------------- */
+/* pooling.rs:87-121: masked sum over seq / mask count; zero mask -> zeros. */
+void cqs_oracle_mean_pool(const float* hidden, const int64_t* mask, size_t b, size_t s, size_t d, float* out) {
+    for (size_t i = 0; i < b; ++i) {
+        float count = 0.0f;
+        for (size_t j = 0; j < s; ++j) count += (float)mask[i * s + j];
+        for (size_t c = 0; c < d; ++c) {
+            float sum = 0.0f;
+            for (size_t j = 0; j < s; ++j) sum += hidden[(i * s + j) * d + c] * (float)mask[i * s + j];
+            out[i * d + c] = count > 0.0f ? sum / count : 0.0f;
+        }
+    }
+}
+/* pooling.rs:128-133 */
+void cqs_oracle_cls_pool(const float* hidden, size_t b, size_t s, size_t d, float* out) {
+    for (size_t i = 0; i < b; ++i) memcpy(out + i * d, hidden + i * s * d, d * sizeof(float));
+}
+/* pooling.rs:145-175: rightmost mask!=0 position, else 0 */
+void cqs_oracle_last_token_pool(const float* hidden, const int64_t* mask, size_t b, size_t s, size_t d, float* out) {
+    for (size_t i = 0; i < b; ++i) {
+        size_t last = 0;
+        for (size_t j = s; j-- > 0;)
+            if (mask[i * s + j] != 0) { last = j; break; }
+        memcpy(out + i * d, hidden + (i * s + last) * d, d * sizeof(float));
+    }
+}
+
+/* ---- multi-threaded baseline --------------------------------------------- */
+typedef struct {
+    const float* rows; size_t lo, hi, dim; const float* query; size_t limit; float threshold;
+    uint64_t* ids; float* scores; size_t count;
+} mt_job;
+static void* mt_worker(void* p) {
+    mt_job* j = (mt_job*)p;
+    cqs_oracle_heap* h = cqs_oracle_heap_new(j->limit);
+    for (size_t r = j->lo; r < j->hi; ++r) {
+        float base, score;
+        if (!cosine_kind(j->query, j->dim, j->rows + r * j->dim, j->dim, 0, &base)) continue;
+        if (!cqs_oracle_apply_scoring_default(base, j->threshold, &score)) continue;
+        cqs_oracle_heap_push_u64(h, (uint64_t)r, score);
+    }
+    j->count = cqs_oracle_heap_into_sorted(h, j->ids, j->scores, j->limit);
+    cqs_oracle_heap_free(h);
+    return NULL;
+}
+size_t cqs_oracle_brute_force_mt(const float* rows, size_t n, size_t dim, const float* query,
+                                 size_t limit, float threshold, int threads,
+                                 uint64_t* ids_out, float* scores_out) {
+    if (threads < 1) threads = 1;
+    mt_job* jobs = (mt_job*)calloc((size_t)threads, sizeof(mt_job));
+    pthread_t* th = (pthread_t*)calloc((size_t)threads, sizeof(pthread_t));
+    size_t per = (n + (size_t)threads - 1) / (size_t)threads;
+    for (int t = 0; t < threads; ++t) {
+        size_t lo = per * (size_t)t, hi = lo + per;
+        if (lo > n) lo = n;
+        if (hi > n) hi = n;
+        jobs[t] = (mt_job){rows, lo, hi, dim, query, limit, threshold,
+                           (uint64_t*)malloc(sizeof(uint64_t) * (limit ? limit : 1)),
+                           (float*)malloc(sizeof(float) * (limit ? limit : 1)), 0};
+        pthread_create(&th[t], NULL, mt_worker, &jobs[t]);
+    }
+    cqs_oracle_heap* h = cqs_oracle_heap_new(limit);
+    for (int t = 0; t < threads; ++t) {
+        pthread_join(th[t], NULL);
+        for (size_t i = 0; i < jobs[t].count; ++i) cqs_oracle_heap_push_u64(h, jobs[t].ids[i], jobs[t].scores[i]);
+        free(jobs[t].ids);
+        free(jobs[t].scores);
+    }
+    size_t c = cqs_oracle_heap_into_sorted(h, ids_out, scores_out, limit);
+    cqs_oracle_heap_free(h);
+    free(jobs);
+    free(th);
+    return c;
+}

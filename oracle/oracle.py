@@ -1,0 +1,222 @@
+"""ctypes wrapper of oracle/libcqs_oracle.so — TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this
+module, and only as the checker / reported CPU baseline.  See cqs_oracle.h for the
+reference file:line each function restates.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcqs_oracle.so")
+_lib = None
+
+DOT_SIMSIMD, DOT_F64, DOT_SEQ = 0, 1, 2
+
+
+def build() -> None:
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build()
+        L = C.CDLL(LIB_PATH)
+        vp, sz, f, d, i = C.c_void_p, C.c_size_t, C.c_float, C.c_double, C.c_int
+        sig = {
+            "cqs_oracle_dot_simsimd": (d, [vp, vp, sz]),
+            "cqs_oracle_dot_f64": (d, [vp, vp, sz]),
+            "cqs_oracle_dot_seq_f32": (f, [vp, vp, sz]),
+            "cqs_oracle_cosine_similarity": (i, [vp, sz, vp, sz, vp]),
+            "cqs_oracle_full_cosine_similarity": (i, [vp, sz, vp, sz, vp]),
+            "cqs_oracle_normalize_l2": (None, [vp, sz]),
+            "cqs_oracle_bytes_to_embedding": (i, [vp, sz, sz, vp]),
+            "cqs_oracle_apply_scoring_default": (i, [f, f, vp]),
+            "cqs_oracle_heap_new": (vp, [sz]),
+            "cqs_oracle_heap_free": (None, [vp]),
+            "cqs_oracle_heap_would_accept": (i, [vp, f]),
+            "cqs_oracle_heap_push_u64": (None, [vp, C.c_uint64, f]),
+            "cqs_oracle_heap_push_str": (None, [vp, C.c_char_p, f]),
+            "cqs_oracle_heap_len": (sz, [vp]),
+            "cqs_oracle_heap_into_sorted": (sz, [vp, vp, vp, sz]),
+            "cqs_oracle_brute_force": (sz, [vp, sz, sz, vp, sz, sz, f, i, vp, vp]),
+            "cqs_oracle_find_neighbors": (sz, [vp, sz, sz, sz, sz, vp, vp]),
+            "cqs_oracle_index_search": (sz, [vp, sz, sz, vp, sz, sz, vp, i, f, i, vp, vp]),
+            "cqs_oracle_cagra_cosine_from_l2sq": (f, [f]),
+            "cqs_oracle_dist_dot_clamped": (f, [vp, vp, sz]),
+            "cqs_oracle_prepare_index_keep": (sz, [vp, sz, sz, vp]),
+            "cqs_oracle_dim_scaled_batch": (sz, [sz, sz, sz, sz]),
+            "cqs_oracle_candidate_count_for": (sz, [sz, sz]),
+            "cqs_oracle_embed_batch_size": (sz, [sz, sz]),
+            "cqs_oracle_mean_pool": (None, [vp, vp, sz, sz, sz, vp]),
+            "cqs_oracle_cls_pool": (None, [vp, sz, sz, sz, vp]),
+            "cqs_oracle_last_token_pool": (None, [vp, vp, sz, sz, sz, vp]),
+            "cqs_oracle_brute_force_mt": (sz, [vp, sz, sz, vp, sz, f, i, vp, vp]),
+        }
+        for name, (res, args) in sig.items():
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def dot(a, b, kind=DOT_SIMSIMD) -> float:
+    a, b = _f32(a), _f32(b)
+    L = lib()
+    if kind == DOT_F64:
+        return L.cqs_oracle_dot_f64(_p(a), _p(b), a.size)
+    if kind == DOT_SEQ:
+        return L.cqs_oracle_dot_seq_f32(_p(a), _p(b), a.size)
+    return L.cqs_oracle_dot_simsimd(_p(a), _p(b), a.size)
+
+
+def cosine_similarity(a, b):
+    a, b = _f32(a), _f32(b)
+    out = C.c_float()
+    ok = lib().cqs_oracle_cosine_similarity(_p(a), a.size, _p(b), b.size, C.byref(out))
+    return out.value if ok else None
+
+
+def full_cosine_similarity(a, b):
+    a, b = _f32(a), _f32(b)
+    out = C.c_float()
+    ok = lib().cqs_oracle_full_cosine_similarity(_p(a), a.size, _p(b), b.size, C.byref(out))
+    return out.value if ok else None
+
+
+def normalize_l2(v) -> np.ndarray:
+    v = _f32(v).copy()
+    lib().cqs_oracle_normalize_l2(_p(v), v.size)
+    return v
+
+
+def bytes_to_embedding(blob: bytes, dim: int):
+    out = np.zeros((dim,), dtype=np.float32)
+    buf = np.frombuffer(blob, dtype=np.uint8)
+    rc = lib().cqs_oracle_bytes_to_embedding(_p(buf) if len(blob) else None, len(blob), dim, _p(out))
+    return out if rc == 0 else None
+
+
+def apply_scoring_default(score: float, threshold: float):
+    out = C.c_float()
+    ok = lib().cqs_oracle_apply_scoring_default(score, threshold, C.byref(out))
+    return out.value if ok else None
+
+
+class BoundedScoreHeap:
+    """candidate.rs:162-330 via the C restatement (string ids)."""
+
+    def __init__(self, capacity: int):
+        self._L = lib()
+        self._h = C.c_void_p(self._L.cqs_oracle_heap_new(capacity))
+        self._ids = []
+        self._cap = capacity
+
+    def would_accept(self, score: float) -> bool:
+        return bool(self._L.cqs_oracle_heap_would_accept(self._h, score))
+
+    def push(self, sid: str, score: float) -> None:
+        self._ids.append(sid)
+        self._L.cqs_oracle_heap_push_str(self._h, sid.encode(), score)
+
+    def into_sorted_vec(self):
+        n = self._L.cqs_oracle_heap_len(self._h)
+        ids = np.zeros((max(n, 1),), dtype=np.uint64)
+        sc = np.zeros((max(n, 1),), dtype=np.float32)
+        c = self._L.cqs_oracle_heap_into_sorted(self._h, _p(ids), _p(sc), n)
+        return [(self._ids[int(ids[i])], float(sc[i])) for i in range(c)]
+
+    def __del__(self):
+        try:
+            self._L.cqs_oracle_heap_free(self._h)
+        except Exception:
+            pass
+
+
+def brute_force(rows, query, limit, threshold=0.0, kind=DOT_SIMSIMD):
+    """search_filtered_with_notes minus SQLite (search/query.rs:348-510).  -> (ids u64, scores f32)."""
+    rows, query = _f32(rows), _f32(query)
+    n, dim = rows.shape
+    ids = np.zeros((max(limit, 1),), dtype=np.uint64)
+    sc = np.zeros((max(limit, 1),), dtype=np.float32)
+    c = lib().cqs_oracle_brute_force(_p(rows), n, dim, _p(query), query.size, limit, threshold, kind, _p(ids), _p(sc))
+    return ids[:c], sc[:c]
+
+
+def brute_force_mt(rows, query, limit, threshold, threads):
+    rows, query = _f32(rows), _f32(query)
+    n, dim = rows.shape
+    ids = np.zeros((max(limit, 1),), dtype=np.uint64)
+    sc = np.zeros((max(limit, 1),), dtype=np.float32)
+    c = lib().cqs_oracle_brute_force_mt(_p(rows), n, dim, _p(query), limit, threshold, threads, _p(ids), _p(sc))
+    return ids[:c], sc[:c]
+
+
+def find_neighbors(rows, target_row, limit):
+    rows = _f32(rows)
+    n, dim = rows.shape
+    ids = np.zeros((100,), dtype=np.uint64)
+    sc = np.zeros((100,), dtype=np.float32)
+    c = lib().cqs_oracle_find_neighbors(_p(rows), n, dim, target_row, limit, _p(ids), _p(sc))
+    return ids[:c], sc[:c]
+
+
+def index_search(rows, query, k, keep_bitset=None, mode=0, threshold=0.0, kind=DOT_SIMSIMD):
+    """Exact VectorIndex::search contract (cagra.rs guards, raw dot, (score desc,row asc))."""
+    rows, query = _f32(rows), _f32(query)
+    n = rows.shape[0]
+    dim = rows.shape[1] if rows.ndim == 2 else 0
+    ids = np.zeros((max(k, 1),), dtype=np.uint64)
+    sc = np.zeros((max(k, 1),), dtype=np.float32)
+    kb = None if keep_bitset is None else np.ascontiguousarray(keep_bitset, dtype=np.uint32)
+    c = lib().cqs_oracle_index_search(_p(rows), n, dim, _p(query), query.size, k, _p(kb), mode, threshold, kind,
+                                      _p(ids), _p(sc))
+    return ids[:c], sc[:c]
+
+
+def prepare_index_keep(rows):
+    rows = _f32(rows)
+    keep = np.zeros((rows.shape[0],), dtype=np.uint8)
+    kept = lib().cqs_oracle_prepare_index_keep(_p(rows), rows.shape[0], rows.shape[1], _p(keep))
+    return keep.astype(bool), kept
+
+
+def mean_pool(hidden, mask):
+    hidden = _f32(hidden)
+    mask = np.ascontiguousarray(mask, dtype=np.int64)
+    b, s, d = hidden.shape
+    out = np.zeros((b, d), dtype=np.float32)
+    lib().cqs_oracle_mean_pool(_p(hidden), _p(mask), b, s, d, _p(out))
+    return out
+
+
+def cls_pool(hidden):
+    hidden = _f32(hidden)
+    b, s, d = hidden.shape
+    out = np.zeros((b, d), dtype=np.float32)
+    lib().cqs_oracle_cls_pool(_p(hidden), b, s, d, _p(out))
+    return out
+
+
+def last_token_pool(hidden, mask):
+    hidden = _f32(hidden)
+    mask = np.ascontiguousarray(mask, dtype=np.int64)
+    b, s, d = hidden.shape
+    out = np.zeros((b, d), dtype=np.float32)
+    lib().cqs_oracle_last_token_pool(_p(hidden), _p(mask), b, s, d, _p(out))
+    return out

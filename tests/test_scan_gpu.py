@@ -1,0 +1,352 @@
+"""GPU parity tests: the HIP scan + top-k (through the C ABI) against the CPU oracle on the
+same seeded inputs, plus the edge cases the reference tests.
+Run on an MI355X with `pytest -m gpu`."""
+import numpy as np
+import pytest
+
+from cqs_amd import DistanceMetric, HipIndex, _lib, merge_keys, synth, unpack_keys
+from parity import assert_topk_parity
+
+pytestmark = pytest.mark.gpu
+NAN, INF = float("nan"), float("inf")
+MARGIN = 64
+
+
+def check(oracle, idx, rows, q, k, keep=None, mode=0, thr=0.0):
+    got_rows, got_scores, counts = idx.search_batch(q, k, keep_bitset=keep, mode=mode, threshold=thr)
+    q2 = np.atleast_2d(q)
+    for i in range(q2.shape[0]):
+        ext_ids, ext_scores = oracle.index_search(rows, q2[i], k + MARGIN, keep, mode, thr)
+        ref_ids, _ = oracle.index_search(rows, q2[i], k, keep, mode, thr)
+        c = int(counts[i])
+        assert_topk_parity(got_rows[i, :c], got_scores[i, :c], ext_ids, ext_scores, len(ref_ids))
+
+
+@pytest.mark.parametrize("n", [1, 63, 255, 256, 257, 1000, 4097])
+@pytest.mark.parametrize("k", [1, 20])
+def test_small_corpora(hip, oracle, n, k):
+    rows = synth.gaussian_unit(n, seed=100 + n)
+    q = synth.gaussian_unit(1, seed=200 + n)[0]
+    idx = HipIndex.build_from_flat(None, rows)
+    check(oracle, idx, rows, q, k)
+    idx.close()
+
+
+@pytest.mark.parametrize("k", [1, 20, 100, 500, 1024])
+def test_reference_self_index_size(hip, oracle, k):
+    """BASELINE configs[0] shape: N = 17 523 rows, D = 768, single query."""
+    rows = synth.gaussian_unit(17523, seed=synth.SEED_CORPUS)
+    qs = synth.gaussian_unit(2, seed=synth.SEED_QUERY)
+    idx = HipIndex.build_from_flat(None, rows)
+    for q in qs:
+        check(oracle, idx, rows, q, k)
+    idx.close()
+
+
+def test_k_larger_than_corpus(hip, oracle):
+    rows = synth.gaussian_unit(37, seed=1)
+    q = synth.gaussian_unit(1, seed=2)[0]
+    idx = HipIndex.build_from_flat(None, rows)
+    r, s, c = idx.search_batch(q, 100)
+    assert c[0] == 37
+    check(oracle, idx, rows, q, 100)
+    idx.close()
+
+
+def test_100k_rows_k20_k500(hip, oracle):
+    rows = synth.gaussian_unit(100_000, seed=31)
+    q = synth.gaussian_unit(1, seed=32)[0]
+    idx = HipIndex.build_from_flat(None, rows)
+    check(oracle, idx, rows, q, 20)
+    check(oracle, idx, rows, q, 500)
+    idx.close()
+
+
+def test_reference_sin_generators(hip, oracle):
+    """The reference's deterministic generators (hnsw/mod.rs:928-940, cagra.rs:1815-1825):
+    near-duplicate rows every ~63 seeds -> dense near-ties."""
+    for scale in (0.1, 10.0):
+        rows = synth.sin_corpus(700, scale=scale)
+        idx = HipIndex.build_from_flat(None, rows)
+        for seed in (0, 17, 333):
+            check(oracle, idx, rows, synth.sin_embedding(seed, scale=scale), 20)
+        idx.close()
+
+
+def test_exact_self_match_first(hip, oracle):
+    """cagra.rs:1893-1899 asserts containment for ANN; the exact backend must rank the query's own row first."""
+    rows = synth.gaussian_unit(3000, seed=41)
+    idx = HipIndex.build_from_flat([f"chunk:{i}" for i in range(3000)], rows)
+    for r in (0, 1234, 2999):
+        res = idx.search(rows[r], 5)
+        assert res[0].id == f"chunk:{r}" and abs(res[0].score - 1.0) < 1e-5
+        assert all(res[i].score >= res[i + 1].score for i in range(4))  # cagra.rs:1924-1940
+    idx.close()
+
+
+def test_duplicate_rows_exact_ties_by_row(hip, oracle):
+    """Bit-identical scores (duplicate chunks) order by row asc (candidate.rs:327; SURVEY §8a caveat 1)."""
+    base = synth.gaussian_unit(40, seed=51)
+    rows = np.concatenate([base, base, base, base[:7]])
+    q = base[3]
+    idx = HipIndex.build_from_flat(None, rows)
+    for k in (1, 2, 3, 4, 10, 127):
+        r, s, c = idx.search_batch(q, k)
+        ids, sc = oracle.index_search(rows, q, k)
+        assert list(r[0, :c[0]]) == list(ids), f"k={k}"
+        assert np.allclose(s[0, :c[0]], sc, atol=1e-5)
+    idx.close()
+
+
+def test_all_rows_identical_heavy_ties(hip, oracle):
+    """Every score equal: the radix threshold search cannot separate by score; ties resolve by row asc."""
+    v = synth.gaussian_unit(1, seed=61)[0]
+    rows = np.tile(v, (20000, 1))
+    idx = HipIndex.build_from_flat(None, rows)
+    for k in (1, 20, 500):
+        r, s, c = idx.search_batch(v, k)
+        assert c[0] == k and list(r[0]) == list(range(k))
+    idx.close()
+
+
+def test_crowded_bin_forces_level2(hip, oracle):
+    """Scores packed inside one 12-bit radix bin (near-duplicate corpus) exercise the second histogram level."""
+    rng = np.random.default_rng(5)
+    v = synth.gaussian_unit(1, seed=71)[0]
+    rows = v[None, :] + 1e-3 * rng.standard_normal((30000, 768)).astype(np.float32)
+    rows = (rows / np.linalg.norm(rows, axis=1, keepdims=True)).astype(np.float32)
+    idx = HipIndex.build_from_flat(None, rows)
+    check(oracle, idx, rows, v, 20)
+    check(oracle, idx, rows, v, 500)
+    idx.close()
+
+
+def test_pipeline_mode_clamp_and_threshold(hip, oracle):
+    """Brute-force semantics (candidate.rs:550 clamp, :513-519 gate): negatives tie at 0.0 ordered by row."""
+    rows = -(synth.gaussian_unit(5000, seed=81) ** 2)
+    rows = (rows / np.linalg.norm(rows, axis=1, keepdims=True)).astype(np.float32)
+    q = np.abs(synth.gaussian_unit(1, seed=82)[0])
+    idx = HipIndex.build_from_flat(None, rows)
+    r, s, c = idx.search_batch(q, 20, mode=_lib.MODE_PIPELINE, threshold=0.0)
+    assert c[0] == 20 and list(r[0]) == list(range(20)) and np.all(s[0] == 0.0)
+    ids, sc = oracle.brute_force(rows, q, 20, 0.0)
+    assert list(ids) == list(r[0])
+    r, s, c = idx.search_batch(q, 20, mode=_lib.MODE_PIPELINE, threshold=0.3)
+    assert c[0] == 0
+    idx.close()
+    # mixed signs with the CLI default threshold 0.3 (cli/definitions.rs:174-183)
+    rows = synth.sin_corpus(400)
+    q = synth.sin_embedding(5)
+    idx = HipIndex.build_from_flat(None, rows)
+    check(oracle, idx, rows, q, 50, mode=_lib.MODE_PIPELINE, thr=0.3)
+    r, s, c = idx.search_batch(q, 50, mode=_lib.MODE_PIPELINE, threshold=0.3)
+    ids, sc = oracle.brute_force(rows, q, 50, 0.3)
+    assert c[0] == len(ids) and np.all(s[0, :c[0]] >= 0.3) and np.all(s[0, :c[0]] <= 1.0)
+    idx.close()
+
+
+def test_non_finite_rows_never_emitted(hip, oracle):
+    rows = synth.gaussian_unit(2000, seed=91)
+    rows[5, 10] = NAN
+    rows[77, 0] = INF
+    rows[1999, 767] = -INF
+    q = rows[6].copy()
+    idx = HipIndex.build_from_flat(None, rows)
+    r, s, c = idx.search_batch(q, 1024)
+    assert c[0] == 1024
+    got = set(int(x) for x in r[0, :c[0]])
+    assert not ({5, 77, 1999} & got) and np.all(np.isfinite(s[0, :c[0]]))
+    check(oracle, idx, rows, q, 20)
+    idx.close()
+
+
+def test_query_guards(hip, oracle):
+    """cagra.rs:443-470: k==0, dim mismatch, non-finite query -> empty; never an error."""
+    rows = synth.gaussian_unit(500, seed=101)
+    idx = HipIndex.build_from_flat(None, rows)
+    q = rows[0]
+    assert idx.search(q, 0) == []
+    assert idx.search(q[:100], 5) == []
+    bad = q.copy(); bad[3] = NAN
+    assert idx.search(bad, 5) == []
+    r, s, c = idx.search_batch(np.stack([q, bad, rows[1]]), 5)  # C ABI: bad query -> count 0, others fine
+    assert list(c) == [5, 0, 5] and r[0, 0] == 0 and r[2, 0] == 1
+    r, s, c = idx.search_batch(q[:100], 5)  # C ABI: dim mismatch -> OK + count 0
+    assert c[0] == 0
+    with pytest.raises(Exception):
+        idx.search_batch(q, 5000)  # k > max_k is an argument error at the C ABI
+    assert len(idx.search(q, 5000)) == 500  # the trait mirror caps k at max_k first (query.rs:232-245)
+    assert not idx.is_poisoned() and idx.max_k() == 1024 and idx.index_scores_are_cosine()
+    assert idx.name() == "HIP" and idx.dim() == 768 and len(idx) == 500 and not idx.is_empty()
+    idx.close()
+    empty = HipIndex.build_from_flat(None, np.zeros((0, 768), np.float32))
+    assert empty.is_empty() and empty.search(q, 5) == []
+    empty.close()
+
+
+def test_bitset_filter(hip, oracle):
+    """cagra.rs:747-775 semantics."""
+    n = 3000
+    rows = synth.gaussian_unit(n, seed=111)
+    q = synth.gaussian_unit(1, seed=112)[0]
+    idx = HipIndex.build_from_flat(None, rows)
+    rng = np.random.default_rng(1)
+    words = (n + 31) // 32
+    keep = rng.integers(0, 2**32, size=words, dtype=np.uint64).astype(np.uint32)
+    check(oracle, idx, rows, q, 20, keep=keep)
+    r, s, c = idx.search_batch(q, 20, keep_bitset=np.zeros(words, np.uint32))
+    assert c[0] == 0
+    allb = np.full(words, 0xFFFFFFFF, np.uint32)
+    r1, s1, c1 = idx.search_batch(q, 20, keep_bitset=allb)
+    r0, s0, c0 = idx.search_batch(q, 20)
+    assert list(r1[0]) == list(r0[0])
+    few = np.zeros(words, np.uint32); few[1] = 0b1011; few[90] = 1 << 31
+    r, s, c = idx.search_batch(q, 20, keep_bitset=few)
+    assert c[0] == 4 and set(r[0, :4]) == {32, 33, 35, 90 * 32 + 31}
+    check(oracle, idx, rows, q, 20, keep=few)
+    # whole 64-row groups filtered out (the kernel skips their HBM reads)
+    blocky = np.zeros(words, np.uint32); blocky[10:14] = 0xFFFFFFFF; blocky[40] = 0x00010000
+    check(oracle, idx, rows, q, 50, keep=blocky)
+    idx.close()
+    # predicate form through the trait mirror
+    ids = [f"src/{'a' if i % 3 else 'b'}.rs:{i}" for i in range(n)]
+    idx = HipIndex.build_from_flat(ids, rows)
+    res = idx.search_with_filter(q, 10, lambda s: s.startswith("src/b"))
+    assert len(res) == 10 and all(x.id.startswith("src/b") for x in res)
+    keepb = np.packbits(np.array([i % 3 == 0 for i in range(n)]), bitorder="little")
+    keepb = np.concatenate([keepb, np.zeros((-len(keepb)) % 4, np.uint8)]).view(np.uint32)
+    oid, _ = oracle.index_search(rows, q, 10, keepb)
+    assert [x.id for x in res] == [ids[int(i)] for i in oid]
+    idx.close()
+
+
+@pytest.mark.parametrize("b", [2, 3, 4, 5, 8, 9, 13, 33])
+def test_query_blocks_match_single(hip, oracle, b):
+    rows = synth.gaussian_unit(6000, seed=121)
+    qs = synth.gaussian_unit(b, seed=122 + b)
+    idx = HipIndex.build_from_flat(None, rows)
+    check(oracle, idx, rows, qs, 20)
+    idx.close()
+
+
+@pytest.mark.parametrize("dim", [4, 100, 256, 384, 512, 1024, 1536, 2048])
+def test_other_dims(hip, oracle, dim):
+    rows = synth.gaussian_unit(1500, dim, seed=131)
+    qs = synth.gaussian_unit(3, dim, seed=132)
+    idx = HipIndex.build_from_flat(None, rows)
+    check(oracle, idx, rows, qs, 10)
+    idx.close()
+
+
+def test_dot_metric_unnormalised(hip, oracle):
+    rng = np.random.default_rng(7)
+    rows = (rng.standard_normal((4000, 768)) * rng.uniform(0.1, 30, (4000, 1))).astype(np.float32)
+    q = rng.standard_normal(768).astype(np.float32)
+    idx = HipIndex.build_from_flat(None, rows, DistanceMetric.DotProduct)
+    r, s, c = idx.search_batch(q, 20)
+    ids, sc = oracle.index_search(rows, q, 20)
+    assert list(r[0]) == list(ids)
+    assert np.allclose(s[0], sc, rtol=1e-5, atol=1e-4)
+    assert not idx.index_scores_are_cosine()
+    idx.close()
+
+
+def test_extend_and_row_base(hip, oracle):
+    rows = synth.gaussian_unit(2500, seed=141)
+    q = synth.gaussian_unit(1, seed=142)[0]
+    idx = HipIndex.build_from_flat(None, rows[:1000])
+    idx.extend(None, rows[1000:1800])
+    idx.extend(None, rows[1800:])
+    assert len(idx) == 2500
+    check(oracle, idx, rows, q, 20)
+    idx.close()
+    # two shards with row_base, merged on the host == whole corpus (associative comparator)
+    a = HipIndex.build_from_flat(None, rows[:1300], row_base=0)
+    b = HipIndex.build_from_flat(None, rows[1300:], row_base=1300)
+    k = 20
+    ra, sa, ca = a.search_batch(q, k)
+    rb, sb, cb = b.search_batch(q, k)
+    assert rb[0].min() >= 1300
+
+    def pack(rows_, scores_):
+        bits = scores_.view(np.uint32).astype(np.uint64)
+        ok = np.where(bits >> 31 != 0, (~bits) & 0xFFFFFFFF, bits ^ 0x80000000)
+        return (ok << np.uint64(32)) | (np.uint64(0xFFFFFFFF) - rows_.astype(np.uint64))
+
+    lists = np.stack([pack(ra[0], sa[0]), pack(rb[0], sb[0])])
+    merged = merge_keys(lists, np.array([ca[0], cb[0]], np.uint32), k)
+    mr, ms = unpack_keys(merged)
+    ext_ids, ext_scores = oracle.index_search(rows, q, k + MARGIN)
+    assert_topk_parity(mr, ms, ext_ids, ext_scores, k)
+    a.close(); b.close()
+
+
+def test_device_api_with_torch(hip, oracle):
+    """cqs_hip_index_search_device: buffers in HBM, launched on torch's current stream."""
+    import torch
+    rows = synth.gaussian_unit(8000, seed=151)
+    qs = synth.gaussian_unit(4, seed=152)
+    d_rows = torch.from_numpy(rows).cuda()
+    d_q = torch.from_numpy(qs).cuda()
+    idx = HipIndex.build_from_device(None, d_rows.data_ptr(), 8000, 768, borrow=True, keepalive=d_rows)
+    k = 20
+    keys = torch.zeros((4, k), dtype=torch.int64, device="cuda")
+    counts = torch.zeros((4,), dtype=torch.int32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    idx.search_device(d_q.data_ptr(), 4, k, keys.data_ptr(), counts.data_ptr(), stream=st)
+    torch.cuda.synchronize()
+    hk = keys.cpu().numpy().view(np.uint64)
+    hc = counts.cpu().numpy()
+    for i in range(4):
+        r, s = unpack_keys(hk[i, :hc[i]])
+        ext_ids, ext_scores = oracle.index_search(rows, qs[i], k + MARGIN)
+        assert_topk_parity(r, s, ext_ids, ext_scores, k)
+        assert np.all(hk[i, :-1] >= hk[i, 1:])  # packed keys sorted descending
+    idx.close()
+
+
+def test_full_size_properties_1m(hip):
+    """BASELINE configs[1] size (1M x 768 fp32) through size-independent properties: planted
+    rows come back first with the right scores, results are sorted, scores equal a direct
+    torch dot of the returned rows, and two half-corpus shards merge to the whole-corpus answer."""
+    import torch
+    n, dim, k = 1_000_000, 768, 20
+    g = torch.Generator(device="cuda"); g.manual_seed(1234)
+    rows = torch.randn((n, dim), generator=g, device="cuda", dtype=torch.float32)
+    rows /= rows.norm(dim=1, keepdim=True)
+    q = torch.randn((dim,), generator=g, device="cuda", dtype=torch.float32)
+    q /= q.norm()
+    planted = [0, 511_111, n - 1]
+    for j, r in enumerate(planted):  # cos = 1 - j*0.05 exactly-ish
+        noise = torch.randn((dim,), generator=g, device="cuda")
+        noise -= (noise @ q) * q
+        noise /= noise.norm()
+        c = 1.0 - 0.05 * j
+        rows[r] = c * q + (1 - c * c) ** 0.5 * noise
+    idx = HipIndex.build_from_device(None, rows.data_ptr(), n, dim, borrow=True, keepalive=rows)
+    keys = torch.zeros((1, k), dtype=torch.int64, device="cuda")
+    counts = torch.zeros((1,), dtype=torch.int32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    idx.search_device(q.data_ptr(), 1, k, keys.data_ptr(), counts.data_ptr(), stream=st)
+    torch.cuda.synchronize()
+    r, s = unpack_keys(keys.cpu().numpy().view(np.uint64)[0])
+    assert counts.item() == k and list(r[:3]) == planted
+    assert np.all(np.diff(s) <= 0)
+    direct = (rows[torch.from_numpy(r.astype(np.int64)).cuda()].double() @ q.double()).cpu().numpy()
+    assert np.max(np.abs(direct - s)) <= 1e-5
+    # exhaustive check of the threshold: nothing outside the list beats the k-th score by > 2e-6
+    allsc = rows @ q
+    assert int((allsc > float(s[-1]) + 2e-6).sum().item()) <= k - 1
+    # two shards + host merge == whole
+    half = n // 2
+    a = HipIndex.build_from_device(None, rows.data_ptr(), half, dim, borrow=True, row_base=0)
+    b = HipIndex.build_from_device(None, rows[half:].data_ptr(), n - half, dim, borrow=True, row_base=half)
+    ka = torch.zeros((2, k), dtype=torch.int64, device="cuda")
+    ca = torch.zeros((2,), dtype=torch.int32, device="cuda")
+    a.search_device(q.data_ptr(), 1, k, ka[0].data_ptr(), ca[0:].data_ptr(), stream=st)
+    b.search_device(q.data_ptr(), 1, k, ka[1].data_ptr(), ca[1:].data_ptr(), stream=st)
+    torch.cuda.synchronize()
+    merged = merge_keys(ka.cpu().numpy().view(np.uint64), ca.cpu().numpy().astype(np.uint32), k)
+    assert list(merged) == list(keys.cpu().numpy().view(np.uint64)[0])
+    for x in (idx, a, b):
+        x.close()
