@@ -1,0 +1,239 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the cqs hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W        (N=1 default; N>1 under torch.distributed.run)
+
+Workload (BASELINE.json configs[1]): synthetic 1 000 000 x 768 fp32 unit vectors per GPU,
+single-query brute-force cosine top-20.  A "step" is one pass of the hot path over one
+batch: at N=1 one query scanned against the 1M-row corpus (3.072 GB of HBM reads); at N>1
+the corpus is row-sharded (1M rows per GPU, N x 1M rows in total - weak scaling), every
+rank contributes one query per step, the N queries are all-gathered, each rank scans its
+shard ONCE for all N queries, per-shard (score,row) candidates are exchanged with one RCCL
+all-gather and merged on the host (north_star).  value = whole-job queries/s.
+
+Inputs (corpus, queries) are resident in HBM before the timed region.  Rank 0 prints ONE
+JSON line with the driver's contract fields plus `roofline` and `cpu_baseline`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E vendor peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 achievable)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--rows", type=int, default=1_000_000, help="corpus rows per GPU")
+    ap.add_argument("--dim", type=int, default=768)
+    ap.add_argument("--k", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=1, help="queries per rank per step")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of each cpu_baseline leg (0 = skip)")
+    return ap.parse_args()
+
+
+def make_unit_rows(torch, n, dim, seed, device):
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    rows = torch.empty((n, dim), dtype=torch.float32, device=device)
+    step = 1 << 18
+    for lo in range(0, n, step):  # chunked so the generator scratch stays small
+        hi = min(n, lo + step)
+        x = torch.randn((hi - lo, dim), generator=g, device=device, dtype=torch.float32)
+        x /= x.norm(dim=1, keepdim=True)
+        rows[lo:hi] = x
+    return rows
+
+
+def cpu_baseline(rows_host, queries_host, k, seconds):
+    """The oracle (C restatement of the reference CPU scan, search/query.rs:453-482 minus SQLite)
+    timed on this host: single-threaded = the reference's per-query behaviour; plus one thread
+    per core over row shards.  Reported baseline only - never part of `value`."""
+    from oracle import oracle
+    n = rows_host.shape[0]
+    out = {"unit": "queries/s", "kind": "port", "cores": 1}
+    t0 = time.perf_counter()
+    done = 0
+    while True:
+        oracle.brute_force(rows_host, queries_host[done % len(queries_host)], k, 0.0)
+        done += 1
+        el = time.perf_counter() - t0
+        if el >= seconds and done >= 2:
+            break
+    out["value"] = done / el
+    cores = os.cpu_count() or 1
+    threads = min(cores, 64)
+    t0 = time.perf_counter()
+    done_mt = 0
+    while True:
+        oracle.brute_force_mt(rows_host, queries_host[done_mt % len(queries_host)], k, 0.0, threads)
+        done_mt += 1
+        el = time.perf_counter() - t0
+        if el >= seconds and done_mt >= 2:
+            break
+    out["mt_value"] = done_mt / el
+    out["mt_cores"] = threads
+    out["host_cores"] = cores
+    out["sample"] = (f"{done} single-thread + {done_mt} {threads}-thread queries, each a full scan of the same "
+                     f"{n}x{rows_host.shape[1]} fp32 corpus held in RAM, k={k}, threshold 0.0 (oracle: "
+                     "simsimd-style AVX2 dot + clamp + BoundedScoreHeap)")
+    return out
+
+
+def main():
+    a = parse()
+    import numpy as np
+    import torch
+    from cqs_amd import HipIndex, unpack_keys
+    from cqs_amd.sharded import ShardedSearch, hip_local_search
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    n, dim, k, bq = a.rows, a.dim, a.k, a.batch
+    K, W = a.steps, a.warmup
+    rows = make_unit_rows(torch, n, dim, 0xC950001 + rank, dev)
+    queries = make_unit_rows(torch, (K + W) * bq, dim, 0xC950002 + 7919 * rank, dev).view(K + W, bq, dim)
+    idx = HipIndex.build_from_device(None, rows.data_ptr(), n, dim, device=local_rank, row_base=rank * n,
+                                     borrow=True, keepalive=rows)
+    st = torch.cuda.current_stream().cuda_stream
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if world == 1:
+        out_keys = torch.zeros((K + W, bq, k), dtype=torch.int64, device=dev)
+        out_counts = torch.zeros((K + W, bq), dtype=torch.int32, device=dev)
+
+        def step(i):
+            idx.search_device(queries[i].data_ptr(), bq, k, out_keys[i].data_ptr(), out_counts[i].data_ptr(), stream=st)
+
+        def finish(lo, hi):
+            torch.cuda.synchronize()
+    else:
+        shard = ShardedSearch(hip_local_search(idx), k)
+        qall = torch.empty((K + W, world * bq, dim), dtype=torch.float32, device=dev)
+        gathered = [None] * (K + W)
+        merged = {}
+
+        def step(i):
+            dist.all_gather_into_tensor(qall[i].view(world, bq, dim), queries[i])  # every rank's queries
+            gathered[i] = shard.gather_candidates(qall[i], k)                     # scan + ONE all-gather
+
+        def finish(lo, hi):
+            torch.cuda.synchronize()
+            host = torch.stack(gathered[lo:hi]).cpu().numpy()  # [steps, world, world*bq, k+1]
+            for s in range(hi - lo):                           # host merge of this rank's own queries
+                mine = host[s][:, rank * bq:(rank + 1) * bq, :]
+                merged[lo + s] = ShardedSearch.merge_host(np.ascontiguousarray(mine), k)
+
+    for i in range(W):
+        step(i)
+    finish(0, W)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(W, W + K):
+        step(i)
+    finish(W, W + K)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- sanity of the last step's answer (outside the timed region) ----
+    i = W + K - 1
+    if world == 1:
+        r, s = unpack_keys(out_keys[i, 0].cpu().numpy().view(np.uint64))
+        assert int(out_counts[i, 0].item()) == k
+    else:
+        r, s = unpack_keys(merged[i][0])
+        assert len(r) == k
+    assert np.all(np.diff(s) <= 0), "top-k not sorted"
+    local = [(int(x) - rank * n) for x in r if rank * n <= int(x) < (rank + 1) * n]
+    if local:
+        direct = (rows[torch.tensor(local, device=dev)].double() @ queries[i, 0].double()).cpu().numpy()
+        mine = np.array([float(sv) for x, sv in zip(r, s) if rank * n <= int(x) < (rank + 1) * n])
+        assert np.max(np.abs(direct - mine)) <= 1e-5, "scores differ from a direct fp64 dot"
+
+    # ---- roofline: the scan kernel's own duration, HIP events on the launch stream ----
+    idx.set_timing(True)
+    for i in range(W, W + K):
+        if world == 1:
+            step(i)
+        else:
+            shard.local_search(qall[i], k)
+    torch.cuda.synchronize()
+    launches, scan_ms = idx.scan_time()
+    idx.set_timing(False)
+    avg_s = scan_ms / max(launches, 1) / 1e3
+    alg_bytes = n * dim * 4  # algorithmic bytes per launch = shard rows x dim x 4 B (corpus read once)
+    achieved = alg_bytes / avg_s / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r01_scan_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {"bound": "hbm", "kernel": "scan_gemv_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": round(avg_s * 1e3, 5), "launches": launches}
+
+    cpu = None
+    if rank == 0 and world == 1 and a.cpu_seconds > 0:
+        nq = min(8, K)
+        cpu = cpu_baseline(rows.cpu().numpy(), queries[W:W + nq, 0].cpu().numpy(), k, a.cpu_seconds)
+
+    if rank == 0:
+        total_q = K * bq * world
+        line = {
+            "metric": "queries/sec @k=%d (brute-force cosine scan + top-k, 768-d fp32)" % k,
+            "value": round(total_q / elapsed, 2),
+            "unit": "queries/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": W,
+            "ms_per_step": round(elapsed / K * 1e3, 5),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: %d x %d fp32 unit vectors per GPU, %d quer%s per rank per step, "
+                                   "brute-force cosine top-%d" % (n, dim, bq, "y" if bq == 1 else "ies", k),
+                       "rows_per_gpu": n, "total_rows": n * world, "dim": dim, "k": k, "queries_per_step": bq * world,
+                       "parallelism": "row-sharded x%d, RCCL all-gather of per-shard candidates, host merge" % world
+                       if world > 1 else "single GPU"},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    idx.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcqs_hip.so")
@@ -75,6 +76,15 @@ def load() -> C.CDLL:
         raise HipLibraryMissing(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C cqs_amd/csrc`. There is no CPU fallback for the cqs_amd product path.")
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7 (same soname
+    # as /opt/rocm's).  If the system copy is loaded first and torch's afterwards, torch finds
+    # no GPU; loading torch first makes both share torch's runtime.  Consumers without torch
+    # (the Rust shim) simply bind the system ROCm runtime.
+    if "torch" not in sys.modules and not os.environ.get("CQS_HIP_NO_TORCH_PRELOAD"):
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
     lib = C.CDLL(LIB_PATH)
     for name, res, args in SIGNATURES:
         fn = getattr(lib, name)  # AttributeError if the header and the library disagree
