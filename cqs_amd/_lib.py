@@ -10,7 +10,8 @@ import os
 import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcqs_hip.so")
+# CQS_HIP_LIB overrides the library file (kernel-variant A/B runs); default = the in-tree build
+LIB_PATH = os.environ.get("CQS_HIP_LIB") or os.path.join(_HERE, "libcqs_hip.so")
 
 OK = 0
 ERR_INVALID = -1

@@ -10,6 +10,7 @@
 #include <atomic>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -19,10 +20,8 @@
 #include "../../include/cqs_hip.h"
 #include "scan_kernels.h"
 
-using cqs::kCandCap;
 using cqs::kMaxK;
 using cqs::kRowsPerBlock;
-using cqs::kSelWords;
 
 struct cqs_hip_index {
     int device = 0;
@@ -41,8 +40,10 @@ struct cqs_hip_index {
     uint32_t k_cap = 0;
     float* d_q = nullptr;
     float* d_scores = nullptr;
-    uint32_t* d_sel = nullptr;
-    uint64_t* d_cand = nullptr;
+    uint32_t* d_work = nullptr;   // scan work-queue heads
+    unsigned long long* d_dbg = nullptr;  // CQS_HIP_DEBUG_STAMPS=1: select_finish phase stamps
+    uint32_t n_cu = 256;
+    float* d_gmax = nullptr;      // [q_cap, n_pad/64] group maxima
     uint64_t* d_out_keys = nullptr;
     uint32_t* d_out_counts = nullptr;
     uint32_t* d_keep = nullptr;
@@ -89,10 +90,11 @@ int32_t fail(cqs_hip_index* idx, int32_t code, const char* what, hipError_t e = 
     } while (0)
 
 void free_scratch(cqs_hip_index* x) {
-    hipFree(x->d_q); hipFree(x->d_scores); hipFree(x->d_sel); hipFree(x->d_cand);
+    hipFree(x->d_q); hipFree(x->d_scores); hipFree(x->d_gmax); hipFree(x->d_work);
+    x->d_work = nullptr;
     hipFree(x->d_out_keys); hipFree(x->d_out_counts);
     hipHostFree(x->h_q); hipHostFree(x->h_out_keys); hipHostFree(x->h_out_counts);
-    x->d_q = x->d_scores = nullptr; x->d_sel = nullptr; x->d_cand = nullptr;
+    x->d_q = x->d_scores = nullptr; x->d_gmax = nullptr;
     x->d_out_keys = nullptr; x->d_out_counts = nullptr;
     x->h_q = nullptr; x->h_out_keys = nullptr; x->h_out_counts = nullptr;
     x->q_cap = 0; x->k_cap = 0; x->scr_n_pad = 0;
@@ -108,8 +110,10 @@ int32_t ensure_scratch(cqs_hip_index* x, uint32_t b, uint32_t k) {
     free_scratch(x);
     HIP_TRY(x, hipMalloc(&x->d_q, (size_t)qc * x->dim * sizeof(float)));
     HIP_TRY(x, hipMalloc(&x->d_scores, (size_t)qc * n_pad * sizeof(float)));
-    HIP_TRY(x, hipMalloc(&x->d_sel, (size_t)qc * kSelWords * sizeof(uint32_t)));
-    HIP_TRY(x, hipMalloc(&x->d_cand, (size_t)qc * kCandCap * sizeof(uint64_t)));
+    HIP_TRY(x, hipMalloc(&x->d_work, cqs::kWorkWords * sizeof(uint32_t)));
+    // work-queue heads must be zero on entry; every search re-zeroes them
+    HIP_TRY(x, hipMemset(x->d_work, 0, cqs::kWorkWords * sizeof(uint32_t)));
+    HIP_TRY(x, hipMalloc(&x->d_gmax, (size_t)qc * (n_pad / cqs::kTaskRows) * sizeof(float)));
     HIP_TRY(x, hipMalloc(&x->d_out_keys, (size_t)qc * kc * sizeof(uint64_t)));
     HIP_TRY(x, hipMalloc(&x->d_out_counts, (size_t)qc * sizeof(uint32_t)));
     HIP_TRY(x, hipHostMalloc(&x->h_q, (size_t)qc * x->dim * sizeof(float), hipHostMallocDefault));
@@ -145,6 +149,12 @@ int32_t enqueue_search(cqs_hip_index* x, const float* d_q, uint32_t b, uint32_t 
     a.mode = mode;
     a.threshold = thr;
     a.nontemporal = x->n * x->dim * sizeof(float) > kNtBytes;
+    a.linear_bins = (x->metric == CQS_HIP_METRIC_COSINE) || (mode == CQS_HIP_MODE_PIPELINE);
+    a.k = k;
+    a.gmax = x->d_gmax;
+    a.work = x->d_work;
+    a.n_cu = x->n_cu;
+    a.dbg = x->d_dbg;
     const bool timed = x->timing && x->ev_used + 2 <= kMaxTimingEvents;
     if (timed) {
         while (x->ev.size() < x->ev_used + 2) {
@@ -159,8 +169,7 @@ int32_t enqueue_search(cqs_hip_index* x, const float* d_q, uint32_t b, uint32_t 
         HIP_TRY(x, hipEventRecord(x->ev[x->ev_used + 1], st));
         x->ev_used += 2;
     }
-    HIP_TRY(x, cqs::launch_select(x->d_scores, a.n, a.n_pad, b, k, (uint32_t)x->row_base, x->d_sel, x->d_cand,
-                                  d_out_keys, d_out_counts, st));
+    HIP_TRY(x, cqs::launch_select(a, (uint32_t)x->row_base, d_out_keys, d_out_counts, st));
     return CQS_HIP_OK;
 }
 
@@ -180,6 +189,13 @@ int32_t create_common(uint64_t n, uint32_t dim, uint32_t metric, int32_t device,
         delete x;
         return CQS_HIP_ERR_DEVICE;
     }
+    if (getenv("CQS_HIP_DEBUG_STAMPS")) {
+        if (hipMalloc(&x->d_dbg, 16 * sizeof(unsigned long long)) == hipSuccess)
+            (void)hipMemset(x->d_dbg, 0, 16 * sizeof(unsigned long long));
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+        x->n_cu = (uint32_t)prop.multiProcessorCount;
     *made = x;
     return CQS_HIP_OK;
 }
@@ -288,6 +304,7 @@ void cqs_hip_index_destroy(cqs_hip_index* x) {
     if (x->stream) hipStreamSynchronize(x->stream);  // src/cagra.rs:289-302
     free_scratch(x);
     hipFree(x->d_keep);
+    hipFree(x->d_dbg);
     if (!x->borrow) hipFree(x->d_rows);
     for (hipEvent_t e : x->ev) hipEventDestroy(e);
     if (x->stream) hipStreamDestroy(x->stream);
@@ -402,6 +419,7 @@ int32_t cqs_hip_index_search(cqs_hip_index* x, const float* queries, uint32_t b,
             if (words > x->keep_words_cap) {
                 HIP_TRY(x, hipStreamSynchronize(x->stream));
                 hipFree(x->d_keep);
+    hipFree(x->d_dbg);
                 x->d_keep = nullptr;
                 x->keep_words_cap = 0;
                 HIP_TRY(x, hipMalloc(&x->d_keep, words * sizeof(uint32_t)));
@@ -434,6 +452,13 @@ int32_t cqs_hip_index_search(cqs_hip_index* x, const float* queries, uint32_t b,
         HIP_TRY(x, hipMemcpyAsync(x->h_out_keys, x->d_out_keys, (size_t)nb * k_eff * sizeof(uint64_t), hipMemcpyDeviceToHost, x->stream));
         HIP_TRY(x, hipMemcpyAsync(x->h_out_counts, x->d_out_counts, (size_t)nb * sizeof(uint32_t), hipMemcpyDeviceToHost, x->stream));
         HIP_TRY(x, hipStreamSynchronize(x->stream));
+        if (x->d_dbg) {  // 100 MHz realtime counter: 10 ns ticks
+            unsigned long long h[16];
+            if (hipMemcpy(h, x->d_dbg, sizeof h, hipMemcpyDeviceToHost) == hipSuccess)
+                fprintf(stderr, "[cqs_hip] select_finish us: zero %.2f hist %.2f decide %.2f groups %.2f scores %.2f sort %.2f emit %.2f | groups=%llu cand=%llu\n",
+                        0.0, (h[1] - h[0]) / 100.0, (h[2] - h[1]) / 100.0, (h[3] - h[2]) / 100.0, (h[4] - h[3]) / 100.0,
+                        (h[5] - h[4]) / 100.0, (h[6] - h[5]) / 100.0, h[8], h[9]);
+        }
         for (uint32_t i = 0; i < nb; ++i) {
             const uint32_t qi = done + i;
             if (bad[qi]) continue;

@@ -1,26 +1,29 @@
 // scan_kernels.hip — gfx950 (MI355X) kernels for the cqs brute-force scan.
 //
-//  scan_gemv_kernel   HBM-streaming fp32 dot of every corpus row with 1..8
-//                     queries.  One wave owns 64 consecutive rows; a row is
-//                     read as dim/256 fully coalesced 1-KiB wave loads
-//                     (16 B/lane), the query lives in registers, lane partials
-//                     are reduced with a transposed butterfly so that 4 rows x
-//                     BQ queries cost ~1 cross-lane op per dot.  Replaces the
-//                     per-row simsimd dot of the reference's brute-force loop
-//                     (src/math.rs:11-28 called from src/search/query.rs:469-481)
-//                     and cuVS' search for the exact backend (src/cagra.rs:605).
-//  select_*           exact top-k over the score rows: 12-bit radix histograms
-//                     (threshold search), candidate compaction, bitonic sort.
-//                     Replaces BoundedScoreHeap (candidate.rs:162-330): same
-//                     comparator (score desc under total order, id asc) on a
-//                     packed 64-bit key.
+//  scan_gemv_kernel   HBM-streaming fp32 dot of every corpus row with 1..8 queries.
+//                     Persistent workgroups pull 64-row tasks from a global work queue
+//                     (one wave = one task); a row is read as dim/256 fully coalesced
+//                     1-KiB wave loads (16 B/lane) issued back to back, the query lives in
+//                     registers, lane partials are reduced with a transposed butterfly so
+//                     that RI rows x BQ queries cost ~1 cross-lane op per dot.  Besides the
+//                     score row it emits one maximum per 64-row group: the pruning index of
+//                     the top-k select.
+//                     Replaces the per-row simsimd dot of the reference's brute-force loop
+//                     (src/math.rs:11-28 called from src/search/query.rs:469-481) and
+//                     cuVS' search for the exact backend (src/cagra.rs:605).
+//  select_finish      exact top-k in ONE workgroup per query: threshold bin from the group-
+//                     maxima histogram -> the few groups that can hold a top-k entry ->
+//                     their scores -> bitonic sort (exact one-block radix fallback for ties).
+//                     Replaces BoundedScoreHeap (candidate.rs:162-330): same comparator
+//                     (score desc under total order, id asc) on a packed 64-bit key.
 //
-// Wave = 64 lanes.  No CUDA-isms, no dual paths: gfx950 only.
+// Wave = 64 lanes.  gfx950 only.
 #include "scan_kernels.h"
 
 namespace cqs {
 
 typedef float f4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) uint32_t gu32;
 
 // ---- ordered keys ----------------------------------------------------------
 // f32 -> u32 preserving IEEE total order (what Rust's f32::total_cmp sorts by).
@@ -34,6 +37,19 @@ constexpr uint32_t kInvalidKey = 0x007FFFFFu;
 
 __device__ __forceinline__ uint64_t pack_key(uint32_t ok, uint32_t global_row) {
     return ((uint64_t)ok << 32) | (uint64_t)(0xFFFFFFFFu - global_row);
+}
+
+// Histogram bin of a valid score; monotone non-decreasing in the score.
+// linear: 4096 bins of width 2^-11 over [-1,1] (cosine / clamped scores: fine
+// resolution exactly where the top-k threshold lives); else the top 12 bits of
+// the ordered key (log-spaced, any range: raw dot products).
+__device__ __forceinline__ uint32_t bin_of(float s, bool linear) {
+    if (linear) {
+        const float t = (s + 1.0f) * 2048.0f;
+        const int b = (int)t;  // t >= 0 for s >= -1; negatives truncate toward 0 and clamp below
+        return (uint32_t)(b < 0 ? 0 : (b > 4095 ? 4095 : b));
+    }
+    return okey(s) >> 20;
 }
 
 // ---- transposed butterfly reduction ---------------------------------------
@@ -58,123 +74,16 @@ __device__ __forceinline__ void treduce(float (&v)[NV], int lane) {
     for (; m >= 1; m >>= 1) v[0] += __shfl_xor(v[0], m, 64);
 }
 
-// ---- scan ------------------------------------------------------------------
-// NCH = ceil(dim / 256): 1-KiB chunks per row.  BQ queries, RI rows per inner
-// iteration (RI*BQ partial sums are reduced together).
-template <int NCH, int BQ, int RI, bool NT>
-__global__ __launch_bounds__(256) void scan_gemv_kernel(
-    const float* __restrict__ rows, uint32_t n, uint32_t n_pad, uint32_t dim,
-    const float* __restrict__ q, float* __restrict__ scores,
-    const uint32_t* __restrict__ keep, uint32_t mode, float thr) {
-    constexpr int NV = RI * BQ;
-    constexpr int LPV = 64 / NV;  // lanes per reduced value
-    const int lane = threadIdx.x & 63;
-    const int wid = threadIdx.x >> 6;
-    const uint32_t base = (blockIdx.x * 4u + (uint32_t)wid) * 64u;  // first row of this wave
-    if (base >= n_pad) return;
-
-    const bool full = (dim == (uint32_t)NCH * 256u);  // no partial last chunk
-    // query fragments: lane owns floats [c*256 + lane*4, +4) of every chunk c
-    f4 qv[BQ][NCH];
-#pragma unroll
-    for (int b = 0; b < BQ; ++b)
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            const uint32_t idx = (uint32_t)c * 256u + (uint32_t)lane * 4u;
-            qv[b][c] = (full || idx < dim) ? *(const f4*)(q + (size_t)b * dim + idx) : (f4)(0.f);
-        }
-
-    // rows this wave must score: inside the corpus and kept by the filter
-    uint64_t mask = ~0ull;
-    if (base + 64u > n) mask = (base >= n) ? 0ull : (~0ull >> (64u - (n - base)));
-    if (keep) {
-        const uint32_t nwords = (n + 31u) / 32u;
-        const uint32_t w = base / 32u;
-        const uint32_t w0 = (w < nwords) ? keep[w] : 0u;
-        const uint32_t w1 = (w + 1u < nwords) ? keep[w + 1u] : 0u;
-        mask &= ((uint64_t)w1 << 32) | (uint64_t)w0;
-    }
-    // wave-uniform by construction; tell the compiler so branches are scalar
-    const uint32_t mlo = __builtin_amdgcn_readfirstlane((uint32_t)mask);
-    const uint32_t mhi = __builtin_amdgcn_readfirstlane((uint32_t)(mask >> 32));
-    mask = ((uint64_t)mhi << 32) | mlo;
-
-    float sc[BQ];
-#pragma unroll
-    for (int b = 0; b < BQ; ++b) sc[b] = -INFINITY;
-
-    const uint32_t last = n - 1u;
-    for (int j = 0; j < 64 / RI; ++j) {
-        const uint32_t m = (uint32_t)(mask >> (RI * j)) & ((1u << RI) - 1u);
-        if (m == 0u) continue;  // all RI rows filtered out / past the end: skip their HBM reads
-        float acc[NV];
-#pragma unroll
-        for (int i = 0; i < NV; ++i) acc[i] = 0.f;
-        f4 x[RI][NCH];
-#pragma unroll
-        for (int r = 0; r < RI; ++r) {
-            uint32_t row = base + (uint32_t)(RI * j + r);
-            row = row > last ? last : row;
-            const float* p = rows + (size_t)row * dim;
-#pragma unroll
-            for (int c = 0; c < NCH; ++c) {
-                const uint32_t idx = (uint32_t)c * 256u + (uint32_t)lane * 4u;
-                if (full || idx < dim) {
-                    if (NT) x[r][c] = __builtin_nontemporal_load((const f4*)(p + idx));
-                    else x[r][c] = *(const f4*)(p + idx);
-                } else {
-                    x[r][c] = (f4)(0.f);
-                }
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < RI; ++r)
-#pragma unroll
-            for (int c = 0; c < NCH; ++c)
-#pragma unroll
-                for (int b = 0; b < BQ; ++b) {
-                    float a = acc[b * RI + r];
-                    a = __builtin_fmaf(x[r][c].x, qv[b][c].x, a);
-                    a = __builtin_fmaf(x[r][c].y, qv[b][c].y, a);
-                    a = __builtin_fmaf(x[r][c].z, qv[b][c].z, a);
-                    a = __builtin_fmaf(x[r][c].w, qv[b][c].w, a);
-                    acc[b * RI + r] = a;
-                }
-        treduce<NV>(acc, lane);
-        // value (b, r) now sits in lanes [(b*RI+r)*LPV, +LPV); lane L = RI*j + r wants it
-#pragma unroll
-        for (int b = 0; b < BQ; ++b) {
-            const float t = __shfl(acc[0], (b * RI + (lane % RI)) * LPV, 64);
-            if (lane / RI == j) sc[b] = t;
-        }
-    }
-
-    // epilogue: lane <-> row base+lane; one coalesced 256-B store per query
-    const uint32_t row = base + (uint32_t)lane;
-    const bool live = (mask >> lane) & 1ull;
-#pragma unroll
-    for (int b = 0; b < BQ; ++b) {
-        float s = sc[b];
-        // non-finite scores are never emitted (src/math.rs:23-27, src/cagra.rs:649-651)
-        if (!live || !(__builtin_fabsf(s) <= 3.4028234664e38f)) s = -INFINITY;
-        else if (mode == 1u) {
-            // candidate.rs:550 clamp(0,1) (Rust clamp keeps -0.0), :513-519 `>= threshold`
-            s = s < 0.f ? 0.f : (s > 1.f ? 1.f : s);
-            if (!(s >= thr)) s = -INFINITY;
-        }
-        scores[(size_t)b * n_pad + row] = s;
-    }
-}
-
-// ---- select: block-wide "find the bin holding the k-th largest" -------------
+// ---- block-wide "find the bin holding the k-th largest" ---------------------
 // hist: kHistBins counters (global or LDS).  Finds T = the highest bin such
 // that count(bins >= T) >= k_rem.  res[0]=T res[1]=count(bins > T) res[2]=hist[T]
 // res[3]=total count.  If total < k_rem: T = 0, res[1] = total - hist[0].
 template <int THREADS>
-__device__ void block_decide(const uint32_t* hist, uint32_t k_rem, uint32_t* s_part /*THREADS*/,
+__device__ void block_decide(const uint32_t* hist, uint32_t k_rem, uint32_t* s_part /*>= THREADS/64*/,
                              uint32_t* res /*4, LDS*/) {
     constexpr int BPT = kHistBins / THREADS;
-    const int t = threadIdx.x;
+    constexpr int NW = THREADS / 64;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     uint32_t h[BPT];
     uint32_t sum = 0;
 #pragma unroll
@@ -182,20 +91,21 @@ __device__ void block_decide(const uint32_t* hist, uint32_t k_rem, uint32_t* s_p
         h[i] = hist[t * BPT + i];
         sum += h[i];
     }
-    // inclusive suffix scan over threads (thread THREADS-1 owns the top bins)
-    s_part[t] = sum;
-    __syncthreads();
-    for (int off = 1; off < THREADS; off <<= 1) {
-        uint32_t add = (t + off < THREADS) ? s_part[t + off] : 0u;
-        __syncthreads();
-        s_part[t] += add;
-        __syncthreads();
+    // inclusive suffix scan over threads (thread THREADS-1 owns the top bins):
+    // shuffles inside a wave, then the totals of the higher waves through LDS
+    uint32_t incl = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t v = __shfl_down(incl, off, 64);
+        if (lane + off < 64) incl += v;
     }
-    const uint32_t incl = s_part[t];
+    if (lane == 0) s_part[w] = incl;
+    __syncthreads();
+    for (int ww = w + 1; ww < NW; ++ww) incl += s_part[ww];
     uint32_t above = incl - sum;  // count in bins owned by higher threads
     if (t == 0) {
         res[3] = incl;
-        if (incl < k_rem) {  // fewer valid entries than requested: take them all
+        if (incl < k_rem) {  // fewer entries than requested: take them all
             res[0] = 0;
             res[1] = incl - h[0];
             res[2] = h[0];
@@ -215,135 +125,160 @@ __device__ void block_decide(const uint32_t* hist, uint32_t k_rem, uint32_t* s_p
     __syncthreads();
 }
 
-// Decision shared (recomputed) by hist2 / collect: lower bound LB on the
-// ordered score key such that {key >= LB} holds the top k and, when `ok`,
-// at most kCandCap entries.
-struct SelPlan {
-    uint32_t lb;       // candidates: okey >= lb (and valid)
-    uint32_t need_l2;  // level-1 bin too crowded: level 2 refines inside bin t1
-    uint32_t t1;
-    uint32_t k_rem;    // k minus entries above bin t1
-    uint32_t above1;
+// ---- scan ------------------------------------------------------------------
+struct ScanParams {
+    const float* rows;
+    uint32_t n, n_pad, dim;
+    const float* q;
+    float* scores;
+    const uint32_t* keep;
+    uint32_t mode;
+    float thr;
+    uint32_t* work;     // work-queue head of this launch
+    uint32_t n_tasks;   // ceil(n_pad / 64)
+    float* gmax;        // [BQ][n_tasks] maximum valid score of each 64-row group (-inf if none)
 };
 
-template <int THREADS>
-__device__ SelPlan plan_level1(const uint32_t* hist1, uint32_t k, uint32_t* s_part, uint32_t* res) {
-    block_decide<THREADS>(hist1, k, s_part, res);
-    SelPlan p;
-    p.t1 = res[0];
-    p.above1 = res[1];
-    const uint32_t cnt = res[2], total = res[3];
-    __syncthreads();
-    p.k_rem = k - (p.above1 < k ? p.above1 : k);
-    if (total <= k) {  // everything valid is selected
-        p.lb = 0;
-        p.need_l2 = 0;
-    } else {
-        p.lb = p.t1 << 20;
-        p.need_l2 = (p.above1 + cnt > kCandCap) ? 1u : 0u;
-    }
-    return p;
-}
-
-// level-1 histogram of the top 12 key bits of every valid score
-__global__ __launch_bounds__(256) void select_hist1_kernel(const float* __restrict__ scores, uint32_t n_pad,
-                                                           uint32_t seg, uint32_t* __restrict__ sel) {
-    __shared__ uint32_t s_hist[kHistBins];
-    const uint32_t qi = blockIdx.y;
-    for (int i = threadIdx.x; i < (int)kHistBins; i += 256) s_hist[i] = 0;
-    __syncthreads();
-    const float* s = scores + (size_t)qi * n_pad;
-    const uint32_t lo = blockIdx.x * seg;
-    uint32_t hi = lo + seg;
-    if (hi > n_pad) hi = n_pad;
-    for (uint32_t i = lo + threadIdx.x * 4u; i < hi; i += 1024u) {
-        const f4 v = *(const f4*)(s + i);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const uint32_t kk = okey(v[e]);
-            if (kk > kInvalidKey) atomicAdd(&s_hist[kk >> 20], 1u);
-        }
-    }
-    __syncthreads();
-    uint32_t* g = sel + (size_t)qi * kSelWords;
-    for (int i = threadIdx.x; i < (int)kHistBins; i += 256) {
-        const uint32_t c = s_hist[i];
-        if (c) atomicAdd(&g[i], c);
-    }
-}
-
-// level-2 histogram (key bits 19..8) inside level-1 bin t1; no-op unless needed
-__global__ __launch_bounds__(256) void select_hist2_kernel(const float* __restrict__ scores, uint32_t n_pad,
-                                                           uint32_t seg, uint32_t k, uint32_t* __restrict__ sel) {
-    __shared__ uint32_t s_hist[kHistBins];
-    __shared__ uint32_t s_part[256];
-    __shared__ uint32_t s_res[4];
-    const uint32_t qi = blockIdx.y;
-    uint32_t* g = sel + (size_t)qi * kSelWords;
-    const SelPlan p = plan_level1<256>(g, k, s_part, s_res);
-    if (!p.need_l2) return;
-    for (int i = threadIdx.x; i < (int)kHistBins; i += 256) s_hist[i] = 0;
-    __syncthreads();
-    const float* s = scores + (size_t)qi * n_pad;
-    const uint32_t lo = blockIdx.x * seg;
-    uint32_t hi = lo + seg;
-    if (hi > n_pad) hi = n_pad;
-    for (uint32_t i = lo + threadIdx.x * 4u; i < hi; i += 1024u) {
-        const f4 v = *(const f4*)(s + i);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const uint32_t kk = okey(v[e]);
-            if (kk > kInvalidKey && (kk >> 20) == p.t1) atomicAdd(&s_hist[(kk >> 8) & 0xFFFu], 1u);
-        }
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < (int)kHistBins; i += 256) {
-        const uint32_t c = s_hist[i];
-        if (c) atomicAdd(&g[kHistBins + i], c);
-    }
-}
-
-// compaction of every entry with key >= LB into the query's candidate list
-__global__ __launch_bounds__(256) void select_collect_kernel(const float* __restrict__ scores, uint32_t n_pad,
-                                                             uint32_t seg, uint32_t k, uint32_t row_base,
-                                                             uint32_t* __restrict__ sel,
-                                                             uint64_t* __restrict__ cand) {
-    __shared__ uint32_t s_part[256];
-    __shared__ uint32_t s_res[4];
-    const uint32_t qi = blockIdx.y;
-    uint32_t* g = sel + (size_t)qi * kSelWords;
-    SelPlan p = plan_level1<256>(g, k, s_part, s_res);
-    uint32_t lb = p.lb;
-    if (p.need_l2) {
-        block_decide<256>(g + kHistBins, p.k_rem, s_part, s_res);
-        lb = (p.t1 << 20) | (s_res[0] << 8);
-        __syncthreads();
-    }
-    uint32_t* cnt = g + 2 * kHistBins;
-    uint64_t* out = cand + (size_t)qi * kCandCap;
-    const float* s = scores + (size_t)qi * n_pad;
-    const uint32_t lo = blockIdx.x * seg;
-    uint32_t hi = lo + seg;
-    if (hi > n_pad) hi = n_pad;
+// NCH = ceil(dim / 256): 1-KiB chunks per row.  BQ queries, RI rows per inner
+// iteration (RI*BQ partial sums are reduced together).  FULL: dim == NCH*256.
+// PIPE: 0 = loads then math per iteration; 1 = explicit double buffer (next iteration's
+// rows in flight while this iteration is reduced).
+template <int NCH, int BQ, int RI, bool NT, bool FULL, int PIPE>
+__global__ __launch_bounds__(256) void scan_gemv_kernel(const ScanParams p) {
+    constexpr int NV = RI * BQ;
+    constexpr int LPV = 64 / NV;  // lanes per reduced value
     const int lane = threadIdx.x & 63;
-    for (uint32_t i0 = lo; i0 < hi; i0 += 1024u) {  // uniform trip count per block
-        const uint32_t i = i0 + threadIdx.x * 4u;
-        f4 v = (f4)(-INFINITY);
-        if (i < hi) v = *(const f4*)(s + i);
+    const uint32_t n = p.n, dim = p.dim;
+
+    // per-lane column offsets: lane owns floats [c*256 + lane*4, +4) of every chunk c.
+    // A partial last chunk is read from a clamped in-row address against a zero query
+    // fragment, so the row loads stay unconditional (no branch, no early wait).
+    uint32_t coff[NCH];
+    f4 qv[BQ][NCH];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const uint32_t kk = okey(v[e]);
-            const bool take = (kk > kInvalidKey) && (kk >= lb);
-            const unsigned long long bal = __ballot(take);
-            if (bal) {
-                const uint32_t tot = (uint32_t)__popcll(bal);
-                uint32_t off = 0;
-                if (lane == 0) off = atomicAdd(cnt, tot);
-                off = __shfl(off, 0, 64);
-                const uint32_t rank = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
-                if (take && off + rank < kCandCap) out[off + rank] = pack_key(kk, row_base + i + (uint32_t)e);
+    for (int c = 0; c < NCH; ++c) {
+        const uint32_t idx = (uint32_t)c * 256u + (uint32_t)lane * 4u;
+        const bool in = FULL || idx < dim;
+        coff[c] = in ? idx : dim - 4u;
+#pragma unroll
+        for (int b = 0; b < BQ; ++b) {
+            const f4 v = *(const f4*)(p.q + (size_t)b * dim + coff[c]);
+            qv[b][c] = in ? v : (f4)(0.f);
+        }
+    }
+
+    const uint32_t last = n - 1u;
+    const uint32_t nwords = (n + 31u) / 32u;
+    uint32_t task = 0;
+    if (lane == 0) task = atomicAdd(p.work, 1u);
+    task = __builtin_amdgcn_readfirstlane(task);
+
+    while (task < p.n_tasks) {
+        uint32_t next = 0;
+        const uint32_t base = task * kTaskRows;
+
+        // rows this wave must score: inside the corpus and kept by the filter
+        uint64_t mask = ~0ull;
+        if (base + 64u > n) mask = (base >= n) ? 0ull : (~0ull >> (64u - (n - base)));
+        if (p.keep) {
+            const uint32_t w = base / 32u;
+            const uint32_t w0 = (w < nwords) ? p.keep[w] : 0u;
+            const uint32_t w1 = (w + 1u < nwords) ? p.keep[w + 1u] : 0u;
+            mask &= ((uint64_t)w1 << 32) | (uint64_t)w0;
+        }
+        // wave-uniform by construction; make the loop branches scalar
+        const uint32_t mlo = __builtin_amdgcn_readfirstlane((uint32_t)mask);
+        const uint32_t mhi = __builtin_amdgcn_readfirstlane((uint32_t)(mask >> 32));
+        mask = ((uint64_t)mhi << 32) | mlo;
+
+        float sc[BQ];
+#pragma unroll
+        for (int b = 0; b < BQ; ++b) sc[b] = -INFINITY;
+
+        // issue the RI*NCH row loads of inner iteration j back to back (all in flight together)
+        auto load_rows = [&](int j, f4 (&x)[RI][NCH]) {
+#pragma unroll
+            for (int r = 0; r < RI; ++r) {
+                uint32_t row = base + (uint32_t)(RI * j + r);
+                row = row > last ? last : row;
+                const float* rp = p.rows + (size_t)row * dim;
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    if (NT) x[r][c] = __builtin_nontemporal_load((const f4*)(rp + coff[c]));
+                    else x[r][c] = *(const f4*)(rp + coff[c]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);  // keep the loads ahead of the math that follows
+        };
+        auto reduce_rows = [&](int j, f4 (&x)[RI][NCH]) {
+            float acc[NV];
+#pragma unroll
+            for (int i = 0; i < NV; ++i) acc[i] = 0.f;
+#pragma unroll
+            for (int r = 0; r < RI; ++r)
+#pragma unroll
+                for (int c = 0; c < NCH; ++c)
+#pragma unroll
+                    for (int b = 0; b < BQ; ++b) {
+                        float a = acc[b * RI + r];
+                        a = __builtin_fmaf(x[r][c].x, qv[b][c].x, a);
+                        a = __builtin_fmaf(x[r][c].y, qv[b][c].y, a);
+                        a = __builtin_fmaf(x[r][c].z, qv[b][c].z, a);
+                        a = __builtin_fmaf(x[r][c].w, qv[b][c].w, a);
+                        acc[b * RI + r] = a;
+                    }
+            treduce<NV>(acc, lane);
+            // value (b, r) now sits in lanes [(b*RI+r)*LPV, +LPV); lane L = RI*j + r wants it
+#pragma unroll
+            for (int b = 0; b < BQ; ++b) {
+                const float t = __shfl(acc[0], (b * RI + (lane % RI)) * LPV, 64);
+                if (lane / RI == j) sc[b] = t;
+            }
+        };
+        if (PIPE == 1 && mask == ~0ull) {
+            f4 xa[RI][NCH], xb[RI][NCH];
+            load_rows(0, xa);
+            for (int j = 0; j < 64 / RI; j += 2) {
+                load_rows(j + 1, xb);
+                // dequeue the next task behind the first row loads: vmcnt retires in issue
+                // order, so an atomic issued ahead of them would stall the first reduction
+                if (j == 0 && lane == 0) next = atomicAdd(p.work, 1u);
+                reduce_rows(j, xa);
+                if (j + 2 < 64 / RI) load_rows(j + 2, xa);
+                reduce_rows(j + 1, xb);
+            }
+        } else {
+            if (lane == 0) next = atomicAdd(p.work, 1u);
+            for (int j = 0; j < 64 / RI; ++j) {
+                const uint32_t m = (uint32_t)(mask >> (RI * j)) & ((1u << RI) - 1u);
+                if (m == 0u) continue;  // all RI rows filtered out / past the end: skip their HBM reads
+                f4 x[RI][NCH];
+                load_rows(j, x);
+                reduce_rows(j, x);
             }
         }
+
+        // epilogue: lane <-> row base+lane; one coalesced 256-B store per query
+        const uint32_t row = base + (uint32_t)lane;
+        const bool live = (mask >> lane) & 1ull;
+#pragma unroll
+        for (int b = 0; b < BQ; ++b) {
+            float s = sc[b];
+            // non-finite scores are never emitted (src/math.rs:23-27, src/cagra.rs:649-651)
+            if (!live || !(__builtin_fabsf(s) <= 3.4028234664e38f)) s = -INFINITY;
+            else if (p.mode == 1u) {
+                // candidate.rs:550 clamp(0,1) (Rust clamp keeps -0.0), :513-519 `>= threshold`
+                s = s < 0.f ? 0.f : (s > 1.f ? 1.f : s);
+                if (!(s >= p.thr)) s = -INFINITY;
+            }
+            if (row < p.n_pad) p.scores[(size_t)b * p.n_pad + row] = s;
+            // group maximum -> pruning index of the select
+            float gm = s;
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) gm = fmaxf(gm, __shfl_xor(gm, off, 64));
+            if (lane == 0) p.gmax[(size_t)b * p.n_tasks + task] = gm;
+        }
+        task = __builtin_amdgcn_readfirstlane(next);
     }
 }
 
@@ -397,88 +332,257 @@ __device__ uint32_t slow_select(const float* __restrict__ s, uint32_t n_pad, uin
     return c < kCandCap ? c : kCandCap;
 }
 
-// final: sort the candidates (bitonic, descending) and emit the top k
-__global__ __launch_bounds__(1024) void select_sort_kernel(const float* __restrict__ scores, uint32_t n_pad,
-                                                           uint32_t k, uint32_t row_base,
-                                                           const uint32_t* __restrict__ sel,
-                                                           const uint64_t* __restrict__ cand,
-                                                           uint64_t* __restrict__ out_keys,
-                                                           uint32_t* __restrict__ out_counts) {
+// ---- select: one workgroup per query -----------------------------------------
+// Two-level exact top-k.  The scan left (a) every score and (b) the maximum of each
+// 64-row group.  The workgroup histograms the group maxima (LDS), takes T = the highest
+// bin with at least k maxima at or above it - then at least k scores have bin >= T, so
+// every top-k entry has bin >= T and lives in a group whose maximum has bin >= T - reads
+// back only those groups (about k of them), and sorts their entries with bin >= T
+// (bitonic, packed keys).  Global loads are issued GB per thread at a time so the phases
+// are bandwidth- not latency-paced.
+constexpr uint32_t kGroupCap = 8192;
+constexpr int kGB = 16;  // independent loads in flight per thread
+
+// Append the flagged items of a wave to a list with ONE counter atomic per wave:
+// returns in slot[u] the list position of item u of this thread (valid where take[u]).
+template <int N>
+__device__ __forceinline__ void wave_slots(const bool (&take)[N], uint32_t* counter, int lane, uint32_t (&slot)[N]) {
+    uint32_t c = 0;
+#pragma unroll
+    for (int u = 0; u < N; ++u) c += take[u] ? 1u : 0u;
+    uint32_t incl = c;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t v = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += v;
+    }
+    const uint32_t total = __shfl(incl, 63, 64);
+    uint32_t base = 0;
+    if (total) {
+        if (lane == 0) base = atomicAdd(counter, total);
+        base = __shfl(base, 0, 64);
+    }
+    uint32_t o = base + incl - c;
+#pragma unroll
+    for (int u = 0; u < N; ++u) {
+        slot[u] = o;
+        o += take[u] ? 1u : 0u;
+    }
+}
+__global__ __launch_bounds__(1024) void select_finish_kernel(const float* __restrict__ scores,
+                                                             const float* __restrict__ gmax, uint32_t n_pad,
+                                                             uint32_t n_tasks, uint32_t k, uint32_t row_base,
+                                                             uint32_t linear, uint64_t* __restrict__ out_keys,
+                                                             uint32_t* __restrict__ out_counts,
+                                                             uint32_t* __restrict__ work,
+                                                             unsigned long long* __restrict__ dbg) {
     __shared__ uint64_t s_keys[kCandCap];
+    __shared__ uint32_t s_groups[kGroupCap];
     __shared__ uint32_t s_hist[kHistBins];
     __shared__ uint32_t s_part[1024];
     __shared__ uint32_t s_res[4];
-    __shared__ uint32_t s_cnt;
+    __shared__ uint32_t s_cnt, s_ng;
     const uint32_t qi = blockIdx.x;
-    const uint32_t raw = sel[(size_t)qi * kSelWords + 2 * kHistBins];
-    uint32_t count;
-    if (raw > kCandCap) {
-        count = slow_select(scores + (size_t)qi * n_pad, n_pad, k, row_base, s_keys, s_hist, s_part, s_res, &s_cnt);
-    } else {
-        count = raw;
-        const uint64_t* c = cand + (size_t)qi * kCandCap;
-        for (uint32_t i = threadIdx.x; i < count; i += 1024u) s_keys[i] = c[i];
-    }
-    uint32_t P = 64;
-    while (P < count) P <<= 1;
-    for (uint32_t i = count + threadIdx.x; i < P; i += 1024u) s_keys[i] = 0ull;
+    const float* s = scores + (size_t)qi * n_pad;
+    const float* gm = gmax + (size_t)qi * n_tasks;
+    const int lane = threadIdx.x & 63;
+    const bool lin = linear != 0u;
+
+#define CQS_STAMP(i) do { if (dbg && threadIdx.x == 0 && blockIdx.x == 0) dbg[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+    CQS_STAMP(0);
+    for (uint32_t i = threadIdx.x; i < kHistBins; i += 1024u) s_hist[i] = 0u;
+    if (threadIdx.x == 0) { s_cnt = 0; s_ng = 0; }
     __syncthreads();
-    for (uint32_t size = 2; size <= P; size <<= 1) {
-        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
-            for (uint32_t t = threadIdx.x; t < P / 2; t += 1024u) {
-                const uint32_t i = 2u * t - (t & (stride - 1u));  // lower index of the pair
-                const uint32_t j = i + stride;
-                const uint64_t a = s_keys[i], b = s_keys[j];
-                const bool desc = ((i & size) == 0u);
-                if ((a < b) == desc) {
-                    s_keys[i] = b;
-                    s_keys[j] = a;
-                }
+
+    // phase 1: histogram of the group maxima
+    float m[kGB];
+    const bool one_pass = n_tasks <= 1024u * kGB;  // the maxima then stay in registers for phase 2
+    for (uint32_t t0 = 0; t0 < n_tasks; t0 += 1024u * kGB) {
+#pragma unroll
+        for (int u = 0; u < kGB; ++u) {
+            const uint32_t t = t0 + (uint32_t)u * 1024u + threadIdx.x;
+            const float v = gm[t < n_tasks ? t : n_tasks - 1u];  // unconditional load, clamped
+            m[u] = t < n_tasks ? v : -INFINITY;
+        }
+#pragma unroll
+        for (int u = 0; u < kGB; ++u)
+            if (m[u] != -INFINITY) atomicAdd(&s_hist[bin_of(m[u], lin)], 1u);
+    }
+    __syncthreads();
+    CQS_STAMP(1);
+    block_decide<1024>(s_hist, k, s_part, s_res);
+    const uint32_t T = (s_res[3] < k) ? 0u : s_res[0];  // fewer groups than k: every valid score is a candidate
+    __syncthreads();
+    CQS_STAMP(2);
+
+    // phase 2: groups whose maximum reaches the threshold bin
+    for (uint32_t t0 = 0; t0 < n_tasks; t0 += 1024u * kGB) {
+        if (!one_pass) {
+#pragma unroll
+            for (int u = 0; u < kGB; ++u) {
+                const uint32_t t = t0 + (uint32_t)u * 1024u + threadIdx.x;
+                const float v = gm[t < n_tasks ? t : n_tasks - 1u];
+                m[u] = t < n_tasks ? v : -INFINITY;
             }
-            __syncthreads();
+        }
+        bool take[kGB];
+        uint32_t slot[kGB];
+#pragma unroll
+        for (int u = 0; u < kGB; ++u) take[u] = (m[u] != -INFINITY) && (bin_of(m[u], lin) >= T);
+        wave_slots<kGB>(take, &s_ng, lane, slot);
+#pragma unroll
+        for (int u = 0; u < kGB; ++u)
+            if (take[u] && slot[u] < kGroupCap) s_groups[slot[u]] = t0 + (uint32_t)u * 1024u + threadIdx.x;
+    }
+    __syncthreads();
+    CQS_STAMP(3);
+    const uint32_t ng = s_ng;
+    uint32_t count = kCandCap + 1u;
+    if (ng <= kGroupCap) {
+        // phase 3: their scores (L2 / Infinity Cache hits: the scan just wrote them)
+        const uint32_t total = ng * kTaskRows;
+        for (uint32_t e0 = 0; e0 < total; e0 += 1024u * kGB) {
+            float v[kGB];
+            uint32_t idx[kGB];
+#pragma unroll
+            for (int u = 0; u < kGB; ++u) {
+                const uint32_t e = e0 + (uint32_t)u * 1024u + threadIdx.x;
+                const uint32_t ec = e < total ? e : total - 1u;
+                idx[u] = s_groups[ec >> 6] * kTaskRows + (ec & 63u);
+                const float x = s[idx[u]];
+                v[u] = e < total ? x : -INFINITY;
+            }
+            bool take[kGB];
+            uint32_t slot[kGB];
+#pragma unroll
+            for (int u = 0; u < kGB; ++u) take[u] = (v[u] != -INFINITY) && (bin_of(v[u], lin) >= T);
+            wave_slots<kGB>(take, &s_cnt, lane, slot);
+#pragma unroll
+            for (int u = 0; u < kGB; ++u)
+                if (take[u] && slot[u] < kCandCap) s_keys[slot[u]] = pack_key(okey(v[u]), row_base + idx[u]);
+        }
+        __syncthreads();
+        count = s_cnt;
+    }
+    if (count > kCandCap)  // heavy ties / crowded threshold bin: exact radix select over the whole row
+        count = slow_select(s, n_pad, k, row_base, s_keys, s_hist, s_part, s_res, &s_cnt);
+
+    CQS_STAMP(4);
+    if (dbg && threadIdx.x == 0 && blockIdx.x == 0) { dbg[8] = ng; dbg[9] = count; }
+    const uint64_t* sorted = s_keys;
+    if (count <= 1024u) {
+        // Rank sort: the keys are distinct, so rank(i) = #{j : key[j] > key[i]} is a permutation.
+        // One key per thread, count broadcast LDS reads, no barriers inside the loop.
+        uint64_t* s_sorted = reinterpret_cast<uint64_t*>(s_groups);  // group list is dead by now
+        __syncthreads();
+        if (threadIdx.x < count) {
+            const uint64_t mine = s_keys[threadIdx.x];
+            uint32_t rank = 0;
+            uint32_t j = 0;
+            for (; j + 4u <= count; j += 4u) {
+                rank += (s_keys[j] > mine) ? 1u : 0u;
+                rank += (s_keys[j + 1] > mine) ? 1u : 0u;
+                rank += (s_keys[j + 2] > mine) ? 1u : 0u;
+                rank += (s_keys[j + 3] > mine) ? 1u : 0u;
+            }
+            for (; j < count; ++j) rank += (s_keys[j] > mine) ? 1u : 0u;
+            s_sorted[rank] = mine;
+        }
+        __syncthreads();
+        sorted = s_sorted;
+    } else {
+        // Bitonic sort, descending (slow path sizes: up to kCandCap).
+        uint32_t P = 2048;
+        while (P < count) P <<= 1;
+        for (uint32_t i = count + threadIdx.x; i < P; i += 1024u) s_keys[i] = 0ull;
+        __syncthreads();
+        for (uint32_t size = 2; size <= P; size <<= 1) {
+            for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+                for (uint32_t t = threadIdx.x; t < P / 2; t += 1024u) {
+                    const uint32_t i = 2u * t - (t & (stride - 1u));  // lower index of the pair
+                    const uint32_t j = i + stride;
+                    const uint64_t a = s_keys[i], b = s_keys[j];
+                    const bool desc = ((i & size) == 0u);
+                    if ((a < b) == desc) {
+                        s_keys[i] = b;
+                        s_keys[j] = a;
+                    }
+                }
+                __syncthreads();
+            }
         }
     }
+    CQS_STAMP(5);
     const uint32_t outc = count < k ? count : k;
-    for (uint32_t i = threadIdx.x; i < k; i += 1024u) out_keys[(size_t)qi * k + i] = (i < outc) ? s_keys[i] : 0ull;
+    for (uint32_t i = threadIdx.x; i < k; i += 1024u) out_keys[(size_t)qi * k + i] = (i < outc) ? sorted[i] : 0ull;
     if (threadIdx.x == 0) out_counts[qi] = outc;
+    // re-arm the scan work-queue heads for the next search (visible at the kernel boundary)
+    if (qi == 0) for (uint32_t i = threadIdx.x; i < kWorkWords; i += 1024u) work[i] = 0u;
+    CQS_STAMP(6);
+#undef CQS_STAMP
 }
 
 // ---- launchers -------------------------------------------------------------
 bool scan_dim_supported(uint32_t dim) { return dim >= 4 && dim % 4 == 0 && dim <= 2048; }
 
+#ifndef CQS_SCAN_PIPE
+#define CQS_SCAN_PIPE 1
+#endif
+#ifndef CQS_SCAN_RI1
+#define CQS_SCAN_RI1 8   // rows per inner iteration of the single-query scan
+#endif
+#ifndef CQS_SCAN_BLOCKS_PER_CU
+#define CQS_SCAN_BLOCKS_PER_CU 2
+#endif
 template <int NCH, int BQ, int RI>
-static hipError_t launch_gemv(const ScanArgs& a, const float* q, float* scores, hipStream_t st) {
-    const dim3 grid(a.n_pad / kRowsPerBlock), block(256);
-    if (a.nontemporal)
-        hipLaunchKernelGGL((scan_gemv_kernel<NCH, BQ, RI, true>), grid, block, 0, st, a.rows, a.n, a.n_pad, a.dim, q,
-                           scores, a.keep, a.mode, a.threshold);
-    else
-        hipLaunchKernelGGL((scan_gemv_kernel<NCH, BQ, RI, false>), grid, block, 0, st, a.rows, a.n, a.n_pad, a.dim, q,
-                           scores, a.keep, a.mode, a.threshold);
+static hipError_t launch_gemv(const ScanArgs& a, uint32_t q0, uint32_t work_slot, hipStream_t st) {
+    ScanParams p;
+    p.rows = a.rows; p.n = a.n; p.n_pad = a.n_pad; p.dim = a.dim;
+    p.q = a.q + (size_t)q0 * a.dim;
+    p.scores = a.scores + (size_t)q0 * a.n_pad;
+    p.keep = a.keep; p.mode = a.mode; p.thr = a.threshold;
+    p.work = a.work + work_slot;
+    p.n_tasks = a.n_pad / kTaskRows;
+    p.gmax = a.gmax + (size_t)q0 * p.n_tasks;
+    // persistent grid: enough workgroups to fill every CU at this kernel's occupancy, never
+    // more than there are 4-task rounds; a workgroup that finds the queue empty just exits.
+    uint32_t blocks = a.n_cu * CQS_SCAN_BLOCKS_PER_CU;
+    const uint32_t need = (p.n_tasks + 3u) / 4u;
+    if (blocks > need) blocks = need;
+    const dim3 grid(blocks), block(256);
+    const bool full = (a.dim == (uint32_t)NCH * 256u);
+#define CQS_LAUNCH(NTV, FULLV) \
+    hipLaunchKernelGGL((scan_gemv_kernel<NCH, BQ, RI, NTV, FULLV, (BQ <= 2 ? CQS_SCAN_PIPE : 0)>), grid, block, 0, st, p)
+    if (a.nontemporal) { if (full) CQS_LAUNCH(true, true); else CQS_LAUNCH(true, false); }
+    else { if (full) CQS_LAUNCH(false, true); else CQS_LAUNCH(false, false); }
+#undef CQS_LAUNCH
     return hipGetLastError();
 }
 
 template <int NCH>
 static hipError_t launch_gemv_groups(const ScanArgs& a, hipStream_t st) {
-    uint32_t done = 0;
+    uint32_t done = 0, slot = 0;
     while (done < a.b) {
         const uint32_t left = a.b - done;
-        const float* q = a.q + (size_t)done * a.dim;
-        float* sc = a.scores + (size_t)done * a.n_pad;
         hipError_t e;
         uint32_t g;
         // register budget ~ 4*NCH*(BQ + RI) + BQ*RI VGPRs: wide rows take fewer queries per pass
         if constexpr (NCH <= 4) {
-            if (left >= 8) { g = 8; e = launch_gemv<NCH, 8, 2>(a, q, sc, st); }
-            else if (left >= 4) { g = 4; e = launch_gemv<NCH, 4, 4>(a, q, sc, st); }
-            else if (left >= 2) { g = 2; e = launch_gemv<NCH, 2, 4>(a, q, sc, st); }
-            else { g = 1; e = launch_gemv<NCH, 1, 4>(a, q, sc, st); }
+            if (left >= 8) { g = 8; e = launch_gemv<NCH, 8, 2>(a, done, slot, st); }
+            else if (left >= 4) { g = 4; e = launch_gemv<NCH, 4, 4>(a, done, slot, st); }
+            else if (left >= 2) { g = 2; e = launch_gemv<NCH, 2, 4>(a, done, slot, st); }
+            else { g = 1; e = launch_gemv<NCH, 1, CQS_SCAN_RI1>(a, done, slot, st); }
         } else {
-            if (left >= 2) { g = 2; e = launch_gemv<NCH, 2, 2>(a, q, sc, st); }
-            else { g = 1; e = launch_gemv<NCH, 1, 2>(a, q, sc, st); }
+            if (left >= 2) { g = 2; e = launch_gemv<NCH, 2, 2>(a, done, slot, st); }
+            else { g = 1; e = launch_gemv<NCH, 1, 2>(a, done, slot, st); }
         }
         if (e != hipSuccess) return e;
         done += g;
+        slot = (slot + 1u) % kWorkWords;
+        if (slot == 0 && done < a.b) {  // queue heads exhausted: recycle them (rare: > 64 launches)
+            e = hipMemsetAsync(a.work, 0, kWorkWords * sizeof(uint32_t), st);
+            if (e != hipSuccess) return e;
+        }
     }
     return hipSuccess;
 }
@@ -499,24 +603,12 @@ hipError_t launch_scan(const ScanArgs& a, hipStream_t st) {
     }
 }
 
-hipError_t launch_select(const float* scores, uint32_t n, uint32_t n_pad, uint32_t b, uint32_t k,
-                         uint32_t row_base, uint32_t* sel, uint64_t* cand, uint64_t* out_keys,
-                         uint32_t* out_counts, hipStream_t st) {
-    (void)n;
-    if (b == 0 || k == 0) return hipSuccess;
-    hipError_t e = hipMemsetAsync(sel, 0, (size_t)b * kSelWords * sizeof(uint32_t), st);
-    if (e != hipSuccess) return e;
-    // segment per block: multiple of 1024 entries, at most 256 blocks per query
-    uint32_t seg = (n_pad + 255u) / 256u;
-    seg = ((seg + 1023u) / 1024u) * 1024u;
-    if (seg < 4096u) seg = 4096u;
-    const uint32_t nb = (n_pad + seg - 1u) / seg;
-    const dim3 grid(nb, b), block(256);
-    hipLaunchKernelGGL(select_hist1_kernel, grid, block, 0, st, scores, n_pad, seg, sel);
-    hipLaunchKernelGGL(select_hist2_kernel, grid, block, 0, st, scores, n_pad, seg, k, sel);
-    hipLaunchKernelGGL(select_collect_kernel, grid, block, 0, st, scores, n_pad, seg, k, row_base, sel, cand);
-    hipLaunchKernelGGL(select_sort_kernel, dim3(b), dim3(1024), 0, st, scores, n_pad, k, row_base, sel, cand, out_keys,
-                       out_counts);
+hipError_t launch_select(const ScanArgs& a, uint32_t row_base, uint64_t* out_keys, uint32_t* out_counts,
+                         hipStream_t st) {
+    if (a.b == 0 || a.k == 0) return hipSuccess;
+    hipLaunchKernelGGL(select_finish_kernel, dim3(a.b), dim3(1024), 0, st, a.scores, a.gmax, a.n_pad,
+                       a.n_pad / kTaskRows, a.k, row_base, a.linear_bins ? 1u : 0u, out_keys, out_counts, a.work,
+                       (unsigned long long*)a.dbg);
     return hipGetLastError();
 }
 
