@@ -553,7 +553,12 @@ static hipError_t launch_gemv(const ScanArgs& a, uint32_t q0, uint32_t work_slot
     const bool full = (a.dim == (uint32_t)NCH * 256u);
 #define CQS_LAUNCH(NTV, FULLV) \
     hipLaunchKernelGGL((scan_gemv_kernel<NCH, BQ, RI, NTV, FULLV, (BQ <= 2 ? CQS_SCAN_PIPE : 0)>), grid, block, 0, st, p)
-    if (a.nontemporal) { if (full) CQS_LAUNCH(true, true); else CQS_LAUNCH(true, false); }
+#ifdef CQS_SCAN_FORCE_NT
+    const bool nt = CQS_SCAN_FORCE_NT;
+#else
+    const bool nt = a.nontemporal;
+#endif
+    if (nt) { if (full) CQS_LAUNCH(true, true); else CQS_LAUNCH(true, false); }
     else { if (full) CQS_LAUNCH(false, true); else CQS_LAUNCH(false, false); }
 #undef CQS_LAUNCH
     return hipGetLastError();

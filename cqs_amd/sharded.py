@@ -59,7 +59,10 @@ class ShardedSearch:
         if self.world == 1:
             out[0] = payload
         else:
-            self.dist.all_gather_into_tensor(out, payload, group=self.group)
+            try:
+                self.dist.all_gather_into_tensor(out, payload, group=self.group)
+            except (RuntimeError, NotImplementedError):  # backends without the fused form (older gloo)
+                self.dist.all_gather(list(out.unbind(0)), payload, group=self.group)
         return out
 
     @staticmethod

@@ -1,0 +1,339 @@
+//! MI355X exact GPU index for cqs: `impl VectorIndex` / `impl IndexBackend` over
+//! libcqs_hip.so (C ABI: include/cqs_hip.h).
+//!
+//! Drop-in location: `src/hip.rs`, `#[cfg(feature = "hip-index")] pub mod hip;` in
+//! `src/lib.rs`, one row in the backend table (`src/index.rs:338-345`):
+//!
+//! ```ignore
+//! crate::hip::HipBackend, cfg(feature = "hip-index");
+//! ```
+//!
+//! Shape follows `CagraIndex` (src/cagra.rs:255-277): the index owns `id_map`
+//! (row -> chunk id, rowid order); the device side is addressed by row number.
+//! Conventions kept from the reference (src/cagra.rs:445-470, 543-626, 1715-1800):
+//! `search` never panics and never returns an error for device trouble - it logs and
+//! returns an empty Vec; `try_open` returns `Ok(None)` to fall through to the next
+//! backend and `Err` only for store errors.
+
+use std::ffi::c_void;
+use std::os::raw::c_char;
+use std::sync::atomic::{AtomicBool, Ordering};
+
+use crate::embedder::Embedding;
+use crate::index::{BackendContext, DistanceMetric, IndexBackend, IndexResult, VectorIndex};
+use crate::store::{ClearHnswDirty, Store, StoreError};
+
+// ---- C ABI (include/cqs_hip.h) ------------------------------------------------
+#[repr(C)]
+struct CqsHipIndex {
+    _private: [u8; 0],
+}
+
+const CQS_HIP_OK: i32 = 0;
+const CQS_HIP_METRIC_COSINE: u32 = 0;
+const CQS_HIP_METRIC_DOT: u32 = 1;
+const CQS_HIP_MODE_RAW: u32 = 0;
+
+#[link(name = "cqs_hip")]
+extern "C" {
+    fn cqs_hip_device_count() -> i32;
+    fn cqs_hip_device_mem(device: i32, free_bytes: *mut u64, total_bytes: *mut u64) -> i32;
+    fn cqs_hip_index_create(
+        rows: *const f32,
+        n: u64,
+        dim: u32,
+        metric: u32,
+        device: i32,
+        row_base: u64,
+        out: *mut *mut CqsHipIndex,
+    ) -> i32;
+    fn cqs_hip_index_extend(idx: *mut CqsHipIndex, rows: *const f32, n_new: u64) -> i32;
+    fn cqs_hip_index_destroy(idx: *mut CqsHipIndex);
+    fn cqs_hip_index_len(idx: *const CqsHipIndex) -> u64;
+    fn cqs_hip_index_max_k(idx: *const CqsHipIndex) -> u32;
+    fn cqs_hip_index_poisoned(idx: *const CqsHipIndex) -> i32;
+    fn cqs_hip_index_last_error(idx: *const CqsHipIndex, buf: *mut c_char, cap: usize) -> usize;
+    fn cqs_hip_index_search(
+        idx: *mut CqsHipIndex,
+        queries: *const f32,
+        b: u32,
+        query_dim: u32,
+        k: u32,
+        keep_bitset: *const u32,
+        mode: u32,
+        threshold: f32,
+        out_rows: *mut u64,
+        out_scores: *mut f32,
+        out_counts: *mut u32,
+    ) -> i32;
+}
+
+/// Exact brute-force GPU index (HBM-resident `[n, dim]` f32 + top-k on device).
+pub struct HipIndex {
+    handle: *mut CqsHipIndex,
+    /// row -> chunk id, rowid order (same role as `CagraIndex::id_map`, src/cagra.rs:266).
+    id_map: Vec<Box<str>>,
+    dim: usize,
+    metric: DistanceMetric,
+    /// Set when the C side reports a device failure; `is_poisoned()` makes the daemon
+    /// rebuild the index (src/index.rs:203-205, src/cagra.rs:472-489).
+    poisoned: AtomicBool,
+}
+
+// SAFETY: the handle serialises device access behind its own mutex (include/cqs_hip.h,
+// "Threading"); `id_map` is immutable after construction.  Same argument as
+// `unsafe impl Send/Sync for CagraIndex` (src/cagra.rs:823-830).
+unsafe impl Send for HipIndex {}
+unsafe impl Sync for HipIndex {}
+
+impl Drop for HipIndex {
+    fn drop(&mut self) {
+        // destroy() synchronises the index's streams first (src/cagra.rs:289-302)
+        unsafe { cqs_hip_index_destroy(self.handle) }
+    }
+}
+
+impl HipIndex {
+    /// `CagraIndex::gpu_available_for` analogue (src/cagra.rs:336-376).
+    pub fn gpu_available_for(n: usize, dim: usize) -> bool {
+        if unsafe { cqs_hip_device_count() } <= 0 {
+            return false;
+        }
+        let (mut free, mut total) = (0u64, 0u64);
+        if unsafe { cqs_hip_device_mem(0, &mut free, &mut total) } != CQS_HIP_OK {
+            return false;
+        }
+        // corpus + score/scratch headroom must fit HBM (288 GB on MI355X: no 2 GiB host cap,
+        // unlike CQS_CAGRA_MAX_BYTES, src/cagra.rs:159-167)
+        (n as u64).saturating_mul(dim as u64).saturating_mul(4).saturating_mul(5) / 4 <= free
+    }
+
+    /// `CagraIndex::build_from_flat` (src/cagra.rs:922-960).
+    pub fn build_from_flat(
+        id_map: Vec<String>,
+        flat_data: Vec<f32>,
+        dim: usize,
+        metric: DistanceMetric,
+    ) -> Result<Self, String> {
+        if id_map.is_empty() || flat_data.len() != id_map.len() * dim {
+            return Err("HIP build: empty or misshapen dataset".into());
+        }
+        let mut handle: *mut CqsHipIndex = std::ptr::null_mut();
+        let m = match metric {
+            DistanceMetric::Cosine => CQS_HIP_METRIC_COSINE,
+            DistanceMetric::DotProduct => CQS_HIP_METRIC_DOT,
+        };
+        let rc = unsafe {
+            cqs_hip_index_create(flat_data.as_ptr(), id_map.len() as u64, dim as u32, m, 0, 0, &mut handle)
+        };
+        if rc != CQS_HIP_OK || handle.is_null() {
+            return Err(format!("cqs_hip_index_create failed: {rc}"));
+        }
+        Ok(Self {
+            handle,
+            id_map: id_map.into_iter().map(String::into_boxed_str).collect(),
+            dim,
+            metric,
+            poisoned: AtomicBool::new(false),
+        })
+    }
+
+    /// Stream the store into a flat buffer (`build_from_store_with_metric`,
+    /// src/cagra.rs:842-916).  Zero / non-finite rows are skipped exactly like
+    /// `prepare_index_data` (src/hnsw/mod.rs:717-731) so `len()` and row->id agree
+    /// with the HNSW backend.
+    pub fn build_from_store<Mode>(store: &Store<Mode>, dim: usize, metric: DistanceMetric) -> Result<Self, String> {
+        let mut id_map: Vec<String> = Vec::new();
+        let mut flat: Vec<f32> = Vec::new();
+        let batch = crate::limits::dim_scaled_batch(10_000, dim, 500, 50_000);
+        for batch_result in store.embedding_batches(batch) {
+            let batch = batch_result.map_err(|e| format!("Failed to fetch batch: {e}"))?;
+            for (chunk_id, embedding) in batch {
+                let v = embedding.as_slice();
+                if v.len() != dim {
+                    return Err(format!("dimension mismatch: expected {dim}, got {}", v.len()));
+                }
+                if !v.iter().any(|x| *x != 0.0) || v.iter().any(|x| !x.is_finite()) {
+                    tracing::warn!(chunk_id = %chunk_id, "Skipping zero / non-finite embedding");
+                    continue;
+                }
+                id_map.push(chunk_id);
+                flat.extend_from_slice(v);
+            }
+        }
+        Self::build_from_flat(id_map, flat, dim, metric)
+    }
+
+    /// Incremental add (the contract `tiered.rs` exposes, src/tiered.rs:1-43).
+    pub fn extend(&mut self, ids: Vec<String>, rows: &[f32]) -> Result<(), String> {
+        if rows.len() != ids.len() * self.dim {
+            return Err("HIP extend: misshapen rows".into());
+        }
+        let rc = unsafe { cqs_hip_index_extend(self.handle, rows.as_ptr(), ids.len() as u64) };
+        if rc != CQS_HIP_OK {
+            return Err(self.last_error());
+        }
+        self.id_map.extend(ids.into_iter().map(String::into_boxed_str));
+        Ok(())
+    }
+
+    fn last_error(&self) -> String {
+        let mut buf = vec![0u8; 512];
+        let n = unsafe { cqs_hip_index_last_error(self.handle, buf.as_mut_ptr() as *mut c_char, buf.len()) };
+        String::from_utf8_lossy(&buf[..n]).into_owned()
+    }
+
+    fn search_impl(&self, query: &Embedding, k: usize, bitset: Option<&[u32]>) -> Vec<IndexResult> {
+        let k = k.min(unsafe { cqs_hip_index_max_k(self.handle) } as usize);
+        let mut rows = vec![0u64; k];
+        let mut scores = vec![0f32; k];
+        let mut count = 0u32;
+        let rc = unsafe {
+            cqs_hip_index_search(
+                self.handle,
+                query.as_slice().as_ptr(),
+                1,
+                query.len() as u32,
+                k as u32,
+                bitset.map_or(std::ptr::null(), |b| b.as_ptr()),
+                CQS_HIP_MODE_RAW,
+                0.0,
+                rows.as_mut_ptr(),
+                scores.as_mut_ptr(),
+                &mut count,
+            )
+        };
+        if rc != CQS_HIP_OK {
+            if unsafe { cqs_hip_index_poisoned(self.handle) } != 0 {
+                self.poisoned.store(true, Ordering::Release);
+            }
+            tracing::error!(error = %self.last_error(), rc, "HIP search failed");
+            return Vec::new();
+        }
+        (0..count as usize)
+            .filter_map(|i| {
+                self.id_map.get(rows[i] as usize).map(|id| IndexResult {
+                    id: id.to_string(),
+                    // exact dot of unit vectors; cap the f32 overshoot like src/cagra.rs:656-661
+                    score: match self.metric {
+                        DistanceMetric::Cosine => scores[i].min(1.0),
+                        DistanceMetric::DotProduct => scores[i],
+                    },
+                })
+            })
+            .collect()
+    }
+}
+
+impl VectorIndex for HipIndex {
+    fn search(&self, query: &Embedding, k: usize) -> Vec<IndexResult> {
+        let _span = tracing::debug_span!("hip_search", k).entered();
+        if self.id_map.is_empty() || k == 0 {
+            return Vec::new();
+        }
+        if query.len() != self.dim {
+            tracing::warn!(expected_dim = self.dim, actual_dim = query.len(), "Query dimension mismatch");
+            return Vec::new();
+        }
+        if self.poisoned.load(Ordering::Acquire) {
+            return Vec::new();
+        }
+        // non-finite queries are rejected inside the C ABI as well (count 0)
+        self.search_impl(query, k, None)
+    }
+
+    fn len(&self) -> usize {
+        unsafe { cqs_hip_index_len(self.handle) as usize }
+    }
+
+    fn name(&self) -> &'static str {
+        "HIP"
+    }
+
+    fn dim(&self) -> usize {
+        self.dim
+    }
+
+    /// GPU-native filtered search: bitset built on the host from the predicate
+    /// (src/cagra.rs:747-757); all-pass / none / k-cap handled by the C ABI
+    /// (src/cagra.rs:760-775).
+    fn search_with_filter(&self, query: &Embedding, k: usize, filter: &dyn Fn(&str) -> bool) -> Vec<IndexResult> {
+        if self.id_map.is_empty() || k == 0 || query.len() != self.dim {
+            return Vec::new();
+        }
+        let n = self.id_map.len();
+        let mut bitset = vec![0u32; n.div_ceil(32)];
+        for (i, id) in self.id_map.iter().enumerate() {
+            if filter(id) {
+                bitset[i / 32] |= 1u32 << (i % 32);
+            }
+        }
+        self.search_impl(query, k, Some(&bitset))
+    }
+
+    fn is_poisoned(&self) -> bool {
+        self.poisoned.load(Ordering::Acquire) || unsafe { cqs_hip_index_poisoned(self.handle) } != 0
+    }
+
+    fn max_k(&self) -> Option<usize> {
+        Some(unsafe { cqs_hip_index_max_k(self.handle) } as usize)
+    }
+
+    /// Scores are the exact dot product of unit vectors = the cosine the brute-force path
+    /// recomputes, so the BLOB refetch can be skipped (src/search/query.rs:1152-1172).
+    fn index_scores_are_cosine(&self) -> bool {
+        matches!(self.metric, DistanceMetric::Cosine)
+    }
+}
+
+/// `IndexBackend` registration; priority above CAGRA (100) and tiered (150).
+pub struct HipBackend;
+
+impl<Mode: ClearHnswDirty> IndexBackend<Mode> for HipBackend {
+    fn name(&self) -> &'static str {
+        "hip"
+    }
+
+    fn priority(&self) -> i32 {
+        200
+    }
+
+    fn try_open(&self, ctx: &BackendContext<'_, Mode>) -> Result<Option<Box<dyn VectorIndex>>, StoreError> {
+        const HIP_THRESHOLD_DEFAULT: u64 = 5000; // same gate as CQS_CAGRA_THRESHOLD (src/cagra.rs:1683-1690)
+        let threshold: u64 = std::env::var("CQS_HIP_THRESHOLD")
+            .ok()
+            .and_then(|v| v.parse().ok())
+            .or_else(|| ctx.policy.and_then(|p| p.cagra_threshold))
+            .unwrap_or(HIP_THRESHOLD_DEFAULT);
+        let chunk_count = ctx.store.chunk_count().unwrap_or(0);
+        let dim = ctx.store.dim();
+        let gpu_available = HipIndex::gpu_available_for(chunk_count as usize, dim);
+        if chunk_count < threshold || !gpu_available {
+            tracing::info!(backend = "hnsw", source = "hip-ineligible", chunk_count, threshold, dim, gpu_available,
+                "Vector index backend selected");
+            return Ok(None);
+        }
+        let metric = match DistanceMetric::from_env() {
+            Ok(Some(m)) => m,
+            Ok(None) => crate::hnsw::HnswIndex::stored_metric(ctx.cqs_dir, "index").unwrap_or(DistanceMetric::Cosine),
+            Err(e) => {
+                tracing::warn!(error = %e, "Invalid CQS_DISTANCE_METRIC - falling through");
+                return Ok(None);
+            }
+        };
+        match HipIndex::build_from_store(ctx.store, dim, metric) {
+            Ok(idx) => {
+                tracing::info!(backend = "hip", source = "rebuilt", vectors = idx.len(), chunk_count,
+                    "Vector index backend selected");
+                Ok(Some(Box::new(idx) as Box<dyn VectorIndex>))
+            }
+            Err(e) => {
+                tracing::warn!(error = %e, "Failed to build HIP index, falling through");
+                Ok(None)
+            }
+        }
+    }
+}
+
+#[allow(dead_code)]
+fn _abi_types(_: *mut c_void) {}
