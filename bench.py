@@ -23,6 +23,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+MFMA_F32_PEAK_TF = 157.3  # dense f32-input MFMA peak (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E vendor peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 achievable)
 
 
@@ -196,9 +197,18 @@ def main():
             traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
-    roofline = {"bound": "hbm", "kernel": "scan_gemv_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": round(avg_s * 1e3, 5), "launches": launches}
+    nq_scan = bq * world
+    if nq_scan >= 9 and dim % 32 == 0:
+        # query blocks >= 9 run on the f32 matrix cores: compute-bound (2*B*n*dim flops per launch)
+        flops = 2.0 * nq_scan * n * dim
+        tf = flops / avg_s / 1e12
+        roofline = {"bound": "mfma", "kernel": "scan_mfma_kernel", "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TF,
+                    "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TF, 4), "traffic": None,
+                    "alg_flops_per_launch": flops, "avg_launch_ms": round(avg_s * 1e3, 5), "launches": launches}
+    else:
+        roofline = {"bound": "hbm", "kernel": "scan_gemv_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": round(avg_s * 1e3, 5), "launches": launches}
 
     cpu = None
     if rank == 0 and world == 1 and a.cpu_seconds > 0:

@@ -108,7 +108,8 @@ int32_t ensure_scratch(cqs_hip_index* x, uint32_t b, uint32_t k) {
     uint32_t qc = x->q_cap > b ? x->q_cap : b;
     uint32_t kc = x->k_cap > k ? x->k_cap : k;
     free_scratch(x);
-    HIP_TRY(x, hipMalloc(&x->d_q, (size_t)qc * x->dim * sizeof(float)));
+    // query block, padded with zero rows to the MFMA query tile (<= 256 past the last chunk)
+    HIP_TRY(x, hipMalloc(&x->d_q, ((size_t)qc + 256) * x->dim * sizeof(float)));
     HIP_TRY(x, hipMalloc(&x->d_scores, (size_t)qc * n_pad * sizeof(float)));
     HIP_TRY(x, hipMalloc(&x->d_work, cqs::kWorkWords * sizeof(uint32_t)));
     // work-queue heads must be zero on entry; every search re-zeroes them
@@ -137,6 +138,13 @@ uint32_t max_query_block(const cqs_hip_index* x) {
 // Enqueue scan + select for queries already on the device.  Caller holds mu.
 int32_t enqueue_search(cqs_hip_index* x, const float* d_q, uint32_t b, uint32_t k, const uint32_t* d_keep,
                        uint32_t mode, float thr, uint64_t* d_out_keys, uint32_t* d_out_counts, hipStream_t st) {
+    if (cqs::use_mfma(b, x->dim)) {
+        // the matrix-core path reads whole query tiles: stage the block in d_q with a zero tail
+        const size_t qbytes = (size_t)b * x->dim * sizeof(float);
+        if (d_q != x->d_q) HIP_TRY(x, hipMemcpyAsync(x->d_q, d_q, qbytes, hipMemcpyDeviceToDevice, st));
+        HIP_TRY(x, hipMemsetAsync((char*)x->d_q + qbytes, 0, (size_t)256 * x->dim * sizeof(float), st));
+        d_q = x->d_q;
+    }
     cqs::ScanArgs a;
     a.rows = x->d_rows;
     a.n = (uint32_t)x->n;

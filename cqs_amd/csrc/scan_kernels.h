@@ -46,6 +46,13 @@ hipError_t launch_scan(const ScanArgs& a, hipStream_t stream);
 hipError_t launch_select(const ScanArgs& a, uint32_t row_base, uint64_t* out_keys, uint32_t* out_counts,
                          hipStream_t stream);
 
+// Batched path (scan_mfma.hip): query block [q0, q0+nq), nq <= 256, on the f32 matrix cores.
+// a.q must be readable and zero-padded up to mfma_query_tile(nq) rows past q0.
+hipError_t launch_scan_mfma(const ScanArgs& a, uint32_t q0, uint32_t nq, uint32_t work_slot, hipStream_t stream);
+uint32_t mfma_query_tile(uint32_t nq);
+constexpr uint32_t kMfmaMinQueries = 9;   // below this the HBM-streaming gemv passes win
+inline bool use_mfma(uint32_t b, uint32_t dim) { return b >= kMfmaMinQueries && dim % 32u == 0; }
+
 bool scan_dim_supported(uint32_t dim);
 
 }  // namespace cqs

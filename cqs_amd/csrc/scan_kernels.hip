@@ -594,6 +594,20 @@ static hipError_t launch_gemv_groups(const ScanArgs& a, hipStream_t st) {
 
 hipError_t launch_scan(const ScanArgs& a, hipStream_t st) {
     if (a.b == 0 || a.n == 0) return hipSuccess;
+    if (use_mfma(a.b, a.dim)) {
+        uint32_t slot = 0;
+        for (uint32_t q0 = 0; q0 < a.b; q0 += 256u) {
+            const uint32_t nq = (a.b - q0) < 256u ? (a.b - q0) : 256u;
+            hipError_t e = launch_scan_mfma(a, q0, nq, slot, st);
+            if (e != hipSuccess) return e;
+            slot = (slot + 1u) % kWorkWords;
+            if (slot == 0 && q0 + 256u < a.b) {
+                e = hipMemsetAsync(a.work, 0, kWorkWords * sizeof(uint32_t), st);
+                if (e != hipSuccess) return e;
+            }
+        }
+        return hipSuccess;
+    }
     const uint32_t nch = (a.dim + 255u) / 256u;
     switch (nch) {
         case 1: return launch_gemv_groups<1>(a, st);

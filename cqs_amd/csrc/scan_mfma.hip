@@ -1,0 +1,232 @@
+// scan_mfma.hip — batched scan: scores[q][row] for a block of 16..256 queries on the
+// gfx950 matrix cores with exact-f32 MFMA (v_mfma_f32_32x32x2_f32: f32 in, f32 accumulate,
+// bit-for-bit a k-ordered fmaf chain; 157 TF peak = the f32 vector rate).
+//
+// Reference counterpart: none in cqs itself (it scores one query per `VectorIndex::search`,
+// src/index.rs:146); BASELINE.json configs[2] asks for "batch-256 query, LDS-tiled batched dot
+// + per-query top-k".  Same outputs as scan_gemv_kernel: score rows (dropped = -inf) and one
+// maximum per 64-row group; select_finish_kernel then takes the top k per query.
+//
+// Tiling (one workgroup = 4 waves = 1 per SIMD, 1 workgroup per CU, persistent + work queue):
+//   workgroup tile  QT queries x RT corpus rows, K staged BK = 32 floats at a time
+//   LDS             sQ[2][QT][36] + sR[2][RT][36] f32 (rows padded 32 -> 36 floats: the
+//                   ds_read_b128 fragment reads of 16 consecutive rows hit 16 distinct
+//                   4-bank slots -> conflict-free), double buffered, register staged
+//                   (global_load_dwordx4 issued before the MFMA phase, ds_write_b128 after it)
+//   wave tile       QW x RW MFMA tiles of 32x32 (acc = QW*RW*16 VGPRs)
+//   MFMA operands   A = queries (i), B = corpus rows (j): lane l feeds A[i=l&31][k] and
+//                   B[k][j=l&31] with k = 8*kg + 4*(l>>5) + c for the c-th of 4 MFMAs of a
+//                   k-group - one ds_read_b128 per operand tile per 4 MFMAs.  Any k labelling
+//                   is valid as long as A and B agree; this one makes both reads 16-B wide.
+//   C layout        lane&31 = corpus row (so a score store is 128 B contiguous per register),
+//                   register r <-> query (r&3) + 8*(r>>2) + 4*(lane>>5).
+// Roofline: compute.  flops = 2*B*n*dim per batch (393 GFLOP at 256 x 1M x 768) against the
+// 157.3 TF f32-MFMA peak; HBM traffic = corpus once + B*n*4 B of scores.
+#include "scan_kernels.h"
+
+namespace cqs {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+
+constexpr int kBK = 32;    // K floats per LDS stage
+constexpr int kLDK = 36;   // padded LDS row stride in floats (144 B)
+
+struct MfmaParams {
+    const float* rows;
+    uint32_t n, n_pad, dim;
+    const float* q;      // [QT, dim] f32 (padded with zero rows up to QT)
+    uint32_t b;          // live queries (<= QT)
+    float* scores;       // [b, n_pad]
+    float* gmax;         // [b, n_pad/64]
+    const uint32_t* keep;
+    uint32_t mode;
+    float thr;
+    uint32_t* work;
+    uint32_t n_tasks;    // n_pad / RT
+};
+
+template <int QW, int WQ, int RW, int WR, bool NT>
+__global__ __launch_bounds__(256, 1) void scan_mfma_kernel(const MfmaParams p) {
+    constexpr int QT = 32 * QW * WQ, RT = 32 * RW * WR;
+    static_assert(WQ * WR == 4, "4 waves per workgroup");
+    static_assert(RT % 64 == 0, "row tile covers whole 64-row groups");
+    constexpr int NF4 = (QT + RT) * (kBK / 4);   // float4 per stage
+    constexpr int PER_T = NF4 / 256;             // float4 per thread per stage
+    static_assert(NF4 % 256 == 0, "stage divides over the workgroup");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sQ = smem;                            // [2][QT][kLDK]
+    float* sR = smem + 2 * QT * kLDK;            // [2][RT][kLDK]
+    __shared__ uint32_t s_task;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wq = wid / WR, wr = wid % WR;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const uint32_t dim = p.dim, n = p.n;
+    const uint32_t stages = dim / kBK;
+    const uint32_t last_row = n - 1u;
+
+    // staging map: float4 f of a stage -> (tile row, 16-B column); consecutive threads read
+    // consecutive 16 B of one row: a full 128-B line per row per stage
+    uint32_t st_row[PER_T], st_c4[PER_T];
+#pragma unroll
+    for (int u = 0; u < PER_T; ++u) {
+        const uint32_t f = (uint32_t)u * 256u + (uint32_t)tid;
+        st_row[u] = f >> 3;
+        st_c4[u] = f & 7u;
+    }
+
+    for (;;) {
+        if (tid == 0) s_task = atomicAdd(p.work, 1u);
+        __syncthreads();
+        const uint32_t task = s_task;
+        __syncthreads();
+        if (task >= p.n_tasks) break;
+        const uint32_t row0 = task * (uint32_t)RT;
+
+        // global source pointers of this thread's staging slots (rows clamped inside the corpus)
+        const float* src[PER_T];
+#pragma unroll
+        for (int u = 0; u < PER_T; ++u) {
+            if (st_row[u] < (uint32_t)QT) {
+                src[u] = p.q + (size_t)st_row[u] * dim + st_c4[u] * 4u;
+            } else {
+                uint32_t r = row0 + (st_row[u] - (uint32_t)QT);
+                r = r > last_row ? last_row : r;
+                src[u] = p.rows + (size_t)r * dim + st_c4[u] * 4u;
+            }
+        }
+        auto stage_load = [&](uint32_t s, f4 (&reg)[PER_T]) {
+#pragma unroll
+            for (int u = 0; u < PER_T; ++u) {
+                const float* a = src[u] + (size_t)s * kBK;
+                if (NT && st_row[u] >= (uint32_t)QT) reg[u] = __builtin_nontemporal_load((const f4*)a);
+                else reg[u] = *(const f4*)a;
+            }
+        };
+        auto stage_write = [&](int buf, const f4 (&reg)[PER_T]) {
+#pragma unroll
+            for (int u = 0; u < PER_T; ++u) {
+                float* dst = (st_row[u] < (uint32_t)QT)
+                                 ? sQ + ((size_t)buf * QT + st_row[u]) * kLDK + st_c4[u] * 4u
+                                 : sR + ((size_t)buf * RT + (st_row[u] - (uint32_t)QT)) * kLDK + st_c4[u] * 4u;
+                *(f4*)dst = reg[u];
+            }
+        };
+
+        f16v acc[QW][RW];
+#pragma unroll
+        for (int a = 0; a < QW; ++a)
+#pragma unroll
+            for (int b = 0; b < RW; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+        f4 reg[PER_T];
+        stage_load(0, reg);
+        stage_write(0, reg);
+        __syncthreads();
+        for (uint32_t s = 0; s < stages; ++s) {
+            const int buf = (int)(s & 1u);
+            if (s + 1u < stages) stage_load(s + 1u, reg);  // in flight under the MFMA phase
+            const float* aQ = sQ + ((size_t)buf * QT + (size_t)(wq * QW) * 32 + l31) * kLDK + 4 * lh;
+            const float* aR = sR + ((size_t)buf * RT + (size_t)(wr * RW) * 32 + l31) * kLDK + 4 * lh;
+#pragma unroll
+            for (int kg = 0; kg < kBK / 8; ++kg) {
+                f4 af[QW], bf[RW];
+#pragma unroll
+                for (int a = 0; a < QW; ++a) af[a] = *(const f4*)(aQ + (size_t)a * 32 * kLDK + kg * 8);
+#pragma unroll
+                for (int b = 0; b < RW; ++b) bf[b] = *(const f4*)(aR + (size_t)b * 32 * kLDK + kg * 8);
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int a = 0; a < QW; ++a)
+#pragma unroll
+                        for (int b = 0; b < RW; ++b)
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a][c], bf[b][c], acc[a][b], 0, 0, 0);
+            }
+            if (s + 1u < stages) stage_write(buf ^ 1, reg);
+            __syncthreads();
+        }
+
+        // ---- epilogue: lane&31 <-> corpus row, register <-> query ----
+        const uint32_t nwords = (n + 31u) / 32u;
+        const uint32_t gpt = (uint32_t)RT / 64u;  // 64-row groups per tile
+#pragma unroll
+        for (int b = 0; b < RW; ++b) {
+            const uint32_t row = row0 + (uint32_t)((wr * RW + b) * 32 + l31);
+            bool live = row < n;
+            if (p.keep && live) {
+                const uint32_t w = row >> 5;
+                live = w < nwords && ((p.keep[w] >> (row & 31u)) & 1u);
+            }
+#pragma unroll
+            for (int a = 0; a < QW; ++a) {
+                // 32-bit element offsets from the uniform base keep one VGPR per store address
+                const uint32_t q_lo = (uint32_t)((wq * QW + a) * 32 + 4 * lh);
+                const uint32_t off0 = q_lo * p.n_pad + row;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const uint32_t dq = (uint32_t)((r & 3) + 8 * (r >> 2));
+                    float s = acc[a][b][r];
+                    if (!live || !(__builtin_fabsf(s) <= 3.4028234664e38f)) s = -INFINITY;
+                    else if (p.mode == 1u) {
+                        s = s < 0.f ? 0.f : (s > 1.f ? 1.f : s);
+                        if (!(s >= p.thr)) s = -INFINITY;
+                    }
+                    acc[a][b][r] = s;
+                    if (q_lo + dq < p.b) p.scores[off0 + dq * p.n_pad] = s;
+                }
+            }
+        }
+        // group maxima: a 64-row group = two adjacent 32-row MFMA tiles of this wave
+#pragma unroll
+        for (int g = 0; g < RW / 2; ++g)
+#pragma unroll
+            for (int a = 0; a < QW; ++a)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float m = fmaxf(acc[a][2 * g][r], acc[a][2 * g + 1][r]);
+#pragma unroll
+                    for (int off = 16; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+                    const uint32_t qi = (uint32_t)((wq * QW + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh);
+                    if (l31 == 0 && qi < p.b)
+                        p.gmax[qi * (p.n_pad / 64u) + task * gpt + (uint32_t)(wr * (RW / 2) + g)] = m;
+                }
+    }
+}
+
+template <int QW, int WQ, int RW, int WR>
+static hipError_t launch_mfma_cfg(const ScanArgs& a, uint32_t q0, uint32_t nq, uint32_t slot, hipStream_t st) {
+    constexpr int QT = 32 * QW * WQ, RT = 32 * RW * WR;
+    MfmaParams p;
+    p.rows = a.rows; p.n = a.n; p.n_pad = a.n_pad; p.dim = a.dim;
+    p.q = a.q + (size_t)q0 * a.dim;
+    p.b = nq;
+    p.scores = a.scores + (size_t)q0 * a.n_pad;
+    p.gmax = a.gmax + (size_t)q0 * (a.n_pad / kTaskRows);
+    p.keep = a.keep; p.mode = a.mode; p.thr = a.threshold;
+    p.work = a.work + slot;
+    p.n_tasks = a.n_pad / (uint32_t)RT;
+    const size_t lds = (size_t)2 * (QT + RT) * kLDK * sizeof(float);
+    uint32_t blocks = a.n_cu < p.n_tasks ? a.n_cu : p.n_tasks;
+    auto kern = a.nontemporal ? scan_mfma_kernel<QW, WQ, RW, WR, true> : scan_mfma_kernel<QW, WQ, RW, WR, false>;
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, st, p);
+    return hipGetLastError();
+}
+
+// Query block [q0, q0+nq) (nq <= 256) through the MFMA kernel.  a.q must be readable (zero
+// padded) up to the next multiple of the chosen query tile.
+hipError_t launch_scan_mfma(const ScanArgs& a, uint32_t q0, uint32_t nq, uint32_t slot, hipStream_t st) {
+    if (nq > 128) return launch_mfma_cfg<2, 4, 4, 1>(a, q0, nq, slot, st);   // 256 q x 128 rows
+    if (nq > 64) return launch_mfma_cfg<2, 2, 2, 2>(a, q0, nq, slot, st);    // 128 q x 128 rows
+    if (nq > 32) return launch_mfma_cfg<2, 1, 2, 4>(a, q0, nq, slot, st);    //  64 q x 256 rows
+    return launch_mfma_cfg<1, 1, 2, 4>(a, q0, nq, slot, st);                 //  32 q x 256 rows
+}
+
+uint32_t mfma_query_tile(uint32_t nq) { return nq > 128 ? 256u : (nq > 64 ? 128u : (nq > 32 ? 64u : 32u)); }
+
+}  // namespace cqs

@@ -229,6 +229,51 @@ def test_query_blocks_match_single(hip, oracle, b):
     idx.close()
 
 
+@pytest.mark.parametrize("b,n,dim,k", [(16, 5000, 768, 20), (64, 9000, 768, 20), (100, 4097, 768, 50),
+                                       (256, 20000, 768, 20), (300, 3000, 768, 20), (40, 2000, 384, 10),
+                                       (32, 2500, 1024, 10), (24, 1500, 100, 10)])
+def test_batched_matrix_core_path(hip, oracle, b, n, dim, k):
+    """Query blocks >= 9 go through the f32-MFMA kernel (dim % 32 == 0), else the gemv passes;
+    either way every query must match the oracle."""
+    rows = synth.gaussian_unit(n, dim, seed=171 + b)
+    qs = synth.gaussian_unit(b, dim, seed=172 + b)
+    qs[1] = rows[n // 2]          # an exact self-match inside the block
+    idx = HipIndex.build_from_flat(None, rows)
+    check(oracle, idx, rows, qs, k)
+    idx.close()
+
+
+def test_batched_filters_modes_and_edges(hip, oracle):
+    n = 6000
+    rows = synth.gaussian_unit(n, seed=181)
+    rows[17, 5] = NAN
+    rows[n - 1, 0] = INF
+    qs = synth.gaussian_unit(48, seed=182)
+    idx = HipIndex.build_from_flat(None, rows)
+    rng = np.random.default_rng(3)
+    keep = rng.integers(0, 2**32, size=(n + 31) // 32, dtype=np.uint64).astype(np.uint32)
+    check(oracle, idx, rows, qs, 20, keep=keep)
+    check(oracle, idx, rows, qs, 30, mode=_lib.MODE_PIPELINE, thr=0.05)
+    bad = qs.copy(); bad[7, 3] = NAN
+    r, s, c = idx.search_batch(bad, 10)
+    assert c[7] == 0 and all(c[i] == 10 for i in range(48) if i != 7)
+    r0, s0, c0 = idx.search_batch(qs, 10)
+    assert np.array_equal(np.delete(r, 7, 0), np.delete(r0, 7, 0))  # neighbours of a bad query are unaffected
+    idx.close()
+
+
+def test_batched_vs_single_scores_close(hip, oracle):
+    """MFMA (k-ordered fma chain) and gemv (lane-partial sums) round differently: scores agree to 1e-6."""
+    rows = synth.gaussian_unit(8000, seed=191)
+    qs = synth.gaussian_unit(64, seed=192)
+    idx = HipIndex.build_from_flat(None, rows)
+    rb, sb, cb = idx.search_batch(qs, 20)
+    for i in (0, 31, 63):
+        r1, s1, c1 = idx.search_batch(qs[i], 20)
+        assert np.max(np.abs(s1[0] - sb[i])) < 2e-6
+    idx.close()
+
+
 @pytest.mark.parametrize("dim", [4, 100, 256, 384, 512, 1024, 1536, 2048])
 def test_other_dims(hip, oracle, dim):
     rows = synth.gaussian_unit(1500, dim, seed=131)
