@@ -57,9 +57,33 @@ SIGNATURES = [
     ("cqs_hip_unpack_keys", None, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     ("cqs_hip_merge_keys", C.c_size_t,
      [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p]),
+    ("cqs_hip_embed_config_default", None, [C.c_void_p]),
+    ("cqs_hip_embedder_create", C.c_int32, [C.c_void_p, C.c_int32, _pp(_c_idx)]),
+    ("cqs_hip_embedder_set_tensor", C.c_int32, [_c_idx, C.c_char_p, C.c_void_p, C.c_uint64]),
+    ("cqs_hip_embedder_finalize", C.c_int32, [_c_idx]),
+    ("cqs_hip_embedder_load_dir", C.c_int32, [C.c_char_p, C.c_void_p, C.c_int32, _pp(_c_idx)]),
+    ("cqs_hip_embedder_destroy", None, [_c_idx]),
+    ("cqs_hip_embedder_dim", C.c_uint32, [_c_idx]),
+    ("cqs_hip_embedder_max_seq", C.c_uint32, [_c_idx]),
+    ("cqs_hip_embedder_poisoned", C.c_int32, [_c_idx]),
+    ("cqs_hip_embedder_last_error", C.c_size_t, [_c_idx, C.c_char_p, C.c_size_t]),
+    ("cqs_hip_embed", C.c_int32, [_c_idx, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
+    ("cqs_hip_embed_hidden", C.c_int32, [_c_idx, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
+    ("cqs_hip_embedder_last_ms", C.c_float, [_c_idx]),
     ("cqs_hip_index_set_timing", None, [_c_idx, C.c_int32]),
     ("cqs_hip_index_scan_time", C.c_int32, [_c_idx, _pp(C.c_uint32), _pp(C.c_double)]),
 ]
+
+
+
+class EmbedConfig(C.Structure):
+    """`cqs_hip_embed_config` (include/cqs_hip.h)."""
+    _fields_ = [("vocab_size", C.c_uint32), ("hidden", C.c_uint32), ("layers", C.c_uint32), ("heads", C.c_uint32),
+                ("kv_heads", C.c_uint32), ("head_dim", C.c_uint32), ("intermediate", C.c_uint32),
+                ("dense_hidden", C.c_uint32), ("sliding_window", C.c_uint32), ("sliding_pattern", C.c_uint32),
+                ("max_seq", C.c_uint32), ("rms_eps", C.c_float), ("rope_theta_global", C.c_float),
+                ("rope_theta_local", C.c_float), ("query_pre_attn_scalar", C.c_float)]
+
 
 _lib = None
 

@@ -1,0 +1,66 @@
+// embed_kernels.h — launch interface of the gfx950 EmbeddingGemma forward kernels.
+// Internal to libcqs_hip.so (public boundary: include/cqs_hip.h, embed section).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace cqs {
+
+typedef __bf16 bf16_t;
+
+// Model geometry (Gemma3 text encoder + sentence-transformers head); see
+// oracle/gemma3_ref.py for the semantics each field drives.
+struct EmbedGeom {
+    uint32_t vocab, hidden, layers, heads, kv_heads, head_dim, inter, dense_hidden;
+    uint32_t window;          // bidirectional sliding window: |q - k| < window (config window // 2 + 1)
+    uint32_t sliding_pattern; // layer i is full attention iff (i + 1) % pattern == 0
+    uint32_t max_seq;
+    float rms_eps, theta_global, theta_local, q_scale;  // q_scale = query_pre_attn_scalar^-0.5
+};
+
+// x[m] = emb[tok[m]] * scale (f32 residual stream); xn[m] = bf16(rmsnorm(x[m]) * (1 + w_in))
+hipError_t launch_embed_norm(const int32_t* tok, const bf16_t* emb, float scale, const float* w_in, float eps,
+                             float* x, bf16_t* xn, uint32_t M, uint32_t H, hipStream_t st);
+
+// x[m] += rmsnorm(y[m]) * (1 + w_post); then the next pre-norm of the new x:
+//   final == 0: xn[m]  = bf16(rmsnorm(x[m]) * (1 + w_next))
+//   final == 1: out[m] = f32 (rmsnorm(x[m]) * (1 + w_next))      (the model's final norm)
+hipError_t launch_add_norm(float* x, const float* y, const float* w_post, const float* w_next, float eps,
+                           bf16_t* xn, float* out, int final, uint32_t M, uint32_t H, hipStream_t st);
+
+// C[M,N] = A[M,K] (bf16, row-major) x W[N,K]^T (bf16, row-major), f32 accumulate on the matrix cores.
+//   GEMM_OUT_BF16 : C bf16 [M, ldc]
+//   GEMM_OUT_F32  : C f32  [M, ldc]
+//   GEMM_OUT_GEGLU: W rows are interleaved per 64: 32 gate rows then the 32 up rows of the same
+//                   channels; C bf16 [M, ldc] gets N/2 columns = gelu_tanh(gate) * up
+// Requires N % 128 == 0, K % 64 == 0.
+enum GemmOut { GEMM_OUT_BF16 = 0, GEMM_OUT_F32 = 1, GEMM_OUT_GEGLU = 2 };
+hipError_t launch_gemm_bf16(const bf16_t* A, const bf16_t* W, void* C, uint32_t M, uint32_t N, uint32_t K,
+                            uint32_t ldc, GemmOut out, hipStream_t st);
+
+// In place on qkv [M, (heads + 2 kv) * 256] bf16: per-head RMSNorm * (1 + w), RoPE from the
+// cos/sin table of the layer type, q additionally scaled by q_scale.  pos[m] = position in sequence.
+hipError_t launch_qk_norm_rope(bf16_t* qkv, const int32_t* pos, const float* wq, const float* wk,
+                               const float* cos_sin /*[max_seq][128][2]*/, float eps, float q_scale,
+                               uint32_t M, uint32_t heads, uint32_t kv_heads, hipStream_t st);
+
+// vt[g][d][vt_col(m)] = v[m][g][d]  (keys contiguous per head dim: the A operand of O^T = V^T P^T)
+hipError_t launch_v_transpose(const bf16_t* qkv, bf16_t* vt, const int32_t* vt_col, uint32_t M, uint32_t heads,
+                              uint32_t kv_heads, uint32_t vt_ld, hipStream_t st);
+
+// Bidirectional (optionally windowed) attention over packed sequences.
+// blk[i] = {sequence, 32-row query block}; seq_start/seq_len in packed tokens; vt_start = first
+// V^T column of the sequence (multiple of 32).  out [M, heads*256] bf16.
+hipError_t launch_attention(const bf16_t* qkv, const bf16_t* vt, bf16_t* out, const int32_t* blk /*[nblk][2]*/,
+                            uint32_t nblk, const int32_t* seq_start, const int32_t* seq_len,
+                            const int32_t* vt_start, uint32_t vt_ld, uint32_t heads, uint32_t kv_heads,
+                            uint32_t window /*0 = full*/, hipStream_t st);
+
+// pooled[b] = bf16(mean over the sequence's tokens of hidden[m]) (masked mean pool)
+hipError_t launch_mean_pool(const float* hidden, const int32_t* seq_start, const int32_t* seq_len, bf16_t* pooled,
+                            uint32_t B, uint32_t H, hipStream_t st);
+
+// f32 -> bf16 (round to nearest even), n elements
+hipError_t launch_f32_to_bf16(const float* in, bf16_t* out, size_t n, hipStream_t st);
+
+}  // namespace cqs

@@ -1,0 +1,575 @@
+// embed_kernels.hip — gfx950 kernels of the EmbeddingGemma-300m forward (Gemma3 text encoder,
+// bidirectional, + sentence-transformers pooling/dense head).  Replaces the ONNX Runtime
+// `session.run` of the reference (src/embedder/core.rs:1097; graph described in SURVEY.md
+// §8a row A20).  Semantics follow oracle/gemma3_ref.py (which is pinned to transformers'
+// Gemma3TextModel); bf16 operands on the matrix cores, f32 accumulation, f32 residual stream.
+//
+// Tokens are PACKED: padding never reaches a kernel (the reference pads every sequence to the
+// longest of the batch, src/embedder/core.rs:1020-1035, and ORT computes on the pad).
+#include "embed_kernels.h"
+
+namespace cqs {
+
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+
+constexpr int kHD = 256;  // head_dim the attention / rope kernels are specialised for
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// ---- row kernels: one wave per token row, lane owns 4 consecutive floats of each 256-chunk ----
+template <int NCH>
+__global__ __launch_bounds__(256) void embed_norm_kernel(const int32_t* __restrict__ tok,
+                                                         const bf16_t* __restrict__ emb, float scale,
+                                                         const float* __restrict__ w_in, float eps,
+                                                         float* __restrict__ x, bf16_t* __restrict__ xn, uint32_t M) {
+    constexpr uint32_t H = NCH * 256;
+    const int lane = threadIdx.x & 63;
+    const uint32_t row = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const size_t src = (size_t)tok[row] * H;
+    float v[NCH][4];
+    float ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const uint32_t col = (uint32_t)c * 256u + (uint32_t)lane * 4u;
+        const bf4 e = *(const bf4*)(emb + src + col);
+        f4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[c][i] = (float)e[i] * scale;
+            o[i] = v[c][i];
+            ss += v[c][i] * v[c][i];
+        }
+        *(f4*)(x + (size_t)row * H + col) = o;
+    }
+    const float inv = rsqrtf(wave_sum(ss) / (float)H + eps);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const uint32_t col = (uint32_t)c * 256u + (uint32_t)lane * 4u;
+        const f4 w = *(const f4*)(w_in + col);
+        bf4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = (bf16_t)(v[c][i] * inv * (1.0f + w[i]));
+        *(bf4*)(xn + (size_t)row * H + col) = o;
+    }
+}
+
+template <int NCH, int FINAL>
+__global__ __launch_bounds__(256) void add_norm_kernel(float* __restrict__ x, const float* __restrict__ y,
+                                                       const float* __restrict__ w_post,
+                                                       const float* __restrict__ w_next, float eps,
+                                                       bf16_t* __restrict__ xn, float* __restrict__ out, uint32_t M) {
+    constexpr uint32_t H = NCH * 256;
+    const int lane = threadIdx.x & 63;
+    const uint32_t row = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (row >= M) return;
+    f4 yv[NCH], xv[NCH];
+    float ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const uint32_t col = (uint32_t)c * 256u + (uint32_t)lane * 4u;
+        yv[c] = *(const f4*)(y + (size_t)row * H + col);
+        xv[c] = *(const f4*)(x + (size_t)row * H + col);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ss += yv[c][i] * yv[c][i];
+    }
+    const float invy = rsqrtf(wave_sum(ss) / (float)H + eps);
+    float sx = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const uint32_t col = (uint32_t)c * 256u + (uint32_t)lane * 4u;
+        const f4 w = *(const f4*)(w_post + col);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            xv[c][i] += yv[c][i] * invy * (1.0f + w[i]);
+            sx += xv[c][i] * xv[c][i];
+        }
+        *(f4*)(x + (size_t)row * H + col) = xv[c];
+    }
+    const float invx = rsqrtf(wave_sum(sx) / (float)H + eps);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const uint32_t col = (uint32_t)c * 256u + (uint32_t)lane * 4u;
+        const f4 w = *(const f4*)(w_next + col);
+        if (FINAL) {
+            f4 o;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = xv[c][i] * invx * (1.0f + w[i]);
+            *(f4*)(out + (size_t)row * H + col) = o;
+        } else {
+            bf4 o;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = (bf16_t)(xv[c][i] * invx * (1.0f + w[i]));
+            *(bf4*)(xn + (size_t)row * H + col) = o;
+        }
+    }
+}
+
+// ---- q/k RMSNorm + RoPE, in place; one wave per (token, head); lane owns dims [4l, 4l+4) ----
+__global__ __launch_bounds__(256) void qk_norm_rope_kernel(bf16_t* __restrict__ qkv, const int32_t* __restrict__ pos,
+                                                           const float* __restrict__ wq, const float* __restrict__ wk,
+                                                           const float* __restrict__ cos_sin, float eps, float q_scale,
+                                                           uint32_t M, uint32_t heads, uint32_t kv_heads) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t nh = heads + kv_heads;
+    const uint32_t wv = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (wv >= M * nh) return;
+    const uint32_t m = wv / nh, h = wv % nh;
+    const uint32_t ld = (heads + 2u * kv_heads) * kHD;
+    bf16_t* p = qkv + (size_t)m * ld + (size_t)h * kHD + lane * 4;
+    const bool is_q = h < heads;
+    const float* w = (is_q ? wq : wk) + lane * 4;
+    const bf4 in = *(const bf4*)p;
+    float v[4];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        v[i] = (float)in[i];
+        ss += v[i] * v[i];
+    }
+    const float inv = rsqrtf(wave_sum(ss) / (float)kHD + eps);
+    // rotate_half pairs dim d with d +/- 128: the partner lives in lane ^ 32, same element
+    const float* cs = cos_sin + ((size_t)pos[m] * 128u + (uint32_t)(lane & 31) * 4u) * 2u;
+    const f4 cs0 = *(const f4*)cs, cs1 = *(const f4*)(cs + 4);  // (cos,sin) x 4 dims
+    const float c4[4] = {cs0[0], cs0[2], cs1[0], cs1[2]};
+    const float s4[4] = {cs0[1], cs0[3], cs1[1], cs1[3]};
+    bf4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float n = v[i] * inv * (1.0f + w[i]);
+        const float other = __shfl_xor(n, 32, 64);
+        // d < 128: n*cos - x[d+128]*sin ; d >= 128: n*cos + x[d-128]*sin
+        float r = (lane < 32) ? (n * c4[i] - other * s4[i]) : (n * c4[i] + other * s4[i]);
+        if (is_q) r *= q_scale;
+        o[i] = (bf16_t)r;
+    }
+    *(bf4*)p = o;
+}
+
+// ---- V transpose: vt[g][d][vt_col[m]] = v[m][g][d]; block = 64 tokens x 256 dims of one kv head ----
+__global__ __launch_bounds__(256) void v_transpose_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ vt,
+                                                          const int32_t* __restrict__ vt_col, uint32_t M,
+                                                          uint32_t heads, uint32_t kv_heads, uint32_t vt_ld) {
+    __shared__ bf16_t tile[64][kHD + 2];
+    const uint32_t g = blockIdx.y;
+    const uint32_t m0 = blockIdx.x * 64u;
+    const uint32_t ld = (heads + 2u * kv_heads) * kHD;
+    const uint32_t voff = (heads + kv_heads + g) * kHD;
+    for (uint32_t i = threadIdx.x; i < 64u * (kHD / 4); i += 256u) {
+        const uint32_t t = i / (kHD / 4), c = (i % (kHD / 4)) * 4u;
+        bf4 v = (bf4)(0.f);
+        if (m0 + t < M) v = *(const bf4*)(qkv + (size_t)(m0 + t) * ld + voff + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) tile[t][c + e] = v[e];
+    }
+    __syncthreads();
+    // each thread writes one head dim for a run of tokens; tokens of one block map to
+    // consecutive vt columns except across a sequence boundary
+    for (uint32_t i = threadIdx.x; i < 64u * kHD; i += 256u) {
+        const uint32_t d = i / 64u, t = i % 64u;
+        if (m0 + t < M) vt[((size_t)g * kHD + d) * vt_ld + (uint32_t)vt_col[m0 + t]] = tile[t][d];
+    }
+}
+
+// ---- attention --------------------------------------------------------------------------
+// One workgroup = the G q-heads sharing a kv head (one wave each) x one 32-row query block.
+// S^T = K Q^T (keys on rows, queries on lanes: softmax is lane-local), O^T += V^T P^T with the
+// S^T accumulator used directly as the B operand (no LDS round trip for P).
+constexpr int kKStride = kHD + 8;   // K tile row: 256 bf16 + 16 B pad -> ds_read_b128 conflict-free
+constexpr int kVStride = 32 + 4;    // V^T tile row: 32 keys + 8 B pad -> ds_read_b64 conflict-free
+
+template <int G>
+__global__ __launch_bounds__(G * 64, 1) void attention_kernel(const bf16_t* __restrict__ qkv,
+                                                              const bf16_t* __restrict__ vt,
+                                                              bf16_t* __restrict__ out,
+                                                              const int32_t* __restrict__ blk,
+                                                              const int32_t* __restrict__ seq_start,
+                                                              const int32_t* __restrict__ seq_len,
+                                                              const int32_t* __restrict__ vt_start, uint32_t vt_ld,
+                                                              uint32_t heads, uint32_t kv_heads, uint32_t window) {
+    __shared__ __attribute__((aligned(16))) bf16_t sK[32 * kKStride];
+    __shared__ __attribute__((aligned(16))) bf16_t sV[kHD * kVStride];
+    constexpr int T = G * 64;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const uint32_t b = (uint32_t)blk[2 * blockIdx.x], qb = (uint32_t)blk[2 * blockIdx.x + 1];
+    const uint32_t g = blockIdx.y;
+    const uint32_t s0 = (uint32_t)seq_start[b], L = (uint32_t)seq_len[b], v0 = (uint32_t)vt_start[b];
+    const uint32_t ld = (heads + 2u * kv_heads) * kHD;
+    const uint32_t head = g * G + (uint32_t)wid;
+    const uint32_t koff = (heads + g) * kHD;
+
+    // Q^T fragments (B operand of K Q^T): lane feeds Q[q = l31][dims 16s + 8*lh + 0..7]
+    const uint32_t qi = qb * 32u + (uint32_t)l31;             // query index in the sequence
+    const uint32_t qtok = s0 + (qi < L ? qi : L - 1u);
+    bf8 qf[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) qf[s] = *(const bf8*)(qkv + (size_t)qtok * ld + head * kHD + 16 * s + 8 * lh);
+
+    f16v o[8];
+#pragma unroll
+    for (int d = 0; d < 8; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    // key blocks that can hold an attendable key for this query block
+    uint32_t kb_lo = 0, kb_hi = (L + 31u) / 32u;  // [lo, hi)
+    if (window) {
+        const uint32_t qlo = qb * 32u, qhi = qlo + 31u;
+        kb_lo = (qlo + 1u > window) ? (qlo + 1u - window) / 32u : 0u;
+        const uint32_t khi = qhi + window - 1u;   // last attendable key
+        const uint32_t hi2 = khi / 32u + 1u;
+        if (hi2 < kb_hi) kb_hi = hi2;
+    }
+
+    for (uint32_t kb = kb_lo; kb < kb_hi; ++kb) {
+        __syncthreads();  // previous tile fully consumed
+        // K tile: 32 keys x 256 dims (16-B pieces; key rows clamped inside the sequence)
+        for (int i = tid; i < 32 * (kHD / 8); i += T) {
+            const uint32_t kr = (uint32_t)i / (kHD / 8), c = ((uint32_t)i % (kHD / 8)) * 8u;
+            uint32_t key = kb * 32u + kr;
+            key = key < L ? key : L - 1u;
+            *(u4*)(sK + kr * kKStride + c) = *(const u4*)(qkv + (size_t)(s0 + key) * ld + koff + c);
+        }
+        // V^T tile: 256 dims x 32 keys (8-B pieces; columns past the sequence hold stale but finite
+        // values of the padded V^T buffer and meet p = 0)
+        for (int i = tid; i < kHD * 4; i += T) {
+            const uint32_t d = (uint32_t)i / 4u, c = ((uint32_t)i % 4u) * 8u;
+            const u4 v = *(const u4*)(vt + ((size_t)g * kHD + d) * vt_ld + v0 + kb * 32u + c);
+            *(u2*)(sV + d * kVStride + c) = (u2){v[0], v[1]};
+            *(u2*)(sV + d * kVStride + c + 4) = (u2){v[2], v[3]};
+        }
+        __syncthreads();
+
+        // S^T[key][q] = sum_dims K[key][d] * Q[q][d]
+        f16v s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+        for (int st = 0; st < 16; ++st) {
+            const bf8 kf = *(const bf8*)(sK + l31 * kKStride + 16 * st + 8 * lh);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[st], s, 0, 0, 0);
+        }
+        // mask + online softmax; this lane's query is qi, register r <-> key (r&3) + 8(r>>2) + 4*lh
+        float mloc = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const uint32_t key = kb * 32u + (uint32_t)((r & 3) + 8 * (r >> 2) + 4 * lh);
+            bool ok = key < L;
+            if (window) {
+                const uint32_t dist = key > qi ? key - qi : qi - key;
+                ok = ok && dist < window;
+            }
+            s[r] = ok ? s[r] : -INFINITY;
+            mloc = fmaxf(mloc, s[r]);
+        }
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+        const float m_new = fmaxf(m_run, mloc);
+        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;   // no attendable key yet: p = 0, alpha = 1
+        const float alpha = (m_run == -INFINITY) ? ((m_new == -INFINITY) ? 1.f : 0.f) : __expf(m_run - m_use);
+        float lsum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            s[r] = __expf(s[r] - m_use);   // exp(-inf) = 0 for masked keys
+            lsum += s[r];
+        }
+        lsum += __shfl_xor(lsum, 32, 64);
+        l_run = l_run * alpha + lsum;
+        m_run = m_new;
+        if (alpha != 1.f) {
+#pragma unroll
+            for (int d = 0; d < 8; ++d)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+        }
+        // P^T as the B operand: k-step st uses registers 8st..8st+7; slot (lh, j) <-> key
+        // 16st + 8(j>>2) + 4lh + (j&3), which the V^T fragment below matches
+        bf8 pf[2];
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pf[st][j] = (bf16_t)s[8 * st + j];
+#pragma unroll
+        for (int d = 0; d < 8; ++d) {
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                const bf16_t* vp = sV + (d * 32 + l31) * kVStride + 16 * st + 4 * lh;
+                const bf4 v_lo = *(const bf4*)vp;        // keys 16st + 4lh + 0..3
+                const bf4 v_hi = *(const bf4*)(vp + 8);  // keys 16st + 8 + 4lh + 0..3
+                bf8 vf;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    vf[j] = v_lo[j];
+                    vf[4 + j] = v_hi[j];
+                }
+                o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[st], o[d], 0, 0, 0);
+            }
+        }
+    }
+
+    // O^T[d][q]: lane <-> query, register r of tile d <-> dim 32d + (r&3) + 8(r>>2) + 4lh
+    if (qi < L) {
+        const float invl = l_run > 0.f ? 1.0f / l_run : 0.f;
+        bf16_t* op = out + (size_t)(s0 + qi) * (heads * kHD) + head * kHD;
+#pragma unroll
+        for (int d = 0; d < 8; ++d)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                bf4 w;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) w[e] = (bf16_t)(o[d][4 * rg + e] * invl);
+                *(bf4*)(op + 32 * d + 8 * rg + 4 * lh) = w;
+            }
+    }
+}
+
+// ---- GEMM: C[M,N] = A[M,K] W[N,K]^T, 128x128x64 tiles, 4 waves (2x2) of 64x64, 32x32x16 bf16 MFMA ----
+// LDS tile [128 rows][64 k] bf16, 16-B chunk c of row r stored at chunk c ^ ((r >> 1) & 7): the 16
+// rows one ds_read_b128 lane group touches then hit 16 distinct 16-B slots of the 256-B bank row.
+__device__ __forceinline__ uint32_t swz(uint32_t row, uint32_t chunk) { return row * 64u + ((chunk ^ ((row >> 1) & 7u)) * 8u); }
+
+__device__ __forceinline__ float gelu_tanh(float x) {
+    const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+    const float u = k0 * (x + k1 * x * x * x);
+    return 0.5f * x * (1.0f + tanhf(u));
+}
+
+template <int OUT>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
+                                                        void* __restrict__ Cv, uint32_t M, uint32_t N, uint32_t K,
+                                                        uint32_t ldc) {
+    __shared__ __attribute__((aligned(16))) bf16_t sA[128 * 64];
+    __shared__ __attribute__((aligned(16))) bf16_t sB[128 * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int wm = wid >> 1, wn = wid & 1;
+
+    // XCD-aware tile order: workgroups b and b+8 share an XCD (round-robin dispatch); give each XCD
+    // a contiguous run of tiles (n fastest) so the tiles sharing an A panel meet in one L2.
+    const uint32_t nt = N / 128u, mt = (M + 127u) / 128u, total = nt * mt;
+    const uint32_t bid = blockIdx.x, xcd = bid % 8u, q = total / 8u, r = total % 8u;
+    const uint32_t tile = (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + bid / 8u;
+    const uint32_t m0 = (tile / nt) * 128u, n0 = (tile % nt) * 128u;
+
+    // staging: 4 x 16 B per thread per operand; chunk f -> (row f>>3, 16-B column f&7)
+    const bf16_t* ga[4];
+    const bf16_t* gb[4];
+    uint32_t lo[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const uint32_t f = (uint32_t)u * 256u + (uint32_t)tid, row = f >> 3, c = f & 7u;
+        uint32_t ar = m0 + row;
+        ar = ar < M ? ar : M - 1u;
+        ga[u] = A + (size_t)ar * K + c * 8u;
+        gb[u] = W + (size_t)(n0 + row) * K + c * 8u;
+        lo[u] = swz(row, c);
+    }
+    f16v acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    u4 ra[4], rb[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        ra[u] = *(const u4*)ga[u];
+        rb[u] = *(const u4*)gb[u];
+    }
+    const uint32_t nk = K / 64u;
+    for (uint32_t kt = 0; kt < nk; ++kt) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            *(u4*)(sA + lo[u]) = ra[u];
+            *(u4*)(sB + lo[u]) = rb[u];
+        }
+        __syncthreads();
+        if (kt + 1u < nk) {  // next tile's global loads fly under this tile's MFMAs
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                ra[u] = *(const u4*)(ga[u] + (size_t)(kt + 1u) * 64u);
+                rb[u] = *(const u4*)(gb[u] + (size_t)(kt + 1u) * 64u);
+            }
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf8 af[2], bfr[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const uint32_t row = (uint32_t)(wm * 64 + i * 32 + l31);
+                af[i] = *(const bf8*)(sA + swz(row, (uint32_t)(2 * ks + lh)));
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const uint32_t row = (uint32_t)(wn * 64 + j * 32 + l31);
+                bfr[j] = *(const bf8*)(sB + swz(row, (uint32_t)(2 * ks + lh)));
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // epilogue: C tile element (row = (e&3) + 8(e>>2) + 4lh, col = l31) of acc[i][j]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const uint32_t row = m0 + (uint32_t)(wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh);
+            if (row >= M) continue;
+            if (OUT == GEMM_OUT_GEGLU) {
+                // this wave's 64 columns = 32 gate channels (j = 0) + the same 32 channels' up (j = 1)
+                const uint32_t ch = (n0 + (uint32_t)(wn * 64)) / 2u + (uint32_t)l31;
+                const float v = gelu_tanh(acc[i][0][e]) * acc[i][1][e];
+                ((bf16_t*)Cv)[(size_t)row * ldc + ch] = (bf16_t)v;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const uint32_t col = n0 + (uint32_t)(wn * 64 + j * 32 + l31);
+                    if (OUT == GEMM_OUT_F32) ((float*)Cv)[(size_t)row * ldc + col] = acc[i][j][e];
+                    else ((bf16_t*)Cv)[(size_t)row * ldc + col] = (bf16_t)acc[i][j][e];
+                }
+            }
+        }
+}
+
+// ---- masked mean pool: one block per sequence, thread per 4 hidden dims ----
+__global__ __launch_bounds__(256) void mean_pool_kernel(const float* __restrict__ hidden,
+                                                        const int32_t* __restrict__ seq_start,
+                                                        const int32_t* __restrict__ seq_len,
+                                                        bf16_t* __restrict__ pooled, uint32_t H) {
+    const uint32_t b = blockIdx.x;
+    const uint32_t s0 = (uint32_t)seq_start[b], L = (uint32_t)seq_len[b];
+    for (uint32_t col = threadIdx.x * 4u; col < H; col += 1024u) {
+        f4 acc = (f4)(0.f);
+        for (uint32_t t = 0; t < L; ++t) acc += *(const f4*)(hidden + (size_t)(s0 + t) * H + col);
+        const float inv = L ? 1.0f / (float)L : 0.f;   // zero mask -> zero vector (src/embedder/pooling.rs:113-119)
+        bf4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = (bf16_t)(acc[i] * inv);
+        *(bf4*)(pooled + (size_t)b * H + col) = o;
+    }
+}
+
+__global__ void f32_to_bf16_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        out[i] = (bf16_t)in[i];
+}
+
+// ---- launchers ---------------------------------------------------------------------------
+hipError_t launch_embed_norm(const int32_t* tok, const bf16_t* emb, float scale, const float* w_in, float eps,
+                             float* x, bf16_t* xn, uint32_t M, uint32_t H, hipStream_t st) {
+    if (M == 0) return hipSuccess;
+    const dim3 grid((M + 3u) / 4u), block(256);
+    switch (H / 256u) {
+        case 1: hipLaunchKernelGGL(embed_norm_kernel<1>, grid, block, 0, st, tok, emb, scale, w_in, eps, x, xn, M); break;
+        case 2: hipLaunchKernelGGL(embed_norm_kernel<2>, grid, block, 0, st, tok, emb, scale, w_in, eps, x, xn, M); break;
+        case 3: hipLaunchKernelGGL(embed_norm_kernel<3>, grid, block, 0, st, tok, emb, scale, w_in, eps, x, xn, M); break;
+        case 4: hipLaunchKernelGGL(embed_norm_kernel<4>, grid, block, 0, st, tok, emb, scale, w_in, eps, x, xn, M); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+template <int FINAL>
+static hipError_t launch_add_norm_t(float* x, const float* y, const float* w_post, const float* w_next, float eps,
+                                    bf16_t* xn, float* out, uint32_t M, uint32_t H, hipStream_t st) {
+    const dim3 grid((M + 3u) / 4u), block(256);
+    switch (H / 256u) {
+        case 1: hipLaunchKernelGGL((add_norm_kernel<1, FINAL>), grid, block, 0, st, x, y, w_post, w_next, eps, xn, out, M); break;
+        case 2: hipLaunchKernelGGL((add_norm_kernel<2, FINAL>), grid, block, 0, st, x, y, w_post, w_next, eps, xn, out, M); break;
+        case 3: hipLaunchKernelGGL((add_norm_kernel<3, FINAL>), grid, block, 0, st, x, y, w_post, w_next, eps, xn, out, M); break;
+        case 4: hipLaunchKernelGGL((add_norm_kernel<4, FINAL>), grid, block, 0, st, x, y, w_post, w_next, eps, xn, out, M); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_add_norm(float* x, const float* y, const float* w_post, const float* w_next, float eps,
+                           bf16_t* xn, float* out, int final, uint32_t M, uint32_t H, hipStream_t st) {
+    if (M == 0) return hipSuccess;
+    return final ? launch_add_norm_t<1>(x, y, w_post, w_next, eps, xn, out, M, H, st)
+                 : launch_add_norm_t<0>(x, y, w_post, w_next, eps, xn, out, M, H, st);
+}
+
+hipError_t launch_gemm_bf16(const bf16_t* A, const bf16_t* W, void* C, uint32_t M, uint32_t N, uint32_t K,
+                            uint32_t ldc, GemmOut out, hipStream_t st) {
+    if (M == 0) return hipSuccess;
+    if (N % 128u || K % 64u) return hipErrorInvalidValue;
+    const dim3 grid((N / 128u) * ((M + 127u) / 128u)), block(256);
+    switch (out) {
+        case GEMM_OUT_BF16: hipLaunchKernelGGL(gemm_bf16_kernel<GEMM_OUT_BF16>, grid, block, 0, st, A, W, C, M, N, K, ldc); break;
+        case GEMM_OUT_F32: hipLaunchKernelGGL(gemm_bf16_kernel<GEMM_OUT_F32>, grid, block, 0, st, A, W, C, M, N, K, ldc); break;
+        case GEMM_OUT_GEGLU: hipLaunchKernelGGL(gemm_bf16_kernel<GEMM_OUT_GEGLU>, grid, block, 0, st, A, W, C, M, N, K, ldc); break;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_qk_norm_rope(bf16_t* qkv, const int32_t* pos, const float* wq, const float* wk,
+                               const float* cos_sin, float eps, float q_scale, uint32_t M, uint32_t heads,
+                               uint32_t kv_heads, hipStream_t st) {
+    if (M == 0) return hipSuccess;
+    const uint32_t waves = M * (heads + kv_heads);
+    hipLaunchKernelGGL(qk_norm_rope_kernel, dim3((waves + 3u) / 4u), dim3(256), 0, st, qkv, pos, wq, wk, cos_sin, eps,
+                       q_scale, M, heads, kv_heads);
+    return hipGetLastError();
+}
+
+hipError_t launch_v_transpose(const bf16_t* qkv, bf16_t* vt, const int32_t* vt_col, uint32_t M, uint32_t heads,
+                              uint32_t kv_heads, uint32_t vt_ld, hipStream_t st) {
+    if (M == 0) return hipSuccess;
+    hipLaunchKernelGGL(v_transpose_kernel, dim3((M + 63u) / 64u, kv_heads), dim3(256), 0, st, qkv, vt, vt_col, M, heads,
+                       kv_heads, vt_ld);
+    return hipGetLastError();
+}
+
+hipError_t launch_attention(const bf16_t* qkv, const bf16_t* vt, bf16_t* out, const int32_t* blk, uint32_t nblk,
+                            const int32_t* seq_start, const int32_t* seq_len, const int32_t* vt_start, uint32_t vt_ld,
+                            uint32_t heads, uint32_t kv_heads, uint32_t window, hipStream_t st) {
+    if (nblk == 0) return hipSuccess;
+    const uint32_t G = heads / kv_heads;
+    const dim3 grid(nblk, kv_heads);
+#define CQS_ATT(GV) hipLaunchKernelGGL(attention_kernel<GV>, grid, dim3(GV * 64), 0, st, qkv, vt, out, blk, seq_start, \
+                                       seq_len, vt_start, vt_ld, heads, kv_heads, window)
+    switch (G) {
+        case 1: CQS_ATT(1); break;
+        case 2: CQS_ATT(2); break;
+        case 3: CQS_ATT(3); break;
+        case 4: CQS_ATT(4); break;
+        default: return hipErrorInvalidValue;
+    }
+#undef CQS_ATT
+    return hipGetLastError();
+}
+
+hipError_t launch_mean_pool(const float* hidden, const int32_t* seq_start, const int32_t* seq_len, bf16_t* pooled,
+                            uint32_t B, uint32_t H, hipStream_t st) {
+    if (B == 0) return hipSuccess;
+    hipLaunchKernelGGL(mean_pool_kernel, dim3(B), dim3(256), 0, st, hidden, seq_start, seq_len, pooled, H);
+    return hipGetLastError();
+}
+
+hipError_t launch_f32_to_bf16(const float* in, bf16_t* out, size_t n, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((uint32_t)blocks), dim3(256), 0, st, in, out, n);
+    return hipGetLastError();
+}
+
+}  // namespace cqs

@@ -1,0 +1,604 @@
+// embedder.hip — host side of the EmbeddingGemma forward behind the C ABI (include/cqs_hip.h,
+// embed section).  Plays the role of the ORT `Session` inside the reference's `Embedder`
+// (src/embedder/core.rs:34-226, `session.run` at :1097): one engine per device, inference
+// serialised behind a mutex exactly like `Mutex<Option<Session>>` (core.rs:35-39), errors
+// reported as status codes (-> `EmbedderError::InferenceFailed`, src/embedder/mod.rs:36-60).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/cqs_hip.h"
+#include "embed_kernels.h"
+
+using cqs::bf16_t;
+
+namespace {
+
+uint16_t f32_to_bf16_bits(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7F800000u) == 0x7F800000u && (u & 0x007FFFFFu)) return (uint16_t)((u >> 16) | 0x0040u);  // keep NaN a NaN
+    return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+float bf16_bits_to_f32(uint16_t h) {
+    uint32_t u = (uint32_t)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+float f16_bits_to_f32(uint16_t h) {
+    const uint32_t s = (h >> 15) & 1u, e = (h >> 10) & 0x1Fu, m = h & 0x3FFu;
+    uint32_t u;
+    if (e == 0) {
+        if (m == 0) u = s << 31;
+        else {
+            int sh = 0;
+            uint32_t mm = m;
+            while (!(mm & 0x400u)) { mm <<= 1; ++sh; }
+            u = (s << 31) | ((uint32_t)(113 - sh) << 23) | ((mm & 0x3FFu) << 13);
+        }
+    } else if (e == 31) u = (s << 31) | 0x7F800000u | (m << 13);
+    else u = (s << 31) | ((e + 112u) << 23) | (m << 13);
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+struct LayerW {
+    bf16_t *wqkv = nullptr, *wo = nullptr, *wgu = nullptr, *wd = nullptr;
+    float *n_in = nullptr, *n_post_attn = nullptr, *n_pre_ffw = nullptr, *n_post_ffw = nullptr, *n_q = nullptr, *n_k = nullptr;
+};
+
+}  // namespace
+
+struct cqs_hip_embedder {
+    int device = 0;
+    cqs_hip_embed_config cfg{};
+    cqs::EmbedGeom g{};
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    float last_ms = -1.f;
+
+    bf16_t* emb = nullptr;
+    float* n_final = nullptr;
+    bf16_t *dense1 = nullptr, *dense2 = nullptr;
+    std::vector<LayerW> L;
+    float *rope_global = nullptr, *rope_local = nullptr;  // [max_seq][128][2]
+    std::map<std::string, bool> seen;
+    bool finalized = false;
+
+    // scratch, sized for tok_cap packed tokens / seq_cap sequences
+    uint32_t tok_cap = 0, seq_cap = 0, vt_ld = 0, blk_cap = 0;
+    float *x = nullptr, *y = nullptr, *hidden = nullptr, *out = nullptr;
+    bf16_t *xn = nullptr, *qkv = nullptr, *vt = nullptr, *attn = nullptr, *h = nullptr, *pooled = nullptr, *d1 = nullptr;
+    int32_t *d_tok = nullptr, *d_pos = nullptr, *d_vtcol = nullptr, *d_seq_start = nullptr, *d_seq_len = nullptr,
+            *d_vt_start = nullptr, *d_blk = nullptr;
+
+    mutable std::mutex mu;
+    std::atomic<bool> poisoned{false};
+    std::string last_error;
+};
+
+namespace {
+
+int32_t efail(cqs_hip_embedder* e, int32_t code, const std::string& what, hipError_t he = hipSuccess) {
+    std::string msg = what;
+    if (he != hipSuccess) msg += std::string(": ") + hipGetErrorString(he);
+    if (e) {
+        e->last_error = msg;
+        if (code == CQS_HIP_ERR_DEVICE) e->poisoned.store(true, std::memory_order_release);
+    }
+    return code;
+}
+#define E_TRY(e, expr)                                                                                  \
+    do {                                                                                                \
+        hipError_t _h = (expr);                                                                         \
+        if (_h != hipSuccess) return efail((e), _h == hipErrorOutOfMemory ? CQS_HIP_ERR_NOMEM : CQS_HIP_ERR_DEVICE, #expr, _h); \
+    } while (0)
+
+template <class T>
+hipError_t dmalloc(T** p, size_t count) { return hipMalloc((void**)p, count * sizeof(T)); }
+
+uint32_t nqkv(const cqs::EmbedGeom& g) { return (g.heads + 2u * g.kv_heads) * g.head_dim; }
+
+int32_t upload_bf16(cqs_hip_embedder* e, bf16_t* dst, const float* src, size_t count) {
+    std::vector<uint16_t> tmp(count);
+    for (size_t i = 0; i < count; ++i) tmp[i] = f32_to_bf16_bits(src[i]);
+    E_TRY(e, hipMemcpy(dst, tmp.data(), count * 2, hipMemcpyHostToDevice));
+    return CQS_HIP_OK;
+}
+int32_t upload_f32(cqs_hip_embedder* e, float* dst, const float* src, size_t count) {
+    E_TRY(e, hipMemcpy(dst, src, count * 4, hipMemcpyHostToDevice));
+    return CQS_HIP_OK;
+}
+
+int32_t ensure_scratch(cqs_hip_embedder* e, uint32_t M, uint32_t B, uint32_t vt_cols, uint32_t nblk) {
+    const cqs::EmbedGeom& g = e->g;
+    if (M <= e->tok_cap && B <= e->seq_cap && vt_cols <= e->vt_ld && nblk <= e->blk_cap) return CQS_HIP_OK;
+    E_TRY(e, hipStreamSynchronize(e->stream));
+    void* all[] = {e->x, e->y, e->hidden, e->out, e->xn, e->qkv, e->vt, e->attn, e->h, e->pooled, e->d1, e->d_tok,
+                   e->d_pos, e->d_vtcol, e->d_seq_start, e->d_seq_len, e->d_vt_start, e->d_blk};
+    for (void* p : all) (void)hipFree(p);
+    const uint32_t Mc = std::max(M, e->tok_cap), Bc = std::max(B, e->seq_cap);
+    const uint32_t vc = std::max(vt_cols, e->vt_ld), bc = std::max(nblk, e->blk_cap);
+    const size_t H = g.hidden;
+    E_TRY(e, dmalloc(&e->x, (size_t)Mc * H));
+    E_TRY(e, dmalloc(&e->y, (size_t)Mc * H));
+    E_TRY(e, dmalloc(&e->hidden, (size_t)Mc * H));
+    E_TRY(e, dmalloc(&e->out, (size_t)Bc * H));
+    E_TRY(e, dmalloc(&e->xn, (size_t)Mc * H));
+    E_TRY(e, dmalloc(&e->qkv, (size_t)Mc * nqkv(g)));
+    E_TRY(e, dmalloc(&e->vt, (size_t)g.kv_heads * g.head_dim * vc));
+    E_TRY(e, hipMemset(e->vt, 0, (size_t)g.kv_heads * g.head_dim * vc * sizeof(bf16_t)));  // pad columns stay finite
+    E_TRY(e, dmalloc(&e->attn, (size_t)Mc * g.heads * g.head_dim));
+    E_TRY(e, dmalloc(&e->h, (size_t)Mc * g.inter));
+    E_TRY(e, dmalloc(&e->pooled, (size_t)Bc * H));
+    E_TRY(e, dmalloc(&e->d1, (size_t)Bc * g.dense_hidden));
+    E_TRY(e, dmalloc(&e->d_tok, (size_t)Mc));
+    E_TRY(e, dmalloc(&e->d_pos, (size_t)Mc));
+    E_TRY(e, dmalloc(&e->d_vtcol, (size_t)Mc));
+    E_TRY(e, dmalloc(&e->d_seq_start, (size_t)Bc));
+    E_TRY(e, dmalloc(&e->d_seq_len, (size_t)Bc));
+    E_TRY(e, dmalloc(&e->d_vt_start, (size_t)Bc));
+    E_TRY(e, dmalloc(&e->d_blk, (size_t)bc * 2));
+    e->tok_cap = Mc; e->seq_cap = Bc; e->vt_ld = vc; e->blk_cap = bc;
+    return CQS_HIP_OK;
+}
+
+// Pack the padded [B, L] batch, run the layers, leave `hidden` (final norm, packed) on the device.
+struct Packed {
+    std::vector<int32_t> tok, pos, vtcol, seq_start, seq_len, vt_start, blk;
+    uint32_t M = 0, vt_cols = 0;
+};
+
+int32_t pack(cqs_hip_embedder* e, const int64_t* ids, const int64_t* mask, uint32_t B, uint32_t L, Packed& p) {
+    p.seq_start.resize(B); p.seq_len.resize(B); p.vt_start.resize(B);
+    uint32_t M = 0, vcols = 0;
+    for (uint32_t b = 0; b < B; ++b) {
+        uint32_t len = 0;
+        while (len < L && mask[(size_t)b * L + len] != 0) ++len;
+        for (uint32_t j = len; j < L; ++j)
+            if (mask[(size_t)b * L + j] != 0)
+                return efail(e, CQS_HIP_ERR_INVALID, "embed: attention_mask must be a right-padded prefix mask");
+        if (len > e->g.max_seq) return efail(e, CQS_HIP_ERR_INVALID, "embed: sequence longer than max_seq");
+        p.seq_start[b] = (int32_t)M; p.seq_len[b] = (int32_t)len; p.vt_start[b] = (int32_t)vcols;
+        for (uint32_t j = 0; j < len; ++j) {
+            const int64_t id = ids[(size_t)b * L + j];
+            if (id < 0 || id >= (int64_t)e->g.vocab) return efail(e, CQS_HIP_ERR_INVALID, "embed: token id out of range");
+            p.tok.push_back((int32_t)id);
+            p.pos.push_back((int32_t)j);
+            p.vtcol.push_back((int32_t)(vcols + j));
+        }
+        for (uint32_t qb = 0; qb * 32u < len; ++qb) { p.blk.push_back((int32_t)b); p.blk.push_back((int32_t)qb); }
+        M += len;
+        vcols += (len + 31u) / 32u * 32u;
+    }
+    p.M = M;
+    p.vt_cols = vcols + 32u;
+    return CQS_HIP_OK;
+}
+
+int32_t run_layers(cqs_hip_embedder* e, const Packed& p, uint32_t B) {
+    const cqs::EmbedGeom& g = e->g;
+    const uint32_t M = p.M, H = g.hidden;
+    hipStream_t st = e->stream;
+    int32_t rc = ensure_scratch(e, M, B, p.vt_cols, (uint32_t)p.blk.size() / 2u);
+    if (rc != CQS_HIP_OK) return rc;
+    E_TRY(e, hipMemcpyAsync(e->d_tok, p.tok.data(), (size_t)M * 4, hipMemcpyHostToDevice, st));
+    E_TRY(e, hipMemcpyAsync(e->d_pos, p.pos.data(), (size_t)M * 4, hipMemcpyHostToDevice, st));
+    E_TRY(e, hipMemcpyAsync(e->d_vtcol, p.vtcol.data(), (size_t)M * 4, hipMemcpyHostToDevice, st));
+    E_TRY(e, hipMemcpyAsync(e->d_seq_start, p.seq_start.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
+    E_TRY(e, hipMemcpyAsync(e->d_seq_len, p.seq_len.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
+    E_TRY(e, hipMemcpyAsync(e->d_vt_start, p.vt_start.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
+    E_TRY(e, hipMemcpyAsync(e->d_blk, p.blk.data(), p.blk.size() * 4, hipMemcpyHostToDevice, st));
+    E_TRY(e, hipEventRecord(e->ev0, st));
+    const uint32_t nblk = (uint32_t)p.blk.size() / 2u;
+    E_TRY(e, cqs::launch_embed_norm(e->d_tok, e->emb, sqrtf((float)H), e->L[0].n_in, g.rms_eps, e->x, e->xn, M, H, st));
+    for (uint32_t l = 0; l < g.layers; ++l) {
+        const LayerW& w = e->L[l];
+        const bool full = ((l + 1u) % g.sliding_pattern) == 0u;
+        E_TRY(e, cqs::launch_gemm_bf16(e->xn, w.wqkv, e->qkv, M, nqkv(g), H, nqkv(g), cqs::GEMM_OUT_BF16, st));
+        E_TRY(e, cqs::launch_qk_norm_rope(e->qkv, e->d_pos, w.n_q, w.n_k, full ? e->rope_global : e->rope_local,
+                                          g.rms_eps, g.q_scale, M, g.heads, g.kv_heads, st));
+        E_TRY(e, cqs::launch_v_transpose(e->qkv, e->vt, e->d_vtcol, M, g.heads, g.kv_heads, e->vt_ld, st));
+        E_TRY(e, cqs::launch_attention(e->qkv, e->vt, e->attn, e->d_blk, nblk, e->d_seq_start, e->d_seq_len,
+                                       e->d_vt_start, e->vt_ld, g.heads, g.kv_heads, full ? 0u : g.window, st));
+        E_TRY(e, cqs::launch_gemm_bf16(e->attn, w.wo, e->y, M, H, g.heads * g.head_dim, H, cqs::GEMM_OUT_F32, st));
+        E_TRY(e, cqs::launch_add_norm(e->x, e->y, w.n_post_attn, w.n_pre_ffw, g.rms_eps, e->xn, nullptr, 0, M, H, st));
+        E_TRY(e, cqs::launch_gemm_bf16(e->xn, w.wgu, e->h, M, 2u * g.inter, H, g.inter, cqs::GEMM_OUT_GEGLU, st));
+        E_TRY(e, cqs::launch_gemm_bf16(e->h, w.wd, e->y, M, H, g.inter, H, cqs::GEMM_OUT_F32, st));
+        const bool last = (l + 1u == g.layers);
+        E_TRY(e, cqs::launch_add_norm(e->x, e->y, w.n_post_ffw, last ? e->n_final : e->L[l + 1].n_in, g.rms_eps, e->xn,
+                                      e->hidden, last ? 1 : 0, M, H, st));
+    }
+    return CQS_HIP_OK;
+}
+
+const char* kLayerTensors[] = {"input_layernorm.weight", "self_attn.q_proj.weight", "self_attn.k_proj.weight",
+                               "self_attn.v_proj.weight", "self_attn.o_proj.weight", "self_attn.q_norm.weight",
+                               "self_attn.k_norm.weight", "post_attention_layernorm.weight",
+                               "pre_feedforward_layernorm.weight", "mlp.gate_proj.weight", "mlp.up_proj.weight",
+                               "mlp.down_proj.weight", "post_feedforward_layernorm.weight"};
+
+// ---- minimal safetensors reader (header = u64 length + JSON {"name":{"dtype","shape","data_offsets"}}) ----
+struct StEntry { std::string dtype; std::vector<uint64_t> shape; uint64_t lo = 0, hi = 0; };
+
+bool parse_safetensors_header(const std::string& js, std::map<std::string, StEntry>& out) {
+    size_t i = 0;
+    auto skip = [&]() { while (i < js.size() && (js[i] == ' ' || js[i] == '\n' || js[i] == '\t' || js[i] == '\r')) ++i; };
+    auto str = [&](std::string& s) -> bool {
+        skip();
+        if (i >= js.size() || js[i] != '"') return false;
+        ++i; s.clear();
+        while (i < js.size() && js[i] != '"') { if (js[i] == '\\' && i + 1 < js.size()) ++i; s.push_back(js[i++]); }
+        if (i >= js.size()) return false;
+        ++i; return true;
+    };
+    auto num = [&](uint64_t& v) -> bool {
+        skip();
+        if (i >= js.size() || js[i] < '0' || js[i] > '9') return false;
+        v = 0;
+        while (i < js.size() && js[i] >= '0' && js[i] <= '9') v = v * 10 + (uint64_t)(js[i++] - '0');
+        return true;
+    };
+    auto numlist = [&](std::vector<uint64_t>& v) -> bool {
+        skip();
+        if (i >= js.size() || js[i] != '[') return false;
+        ++i; v.clear(); skip();
+        if (i < js.size() && js[i] == ']') { ++i; return true; }
+        for (;;) {
+            uint64_t x;
+            if (!num(x)) return false;
+            v.push_back(x); skip();
+            if (i < js.size() && js[i] == ',') { ++i; continue; }
+            if (i < js.size() && js[i] == ']') { ++i; return true; }
+            return false;
+        }
+    };
+    // skip a JSON value we do not care about (the __metadata__ object)
+    std::function<bool()> skipval = [&]() -> bool {
+        skip();
+        if (i >= js.size()) return false;
+        if (js[i] == '"') { std::string t; return str(t); }
+        if (js[i] == '{' || js[i] == '[') {
+            const char open = js[i], close = open == '{' ? '}' : ']';
+            ++i; skip();
+            if (i < js.size() && js[i] == close) { ++i; return true; }
+            for (;;) {
+                if (open == '{') { std::string k; if (!str(k)) return false; skip(); if (js[i++] != ':') return false; }
+                if (!skipval()) return false;
+                skip();
+                if (i < js.size() && js[i] == ',') { ++i; continue; }
+                if (i < js.size() && js[i] == close) { ++i; return true; }
+                return false;
+            }
+        }
+        while (i < js.size() && js[i] != ',' && js[i] != '}' && js[i] != ']') ++i;
+        return true;
+    };
+    skip();
+    if (i >= js.size() || js[i] != '{') return false;
+    ++i;
+    for (;;) {
+        skip();
+        if (i < js.size() && js[i] == '}') return true;
+        std::string name;
+        if (!str(name)) return false;
+        skip();
+        if (i >= js.size() || js[i++] != ':') return false;
+        if (name == "__metadata__") { if (!skipval()) return false; }
+        else {
+            skip();
+            if (i >= js.size() || js[i++] != '{') return false;
+            StEntry en;
+            for (;;) {
+                std::string k;
+                if (!str(k)) return false;
+                skip();
+                if (i >= js.size() || js[i++] != ':') return false;
+                if (k == "dtype") { if (!str(en.dtype)) return false; }
+                else if (k == "shape") { if (!numlist(en.shape)) return false; }
+                else if (k == "data_offsets") {
+                    std::vector<uint64_t> o;
+                    if (!numlist(o) || o.size() != 2) return false;
+                    en.lo = o[0]; en.hi = o[1];
+                } else if (!skipval()) return false;
+                skip();
+                if (i < js.size() && js[i] == ',') { ++i; continue; }
+                if (i < js.size() && js[i] == '}') { ++i; break; }
+                return false;
+            }
+            out[name] = en;
+        }
+        skip();
+        if (i < js.size() && js[i] == ',') { ++i; continue; }
+        if (i < js.size() && js[i] == '}') return true;
+        return false;
+    }
+}
+
+// Feed every tensor of a safetensors file to set_tensor, renaming with `rename(name)` ("" = skip).
+int32_t load_safetensors(cqs_hip_embedder* e, const std::string& path, const std::function<std::string(const std::string&)>& rename) {
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) return efail(e, CQS_HIP_ERR_INVALID, "load_dir: cannot open " + path);
+    uint64_t hl = 0;
+    if (fread(&hl, 8, 1, f) != 1 || hl > (64ull << 20)) { fclose(f); return efail(e, CQS_HIP_ERR_INVALID, "load_dir: bad safetensors header in " + path); }
+    std::string js(hl, '\0');
+    if (fread(&js[0], 1, hl, f) != hl) { fclose(f); return efail(e, CQS_HIP_ERR_INVALID, "load_dir: truncated header in " + path); }
+    std::map<std::string, StEntry> ents;
+    if (!parse_safetensors_header(js, ents)) { fclose(f); return efail(e, CQS_HIP_ERR_INVALID, "load_dir: cannot parse header of " + path); }
+    std::vector<uint8_t> raw;
+    std::vector<float> vals;
+    for (auto& kv : ents) {
+        const std::string name = rename(kv.first);
+        if (name.empty()) continue;
+        const StEntry& en = kv.second;
+        uint64_t count = 1;
+        for (uint64_t d : en.shape) count *= d;
+        const uint64_t esz = en.dtype == "F32" ? 4 : ((en.dtype == "BF16" || en.dtype == "F16") ? 2 : 0);
+        if (!esz || en.hi - en.lo != count * esz) { fclose(f); return efail(e, CQS_HIP_ERR_INVALID, "load_dir: unsupported dtype/shape for " + kv.first); }
+        raw.resize(count * esz);
+        if (fseek(f, (long)(8 + hl + en.lo), SEEK_SET) != 0 || fread(raw.data(), 1, raw.size(), f) != raw.size()) {
+            fclose(f);
+            return efail(e, CQS_HIP_ERR_INVALID, "load_dir: truncated data for " + kv.first);
+        }
+        vals.resize(count);
+        if (esz == 4) memcpy(vals.data(), raw.data(), count * 4);
+        else {
+            const uint16_t* h = (const uint16_t*)raw.data();
+            for (uint64_t i = 0; i < count; ++i) vals[i] = en.dtype == "BF16" ? bf16_bits_to_f32(h[i]) : f16_bits_to_f32(h[i]);
+        }
+        const int32_t rc = cqs_hip_embedder_set_tensor(e, name.c_str(), vals.data(), count);
+        if (rc != CQS_HIP_OK) { fclose(f); return rc; }
+    }
+    fclose(f);
+    return CQS_HIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void cqs_hip_embed_config_default(cqs_hip_embed_config* c) {
+    if (!c) return;
+    c->vocab_size = 262144; c->hidden = 768; c->layers = 24; c->heads = 3; c->kv_heads = 1; c->head_dim = 256;
+    c->intermediate = 1152; c->dense_hidden = 3072; c->sliding_window = 512; c->sliding_pattern = 6; c->max_seq = 2048;
+    c->rms_eps = 1e-6f; c->rope_theta_global = 1e6f; c->rope_theta_local = 1e4f; c->query_pre_attn_scalar = 256.f;
+}
+
+int32_t cqs_hip_embedder_create(const cqs_hip_embed_config* c, int32_t device, cqs_hip_embedder** out) {
+    if (!c || !out) return CQS_HIP_ERR_INVALID;
+    *out = nullptr;
+    if (c->head_dim != 256 || c->hidden == 0 || c->hidden % 256 || c->hidden > 1024 || c->intermediate % 64 ||
+        c->dense_hidden % 128 || c->kv_heads == 0 || c->heads % c->kv_heads || c->heads / c->kv_heads > 4 ||
+        c->layers == 0 || c->sliding_pattern == 0 || c->max_seq == 0 || c->vocab_size == 0 || c->hidden % 128)
+        return CQS_HIP_ERR_INVALID;
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0) return CQS_HIP_ERR_NO_DEVICE;
+    if (device < 0 || device >= cnt) return CQS_HIP_ERR_INVALID;
+    cqs_hip_embedder* e = new (std::nothrow) cqs_hip_embedder();
+    if (!e) return CQS_HIP_ERR_NOMEM;
+    e->device = device;
+    e->cfg = *c;
+    cqs::EmbedGeom& g = e->g;
+    g.vocab = c->vocab_size; g.hidden = c->hidden; g.layers = c->layers; g.heads = c->heads; g.kv_heads = c->kv_heads;
+    g.head_dim = c->head_dim; g.inter = c->intermediate; g.dense_hidden = c->dense_hidden;
+    g.window = c->sliding_window / 2u + 1u;  // bidirectional (configuration_gemma3.py:105-106)
+    g.sliding_pattern = c->sliding_pattern; g.max_seq = c->max_seq; g.rms_eps = c->rms_eps;
+    g.theta_global = c->rope_theta_global; g.theta_local = c->rope_theta_local;
+    g.q_scale = 1.0f / sqrtf(c->query_pre_attn_scalar);
+    bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) == hipSuccess &&
+              hipEventCreate(&e->ev0) == hipSuccess && hipEventCreate(&e->ev1) == hipSuccess;
+    const size_t H = g.hidden, D = g.head_dim;
+    e->L.resize(g.layers);
+    ok = ok && dmalloc(&e->emb, (size_t)g.vocab * H) == hipSuccess && dmalloc(&e->n_final, H) == hipSuccess &&
+         dmalloc(&e->dense1, (size_t)g.dense_hidden * H) == hipSuccess && dmalloc(&e->dense2, H * g.dense_hidden) == hipSuccess &&
+         dmalloc(&e->rope_global, (size_t)g.max_seq * 256) == hipSuccess && dmalloc(&e->rope_local, (size_t)g.max_seq * 256) == hipSuccess;
+    for (uint32_t l = 0; ok && l < g.layers; ++l) {
+        LayerW& w = e->L[l];
+        ok = dmalloc(&w.wqkv, (size_t)nqkv(g) * H) == hipSuccess && dmalloc(&w.wo, H * g.heads * D) == hipSuccess &&
+             dmalloc(&w.wgu, (size_t)2 * g.inter * H) == hipSuccess && dmalloc(&w.wd, H * g.inter) == hipSuccess &&
+             dmalloc(&w.n_in, H) == hipSuccess && dmalloc(&w.n_post_attn, H) == hipSuccess && dmalloc(&w.n_pre_ffw, H) == hipSuccess &&
+             dmalloc(&w.n_post_ffw, H) == hipSuccess && dmalloc(&w.n_q, D) == hipSuccess && dmalloc(&w.n_k, D) == hipSuccess;
+    }
+    if (!ok) { cqs_hip_embedder_destroy(e); return CQS_HIP_ERR_NOMEM; }
+    // RoPE tables, computed like transformers does (fp32 inv_freq, fp32 angle; modeling_gemma3.py:188-224)
+    std::vector<float> tab((size_t)g.max_seq * 256);
+    for (int t = 0; t < 2; ++t) {
+        const float theta = t == 0 ? g.theta_global : g.theta_local;
+        for (uint32_t pz = 0; pz < g.max_seq; ++pz)
+            for (uint32_t i = 0; i < 128; ++i) {
+                const float inv = 1.0f / powf(theta, (float)(2 * i) / 256.0f);
+                const float a = (float)pz * inv;
+                tab[((size_t)pz * 128 + i) * 2] = cosf(a);
+                tab[((size_t)pz * 128 + i) * 2 + 1] = sinf(a);
+            }
+        if (hipMemcpy(t == 0 ? e->rope_global : e->rope_local, tab.data(), tab.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+            cqs_hip_embedder_destroy(e);
+            return CQS_HIP_ERR_DEVICE;
+        }
+    }
+    *out = e;
+    return CQS_HIP_OK;
+}
+
+int32_t cqs_hip_embedder_set_tensor(cqs_hip_embedder* e, const char* cname, const float* data, uint64_t count) {
+    if (!e || !cname || !data) return CQS_HIP_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (e->finalized) return efail(e, CQS_HIP_ERR_INVALID, "set_tensor after finalize");
+    if (hipSetDevice(e->device) != hipSuccess) return efail(e, CQS_HIP_ERR_DEVICE, "hipSetDevice");
+    const cqs::EmbedGeom& g = e->g;
+    const std::string name(cname);
+    const size_t H = g.hidden, D = g.head_dim, I = g.inter;
+    auto need = [&](size_t n) { return count == n; };
+    int32_t rc = CQS_HIP_ERR_INVALID;
+    if (name == "embed_tokens.weight") { if (need((size_t)g.vocab * H)) rc = upload_bf16(e, e->emb, data, count); }
+    else if (name == "norm.weight") { if (need(H)) rc = upload_f32(e, e->n_final, data, count); }
+    else if (name == "dense1.weight") { if (need((size_t)g.dense_hidden * H)) rc = upload_bf16(e, e->dense1, data, count); }
+    else if (name == "dense2.weight") { if (need((size_t)g.dense_hidden * H)) rc = upload_bf16(e, e->dense2, data, count); }
+    else if (name.rfind("layers.", 0) == 0) {
+        const size_t dot = name.find('.', 7);
+        if (dot == std::string::npos) return efail(e, CQS_HIP_ERR_INVALID, "set_tensor: bad name " + name);
+        const uint32_t l = (uint32_t)atoi(name.substr(7, dot - 7).c_str());
+        if (l >= g.layers) return efail(e, CQS_HIP_ERR_INVALID, "set_tensor: layer out of range in " + name);
+        LayerW& w = e->L[l];
+        const std::string t = name.substr(dot + 1);
+        if (t == "input_layernorm.weight") { if (need(H)) rc = upload_f32(e, w.n_in, data, count); }
+        else if (t == "post_attention_layernorm.weight") { if (need(H)) rc = upload_f32(e, w.n_post_attn, data, count); }
+        else if (t == "pre_feedforward_layernorm.weight") { if (need(H)) rc = upload_f32(e, w.n_pre_ffw, data, count); }
+        else if (t == "post_feedforward_layernorm.weight") { if (need(H)) rc = upload_f32(e, w.n_post_ffw, data, count); }
+        else if (t == "self_attn.q_norm.weight") { if (need(D)) rc = upload_f32(e, w.n_q, data, count); }
+        else if (t == "self_attn.k_norm.weight") { if (need(D)) rc = upload_f32(e, w.n_k, data, count); }
+        // q | k | v rows stacked into one [nqkv, H] matrix: one GEMM produces all three
+        else if (t == "self_attn.q_proj.weight") { if (need(g.heads * D * H)) rc = upload_bf16(e, w.wqkv, data, count); }
+        else if (t == "self_attn.k_proj.weight") { if (need(g.kv_heads * D * H)) rc = upload_bf16(e, w.wqkv + (size_t)g.heads * D * H, data, count); }
+        else if (t == "self_attn.v_proj.weight") { if (need(g.kv_heads * D * H)) rc = upload_bf16(e, w.wqkv + (size_t)(g.heads + g.kv_heads) * D * H, data, count); }
+        else if (t == "self_attn.o_proj.weight") { if (need(H * g.heads * D)) rc = upload_bf16(e, w.wo, data, count); }
+        else if (t == "mlp.down_proj.weight") { if (need(H * I)) rc = upload_bf16(e, w.wd, data, count); }
+        else if (t == "mlp.gate_proj.weight" || t == "mlp.up_proj.weight") {
+            // gate / up rows interleaved per 32 channels: rows [64c, 64c+32) = gate channels [32c, 32c+32),
+            // rows [64c+32, 64c+64) = the same channels' up rows -> the GEMM epilogue fuses gelu(gate)*up
+            if (need(I * H)) {
+                const size_t off = (t == "mlp.up_proj.weight") ? 32 : 0;
+                rc = CQS_HIP_OK;
+                for (size_t c = 0; c < I / 32 && rc == CQS_HIP_OK; ++c)
+                    rc = upload_bf16(e, w.wgu + (64 * c + off) * H, data + 32 * c * H, 32 * H);
+            }
+        } else return efail(e, CQS_HIP_ERR_INVALID, "set_tensor: unknown tensor " + name);
+    } else return efail(e, CQS_HIP_ERR_INVALID, "set_tensor: unknown tensor " + name);
+    if (rc == CQS_HIP_ERR_INVALID) return efail(e, rc, "set_tensor: wrong element count for " + name);
+    if (rc == CQS_HIP_OK) e->seen[name] = true;
+    return rc;
+}
+
+int32_t cqs_hip_embedder_finalize(cqs_hip_embedder* e) {
+    if (!e) return CQS_HIP_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(e->mu);
+    std::vector<std::string> need = {"embed_tokens.weight", "norm.weight", "dense1.weight", "dense2.weight"};
+    for (uint32_t l = 0; l < e->g.layers; ++l)
+        for (const char* t : kLayerTensors) need.push_back("layers." + std::to_string(l) + "." + t);
+    for (const std::string& n : need)
+        if (!e->seen.count(n)) return efail(e, CQS_HIP_ERR_INVALID, "finalize: missing tensor " + n);
+    e->finalized = true;
+    return CQS_HIP_OK;
+}
+
+int32_t cqs_hip_embedder_load_dir(const char* dir, const cqs_hip_embed_config* cfg, int32_t device, cqs_hip_embedder** out) {
+    if (!dir || !out) return CQS_HIP_ERR_INVALID;
+    cqs_hip_embed_config c;
+    if (cfg) c = *cfg; else cqs_hip_embed_config_default(&c);
+    cqs_hip_embedder* e = nullptr;
+    int32_t rc = cqs_hip_embedder_create(&c, device, &e);
+    if (rc != CQS_HIP_OK) return rc;
+    const std::string d(dir);
+    auto strip = [](const std::string& n) -> std::string {  // HF checkpoints prefix text-model tensors with "model."
+        if (n.rfind("model.", 0) == 0) return n.substr(6);
+        return n;
+    };
+    rc = load_safetensors(e, d + "/model.safetensors", strip);
+    if (rc == CQS_HIP_OK)
+        rc = load_safetensors(e, d + "/2_Dense/model.safetensors", [](const std::string& n) { return n == "linear.weight" ? std::string("dense1.weight") : std::string(); });
+    if (rc == CQS_HIP_OK)
+        rc = load_safetensors(e, d + "/3_Dense/model.safetensors", [](const std::string& n) { return n == "linear.weight" ? std::string("dense2.weight") : std::string(); });
+    if (rc == CQS_HIP_OK) rc = cqs_hip_embedder_finalize(e);
+    if (rc != CQS_HIP_OK) {
+        fprintf(stderr, "[cqs_hip] embedder load_dir failed: %s\n", e->last_error.c_str());
+        cqs_hip_embedder_destroy(e);
+        return rc;
+    }
+    *out = e;
+    return CQS_HIP_OK;
+}
+
+void cqs_hip_embedder_destroy(cqs_hip_embedder* e) {
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    void* g[] = {e->emb, e->n_final, e->dense1, e->dense2, e->rope_global, e->rope_local, e->x, e->y, e->hidden, e->out,
+                 e->xn, e->qkv, e->vt, e->attn, e->h, e->pooled, e->d1, e->d_tok, e->d_pos, e->d_vtcol, e->d_seq_start,
+                 e->d_seq_len, e->d_vt_start, e->d_blk};
+    for (void* p : g) (void)hipFree(p);
+    for (LayerW& w : e->L) {
+        void* ws[] = {w.wqkv, w.wo, w.wgu, w.wd, w.n_in, w.n_post_attn, w.n_pre_ffw, w.n_post_ffw, w.n_q, w.n_k};
+        for (void* p : ws) (void)hipFree(p);
+    }
+    if (e->ev0) (void)hipEventDestroy(e->ev0);
+    if (e->ev1) (void)hipEventDestroy(e->ev1);
+    if (e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+}
+
+uint32_t cqs_hip_embedder_dim(const cqs_hip_embedder* e) { return e ? e->g.hidden : 0; }
+uint32_t cqs_hip_embedder_max_seq(const cqs_hip_embedder* e) { return e ? e->g.max_seq : 0; }
+int32_t cqs_hip_embedder_poisoned(const cqs_hip_embedder* e) { return e && e->poisoned.load(std::memory_order_acquire) ? 1 : 0; }
+float cqs_hip_embedder_last_ms(const cqs_hip_embedder* e) { return e ? e->last_ms : -1.f; }
+size_t cqs_hip_embedder_last_error(const cqs_hip_embedder* e, char* buf, size_t cap) {
+    if (!e || !buf || cap == 0) return 0;
+    std::lock_guard<std::mutex> lk(e->mu);
+    const size_t m = e->last_error.size() < cap - 1 ? e->last_error.size() : cap - 1;
+    memcpy(buf, e->last_error.data(), m);
+    buf[m] = 0;
+    return m;
+}
+
+static int32_t embed_common(cqs_hip_embedder* e, const int64_t* ids, const int64_t* mask, uint32_t B, uint32_t L,
+                            float* out, bool want_hidden) {
+    if (!e) return CQS_HIP_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (e->poisoned.load(std::memory_order_acquire)) return CQS_HIP_ERR_POISONED;
+    if (!e->finalized) return efail(e, CQS_HIP_ERR_INVALID, "embed: weights not finalized");
+    if (B == 0) return CQS_HIP_OK;
+    if (!ids || !mask || !out || L == 0) return efail(e, CQS_HIP_ERR_INVALID, "embed: null buffer / empty sequence");
+    E_TRY(e, hipSetDevice(e->device));
+    const uint32_t H = e->g.hidden;
+    Packed p;
+    int32_t rc = pack(e, ids, mask, B, L, p);
+    if (rc != CQS_HIP_OK) return rc;
+    if (want_hidden) memset(out, 0, (size_t)B * L * H * sizeof(float));
+    else memset(out, 0, (size_t)B * H * sizeof(float));
+    if (p.M == 0) return CQS_HIP_OK;  // every mask row empty: zero vectors (src/embedder/pooling.rs:113-119)
+    rc = run_layers(e, p, B);
+    if (rc != CQS_HIP_OK) return rc;
+    hipStream_t st = e->stream;
+    if (want_hidden) {
+        E_TRY(e, hipEventRecord(e->ev1, st));
+        std::vector<float> packed((size_t)p.M * H);
+        E_TRY(e, hipMemcpyAsync(packed.data(), e->hidden, packed.size() * 4, hipMemcpyDeviceToHost, st));
+        E_TRY(e, hipStreamSynchronize(st));
+        for (uint32_t b = 0; b < B; ++b)
+            memcpy(out + (size_t)b * L * H, packed.data() + (size_t)p.seq_start[b] * H, (size_t)p.seq_len[b] * H * 4);
+    } else {
+        const cqs::EmbedGeom& g = e->g;
+        E_TRY(e, cqs::launch_mean_pool(e->hidden, e->d_seq_start, e->d_seq_len, e->pooled, B, H, st));
+        E_TRY(e, cqs::launch_gemm_bf16(e->pooled, e->dense1, e->d1, B, g.dense_hidden, H, g.dense_hidden, cqs::GEMM_OUT_BF16, st));
+        E_TRY(e, cqs::launch_gemm_bf16(e->d1, e->dense2, e->out, B, H, g.dense_hidden, H, cqs::GEMM_OUT_F32, st));
+        E_TRY(e, hipEventRecord(e->ev1, st));
+        E_TRY(e, hipMemcpyAsync(out, e->out, (size_t)B * H * 4, hipMemcpyDeviceToHost, st));
+        E_TRY(e, hipStreamSynchronize(st));
+        for (uint32_t b = 0; b < B; ++b)  // empty rows: exact zeros, like the reference's zero-mask pooling
+            if (p.seq_len[b] == 0) memset(out + (size_t)b * H, 0, (size_t)H * 4);
+    }
+    float ms = -1.f;
+    if (hipEventElapsedTime(&ms, e->ev0, e->ev1) == hipSuccess) e->last_ms = ms;
+    return CQS_HIP_OK;
+}
+
+int32_t cqs_hip_embed(cqs_hip_embedder* e, const int64_t* ids, const int64_t* mask, uint32_t B, uint32_t L, float* out) {
+    return embed_common(e, ids, mask, B, L, out, false);
+}
+int32_t cqs_hip_embed_hidden(cqs_hip_embedder* e, const int64_t* ids, const int64_t* mask, uint32_t B, uint32_t L, float* out) {
+    return embed_common(e, ids, mask, B, L, out, true);
+}
+
+}  // extern "C"

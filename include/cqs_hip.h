@@ -160,6 +160,73 @@ size_t cqs_hip_merge_keys(const uint64_t* lists, const uint32_t* counts, size_t 
 void    cqs_hip_index_set_timing(cqs_hip_index* idx, int32_t enable);
 int32_t cqs_hip_index_scan_time(cqs_hip_index* idx, uint32_t* launches, double* total_ms);
 
+/* ==== embed section ==========================================================
+ * EmbeddingGemma-300m forward (Gemma3 text encoder, bidirectional, + mean pool + 2 dense):
+ * replaces the ONNX Runtime session the reference runs inside `Embedder::embed_batch`
+ * (src/embedder/core.rs:1091-1203: inputs `input_ids` / `attention_mask` i64 [B, L]
+ * right-padded with pad_id 0 by `pad_2d_i64_from_encodings`, src/embedder/pooling.rs:40-57;
+ * output `sentence_embedding` f32 [B, 768], L2-normalised afterwards by the caller,
+ * core.rs:1196-1203).  Tokenisation, prefixes, batching by `embed_batch_size()` and the
+ * query caches stay on the host exactly as in the reference.
+ * Compute: bf16 operands on the matrix cores, f32 accumulation, f32 residual stream. */
+typedef struct cqs_hip_embedder cqs_hip_embedder;
+
+typedef struct cqs_hip_embed_config {
+    uint32_t vocab_size;       /* 262144 */
+    uint32_t hidden;           /* 768  (multiple of 256) */
+    uint32_t layers;           /* 24 */
+    uint32_t heads;            /* 3 */
+    uint32_t kv_heads;         /* 1   (heads / kv_heads <= 4) */
+    uint32_t head_dim;         /* 256 (only value supported) */
+    uint32_t intermediate;     /* 1152 (multiple of 64) */
+    uint32_t dense_hidden;     /* 3072 (multiple of 128) */
+    uint32_t sliding_window;   /* 512: config value; the bidirectional mask is |q-k| < window/2 + 1 */
+    uint32_t sliding_pattern;  /* 6: layer i is full attention iff (i+1) % pattern == 0 */
+    uint32_t max_seq;          /* 2048 (src/embedder/models.rs:455-470) */
+    float rms_eps;             /* 1e-6 */
+    float rope_theta_global;   /* 1e6 */
+    float rope_theta_local;    /* 1e4 */
+    float query_pre_attn_scalar; /* 256 */
+} cqs_hip_embed_config;
+
+/* Fills *cfg with the EmbeddingGemma-300m geometry (`ModelConfig::embeddinggemma_300m`,
+ * src/embedder/models.rs:455-470; dimensions from the public model card). */
+void cqs_hip_embed_config_default(cqs_hip_embed_config* cfg);
+
+/* Lifecycle: create (empty) -> set_tensor for every weight -> finalize -> embed* -> destroy.
+ * Tensor names are the Hugging Face Gemma3TextModel names (`embed_tokens.weight`,
+ * `layers.N.self_attn.q_proj.weight`, ..., `norm.weight`) plus `dense1.weight` [dense_hidden, hidden]
+ * and `dense2.weight` [hidden, dense_hidden]; data is f32 row-major and is converted to bf16
+ * (matrices) or kept f32 (norm weights) on the device. */
+int32_t cqs_hip_embedder_create(const cqs_hip_embed_config* cfg, int32_t device, cqs_hip_embedder** out);
+int32_t cqs_hip_embedder_set_tensor(cqs_hip_embedder* e, const char* name, const float* data, uint64_t count);
+int32_t cqs_hip_embedder_finalize(cqs_hip_embedder* e);
+/* Convenience loader replacing `create_session(model_path, ..)` (src/embedder/provider.rs:349-447):
+ * reads `model.safetensors` (+ `2_Dense/model.safetensors`, `3_Dense/model.safetensors`, tensor
+ * `linear.weight`) from a local model directory — the hook the reference exposes for local files
+ * is CQS_ONNX_DIR (src/embedder/download.rs:12-41).  F32 / BF16 / F16 tensors. */
+int32_t cqs_hip_embedder_load_dir(const char* model_dir, const cqs_hip_embed_config* cfg, int32_t device,
+                                  cqs_hip_embedder** out);
+void cqs_hip_embedder_destroy(cqs_hip_embedder* e);
+
+uint32_t cqs_hip_embedder_dim(const cqs_hip_embedder* e);        /* `embedding_dim()` core.rs:961 */
+uint32_t cqs_hip_embedder_max_seq(const cqs_hip_embedder* e);
+int32_t  cqs_hip_embedder_poisoned(const cqs_hip_embedder* e);
+size_t   cqs_hip_embedder_last_error(const cqs_hip_embedder* e, char* buf, size_t cap);
+
+/* The `session.run` replacement.  input_ids / attention_mask: i64 [batch, seq_len], host; every
+ * mask row must be 1...10...0 (right padding).  out: f32 [batch, hidden], host, NOT normalised
+ * (the reference normalises per row right after, core.rs:1196-1203).  A row whose mask is all
+ * zero yields a zero vector (src/embedder/pooling.rs:113-119).  Errors: bad mask / token id out
+ * of range -> CQS_HIP_ERR_INVALID (`EmbedderError::InferenceFailed` in the shim). */
+int32_t cqs_hip_embed(cqs_hip_embedder* e, const int64_t* input_ids, const int64_t* attention_mask,
+                      uint32_t batch, uint32_t seq_len, float* out);
+/* Diagnostic twin: final-norm hidden states f32 [batch, seq_len, hidden] (zeros at padded positions). */
+int32_t cqs_hip_embed_hidden(cqs_hip_embedder* e, const int64_t* input_ids, const int64_t* attention_mask,
+                             uint32_t batch, uint32_t seq_len, float* out_hidden);
+/* Milliseconds of device time of the most recent cqs_hip_embed* call (HIP events on its stream). */
+float cqs_hip_embedder_last_ms(const cqs_hip_embedder* e);
+
 #ifdef __cplusplus
 }
 #endif
