@@ -37,6 +37,9 @@ def parse():
     ap.add_argument("--k", type=int, default=20)
     ap.add_argument("--batch", type=int, default=1, help="queries per rank per step")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of each cpu_baseline leg (0 = skip)")
+    ap.add_argument("--embed-steps", type=int, default=8, help="timed embedding batches per rank (0 = skip the embed leg)")
+    ap.add_argument("--embed-batch", type=int, default=32, help="sequences per embedding batch (reference: embed_batch_size() = 32)")
+    ap.add_argument("--embed-len", type=int, default=512, help="tokens per sequence of the fixed-length embed leg")
     return ap.parse_args()
 
 
@@ -86,6 +89,90 @@ def cpu_baseline(rows_host, queries_host, k, seconds):
                      f"{n}x{rows_host.shape[1]} fp32 corpus held in RAM, k={k}, threshold 0.0 (oracle: "
                      "simsimd-style AVX2 dot + clamp + BoundedScoreHeap)")
     return out
+
+
+def embed_leg(a, rank, world, dist, torch, np, dev):
+    """Index-build leg of the metric ("index embed chunks/sec"): EmbeddingGemma-300m geometry with seeded
+    random weights (no network for the real checkpoint), synthetic token ids, batch = the reference's
+    embed_batch_size() (32), (a) fixed L and (b) log-normal lengths ("few hundred tokens").
+    Data-parallel over ranks: replicated weights, no collective."""
+    from cqs_amd.embedder import HipEmbedEngine, default_config
+    cfg = default_config()
+    eng = HipEmbedEngine(cfg, device=dev.index)
+    rng = np.random.default_rng(0xC950003)
+    H, D, I, V, NL = 768, 256, 1152, cfg.vocab_size, cfg.layers
+
+    def lin(n, k):
+        return rng.standard_normal((n, k), dtype=np.float32) * np.float32(1.0 / np.sqrt(k))
+
+    eng.set_tensor("embed_tokens.weight", rng.standard_normal((V, H), dtype=np.float32) * np.float32(0.05))
+    for l in range(NL):
+        p = f"layers.{l}."
+        for nme in ("input_layernorm", "post_attention_layernorm", "pre_feedforward_layernorm", "post_feedforward_layernorm"):
+            eng.set_tensor(p + nme + ".weight", rng.standard_normal(H, dtype=np.float32) * np.float32(0.1))
+        eng.set_tensor(p + "self_attn.q_norm.weight", rng.standard_normal(D, dtype=np.float32) * np.float32(0.1))
+        eng.set_tensor(p + "self_attn.k_norm.weight", rng.standard_normal(D, dtype=np.float32) * np.float32(0.1))
+        eng.set_tensor(p + "self_attn.q_proj.weight", lin(3 * D, H))
+        eng.set_tensor(p + "self_attn.k_proj.weight", lin(D, H))
+        eng.set_tensor(p + "self_attn.v_proj.weight", lin(D, H))
+        eng.set_tensor(p + "self_attn.o_proj.weight", lin(H, 3 * D))
+        eng.set_tensor(p + "mlp.gate_proj.weight", lin(I, H))
+        eng.set_tensor(p + "mlp.up_proj.weight", lin(I, H))
+        eng.set_tensor(p + "mlp.down_proj.weight", lin(H, I))
+    eng.set_tensor("norm.weight", rng.standard_normal(H, dtype=np.float32) * np.float32(0.1))
+    eng.set_tensor("dense1.weight", lin(3072, H))
+    eng.set_tensor("dense2.weight", lin(H, 3072))
+    eng.set_weights({})
+
+    def flops_of(lens):
+        gemm = 2.0 * NL * (H * 1280 + H * H + H * 2 * I + I * H)           # per token (SURVEY §8d: 0.203 GFLOP)
+        att = 0.0
+        W = cfg.sliding_window // 2 + 1
+        for L in lens:
+            pos = np.arange(L)
+            local = np.minimum(pos + W, L) - np.maximum(pos - W + 1, 0)    # keys with |q-k| < W
+            n_full = NL // cfg.sliding_pattern
+            att += 4.0 * 3 * D * (n_full * L * L + (NL - n_full) * float(local.sum()))
+        head = 2.0 * 2 * H * 3072 * len(lens)
+        return gemm * float(np.sum(lens)) + att + head
+
+    def run(lens, steps):
+        B, L = len(lens), int(max(lens))
+        ids = np.zeros((B, L), np.int64)
+        mask = np.zeros((B, L), np.int64)
+        for i, n in enumerate(lens):
+            ids[i, :n] = rng.integers(1, V, size=n)
+            mask[i, :n] = 1
+        out = eng.run(ids, mask)                      # warm-up (also sizes the scratch)
+        assert np.all(np.isfinite(out))
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        dev_ms = 0.0
+        for _ in range(steps):
+            eng.run(ids, mask)
+            dev_ms += eng.last_ms()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        toks = int(np.sum(lens))
+        tf = flops_of(lens) * steps / (dev_ms / 1e3) / 1e12
+        return {"chunks_per_sec": round(B * steps * world / el, 1), "tokens_per_sec": round(toks * steps * world / el, 1),
+                "ms_per_batch": round(el / steps * 1e3, 3), "device_ms_per_batch": round(dev_ms / steps, 3),
+                "batch": B, "tokens_per_batch": toks,
+                "roofline": {"bound": "mfma", "achieved": round(tf, 1), "peak": 2500.0, "unit": "TFLOP/s",
+                             "frac": round(tf / 2500.0, 4), "dtype": "bf16"}}
+
+    fixed = run([a.embed_len] * a.embed_batch, a.embed_steps)
+    lens = np.clip(np.exp(rng.normal(np.log(300.0), 0.6, size=a.embed_batch)).astype(int), 8, cfg.max_seq)
+    ragged = run(list(lens), a.embed_steps)
+    eng.close()
+    return {"model": "EmbeddingGemma-300m geometry (24 x [768 | 3x256 q, 1 kv | 1152], vocab 262144), seeded weights",
+            "steps": a.embed_steps, "fixed_len_%d" % a.embed_len: fixed, "lognormal_len": ragged,
+            "note": "host-buffer API (ids in, embeddings out per batch, PCIe-inclusive); timed wall-clock, max over ranks"}
 
 
 def main():
@@ -215,6 +302,13 @@ def main():
         nq = min(8, K)
         cpu = cpu_baseline(rows.cpu().numpy(), queries[W:W + nq, 0].cpu().numpy(), k, a.cpu_seconds)
 
+    embed = None
+    if a.embed_steps > 0:
+        idx.close()
+        del rows
+        torch.cuda.empty_cache()
+        embed = embed_leg(a, rank, world, dist, torch, np, dev)
+
     if rank == 0:
         total_q = K * bq * world
         line = {
@@ -237,9 +331,11 @@ def main():
                        if world > 1 else "single GPU"},
             "roofline": roofline,
             "cpu_baseline": cpu,
+            "embed": embed,
         }
         print(json.dumps(line), flush=True)
-    idx.close()
+    if a.embed_steps <= 0:
+        idx.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -22,10 +22,10 @@ struct EmbedGeom {
 hipError_t launch_embed_norm(const int32_t* tok, const bf16_t* emb, float scale, const float* w_in, float eps,
                              float* x, bf16_t* xn, uint32_t M, uint32_t H, hipStream_t st);
 
-// x[m] += rmsnorm(y[m]) * (1 + w_post); then the next pre-norm of the new x:
+// x[m] += rmsnorm(y[m]) * (1 + w_post)  (y = the branch's GEMM output, bf16); then the next pre-norm of the new x:
 //   final == 0: xn[m]  = bf16(rmsnorm(x[m]) * (1 + w_next))
 //   final == 1: out[m] = f32 (rmsnorm(x[m]) * (1 + w_next))      (the model's final norm)
-hipError_t launch_add_norm(float* x, const float* y, const float* w_post, const float* w_next, float eps,
+hipError_t launch_add_norm(float* x, const bf16_t* y, const float* w_post, const float* w_next, float eps,
                            bf16_t* xn, float* out, int final, uint32_t M, uint32_t H, hipStream_t st);
 
 // C[M,N] = A[M,K] (bf16, row-major) x W[N,K]^T (bf16, row-major), f32 accumulate on the matrix cores.

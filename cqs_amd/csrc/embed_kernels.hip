@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void embed_norm_kernel(const int32_t* __restri
 }
 
 template <int NCH, int FINAL>
-__global__ __launch_bounds__(256) void add_norm_kernel(float* __restrict__ x, const float* __restrict__ y,
+__global__ __launch_bounds__(256) void add_norm_kernel(float* __restrict__ x, const bf16_t* __restrict__ y,
                                                        const float* __restrict__ w_post,
                                                        const float* __restrict__ w_next, float eps,
                                                        bf16_t* __restrict__ xn, float* __restrict__ out, uint32_t M) {
@@ -77,7 +77,9 @@ __global__ __launch_bounds__(256) void add_norm_kernel(float* __restrict__ x, co
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         const uint32_t col = (uint32_t)c * 256u + (uint32_t)lane * 4u;
-        yv[c] = *(const f4*)(y + (size_t)row * H + col);
+        const bf4 yb = *(const bf4*)(y + (size_t)row * H + col);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) yv[c][i] = (float)yb[i];
         xv[c] = *(const f4*)(x + (size_t)row * H + col);
 #pragma unroll
         for (int i = 0; i < 4; ++i) ss += yv[c][i] * yv[c][i];
@@ -232,24 +234,53 @@ __global__ __launch_bounds__(G * 64, 1) void attention_kernel(const bf16_t* __re
         if (hi2 < kb_hi) kb_hi = hi2;
     }
 
+    // K / V^T tiles are staged through registers one key block ahead: the global loads of block
+    // kb+1 are in flight while block kb is on the matrix cores (one wave per SIMD: nothing else
+    // would hide their latency).
+    constexpr int KCH = (32 * (kHD / 8) + T - 1) / T;   // 16-B pieces per thread, K tile
+    constexpr int VCH = (kHD * 4 + T - 1) / T;          // 16-B pieces per thread, V^T tile
+    u4 rk[KCH], rv[VCH];
+    auto stage_load = [&](uint32_t kb) {
+#pragma unroll
+        for (int u = 0; u < KCH; ++u) {
+            const int i = u * T + tid;
+            const uint32_t kr = (uint32_t)i / (kHD / 8), c = ((uint32_t)i % (kHD / 8)) * 8u;
+            uint32_t key = kb * 32u + (kr < 32u ? kr : 31u);
+            key = key < L ? key : L - 1u;   // rows past the sequence: any finite row, masked later
+            rk[u] = *(const u4*)(qkv + (size_t)(s0 + key) * ld + koff + c);
+        }
+#pragma unroll
+        for (int u = 0; u < VCH; ++u) {
+            const int i = u * T + tid;
+            const uint32_t d = ((uint32_t)i / 4u) % kHD, c = ((uint32_t)i % 4u) * 8u;
+            rv[u] = *(const u4*)(vt + ((size_t)g * kHD + d) * vt_ld + v0 + kb * 32u + c);
+        }
+    };
+    auto stage_write = [&]() {
+#pragma unroll
+        for (int u = 0; u < KCH; ++u) {
+            const int i = u * T + tid;
+            if (i < 32 * (kHD / 8)) {
+                const uint32_t kr = (uint32_t)i / (kHD / 8), c = ((uint32_t)i % (kHD / 8)) * 8u;
+                *(u4*)(sK + kr * kKStride + c) = rk[u];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < VCH; ++u) {
+            const int i = u * T + tid;
+            if (i < kHD * 4) {
+                const uint32_t d = (uint32_t)i / 4u, c = ((uint32_t)i % 4u) * 8u;
+                *(u2*)(sV + d * kVStride + c) = (u2){rv[u][0], rv[u][1]};
+                *(u2*)(sV + d * kVStride + c + 4) = (u2){rv[u][2], rv[u][3]};
+            }
+        }
+    };
+    if (kb_lo < kb_hi) stage_load(kb_lo);
     for (uint32_t kb = kb_lo; kb < kb_hi; ++kb) {
         __syncthreads();  // previous tile fully consumed
-        // K tile: 32 keys x 256 dims (16-B pieces; key rows clamped inside the sequence)
-        for (int i = tid; i < 32 * (kHD / 8); i += T) {
-            const uint32_t kr = (uint32_t)i / (kHD / 8), c = ((uint32_t)i % (kHD / 8)) * 8u;
-            uint32_t key = kb * 32u + kr;
-            key = key < L ? key : L - 1u;
-            *(u4*)(sK + kr * kKStride + c) = *(const u4*)(qkv + (size_t)(s0 + key) * ld + koff + c);
-        }
-        // V^T tile: 256 dims x 32 keys (8-B pieces; columns past the sequence hold stale but finite
-        // values of the padded V^T buffer and meet p = 0)
-        for (int i = tid; i < kHD * 4; i += T) {
-            const uint32_t d = (uint32_t)i / 4u, c = ((uint32_t)i % 4u) * 8u;
-            const u4 v = *(const u4*)(vt + ((size_t)g * kHD + d) * vt_ld + v0 + kb * 32u + c);
-            *(u2*)(sV + d * kVStride + c) = (u2){v[0], v[1]};
-            *(u2*)(sV + d * kVStride + c + 4) = (u2){v[2], v[3]};
-        }
+        stage_write();
         __syncthreads();
+        if (kb + 1u < kb_hi) stage_load(kb + 1u);
 
         // S^T[key][q] = sum_dims K[key][d] * Q[q][d]
         f16v s;
@@ -448,20 +479,25 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
         }
 }
 
-// ---- masked mean pool: one block per sequence, thread per 4 hidden dims ----
+// ---- masked mean pool: block = (sequence, 256 hidden dims); 4 waves split the tokens ----
 __global__ __launch_bounds__(256) void mean_pool_kernel(const float* __restrict__ hidden,
                                                         const int32_t* __restrict__ seq_start,
                                                         const int32_t* __restrict__ seq_len,
                                                         bf16_t* __restrict__ pooled, uint32_t H) {
-    const uint32_t b = blockIdx.x;
+    __shared__ f4 part[4][64];
+    const uint32_t b = blockIdx.x, col = blockIdx.y * 256u + (threadIdx.x & 63u) * 4u;
     const uint32_t s0 = (uint32_t)seq_start[b], L = (uint32_t)seq_len[b];
-    for (uint32_t col = threadIdx.x * 4u; col < H; col += 1024u) {
-        f4 acc = (f4)(0.f);
-        for (uint32_t t = 0; t < L; ++t) acc += *(const f4*)(hidden + (size_t)(s0 + t) * H + col);
+    const uint32_t w = threadIdx.x >> 6;
+    f4 acc = (f4)(0.f);
+    for (uint32_t t = w; t < L; t += 4u) acc += *(const f4*)(hidden + (size_t)(s0 + t) * H + col);
+    part[w][threadIdx.x & 63u] = acc;
+    __syncthreads();
+    if (w == 0) {
+        const f4 sum = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
         const float inv = L ? 1.0f / (float)L : 0.f;   // zero mask -> zero vector (src/embedder/pooling.rs:113-119)
         bf4 o;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) o[i] = (bf16_t)(acc[i] * inv);
+        for (int i = 0; i < 4; ++i) o[i] = (bf16_t)(sum[i] * inv);
         *(bf4*)(pooled + (size_t)b * H + col) = o;
     }
 }
@@ -487,7 +523,7 @@ hipError_t launch_embed_norm(const int32_t* tok, const bf16_t* emb, float scale,
 }
 
 template <int FINAL>
-static hipError_t launch_add_norm_t(float* x, const float* y, const float* w_post, const float* w_next, float eps,
+static hipError_t launch_add_norm_t(float* x, const bf16_t* y, const float* w_post, const float* w_next, float eps,
                                     bf16_t* xn, float* out, uint32_t M, uint32_t H, hipStream_t st) {
     const dim3 grid((M + 3u) / 4u), block(256);
     switch (H / 256u) {
@@ -500,7 +536,7 @@ static hipError_t launch_add_norm_t(float* x, const float* y, const float* w_pos
     return hipGetLastError();
 }
 
-hipError_t launch_add_norm(float* x, const float* y, const float* w_post, const float* w_next, float eps,
+hipError_t launch_add_norm(float* x, const bf16_t* y, const float* w_post, const float* w_next, float eps,
                            bf16_t* xn, float* out, int final, uint32_t M, uint32_t H, hipStream_t st) {
     if (M == 0) return hipSuccess;
     return final ? launch_add_norm_t<1>(x, y, w_post, w_next, eps, xn, out, M, H, st)
@@ -560,7 +596,7 @@ hipError_t launch_attention(const bf16_t* qkv, const bf16_t* vt, bf16_t* out, co
 hipError_t launch_mean_pool(const float* hidden, const int32_t* seq_start, const int32_t* seq_len, bf16_t* pooled,
                             uint32_t B, uint32_t H, hipStream_t st) {
     if (B == 0) return hipSuccess;
-    hipLaunchKernelGGL(mean_pool_kernel, dim3(B), dim3(256), 0, st, hidden, seq_start, seq_len, pooled, H);
+    hipLaunchKernelGGL(mean_pool_kernel, dim3(B, H / 256u), dim3(256), 0, st, hidden, seq_start, seq_len, pooled, H);
     return hipGetLastError();
 }
 

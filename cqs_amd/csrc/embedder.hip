@@ -80,8 +80,8 @@ struct cqs_hip_embedder {
 
     // scratch, sized for tok_cap packed tokens / seq_cap sequences
     uint32_t tok_cap = 0, seq_cap = 0, vt_ld = 0, blk_cap = 0;
-    float *x = nullptr, *y = nullptr, *hidden = nullptr, *out = nullptr;
-    bf16_t *xn = nullptr, *qkv = nullptr, *vt = nullptr, *attn = nullptr, *h = nullptr, *pooled = nullptr, *d1 = nullptr;
+    float *x = nullptr, *hidden = nullptr, *out = nullptr;
+    bf16_t *y = nullptr, *xn = nullptr, *qkv = nullptr, *vt = nullptr, *attn = nullptr, *h = nullptr, *pooled = nullptr, *d1 = nullptr;
     int32_t *d_tok = nullptr, *d_pos = nullptr, *d_vtcol = nullptr, *d_seq_start = nullptr, *d_seq_len = nullptr,
             *d_vt_start = nullptr, *d_blk = nullptr;
 
@@ -214,10 +214,10 @@ int32_t run_layers(cqs_hip_embedder* e, const Packed& p, uint32_t B) {
         E_TRY(e, cqs::launch_v_transpose(e->qkv, e->vt, e->d_vtcol, M, g.heads, g.kv_heads, e->vt_ld, st));
         E_TRY(e, cqs::launch_attention(e->qkv, e->vt, e->attn, e->d_blk, nblk, e->d_seq_start, e->d_seq_len,
                                        e->d_vt_start, e->vt_ld, g.heads, g.kv_heads, full ? 0u : g.window, st));
-        E_TRY(e, cqs::launch_gemm_bf16(e->attn, w.wo, e->y, M, H, g.heads * g.head_dim, H, cqs::GEMM_OUT_F32, st));
+        E_TRY(e, cqs::launch_gemm_bf16(e->attn, w.wo, e->y, M, H, g.heads * g.head_dim, H, cqs::GEMM_OUT_BF16, st));
         E_TRY(e, cqs::launch_add_norm(e->x, e->y, w.n_post_attn, w.n_pre_ffw, g.rms_eps, e->xn, nullptr, 0, M, H, st));
         E_TRY(e, cqs::launch_gemm_bf16(e->xn, w.wgu, e->h, M, 2u * g.inter, H, g.inter, cqs::GEMM_OUT_GEGLU, st));
-        E_TRY(e, cqs::launch_gemm_bf16(e->h, w.wd, e->y, M, H, g.inter, H, cqs::GEMM_OUT_F32, st));
+        E_TRY(e, cqs::launch_gemm_bf16(e->h, w.wd, e->y, M, H, g.inter, H, cqs::GEMM_OUT_BF16, st));
         const bool last = (l + 1u == g.layers);
         E_TRY(e, cqs::launch_add_norm(e->x, e->y, w.n_post_ffw, last ? e->n_final : e->L[l + 1].n_in, g.rms_eps, e->xn,
                                       e->hidden, last ? 1 : 0, M, H, st));
