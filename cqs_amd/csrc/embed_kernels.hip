@@ -379,8 +379,9 @@ template <int OUT>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
                                                         void* __restrict__ Cv, uint32_t M, uint32_t N, uint32_t K,
                                                         uint32_t ldc) {
-    __shared__ __attribute__((aligned(16))) bf16_t sA[128 * 64];
-    __shared__ __attribute__((aligned(16))) bf16_t sB[128 * 64];
+    // ONE shared array (a second __shared__ object beside an LDS-DMA staging array can make hipcc
+    // drain vmcnt before every ds_read): [buf][A|B][128 rows][64 k]
+    __shared__ __attribute__((aligned(16))) bf16_t smem[2 * 2 * 128 * 64];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
     const int wm = wid >> 1, wn = wid & 1;
@@ -392,19 +393,32 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
     const uint32_t tile = (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + bid / 8u;
     const uint32_t m0 = (tile / nt) * 128u, n0 = (tile % nt) * 128u;
 
-    // staging: 4 x 16 B per thread per operand; chunk f -> (row f>>3, 16-B column f&7)
+    // LDS-DMA staging (global_load_lds, 16 B per lane): one wave instruction fills 1 KiB = 8 tile
+    // rows, lane l -> row (l >> 3), physical 16-B chunk (l & 7).  The swizzle therefore goes on the
+    // SOURCE: the lane fetches logical chunk (l & 7) ^ ((row >> 1) & 7) of its row.  Each wave stages
+    // 32 rows of A and 32 rows of B per K-step (4 + 4 instructions).
     const bf16_t* ga[4];
     const bf16_t* gb[4];
-    uint32_t lo[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-        const uint32_t f = (uint32_t)u * 256u + (uint32_t)tid, row = f >> 3, c = f & 7u;
+        const uint32_t row = (uint32_t)(wid * 32 + u * 8 + (lane >> 3));
+        const uint32_t c = (uint32_t)(lane & 7) ^ ((row >> 1) & 7u);
         uint32_t ar = m0 + row;
         ar = ar < M ? ar : M - 1u;
         ga[u] = A + (size_t)ar * K + c * 8u;
         gb[u] = W + (size_t)(n0 + row) * K + c * 8u;
-        lo[u] = swz(row, c);
     }
+    auto stage = [&](uint32_t kt, int buf) {
+        bf16_t* dA = smem + (size_t)buf * (2 * 128 * 64) + (size_t)(wid * 32) * 64;
+        bf16_t* dB = dA + 128 * 64;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ga[u] + (size_t)kt * 64u),
+                                             (__attribute__((address_space(3))) void*)(dA + u * 8 * 64), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gb[u] + (size_t)kt * 64u),
+                                             (__attribute__((address_space(3))) void*)(dB + u * 8 * 64), 16, 0, 0);
+        }
+    };
     f16v acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -413,27 +427,16 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    u4 ra[4], rb[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        ra[u] = *(const u4*)ga[u];
-        rb[u] = *(const u4*)gb[u];
-    }
     const uint32_t nk = K / 64u;
+    stage(0, 0);
     for (uint32_t kt = 0; kt < nk; ++kt) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            *(u4*)(sA + lo[u]) = ra[u];
-            *(u4*)(sB + lo[u]) = rb[u];
-        }
+        const int buf = (int)(kt & 1u);
+        // one barrier per K-step: it drains this wave's DMA (tile kt has landed for everyone) and
+        // proves every wave is done reading the other buffer, which the next stage overwrites
         __syncthreads();
-        if (kt + 1u < nk) {  // next tile's global loads fly under this tile's MFMAs
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                ra[u] = *(const u4*)(ga[u] + (size_t)(kt + 1u) * 64u);
-                rb[u] = *(const u4*)(gb[u] + (size_t)(kt + 1u) * 64u);
-            }
-        }
+        if (kt + 1u < nk) stage(kt + 1u, buf ^ 1);   // flies under this tile's MFMAs
+        const bf16_t* sA = smem + (size_t)buf * (2 * 128 * 64);
+        const bf16_t* sB = sA + 128 * 64;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             bf8 af[2], bfr[2];
@@ -453,7 +456,6 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
         }
-        __syncthreads();
     }
 
     // epilogue: C tile element (row = (e&3) + 8(e>>2) + 4lh, col = l31) of acc[i][j]
