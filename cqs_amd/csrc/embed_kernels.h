@@ -49,7 +49,7 @@ hipError_t launch_v_transpose(const bf16_t* qkv, bf16_t* vt, const int32_t* vt_c
                               uint32_t kv_heads, uint32_t vt_ld, hipStream_t st);
 
 // Bidirectional (optionally windowed) attention over packed sequences.
-// blk[i] = {sequence, 32-row query block}; seq_start/seq_len in packed tokens; vt_start = first
+// blk[i] = {sequence, 128-row query super-block}; seq_start/seq_len in packed tokens; vt_start = first
 // V^T column of the sequence (multiple of 32).  out [M, heads*256] bf16.
 hipError_t launch_attention(const bf16_t* qkv, const bf16_t* vt, bf16_t* out, const int32_t* blk /*[nblk][2]*/,
                             uint32_t nblk, const int32_t* seq_start, const int32_t* seq_len,

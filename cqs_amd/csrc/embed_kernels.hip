@@ -183,96 +183,102 @@ __global__ __launch_bounds__(256) void v_transpose_kernel(const bf16_t* __restri
 }
 
 // ---- attention --------------------------------------------------------------------------
-// One workgroup = the G q-heads sharing a kv head (one wave each) x one 32-row query block.
 // S^T = K Q^T (keys on rows, queries on lanes: softmax is lane-local), O^T += V^T P^T with the
 // S^T accumulator used directly as the B operand (no LDS round trip for P).
-constexpr int kKStride = kHD + 8;   // K tile row: 256 bf16 + 16 B pad -> ds_read_b128 conflict-free
-constexpr int kVStride = 32 + 4;    // V^T tile row: 32 keys + 8 B pad -> ds_read_b64 conflict-free
+// LDS tiles are split by the MFMA lane group g = lane >> 4 so that a fragment read's bank only depends
+// on its row:  sK[g][key][8 k-steps x 8 dims + 8 pad]  (row stride 144 B: 16 rows -> 16 distinct 16-B slots)
+//              sV[g][dim][8 keys = the group's B-operand slots]  (row stride 16 B: 16 rows = one 256-B bank row)
+constexpr int kKRow = 64 + 8;               // elements per sK row
+constexpr int kKSub = 32 * kKRow;           // elements per lane-group sub-tile (4608 B = 18 x 256 B)
+constexpr int kVSub = kHD * 8;              // elements per lane-group sub-tile of sV
 
-template <int G>
-__global__ __launch_bounds__(G * 64, 1) void attention_kernel(const bf16_t* __restrict__ qkv,
-                                                              const bf16_t* __restrict__ vt,
-                                                              bf16_t* __restrict__ out,
-                                                              const int32_t* __restrict__ blk,
-                                                              const int32_t* __restrict__ seq_start,
-                                                              const int32_t* __restrict__ seq_len,
-                                                              const int32_t* __restrict__ vt_start, uint32_t vt_ld,
-                                                              uint32_t heads, uint32_t kv_heads, uint32_t window) {
-    __shared__ __attribute__((aligned(16))) bf16_t sK[32 * kKStride];
-    __shared__ __attribute__((aligned(16))) bf16_t sV[kHD * kVStride];
-    constexpr int T = G * 64;
+// One workgroup = 8 waves (2 per SIMD: one wave's MFMAs overlap the other's softmax VALU) = 128
+// consecutive queries of ONE q-head of one sequence, 16 queries per wave (16x16x32 MFMA tiles keep the
+// wave at ~150 VGPRs: O^T 64 + Q 32 + S 8, no accumulator spills into AGPRs).  The K / V^T tiles of
+// the head's kv group are staged once per 32-key block for all eight waves.
+//   S^T (32 keys x 16 q)  = K (A: 16 keys x 32 dims per tile) x Q^T (B, registers)     16 MFMAs
+//   O^T (256 d x 16 q)   += V^T (A: 16 dims x 32 keys) x P^T (B = the S^T registers)    16 MFMAs
+// C layout of 16x16: col = lane&15 (query), row = 4*(lane>>4) + reg.  So lane group g = lane>>4 owns
+// keys {4g..4g+3} of each 16-key tile; used as the B operand its 8 slots are keys
+// {4g..4g+3, 16+4g..16+4g+3} of the block, and the V^T fragment is read in the same order.
+constexpr float kRescaleThr = 8.0f;  // defer the O rescale while the running max grows by < e^8 (P stays < 2981)
+typedef float f4v __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(512) void attention_kernel(const bf16_t* __restrict__ qkv,
+                                                        const bf16_t* __restrict__ vt,
+                                                        bf16_t* __restrict__ out,
+                                                        const int32_t* __restrict__ blk,
+                                                        const int32_t* __restrict__ seq_start,
+                                                        const int32_t* __restrict__ seq_len,
+                                                        const int32_t* __restrict__ vt_start, uint32_t vt_ld,
+                                                        uint32_t heads, uint32_t kv_heads, uint32_t window) {
+    __shared__ __attribute__((aligned(16))) bf16_t smem[4 * kKSub + 4 * kVSub];
+    bf16_t* sK = smem;
+    bf16_t* sV = smem + 4 * kKSub;
+    constexpr int T = 512;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int l31 = lane & 31, lh = lane >> 5;
-    const uint32_t b = (uint32_t)blk[2 * blockIdx.x], qb = (uint32_t)blk[2 * blockIdx.x + 1];
-    const uint32_t g = blockIdx.y;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const uint32_t b = (uint32_t)blk[2 * blockIdx.x], sb = (uint32_t)blk[2 * blockIdx.x + 1];
+    const uint32_t head = blockIdx.y;
+    const uint32_t g = head / (heads / kv_heads);
     const uint32_t s0 = (uint32_t)seq_start[b], L = (uint32_t)seq_len[b], v0 = (uint32_t)vt_start[b];
     const uint32_t ld = (heads + 2u * kv_heads) * kHD;
-    const uint32_t head = g * G + (uint32_t)wid;
     const uint32_t koff = (heads + g) * kHD;
+    const uint32_t q0 = sb * 128u + (uint32_t)wid * 16u;   // this wave's first query
+    const bool wave_live = q0 < L;                          // waves past the sequence only help staging
+    const uint32_t qi = q0 + (uint32_t)l15;                 // this lane's query
 
-    // Q^T fragments (B operand of K Q^T): lane feeds Q[q = l31][dims 16s + 8*lh + 0..7]
-    const uint32_t qi = qb * 32u + (uint32_t)l31;             // query index in the sequence
+    // Q^T fragments (B operand): lane feeds Q[q = l15][dims 32s + 8*lg + 0..7], s = 0..7
     const uint32_t qtok = s0 + (qi < L ? qi : L - 1u);
-    bf8 qf[16];
+    bf8 qf[8];
 #pragma unroll
-    for (int s = 0; s < 16; ++s) qf[s] = *(const bf8*)(qkv + (size_t)qtok * ld + head * kHD + 16 * s + 8 * lh);
+    for (int s = 0; s < 8; ++s) qf[s] = *(const bf8*)(qkv + (size_t)qtok * ld + head * kHD + 32 * s + 8 * lg);
 
-    f16v o[8];
+    f4v o[16];
 #pragma unroll
-    for (int d = 0; d < 8; ++d)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+    for (int d = 0; d < 16; ++d) o[d] = (f4v)(0.f);
     float m_run = -INFINITY, l_run = 0.f;
 
-    // key blocks that can hold an attendable key for this query block
-    uint32_t kb_lo = 0, kb_hi = (L + 31u) / 32u;  // [lo, hi)
+    // key blocks that can hold an attendable key: workgroup range (staging) and this wave's own range
+    const uint32_t nkb = (L + 31u) / 32u;
+    uint32_t kb_lo = 0, kb_hi = nkb, wkb_lo = 0, wkb_hi = nkb;
     if (window) {
-        const uint32_t qlo = qb * 32u, qhi = qlo + 31u;
-        kb_lo = (qlo + 1u > window) ? (qlo + 1u - window) / 32u : 0u;
-        const uint32_t khi = qhi + window - 1u;   // last attendable key
-        const uint32_t hi2 = khi / 32u + 1u;
-        if (hi2 < kb_hi) kb_hi = hi2;
+        const uint32_t glo = sb * 128u, ghi = glo + 127u;          // workgroup's queries
+        kb_lo = (glo + 1u > window) ? (glo + 1u - window) / 32u : 0u;
+        kb_hi = (ghi + window - 1u) / 32u + 1u;
+        if (kb_hi > nkb) kb_hi = nkb;
+        const uint32_t qhi = q0 + 15u;                              // this wave's queries
+        wkb_lo = (q0 + 1u > window) ? (q0 + 1u - window) / 32u : 0u;
+        wkb_hi = (qhi + window - 1u) / 32u + 1u;
     }
 
-    // K / V^T tiles are staged through registers one key block ahead: the global loads of block
-    // kb+1 are in flight while block kb is on the matrix cores (one wave per SIMD: nothing else
-    // would hide their latency).
-    constexpr int KCH = (32 * (kHD / 8) + T - 1) / T;   // 16-B pieces per thread, K tile
-    constexpr int VCH = (kHD * 4 + T - 1) / T;          // 16-B pieces per thread, V^T tile
-    u4 rk[KCH], rv[VCH];
+    // K / V^T tiles go through registers one key block ahead (2 + 2 x 16 B per thread)
+    u4 rk[2], rv[2];
     auto stage_load = [&](uint32_t kb) {
 #pragma unroll
-        for (int u = 0; u < KCH; ++u) {
+        for (int u = 0; u < 2; ++u) {
             const int i = u * T + tid;
             const uint32_t kr = (uint32_t)i / (kHD / 8), c = ((uint32_t)i % (kHD / 8)) * 8u;
-            uint32_t key = kb * 32u + (kr < 32u ? kr : 31u);
+            uint32_t key = kb * 32u + kr;
             key = key < L ? key : L - 1u;   // rows past the sequence: any finite row, masked later
             rk[u] = *(const u4*)(qkv + (size_t)(s0 + key) * ld + koff + c);
-        }
-#pragma unroll
-        for (int u = 0; u < VCH; ++u) {
-            const int i = u * T + tid;
-            const uint32_t d = ((uint32_t)i / 4u) % kHD, c = ((uint32_t)i % 4u) * 8u;
-            rv[u] = *(const u4*)(vt + ((size_t)g * kHD + d) * vt_ld + v0 + kb * 32u + c);
+            const uint32_t d = (uint32_t)i / 4u, cv = ((uint32_t)i % 4u) * 8u;
+            rv[u] = *(const u4*)(vt + ((size_t)g * kHD + d) * vt_ld + v0 + kb * 32u + cv);
         }
     };
     auto stage_write = [&]() {
 #pragma unroll
-        for (int u = 0; u < KCH; ++u) {
+        for (int u = 0; u < 2; ++u) {
             const int i = u * T + tid;
-            if (i < 32 * (kHD / 8)) {
-                const uint32_t kr = (uint32_t)i / (kHD / 8), c = ((uint32_t)i % (kHD / 8)) * 8u;
-                *(u4*)(sK + kr * kKStride + c) = rk[u];
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < VCH; ++u) {
-            const int i = u * T + tid;
-            if (i < kHD * 4) {
-                const uint32_t d = (uint32_t)i / 4u, c = ((uint32_t)i % 4u) * 8u;
-                *(u2*)(sV + d * kVStride + c) = (u2){rv[u][0], rv[u][1]};
-                *(u2*)(sV + d * kVStride + c + 4) = (u2){rv[u][2], rv[u][3]};
-            }
+            // K: 16-B chunk cc of key row kr = dims 8cc..8cc+7 = k-step cc/4, lane group cc%4
+            const uint32_t kr = (uint32_t)i / (kHD / 8), cc = (uint32_t)i % (kHD / 8);
+            *(u4*)(sK + (cc & 3u) * kKSub + kr * kKRow + (cc >> 2) * 8u) = rk[u];
+            // V^T: chunk a of dim row d = keys 8a..8a+7: keys 8a+0..3 are slots 4(a/2)..+3 of lane group
+            // 2(a%2), keys 8a+4..7 the same slots of lane group 2(a%2)+1
+            const uint32_t d = (uint32_t)i / 4u, a = (uint32_t)i % 4u;
+            bf16_t* vd = sV + (2u * (a & 1u)) * kVSub + d * 8u + 4u * (a >> 1);
+            *(u2*)vd = (u2){rv[u][0], rv[u][1]};
+            *(u2*)(vd + kVSub) = (u2){rv[u][2], rv[u][3]};
         }
     };
     if (kb_lo < kb_hi) stage_load(kb_lo);
@@ -280,87 +286,112 @@ __global__ __launch_bounds__(G * 64, 1) void attention_kernel(const bf16_t* __re
         __syncthreads();  // previous tile fully consumed
         stage_write();
         __syncthreads();
+#ifndef CQS_ATT_ABLATE_NOLOAD
         if (kb + 1u < kb_hi) stage_load(kb + 1u);
+#endif
+        if (!wave_live || kb < wkb_lo || kb >= wkb_hi) continue;   // wave-uniform
+#ifdef CQS_ATT_ABLATE_NOCOMPUTE
+        if (kb != kb_lo) continue;
+#endif
 
-        // S^T[key][q] = sum_dims K[key][d] * Q[q][d]
-        f16v s;
+        // S^T tiles: keys [0,16) and [16,32) of the block x this wave's 16 queries.  Fragment reads are
+        // issued 8 at a time AHEAD of their MFMAs (left alone, hipcc emits read -> wait -> MFMA pairs and
+        // every MFMA eats a full LDS round trip).
+        f4v sc[2];
+        sc[0] = (f4v)(0.f);
+        sc[1] = (f4v)(0.f);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+        for (int half = 0; half < 2; ++half) {
+            bf8 kf[8];
 #pragma unroll
-        for (int st = 0; st < 16; ++st) {
-            const bf8 kf = *(const bf8*)(sK + l31 * kKStride + 16 * st + 8 * lh);
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[st], s, 0, 0, 0);
+            for (int i = 0; i < 8; ++i) {
+                const int st = half * 4 + (i >> 1), kt = i & 1;
+                kf[i] = *(const bf8*)(sK + lg * kKSub + (kt * 16 + l15) * kKRow + 8 * st);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int st = half * 4 + (i >> 1), kt = i & 1;
+                sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[i], qf[st], sc[kt], 0, 0, 0);
+            }
         }
-        // mask + online softmax; this lane's query is qi, register r <-> key (r&3) + 8(r>>2) + 4*lh
+        // mask (only on blocks that touch the sequence end or the window edge) + online softmax over this
+        // lane's 8 keys; the query's other 24 keys live in lanes ^16, ^32, ^48
+        const uint32_t k_first = kb * 32u, k_last = k_first + 31u;
+        const bool interior = k_last < L && (!window || ((q0 + 15u < k_first + window) && (k_last < q0 + window)));
         float mloc = -INFINITY;
+        if (interior) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const uint32_t key = kb * 32u + (uint32_t)((r & 3) + 8 * (r >> 2) + 4 * lh);
-            bool ok = key < L;
-            if (window) {
-                const uint32_t dist = key > qi ? key - qi : qi - key;
-                ok = ok && dist < window;
-            }
-            s[r] = ok ? s[r] : -INFINITY;
-            mloc = fmaxf(mloc, s[r]);
-        }
-        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-        const float m_new = fmaxf(m_run, mloc);
-        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;   // no attendable key yet: p = 0, alpha = 1
-        const float alpha = (m_run == -INFINITY) ? ((m_new == -INFINITY) ? 1.f : 0.f) : __expf(m_run - m_use);
-        float lsum = 0.f;
+            for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            s[r] = __expf(s[r] - m_use);   // exp(-inf) = 0 for masked keys
-            lsum += s[r];
-        }
-        lsum += __shfl_xor(lsum, 32, 64);
-        l_run = l_run * alpha + lsum;
-        m_run = m_new;
-        if (alpha != 1.f) {
+                for (int r = 0; r < 4; ++r) mloc = fmaxf(mloc, sc[kt][r]);
+        } else {
 #pragma unroll
-            for (int d = 0; d < 8; ++d)
+            for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
-        }
-        // P^T as the B operand: k-step st uses registers 8st..8st+7; slot (lh, j) <-> key
-        // 16st + 8(j>>2) + 4lh + (j&3), which the V^T fragment below matches
-        bf8 pf[2];
-#pragma unroll
-        for (int st = 0; st < 2; ++st)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) pf[st][j] = (bf16_t)s[8 * st + j];
-#pragma unroll
-        for (int d = 0; d < 8; ++d) {
-#pragma unroll
-            for (int st = 0; st < 2; ++st) {
-                const bf16_t* vp = sV + (d * 32 + l31) * kVStride + 16 * st + 4 * lh;
-                const bf4 v_lo = *(const bf4*)vp;        // keys 16st + 4lh + 0..3
-                const bf4 v_hi = *(const bf4*)(vp + 8);  // keys 16st + 8 + 4lh + 0..3
-                bf8 vf;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    vf[j] = v_lo[j];
-                    vf[4 + j] = v_hi[j];
+                for (int r = 0; r < 4; ++r) {
+                    const uint32_t key = k_first + (uint32_t)(kt * 16 + 4 * lg + r);
+                    bool ok = key < L;
+                    if (window) {
+                        const uint32_t dist = key > qi ? key - qi : qi - key;
+                        ok = ok && dist < window;
+                    }
+                    sc[kt][r] = ok ? sc[kt][r] : -INFINITY;
+                    mloc = fmaxf(mloc, sc[kt][r]);
                 }
-                o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[st], o[d], 0, 0, 0);
+        }
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+        // Deferred rescale: the running max only moves when the block max exceeds it by more than
+        // kRescaleThr; until then P = exp(s - m_run) <= e^8, exact in f32 and fine in bf16.
+        const bool need = mloc > m_run + kRescaleThr || (m_run == -INFINITY && mloc != -INFINITY);
+        if (__any(need)) {
+            const float m_new = need ? mloc : m_run;
+            const float a = need ? ((m_run == -INFINITY) ? 0.f : __expf(m_run - m_new)) : 1.f;
+            l_run *= a;
+#pragma unroll
+            for (int d = 0; d < 16; ++d) o[d] *= a;
+            m_run = m_new;
+        }
+        const float m_use = (m_run == -INFINITY) ? 0.f : m_run;   // no attendable key yet: every p = 0
+        float lsum = 0.f;
+        bf8 pf;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float pv = __expf(sc[kt][r] - m_use);   // exp(-inf) = 0 for masked keys
+                lsum += pv;
+                pf[kt * 4 + r] = (bf16_t)pv;                    // slot (lg, 4kt + r) <-> key 16kt + 4lg + r
             }
+        lsum += __shfl_xor(lsum, 16, 64);
+        lsum += __shfl_xor(lsum, 32, 64);
+        l_run += lsum;
+        // slots 0..3 = keys 4lg + 0..3, slots 4..7 = keys 16 + 4lg + 0..3: one 16-B read per dim tile,
+        // again 8 reads ahead of their 8 MFMAs
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            bf8 vf[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) vf[i] = *(const bf8*)(sV + lg * kVSub + ((half * 8 + i) * 16 + l15) * 8);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                o[half * 8 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[i], pf, o[half * 8 + i], 0, 0, 0);
         }
     }
 
-    // O^T[d][q]: lane <-> query, register r of tile d <-> dim 32d + (r&3) + 8(r>>2) + 4lh
-    if (qi < L) {
+    // O^T[d][q]: lane <-> query l15, register r of tile d <-> dim 16d + 4lg + r
+    if (wave_live && qi < L) {
         const float invl = l_run > 0.f ? 1.0f / l_run : 0.f;
         bf16_t* op = out + (size_t)(s0 + qi) * (heads * kHD) + head * kHD;
 #pragma unroll
-        for (int d = 0; d < 8; ++d)
+        for (int d = 0; d < 16; ++d) {
+            bf4 w;
 #pragma unroll
-            for (int rg = 0; rg < 4; ++rg) {
-                bf4 w;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) w[e] = (bf16_t)(o[d][4 * rg + e] * invl);
-                *(bf4*)(op + 32 * d + 8 * rg + 4 * lh) = w;
-            }
+            for (int e = 0; e < 4; ++e) w[e] = (bf16_t)(o[d][e] * invl);
+            *(bf4*)(op + 16 * d + 4 * lg) = w;
+        }
     }
 }
 
@@ -437,24 +468,31 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
         if (kt + 1u < nk) stage(kt + 1u, buf ^ 1);   // flies under this tile's MFMAs
         const bf16_t* sA = smem + (size_t)buf * (2 * 128 * 64);
         const bf16_t* sB = sA + 128 * 64;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            bf8 af[2], bfr[2];
+        // fragments of k-step ks+1 are read while the MFMAs of k-step ks run (two register sets)
+        bf8 af[2][2], bfr[2][2];
+        auto read_frags = [&](int ks, int set) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const uint32_t row = (uint32_t)(wm * 64 + i * 32 + l31);
-                af[i] = *(const bf8*)(sA + swz(row, (uint32_t)(2 * ks + lh)));
+                af[set][i] = *(const bf8*)(sA + swz(row, (uint32_t)(2 * ks + lh)));
             }
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const uint32_t row = (uint32_t)(wn * 64 + j * 32 + l31);
-                bfr[j] = *(const bf8*)(sB + swz(row, (uint32_t)(2 * ks + lh)));
+                bfr[set][j] = *(const bf8*)(sB + swz(row, (uint32_t)(2 * ks + lh)));
             }
+        };
+        read_frags(0, 0);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int cur = ks & 1;
+            if (ks + 1 < 4) read_frags(ks + 1, cur ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cur][i], bfr[cur][j], acc[i][j], 0, 0, 0);
         }
     }
 
@@ -580,18 +618,9 @@ hipError_t launch_attention(const bf16_t* qkv, const bf16_t* vt, bf16_t* out, co
                             const int32_t* seq_start, const int32_t* seq_len, const int32_t* vt_start, uint32_t vt_ld,
                             uint32_t heads, uint32_t kv_heads, uint32_t window, hipStream_t st) {
     if (nblk == 0) return hipSuccess;
-    const uint32_t G = heads / kv_heads;
-    const dim3 grid(nblk, kv_heads);
-#define CQS_ATT(GV) hipLaunchKernelGGL(attention_kernel<GV>, grid, dim3(GV * 64), 0, st, qkv, vt, out, blk, seq_start, \
-                                       seq_len, vt_start, vt_ld, heads, kv_heads, window)
-    switch (G) {
-        case 1: CQS_ATT(1); break;
-        case 2: CQS_ATT(2); break;
-        case 3: CQS_ATT(3); break;
-        case 4: CQS_ATT(4); break;
-        default: return hipErrorInvalidValue;
-    }
-#undef CQS_ATT
+    if (kv_heads == 0 || heads % kv_heads) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(attention_kernel, dim3(nblk, heads), dim3(512), 0, st, qkv, vt, out, blk, seq_start, seq_len,
+                       vt_start, vt_ld, heads, kv_heads, window);
     return hipGetLastError();
 }
 

@@ -180,7 +180,7 @@ int32_t pack(cqs_hip_embedder* e, const int64_t* ids, const int64_t* mask, uint3
             p.pos.push_back((int32_t)j);
             p.vtcol.push_back((int32_t)(vcols + j));
         }
-        for (uint32_t qb = 0; qb * 32u < len; ++qb) { p.blk.push_back((int32_t)b); p.blk.push_back((int32_t)qb); }
+        for (uint32_t sb = 0; sb * 128u < len; ++sb) { p.blk.push_back((int32_t)b); p.blk.push_back((int32_t)sb); }
         M += len;
         vcols += (len + 31u) / 32u * 32u;
     }
