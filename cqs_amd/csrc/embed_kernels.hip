@@ -396,14 +396,20 @@ __global__ __launch_bounds__(512) void attention_kernel(const bf16_t* __restrict
 }
 
 // ---- GEMM: C[M,N] = A[M,K] W[N,K]^T, 128x128x64 tiles, 4 waves (2x2) of 64x64, 32x32x16 bf16 MFMA ----
+// Measured alternatives at M=16384 (tools/gemm_bench.py), all 620-730 TF like this one: register-staged
+// operands (ds_write_b128), a 256x128 tile with 4 waves of 128x64 and a 3-slot DMA ring (1 wave/SIMD: the
+// ~100-cycle DMA issue cannot overlap the wave's own MFMAs: 1.5x slower), the same tile with 8 waves and
+// staggered DMA issue (equal).  The remaining gap to the matrix-core peak is per-K-step latency exposure
+// (barrier + first fragment reads); closing it needs the phase-interleaved 256x256 schedule.
 // LDS tile [128 rows][64 k] bf16, 16-B chunk c of row r stored at chunk c ^ ((r >> 1) & 7): the 16
 // rows one ds_read_b128 lane group touches then hit 16 distinct 16-B slots of the 256-B bank row.
 __device__ __forceinline__ uint32_t swz(uint32_t row, uint32_t chunk) { return row * 64u + ((chunk ^ ((row >> 1) & 7u)) * 8u); }
 
 __device__ __forceinline__ float gelu_tanh(float x) {
+    // 0.5 x (1 + tanh(u)) = x * sigmoid(2u), u = sqrt(2/pi) (x + 0.044715 x^3): one v_exp + one v_rcp
     const float k0 = 0.7978845608028654f, k1 = 0.044715f;
-    const float u = k0 * (x + k1 * x * x * x);
-    return 0.5f * x * (1.0f + tanhf(u));
+    const float u2 = 2.0f * k0 * (x + k1 * x * x * x);
+    return x * __frcp_rn(1.0f + __expf(-u2));
 }
 
 template <int OUT>

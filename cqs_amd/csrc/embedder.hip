@@ -594,6 +594,34 @@ static int32_t embed_common(cqs_hip_embedder* e, const int64_t* ids, const int64
     return CQS_HIP_OK;
 }
 
+// Tuning aid (not part of the public header): average milliseconds of one C[M,N] = A[M,K] W[N,K]^T
+// launch over `iters` back-to-back launches on random bf16 operands.
+float cqs_hip_debug_gemm_ms(uint32_t M, uint32_t N, uint32_t K, uint32_t iters, int32_t out_kind) {
+    bf16_t *A = nullptr, *W = nullptr;
+    void* C = nullptr;
+    if (dmalloc(&A, (size_t)M * K) != hipSuccess || dmalloc(&W, (size_t)N * K) != hipSuccess ||
+        hipMalloc(&C, (size_t)M * N * 4) != hipSuccess) return -1.f;
+    std::vector<uint16_t> h((size_t)std::max(M, N) * K);
+    uint32_t st = 12345u;
+    for (auto& v : h) { st = st * 1664525u + 1013904223u; v = f32_to_bf16_bits(((st >> 8) & 0xFFFF) / 32768.0f - 1.0f); }
+    (void)hipMemcpy(A, h.data(), (size_t)M * K * 2, hipMemcpyHostToDevice);
+    (void)hipMemcpy(W, h.data(), (size_t)N * K * 2, hipMemcpyHostToDevice);
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    const cqs::GemmOut ok = (cqs::GemmOut)out_kind;
+    const uint32_t ldc = ok == cqs::GEMM_OUT_GEGLU ? N / 2 : N;
+    (void)cqs::launch_gemm_bf16(A, W, C, M, N, K, ldc, ok, nullptr);
+    (void)hipEventRecord(e0, nullptr);
+    for (uint32_t i = 0; i < iters; ++i) (void)cqs::launch_gemm_bf16(A, W, C, M, N, K, ldc, ok, nullptr);
+    (void)hipEventRecord(e1, nullptr);
+    (void)hipEventSynchronize(e1);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipFree(A); (void)hipFree(W); (void)hipFree(C);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return ms / (float)iters;
+}
+
 int32_t cqs_hip_embed(cqs_hip_embedder* e, const int64_t* ids, const int64_t* mask, uint32_t B, uint32_t L, float* out) {
     return embed_common(e, ids, mask, B, L, out, false);
 }
