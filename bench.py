@@ -91,7 +91,7 @@ def cpu_baseline(rows_host, queries_host, k, seconds):
     return out
 
 
-def embed_leg(a, rank, world, dist, torch, np, dev):
+def embed_leg(a, rank, world, dist, torch, np, dev, all_reduce_max):
     """Index-build leg of the metric ("index embed chunks/sec"): EmbeddingGemma-300m geometry with seeded
     random weights (no network for the real checkpoint), synthetic token ids, batch = the reference's
     embed_batch_size() (32), (a) fixed L and (b) log-normal lengths ("few hundred tokens").
@@ -155,9 +155,7 @@ def embed_leg(a, rank, world, dist, torch, np, dev):
             dev_ms += eng.last_ms()
         el = time.perf_counter() - t0
         if dist is not None:
-            t = torch.tensor([el], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            el = float(t.item())
+            el = all_reduce_max(el)
         toks = int(np.sum(lens))
         tf = flops_of(lens) * steps / (dev_ms / 1e3) / 1e12
         return {"chunks_per_sec": round(B * steps * world / el, 1), "tokens_per_sec": round(toks * steps * world / el, 1),
@@ -188,12 +186,37 @@ def main():
     if world != a.gpus:
         if world == 1 and a.gpus > 1:
             raise SystemExit("--gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
+    # CQS_BENCH_REHEARSAL=1: rehearse the N>1 code path on ONE GPU (all ranks on cuda:0, gloo collectives
+    # staged through host memory).  Logic check only - never a performance number.
+    rehearsal = os.environ.get("CQS_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+
+    def all_gather_dev(out, inp):
+        """One fused all-gather of a device tensor (RCCL over xGMI; host-staged gloo in rehearsal mode)."""
+        # flat views: output numel = world x input numel is the one shape contract every backend accepts
+        if dist is None:
+            out.view(-1).copy_(inp.contiguous().view(-1))
+        elif rehearsal:
+            o = torch.empty((out.numel(),), dtype=out.dtype)
+            dist.all_gather_into_tensor(o, inp.cpu().contiguous().view(-1))
+            out.view(-1).copy_(o)
+        else:
+            dist.all_gather_into_tensor(out.view(-1), inp.contiguous().view(-1))
+
+    def all_reduce_max(x):
+        t = torch.tensor([x], dtype=torch.float64, device="cpu" if rehearsal else dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
     n, dim, k, bq = a.rows, a.dim, a.k, a.batch
     K, W = a.steps, a.warmup
@@ -208,7 +231,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    if world == 1:
+    sharded_path = world > 1 or os.environ.get("CQS_BENCH_FORCE_SHARDED") == "1"   # the env knob exercises the N>1 code on 1 rank
+    if not sharded_path:
         out_keys = torch.zeros((K + W, bq, k), dtype=torch.int64, device=dev)
         out_counts = torch.zeros((K + W, bq), dtype=torch.int32, device=dev)
 
@@ -218,13 +242,13 @@ def main():
         def finish(lo, hi):
             torch.cuda.synchronize()
     else:
-        shard = ShardedSearch(hip_local_search(idx), k)
+        shard = ShardedSearch(hip_local_search(idx), k, all_gather=all_gather_dev)
         qall = torch.empty((K + W, world * bq, dim), dtype=torch.float32, device=dev)
         gathered = [None] * (K + W)
         merged = {}
 
         def step(i):
-            dist.all_gather_into_tensor(qall[i].view(world, bq, dim), queries[i])  # every rank's queries
+            all_gather_dev(qall[i].view(world, bq, dim), queries[i])               # every rank's queries
             gathered[i] = shard.gather_candidates(qall[i], k)                     # scan + ONE all-gather
 
         def finish(lo, hi):
@@ -245,13 +269,11 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = all_reduce_max(elapsed)
 
     # ---- sanity of the last step's answer (outside the timed region) ----
     i = W + K - 1
-    if world == 1:
+    if not sharded_path:
         r, s = unpack_keys(out_keys[i, 0].cpu().numpy().view(np.uint64))
         assert int(out_counts[i, 0].item()) == k
     else:
@@ -262,12 +284,14 @@ def main():
     if local:
         direct = (rows[torch.tensor(local, device=dev)].double() @ queries[i, 0].double()).cpu().numpy()
         mine = np.array([float(sv) for x, sv in zip(r, s) if rank * n <= int(x) < (rank + 1) * n])
-        assert np.max(np.abs(direct - mine)) <= 1e-5, "scores differ from a direct fp64 dot"
+        assert np.max(np.abs(direct - mine)) <= 1e-5, (
+            "scores differ from a direct fp64 dot: rank %d max|d|=%g rows=%s got=%s want=%s"
+            % (rank, float(np.max(np.abs(direct - mine))), list(r[:6]), list(mine[:4]), list(direct[:4])))
 
     # ---- roofline: the scan kernel's own duration, HIP events on the launch stream ----
     idx.set_timing(True)
     for i in range(W, W + K):
-        if world == 1:
+        if not sharded_path:
             step(i)
         else:
             shard.local_search(qall[i], k)
@@ -278,10 +302,14 @@ def main():
     alg_bytes = n * dim * 4  # algorithmic bytes per launch = shard rows x dim x 4 B (corpus read once)
     achieved = alg_bytes / avg_s / 1e9
     traffic = None
+    nq_scan_probe = bq * world
     tpath = os.path.join(ROOT, "profiles", "r01_scan_traffic.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            tj = json.load(open(tpath))
+            # PMC traffic was measured on the default workload only (rocprofv3 --pmc passes, profiles/)
+            if tj.get("alg_bytes_per_launch") == alg_bytes and nq_scan_probe == 1:
+                traffic = tj.get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
     nq_scan = bq * world
@@ -307,7 +335,7 @@ def main():
         idx.close()
         del rows
         torch.cuda.empty_cache()
-        embed = embed_leg(a, rank, world, dist, torch, np, dev)
+        embed = embed_leg(a, rank, world, dist, torch, np, dev, all_reduce_max)
 
     if rank == 0:
         total_q = K * bq * world

@@ -381,7 +381,7 @@ int32_t cqs_hip_index_search_device(cqs_hip_index* x, const float* d_queries, ui
     if (mode > CQS_HIP_MODE_PIPELINE) return fail(x, CQS_HIP_ERR_INVALID, "search_device: bad mode");
     if (b > max_query_block(x)) return fail(x, CQS_HIP_ERR_INVALID, "search_device: batch exceeds scratch budget");
     HIP_TRY(x, hipSetDevice(x->device));
-    hipStream_t st = stream ? (hipStream_t)stream : x->stream;
+    hipStream_t st = (hipStream_t)stream;  // NULL = the HIP null (legacy default) stream, e.g. torch's default stream
     if (x->n == 0) {
         HIP_TRY(x, hipMemsetAsync(d_out_counts, 0, (size_t)b * sizeof(uint32_t), st));
         return CQS_HIP_OK;

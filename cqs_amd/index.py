@@ -310,7 +310,7 @@ class HipIndex(VectorIndex):
         """Enqueue `cqs_hip_index_search_device` on `stream` (raw device pointers / hipStream_t as ints)."""
         rc = self._lib.cqs_hip_index_search_device(
             self._h, C.c_void_p(d_queries), b, k, C.c_void_p(d_keep) if d_keep else None, mode, threshold,
-            C.c_void_p(d_out_keys), C.c_void_p(d_out_counts), C.c_void_p(stream) if stream else None)
+            C.c_void_p(d_out_keys), C.c_void_p(d_out_counts), C.c_void_p(stream) if stream else None)  # 0 -> NULL = null stream
         if rc != _lib.OK:
             raise HipError(rc, self.last_error())
 

@@ -37,14 +37,16 @@ class ShardedSearch:
     on this rank's device, keys packed as in include/cqs_hip.h and sorted descending.
     """
 
-    def __init__(self, local_search: Callable, k_max: int, group=None):
+    def __init__(self, local_search: Callable, k_max: int, group=None, all_gather: Optional[Callable] = None):
         import torch.distributed as dist
         self.dist = dist
         self.group = group
-        self.world = dist.get_world_size(group)
-        self.rank = dist.get_rank(group)
+        inited = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if inited else 1   # no process group = one shard
+        self.rank = dist.get_rank(group) if inited else 0
         self.local_search = local_search
         self.k_max = k_max
+        self._all_gather = all_gather   # optional override: f(out[world, ...], inp) (bench rehearsal mode)
 
     def gather_candidates(self, queries, k: int):
         """Local scan + ONE all-gather of (keys, counts) -> tensors [world, b, k] / [world, b] on device."""
@@ -58,9 +60,11 @@ class ShardedSearch:
         out = torch.empty((self.world, b, k + 1), dtype=torch.int64, device=keys.device)
         if self.world == 1:
             out[0] = payload
+        elif self._all_gather is not None:
+            self._all_gather(out, payload)
         else:
             try:
-                self.dist.all_gather_into_tensor(out, payload, group=self.group)
+                self.dist.all_gather_into_tensor(out.view(-1), payload.view(-1), group=self.group)
             except (RuntimeError, NotImplementedError):  # backends without the fused form (older gloo)
                 self.dist.all_gather(list(out.unbind(0)), payload, group=self.group)
         return out

@@ -128,7 +128,8 @@ int32_t cqs_hip_index_search(cqs_hip_index* idx, const float* queries, uint32_t 
 /* ---- search: device buffers, asynchronous ----------------------------------
  * Same computation with every buffer in the index's device memory space and
  * no host synchronisation: work is enqueued on `stream` (a hipStream_t; NULL =
- * the index's own stream) and the call returns.  Used by the bench (inputs
+ * the HIP null stream, which is what PyTorch's default stream is) and the call
+ * returns; results are ordered after it on that stream only.  Used by the bench (inputs
  * resident in HBM) and by the sharded multi-GPU path, whose per-shard
  * candidates feed an RCCL all-gather straight from HBM.
  * d_queries [b*dim] f32 must hold finite values (the caller checks; the host

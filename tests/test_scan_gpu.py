@@ -395,3 +395,25 @@ def test_full_size_properties_1m(hip):
     assert list(merged) == list(keys.cpu().numpy().view(np.uint64)[0])
     for x in (idx, a, b):
         x.close()
+
+
+def test_device_api_null_stream_orders_with_torch(hip, oracle):
+    """stream = NULL must mean the HIP null stream (= torch's default stream): a torch op enqueued right
+    after the search sees the results without any explicit synchronisation (regression: the search used
+    to run on the index's private stream and raced with the consumer)."""
+    import torch
+    rows = synth.gaussian_unit(50_000, seed=201)
+    qs = synth.gaussian_unit(6, seed=202)
+    d_rows = torch.from_numpy(rows).cuda()
+    idx = HipIndex.build_from_device(None, d_rows.data_ptr(), 50_000, 768, borrow=True, keepalive=d_rows)
+    k = 20
+    for i in range(6):
+        d_q = torch.from_numpy(qs[i:i + 1]).cuda()
+        keys = torch.zeros((1, k), dtype=torch.int64, device="cuda")
+        counts = torch.zeros((1,), dtype=torch.int32, device="cuda")
+        idx.search_device(d_q.data_ptr(), 1, k, keys.data_ptr(), counts.data_ptr(), stream=0)
+        snapshot = keys.clone()          # default-stream consumer, no synchronize() in between
+        r, s = unpack_keys(snapshot.cpu().numpy().view(np.uint64)[0])
+        ext_ids, ext_scores = oracle.index_search(rows, qs[i], k + MARGIN)
+        assert_topk_parity(r, s, ext_ids, ext_scores, k)
+    idx.close()
