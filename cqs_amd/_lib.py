@@ -40,6 +40,8 @@ SIGNATURES = [
      [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int32, C.c_uint64, C.c_int32, _pp(_c_idx)]),
     ("cqs_hip_index_extend", C.c_int32, [_c_idx, C.c_void_p, C.c_uint64]),
     ("cqs_hip_index_destroy", None, [_c_idx]),
+    ("cqs_hip_index_save", C.c_int32, [_c_idx, C.c_char_p, _pp(C.c_uint64)]),
+    ("cqs_hip_index_load", C.c_int32, [C.c_char_p, C.c_uint32, C.c_uint64, C.c_int32, C.c_uint64, _pp(_c_idx)]),
     ("cqs_hip_index_len", C.c_uint64, [_c_idx]),
     ("cqs_hip_index_dim", C.c_uint32, [_c_idx]),
     ("cqs_hip_index_metric", C.c_uint32, [_c_idx]),

@@ -306,6 +306,84 @@ int32_t cqs_hip_index_extend(cqs_hip_index* x, const float* rows, uint64_t n_new
     return CQS_HIP_OK;
 }
 
+namespace {
+struct FlatHeader {
+    char magic[8];
+    uint32_t version, dim, metric, pad;
+    uint64_t rows, checksum;
+    uint8_t reserved[24];
+};
+static_assert(sizeof(FlatHeader) == 64, "header is 64 bytes");
+const char kFlatMagic[8] = {'C', 'Q', 'S', 'H', 'I', 'P', 'F', '1'};
+
+uint64_t content_checksum(const void* data, size_t bytes) {  // 64-bit multiply-rotate hash over 8-byte words
+    const uint64_t P1 = 0x9E3779B185EBCA87ull, P2 = 0xC2B2AE3D27D4EB4Full;
+    uint64_t h = 0x27D4EB2F165667C5ull ^ (uint64_t)bytes;
+    const uint8_t* p = (const uint8_t*)data;
+    size_t i = 0;
+    for (; i + 8 <= bytes; i += 8) {
+        uint64_t w;
+        memcpy(&w, p + i, 8);
+        h ^= w * P1;
+        h = ((h << 31) | (h >> 33)) * P2;
+    }
+    uint64_t tail = 0;
+    if (i < bytes) memcpy(&tail, p + i, bytes - i);
+    h ^= tail * P1;
+    h ^= h >> 29;
+    h *= P2;
+    h ^= h >> 32;
+    return h;
+}
+}  // namespace
+
+int32_t cqs_hip_index_save(cqs_hip_index* x, const char* path, uint64_t* out_checksum) {
+    if (!x || !path) return CQS_HIP_ERR_INVALID;
+    std::lock_guard<std::mutex> g(x->mu);
+    if (x->poisoned.load(std::memory_order_acquire)) return CQS_HIP_ERR_POISONED;  // src/cagra.rs:1103-1107
+    HIP_TRY(x, hipSetDevice(x->device));
+    const size_t bytes = (size_t)x->n * x->dim * sizeof(float);
+    std::vector<float> host((size_t)x->n * x->dim);
+    if (bytes) HIP_TRY(x, hipMemcpy(host.data(), x->d_rows, bytes, hipMemcpyDeviceToHost));
+    FlatHeader h{};
+    memcpy(h.magic, kFlatMagic, 8);
+    h.version = 1; h.dim = x->dim; h.metric = x->metric; h.rows = x->n;
+    h.checksum = content_checksum(host.data(), bytes);
+    const std::string tmp = std::string(path) + ".tmp";
+    FILE* f = fopen(tmp.c_str(), "wb");
+    if (!f) return fail(x, CQS_HIP_ERR_INVALID, "save: cannot create temp file");
+    const bool ok = fwrite(&h, sizeof h, 1, f) == 1 && (bytes == 0 || fwrite(host.data(), 1, bytes, f) == bytes) &&
+                    fflush(f) == 0;
+    fclose(f);
+    if (!ok || rename(tmp.c_str(), path) != 0) {
+        remove(tmp.c_str());
+        return fail(x, CQS_HIP_ERR_INVALID, "save: write / rename failed");
+    }
+    if (out_checksum) *out_checksum = h.checksum;
+    return CQS_HIP_OK;
+}
+
+int32_t cqs_hip_index_load(const char* path, uint32_t expected_dim, uint64_t expected_rows, int32_t device,
+                           uint64_t row_base, cqs_hip_index** out) {
+    if (!path || !out) return CQS_HIP_ERR_INVALID;
+    *out = nullptr;
+    FILE* f = fopen(path, "rb");
+    if (!f) return CQS_HIP_ERR_INVALID;
+    FlatHeader h{};
+    bool ok = fread(&h, sizeof h, 1, f) == 1 && memcmp(h.magic, kFlatMagic, 8) == 0 && h.version == 1 &&
+              h.dim == expected_dim && (expected_rows == 0 || h.rows == expected_rows) && h.metric <= CQS_HIP_METRIC_DOT;
+    std::vector<float> host;
+    if (ok) {
+        const size_t bytes = (size_t)h.rows * h.dim * sizeof(float);
+        host.resize((size_t)h.rows * h.dim);
+        ok = (bytes == 0 || fread(host.data(), 1, bytes, f) == bytes) && fgetc(f) == EOF &&
+             content_checksum(host.data(), bytes) == h.checksum;
+    }
+    fclose(f);
+    if (!ok) return CQS_HIP_ERR_INVALID;
+    return cqs_hip_index_create(host.data(), h.rows, h.dim, h.metric, device, row_base, out);
+}
+
 void cqs_hip_index_destroy(cqs_hip_index* x) {
     if (!x) return;
     hipSetDevice(x->device);

@@ -198,6 +198,77 @@ class HipIndex(VectorIndex):
         if ids is not None:
             self.id_map.extend(ids)
 
+    # ---- persistence: blob + CagraMeta-style sidecar (src/cagra.rs:973-1157, 1174-1330) -----------
+    META_MAGIC = "cqs-hip-flat-meta"
+    META_VERSION = 1
+
+    def save(self, path: str) -> None:
+        """`CagraIndex::save`: rows blob through the C ABI (atomic tmp -> rename) + `{path}.meta` JSON
+        {magic, version, dim, chunk_count, id_map, checksum, metric} (also tmp -> rename)."""
+        import json
+        import os
+        ck = C.c_uint64()
+        rc = self._lib.cqs_hip_index_save(self._h, path.encode(), C.byref(ck))
+        if rc != _lib.OK:
+            raise HipError(rc, self.last_error())
+        meta = {"magic": self.META_MAGIC, "version": self.META_VERSION, "dim": self.dim(), "chunk_count": len(self),
+                "id_map": self.id_map, "checksum": f"{ck.value:016x}", "metric": self.metric.as_str()}
+        tmp = path + ".meta.tmp"
+        try:
+            with open(tmp, "w") as f:
+                json.dump(meta, f)
+            os.replace(tmp, path + ".meta")
+        except OSError:
+            for p in (path, path + ".meta", tmp):   # a blob without its sidecar is useless (cagra.rs:1143-1147)
+                try:
+                    os.remove(p)
+                except OSError:
+                    pass
+            raise
+
+    @classmethod
+    def load(cls, path: str, dim: int, chunk_count: int, device: int = 0) -> "HipIndex":
+        """`CagraIndex::load`: sidecar magic / version / dim / chunk_count must match the store, the blob's
+        checksum must match the sidecar; anything else raises ValueError (caller deletes + rebuilds)."""
+        import json
+        lib = _lib.load()
+        try:
+            with open(path + ".meta") as f:
+                meta = json.load(f)
+        except (OSError, ValueError) as e:
+            raise ValueError(f"HIP index sidecar unreadable: {e}")
+        if meta.get("magic") != cls.META_MAGIC or meta.get("version") != cls.META_VERSION:
+            raise ValueError("HIP index sidecar: bad magic / version")
+        if meta.get("dim") != dim or meta.get("chunk_count") != chunk_count:
+            raise ValueError("HIP index sidecar: stale (dim / chunk_count mismatch)")
+        ids = meta.get("id_map")
+        if ids is not None and len(ids) != chunk_count:
+            raise ValueError("HIP index sidecar: id_map length mismatch")
+        # the sidecar must describe THIS blob: compare its checksum with the blob header's
+        import struct
+        try:
+            with open(path, "rb") as f:
+                magic, _ver, _dim, _metric, _pad, _rows, blob_ck = struct.unpack("<8sIIIIQQ", f.read(40))
+        except (OSError, struct.error) as e:
+            raise ValueError(f"HIP index blob unreadable: {e}")
+        if magic != b"CQSHIPF1" or meta.get("checksum") != f"{blob_ck:016x}":
+            raise ValueError("HIP index sidecar does not match the blob (checksum)")
+        h = C.c_void_p()
+        rc = lib.cqs_hip_index_load(path.encode(), dim, chunk_count, device, 0, C.byref(h))   # verifies the content
+        if rc != _lib.OK:
+            raise ValueError(f"HIP index blob rejected (rc={rc})")
+        return cls(h.value, ids, DistanceMetric.parse(meta.get("metric", "cosine")))
+
+    @staticmethod
+    def delete_persisted(path: str) -> None:
+        """`CagraIndex::delete_persisted` (src/cagra.rs:1739-1750)."""
+        import os
+        for p in (path, path + ".meta"):
+            try:
+                os.remove(p)
+            except OSError:
+                pass
+
     def close(self) -> None:
         if self._h:
             self._lib.cqs_hip_index_destroy(self._h)
@@ -356,6 +427,7 @@ class BackendContext:
     ef_search: Optional[int] = None
     hip_threshold: int = 5000  # same gate as CQS_CAGRA_THRESHOLD (src/cagra.rs:1683-1690)
     device: int = 0
+    persist: bool = True       # CQS_CAGRA_PERSIST analogue (src/cagra.rs:1013)
 
 
 def dim_scaled_batch(baseline: int, dim: int, lo: int, hi: int) -> int:
@@ -390,6 +462,16 @@ class HipBackend:
         if n * dim * 4 * 1.25 > free.value:  # gpu_available_for (src/cagra.rs:336-376)
             log.warning("HIP backend: corpus does not fit device memory, falling through")
             return None
+        import os
+        path = os.path.join(ctx.cqs_dir, "index.hipflat")
+        if ctx.persist and os.path.exists(path):           # persisted first (src/cagra.rs:1726-1752)
+            try:
+                idx = HipIndex.load(path, dim, n, ctx.device)
+                log.info("Vector index backend selected backend=hip source=persisted vectors=%d", len(idx))
+                return idx
+            except ValueError as e:
+                log.warning("HIP persisted load failed, rebuilding from store: %s", e)
+                HipIndex.delete_persisted(path)
         embeddings = []
         for batch in ctx.store.embedding_batches(dim_scaled_batch(10_000, dim, 500, 50_000)):
             embeddings.extend(batch)
@@ -399,4 +481,9 @@ class HipBackend:
             log.warning("HIP backend build failed, falling through: %s", e)
             return None
         log.info("Vector index backend selected backend=hip source=rebuilt vectors=%d", len(idx))
+        if ctx.persist and len(idx) == n:                  # best-effort save (src/cagra.rs:1786-1795)
+            try:
+                idx.save(path)
+            except (HipError, OSError) as e:
+                log.warning("Failed to persist HIP index (will rebuild next restart): %s", e)
         return idx

@@ -90,6 +90,20 @@ int32_t cqs_hip_index_extend(cqs_hip_index* idx, const float* rows, uint64_t n_n
 /* Synchronises the index's streams, then frees everything (src/cagra.rs:289-302). */
 void cqs_hip_index_destroy(cqs_hip_index* idx);
 
+/* ---- persistence (the `index.cagra` + `.meta` pair of the reference, src/cagra.rs:973-1157,
+ * 1174-1330) -----------------------------------------------------------------
+ * save: writes `path` = 64-byte header {magic "CQSHIPF1", version, dim, metric, rows, checksum} +
+ * the raw little-endian f32 rows, through `path.tmp` + rename (atomic like
+ * save_blob_atomic_with_rollback, src/cagra.rs:1468-1592).  *out_checksum receives the 64-bit
+ * content checksum for the caller's sidecar (the shim writes the CagraMeta-style JSON: magic,
+ * version, dim, chunk_count, id_map, checksum, metric).  A poisoned index refuses to save.
+ * load: validates magic / version / dim / rows (expected_rows 0 = any) / file size / checksum;
+ * any mismatch -> CQS_HIP_ERR_INVALID and the caller deletes the files and rebuilds
+ * (src/cagra.rs:1739-1750). */
+int32_t cqs_hip_index_save(cqs_hip_index* idx, const char* path, uint64_t* out_checksum);
+int32_t cqs_hip_index_load(const char* path, uint32_t expected_dim, uint64_t expected_rows, int32_t device,
+                           uint64_t row_base, cqs_hip_index** out);
+
 /* ---- index properties (VectorIndex, src/index.rs:139-239) ------------------ */
 uint64_t cqs_hip_index_len(const cqs_hip_index* idx);       /* len()  :149 */
 uint32_t cqs_hip_index_dim(const cqs_hip_index* idx);       /* dim()  :160 */

@@ -48,6 +48,12 @@ extern "C" {
         out: *mut *mut CqsHipIndex,
     ) -> i32;
     fn cqs_hip_index_extend(idx: *mut CqsHipIndex, rows: *const f32, n_new: u64) -> i32;
+    // persistence (the index.cagra + .meta analogue, src/cagra.rs:973-1157, 1174-1330): the blob is written /
+    // validated by the library, the CagraMeta-style sidecar (magic, version, dim, chunk_count, id_map,
+    // checksum, metric) by `HipIndex::save` / `HipIndex::load` below via serde_json like src/cagra.rs:1128-1147
+    fn cqs_hip_index_save(idx: *mut CqsHipIndex, path: *const c_char, out_checksum: *mut u64) -> i32;
+    fn cqs_hip_index_load(path: *const c_char, expected_dim: u32, expected_rows: u64, device: i32, row_base: u64,
+                          out: *mut *mut CqsHipIndex) -> i32;
     fn cqs_hip_index_destroy(idx: *mut CqsHipIndex);
     fn cqs_hip_index_len(idx: *const CqsHipIndex) -> u64;
     fn cqs_hip_index_max_k(idx: *const CqsHipIndex) -> u32;

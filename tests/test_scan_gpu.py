@@ -417,3 +417,58 @@ def test_device_api_null_stream_orders_with_torch(hip, oracle):
         ext_ids, ext_scores = oracle.index_search(rows, qs[i], k + MARGIN)
         assert_topk_parity(r, s, ext_ids, ext_scores, k)
     idx.close()
+
+
+class _FakeStore:
+    """Just enough of `Store` for a backend: dim, chunk_count(), embedding_batches() in rowid order
+    (src/store/chunks/async_helpers.rs:189-203)."""
+
+    def __init__(self, ids, rows):
+        self.ids, self.rows, self.dim = ids, rows, rows.shape[1]
+
+    def chunk_count(self):
+        return len(self.ids)
+
+    def embedding_batches(self, batch):
+        for i in range(0, len(self.ids), batch):
+            yield [(self.ids[j], self.rows[j]) for j in range(i, min(len(self.ids), i + batch))]
+
+
+def test_backend_try_open_and_persistence(hip, oracle, tmp_path):
+    """`IndexBackend::try_open` contract (src/index.rs:271-291; CagraBackend src/cagra.rs:1676-1802):
+    below threshold -> None; build from the store; persisted blob + sidecar reused on the next open;
+    a corrupted / stale pair is rejected, deleted and rebuilt."""
+    from cqs_amd import BackendContext, HipBackend
+    n = 1200
+    rows = synth.gaussian_unit(n, seed=211)
+    ids = [f"src/f{i % 7}.rs:{i}:abcd" for i in range(n)]
+    store = _FakeStore(ids, rows)
+    be = HipBackend()
+    assert be.name() == "hip" and be.priority() > 150
+    assert be.try_open(BackendContext(str(tmp_path), store, hip_threshold=5000)) is None      # gate
+    idx = be.try_open(BackendContext(str(tmp_path), store, hip_threshold=1000))
+    assert idx is not None and len(idx) == n and (tmp_path / "index.hipflat").exists()
+    q = rows[77]
+    res = idx.search(q, 5)
+    assert res[0].id == ids[77]
+    idx.close()
+    idx2 = be.try_open(BackendContext(str(tmp_path), store, hip_threshold=1000))                # persisted path
+    assert [r.id for r in idx2.search(q, 5)] == [r.id for r in res]
+    idx2.close()
+    # flip one byte of the blob: checksum mismatch -> rejected, files deleted, rebuilt from the store
+    blob = tmp_path / "index.hipflat"
+    raw = bytearray(blob.read_bytes()); raw[64 + 123] ^= 0x40; blob.write_bytes(bytes(raw))
+    with pytest.raises(ValueError):
+        HipIndex.load(str(blob), 768, n)
+    idx3 = be.try_open(BackendContext(str(tmp_path), store, hip_threshold=1000))
+    assert idx3 is not None and [r.id for r in idx3.search(q, 5)] == [r.id for r in res]
+    idx3.close()
+    with pytest.raises(ValueError):                       # stale sidecar (chunk_count changed)
+        HipIndex.load(str(blob), 768, n + 1)
+    with pytest.raises(ValueError):
+        HipIndex.load(str(blob), 1024, n)
+    # zero / non-finite rows are skipped at build like prepare_index_data (src/hnsw/mod.rs:717-731)
+    rows2 = rows.copy(); rows2[5] = 0; rows2[9, 3] = NAN
+    idx4 = be.try_open(BackendContext(str(tmp_path / "b"), _FakeStore(ids, rows2), hip_threshold=1000, persist=False))
+    assert len(idx4) == n - 2 and ids[5] not in idx4.id_map and ids[9] not in idx4.id_map
+    idx4.close()
