@@ -114,7 +114,7 @@ int32_t ensure_scratch(cqs_hip_index* x, uint32_t b, uint32_t k) {
     HIP_TRY(x, hipMalloc(&x->d_work, cqs::kWorkWords * sizeof(uint32_t)));
     // work-queue heads must be zero on entry; every search re-zeroes them
     HIP_TRY(x, hipMemset(x->d_work, 0, cqs::kWorkWords * sizeof(uint32_t)));
-    HIP_TRY(x, hipMalloc(&x->d_gmax, (size_t)qc * (n_pad / cqs::kTaskRows) * sizeof(float)));
+    HIP_TRY(x, hipMalloc(&x->d_gmax, (size_t)qc * (n_pad / cqs::kTaskRowsSmall) * sizeof(float)));
     HIP_TRY(x, hipMalloc(&x->d_out_keys, (size_t)qc * kc * sizeof(uint64_t)));
     HIP_TRY(x, hipMalloc(&x->d_out_counts, (size_t)qc * sizeof(uint32_t)));
     HIP_TRY(x, hipHostMalloc(&x->h_q, (size_t)qc * x->dim * sizeof(float), hipHostMallocDefault));
@@ -163,6 +163,9 @@ int32_t enqueue_search(cqs_hip_index* x, const float* d_q, uint32_t b, uint32_t 
     a.work = x->d_work;
     a.n_cu = x->n_cu;
     a.dbg = x->d_dbg;
+    // corpora that would give a CU fewer than ~8 of the 64-row tasks use 16-row tasks (and maxima groups)
+    a.group_rows = (!cqs::use_mfma(b, x->dim) && a.n_pad / cqs::kTaskRows < 8u * x->n_cu) ? cqs::kTaskRowsSmall
+                                                                                           : cqs::kTaskRows;
     const bool timed = x->timing && x->ev_used + 2 <= kMaxTimingEvents;
     if (timed) {
         while (x->ev.size() < x->ev_used + 2) {

@@ -7,7 +7,8 @@
 namespace cqs {
 
 // Geometry shared by host and device code.
-constexpr uint32_t kTaskRows = 64;        // rows one wave scores per work-queue task
+constexpr uint32_t kTaskRows = 64;        // rows one wave scores per work-queue task (large corpora; MFMA path)
+constexpr uint32_t kTaskRowsSmall = 16;   // small corpora: finer tasks so every CU gets several waves
 constexpr uint32_t kRowsPerBlock = 256;   // n_pad granule (score row stride)
 constexpr uint32_t kHistBins = 4096;      // threshold-search histogram bins
 constexpr uint32_t kCandCap = 8192;       // candidates one sort block holds in LDS
@@ -30,7 +31,8 @@ struct ScanArgs {
     bool nontemporal;       // stream the corpus past L2 (corpus >> Infinity Cache)
     bool linear_bins;       // scores bounded in [-1,1] (cosine / pipeline mode): linear histogram bins
     uint32_t k;
-    float* gmax;            // [b, n_pad/64] per-group maxima (written by the scan)
+    float* gmax;            // [b, n_pad/group_rows] per-group maxima (written by the scan)
+    uint32_t group_rows;    // kTaskRows or kTaskRowsSmall: rows per work-queue task = rows per maxima group
     uint32_t* work;         // [kWorkWords] work-queue heads (zero on entry)
     uint32_t n_cu;          // compute units of the device
     void* dbg;              // nullable: 16 x u64 phase stamps of select_finish (CQS_HIP_DEBUG_STAMPS=1)

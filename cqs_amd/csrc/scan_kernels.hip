@@ -135,7 +135,7 @@ struct ScanParams {
     uint32_t mode;
     float thr;
     uint32_t* work;     // work-queue head of this launch
-    uint32_t n_tasks;   // ceil(n_pad / 64)
+    uint32_t n_tasks;   // n_pad / TR
     float* gmax;        // [BQ][n_tasks] maximum valid score of each 64-row group (-inf if none)
 };
 
@@ -143,7 +143,8 @@ struct ScanParams {
 // iteration (RI*BQ partial sums are reduced together).  FULL: dim == NCH*256.
 // PIPE: 0 = loads then math per iteration; 1 = explicit double buffer (next iteration's
 // rows in flight while this iteration is reduced).
-template <int NCH, int BQ, int RI, bool NT, bool FULL, int PIPE>
+// TR: rows per task (64, or 16 for corpora too small to give every CU several 64-row tasks).
+template <int NCH, int BQ, int RI, bool NT, bool FULL, int PIPE, int TR>
 __global__ __launch_bounds__(256) void scan_gemv_kernel(const ScanParams p) {
     constexpr int NV = RI * BQ;
     constexpr int LPV = 64 / NV;  // lanes per reduced value
@@ -169,22 +170,26 @@ __global__ __launch_bounds__(256) void scan_gemv_kernel(const ScanParams p) {
 
     const uint32_t last = n - 1u;
     const uint32_t nwords = (n + 31u) / 32u;
-    uint32_t task = 0;
-    if (lane == 0) task = atomicAdd(p.work, 1u);
-    task = __builtin_amdgcn_readfirstlane(task);
+    // First task = the wave's own index (no atomic); later tasks come from the shared queue, whose
+    // head counts from the number of waves.  A grid that covers every task never touches the queue
+    // (one queue word sustains only ~88 dequeues/us: a start-up burst from every wave costs 10-25 us).
+    const uint32_t total_waves = gridDim.x * 4u;
+    const bool use_queue = p.n_tasks > total_waves;
+    uint32_t task = blockIdx.x * 4u + (threadIdx.x >> 6);
 
     while (task < p.n_tasks) {
         uint32_t next = 0;
-        const uint32_t base = task * kTaskRows;
+        const uint32_t base = task * (uint32_t)TR;
 
-        // rows this wave must score: inside the corpus and kept by the filter
-        uint64_t mask = ~0ull;
-        if (base + 64u > n) mask = (base >= n) ? 0ull : (~0ull >> (64u - (n - base)));
+        // rows this wave must score (low TR bits): inside the corpus and kept by the filter
+        constexpr uint64_t kAll = TR == 64 ? ~0ull : ((1ull << (TR & 63)) - 1ull);
+        uint64_t mask = kAll;
+        if (base + (uint32_t)TR > n) mask = (base >= n) ? 0ull : (kAll >> ((uint32_t)TR - (n - base)));
         if (p.keep) {
             const uint32_t w = base / 32u;
             const uint32_t w0 = (w < nwords) ? p.keep[w] : 0u;
             const uint32_t w1 = (w + 1u < nwords) ? p.keep[w + 1u] : 0u;
-            mask &= ((uint64_t)w1 << 32) | (uint64_t)w0;
+            mask &= (((uint64_t)w1 << 32) | (uint64_t)w0) >> (base & 31u);
         }
         // wave-uniform by construction; make the loop branches scalar
         const uint32_t mlo = __builtin_amdgcn_readfirstlane((uint32_t)mask);
@@ -235,21 +240,21 @@ __global__ __launch_bounds__(256) void scan_gemv_kernel(const ScanParams p) {
                 if (lane / RI == j) sc[b] = t;
             }
         };
-        if (PIPE == 1 && mask == ~0ull) {
+        if (PIPE == 1 && mask == kAll) {
             f4 xa[RI][NCH], xb[RI][NCH];
             load_rows(0, xa);
-            for (int j = 0; j < 64 / RI; j += 2) {
+            for (int j = 0; j < TR / RI; j += 2) {
                 load_rows(j + 1, xb);
                 // dequeue the next task behind the first row loads: vmcnt retires in issue
                 // order, so an atomic issued ahead of them would stall the first reduction
-                if (j == 0 && lane == 0) next = atomicAdd(p.work, 1u);
+                if (j == 0 && use_queue && lane == 0) next = total_waves + atomicAdd(p.work, 1u);
                 reduce_rows(j, xa);
-                if (j + 2 < 64 / RI) load_rows(j + 2, xa);
+                if (j + 2 < TR / RI) load_rows(j + 2, xa);
                 reduce_rows(j + 1, xb);
             }
         } else {
-            if (lane == 0) next = atomicAdd(p.work, 1u);
-            for (int j = 0; j < 64 / RI; ++j) {
+            if (use_queue && lane == 0) next = total_waves + atomicAdd(p.work, 1u);
+            for (int j = 0; j < TR / RI; ++j) {
                 const uint32_t m = (uint32_t)(mask >> (RI * j)) & ((1u << RI) - 1u);
                 if (m == 0u) continue;  // all RI rows filtered out / past the end: skip their HBM reads
                 f4 x[RI][NCH];
@@ -258,9 +263,9 @@ __global__ __launch_bounds__(256) void scan_gemv_kernel(const ScanParams p) {
             }
         }
 
-        // epilogue: lane <-> row base+lane; one coalesced 256-B store per query
+        // epilogue: lane <-> row base+lane (lanes < TR); one coalesced store per query
         const uint32_t row = base + (uint32_t)lane;
-        const bool live = (mask >> lane) & 1ull;
+        const bool live = lane < TR && ((mask >> lane) & 1ull);
 #pragma unroll
         for (int b = 0; b < BQ; ++b) {
             float s = sc[b];
@@ -271,14 +276,14 @@ __global__ __launch_bounds__(256) void scan_gemv_kernel(const ScanParams p) {
                 s = s < 0.f ? 0.f : (s > 1.f ? 1.f : s);
                 if (!(s >= p.thr)) s = -INFINITY;
             }
-            if (row < p.n_pad) p.scores[(size_t)b * p.n_pad + row] = s;
+            if (lane < TR && row < p.n_pad) p.scores[(size_t)b * p.n_pad + row] = s;
             // group maximum -> pruning index of the select
             float gm = s;
 #pragma unroll
             for (int off = 32; off >= 1; off >>= 1) gm = fmaxf(gm, __shfl_xor(gm, off, 64));
             if (lane == 0) p.gmax[(size_t)b * p.n_tasks + task] = gm;
         }
-        task = __builtin_amdgcn_readfirstlane(next);
+        task = use_queue ? (uint32_t)__builtin_amdgcn_readfirstlane(next) : p.n_tasks;
     }
 }
 
@@ -371,8 +376,9 @@ __device__ __forceinline__ void wave_slots(const bool (&take)[N], uint32_t* coun
 }
 __global__ __launch_bounds__(1024) void select_finish_kernel(const float* __restrict__ scores,
                                                              const float* __restrict__ gmax, uint32_t n_pad,
-                                                             uint32_t n_tasks, uint32_t k, uint32_t row_base,
-                                                             uint32_t linear, uint64_t* __restrict__ out_keys,
+                                                             uint32_t n_tasks, uint32_t grows_log2, uint32_t k,
+                                                             uint32_t row_base, uint32_t linear,
+                                                             uint64_t* __restrict__ out_keys,
                                                              uint32_t* __restrict__ out_counts,
                                                              uint32_t* __restrict__ work,
                                                              unsigned long long* __restrict__ dbg) {
@@ -440,7 +446,8 @@ __global__ __launch_bounds__(1024) void select_finish_kernel(const float* __rest
     uint32_t count = kCandCap + 1u;
     if (ng <= kGroupCap) {
         // phase 3: their scores (L2 / Infinity Cache hits: the scan just wrote them)
-        const uint32_t total = ng * kTaskRows;
+        const uint32_t grows = 1u << grows_log2;
+        const uint32_t total = ng << grows_log2;
         for (uint32_t e0 = 0; e0 < total; e0 += 1024u * kGB) {
             float v[kGB];
             uint32_t idx[kGB];
@@ -448,7 +455,7 @@ __global__ __launch_bounds__(1024) void select_finish_kernel(const float* __rest
             for (int u = 0; u < kGB; ++u) {
                 const uint32_t e = e0 + (uint32_t)u * 1024u + threadIdx.x;
                 const uint32_t ec = e < total ? e : total - 1u;
-                idx[u] = s_groups[ec >> 6] * kTaskRows + (ec & 63u);
+                idx[u] = (s_groups[ec >> grows_log2] << grows_log2) + (ec & (grows - 1u));
                 const float x = s[idx[u]];
                 v[u] = e < total ? x : -INFINITY;
             }
@@ -542,24 +549,29 @@ static hipError_t launch_gemv(const ScanArgs& a, uint32_t q0, uint32_t work_slot
     p.scores = a.scores + (size_t)q0 * a.n_pad;
     p.keep = a.keep; p.mode = a.mode; p.thr = a.threshold;
     p.work = a.work + work_slot;
-    p.n_tasks = a.n_pad / kTaskRows;
+    p.n_tasks = a.n_pad / a.group_rows;
     p.gmax = a.gmax + (size_t)q0 * p.n_tasks;
     // persistent grid: enough workgroups to fill every CU at this kernel's occupancy, never
     // more than there are 4-task rounds; a workgroup that finds the queue empty just exits.
     uint32_t blocks = a.n_cu * CQS_SCAN_BLOCKS_PER_CU;
     const uint32_t need = (p.n_tasks + 3u) / 4u;
     if (blocks > need) blocks = need;
+    // small corpora: one task per wave, up to 8 workgroups per CU, no work queue at all
+    if (need <= a.n_cu * 8u) blocks = need;
     const dim3 grid(blocks), block(256);
     const bool full = (a.dim == (uint32_t)NCH * 256u);
-#define CQS_LAUNCH(NTV, FULLV) \
-    hipLaunchKernelGGL((scan_gemv_kernel<NCH, BQ, RI, NTV, FULLV, (BQ <= 2 ? CQS_SCAN_PIPE : 0)>), grid, block, 0, st, p)
+    // small corpora never stream past the caches, so the 16-row variant is built without nt loads only
+#define CQS_LAUNCH(NTV, FULLV, TRV) \
+    hipLaunchKernelGGL((scan_gemv_kernel<NCH, BQ, (RI < TRV / 2 ? RI : TRV / 2), NTV, FULLV, (BQ <= 2 ? CQS_SCAN_PIPE : 0), TRV>), \
+                       grid, block, 0, st, p)
 #ifdef CQS_SCAN_FORCE_NT
     const bool nt = CQS_SCAN_FORCE_NT;
 #else
     const bool nt = a.nontemporal;
 #endif
-    if (nt) { if (full) CQS_LAUNCH(true, true); else CQS_LAUNCH(true, false); }
-    else { if (full) CQS_LAUNCH(false, true); else CQS_LAUNCH(false, false); }
+    if (a.group_rows == kTaskRowsSmall) { if (full) CQS_LAUNCH(false, true, 16); else CQS_LAUNCH(false, false, 16); }
+    else if (nt) { if (full) CQS_LAUNCH(true, true, 64); else CQS_LAUNCH(true, false, 64); }
+    else { if (full) CQS_LAUNCH(false, true, 64); else CQS_LAUNCH(false, false, 64); }
 #undef CQS_LAUNCH
     return hipGetLastError();
 }
@@ -626,7 +638,8 @@ hipError_t launch_select(const ScanArgs& a, uint32_t row_base, uint64_t* out_key
                          hipStream_t st) {
     if (a.b == 0 || a.k == 0) return hipSuccess;
     hipLaunchKernelGGL(select_finish_kernel, dim3(a.b), dim3(1024), 0, st, a.scores, a.gmax, a.n_pad,
-                       a.n_pad / kTaskRows, a.k, row_base, a.linear_bins ? 1u : 0u, out_keys, out_counts, a.work,
+                       a.n_pad / a.group_rows, a.group_rows == kTaskRows ? 6u : 4u, a.k, row_base,
+                       a.linear_bins ? 1u : 0u, out_keys, out_counts, a.work,
                        (unsigned long long*)a.dbg);
     return hipGetLastError();
 }

@@ -76,11 +76,9 @@ __global__ __launch_bounds__(256, 1) void scan_mfma_kernel(const MfmaParams p) {
         st_c4[u] = f & 7u;
     }
 
-    for (;;) {
-        if (tid == 0) s_task = atomicAdd(p.work, 1u);
-        __syncthreads();
-        const uint32_t task = s_task;
-        __syncthreads();
+    // first tile = the workgroup's own index; later tiles from the shared queue (head counts from gridDim.x)
+    uint32_t task = blockIdx.x;
+    for (;; ) {
         if (task >= p.n_tasks) break;
         const uint32_t row0 = task * (uint32_t)RT;
 
@@ -194,6 +192,10 @@ __global__ __launch_bounds__(256, 1) void scan_mfma_kernel(const MfmaParams p) {
                     if (l31 == 0 && qi < p.b)
                         p.gmax[qi * (p.n_pad / 64u) + task * gpt + (uint32_t)(wr * (RW / 2) + g)] = m;
                 }
+        __syncthreads();   // everyone is done with s_task / the tile before the next dequeue
+        if (tid == 0) s_task = gridDim.x + atomicAdd(p.work, 1u);
+        __syncthreads();
+        task = s_task;
     }
 }
 
@@ -205,7 +207,7 @@ static hipError_t launch_mfma_cfg(const ScanArgs& a, uint32_t q0, uint32_t nq, u
     p.q = a.q + (size_t)q0 * a.dim;
     p.b = nq;
     p.scores = a.scores + (size_t)q0 * a.n_pad;
-    p.gmax = a.gmax + (size_t)q0 * (a.n_pad / kTaskRows);
+    p.gmax = a.gmax + (size_t)q0 * (a.n_pad / kTaskRows);   // the matrix-core path always uses 64-row groups
     p.keep = a.keep; p.mode = a.mode; p.thr = a.threshold;
     p.work = a.work + slot;
     p.n_tasks = a.n_pad / (uint32_t)RT;
