@@ -129,22 +129,31 @@ __global__ __launch_bounds__(256, 1) void scan_mfma_kernel(const MfmaParams p) {
             if (s + 1u < stages) stage_load(s + 1u, reg);  // in flight under the MFMA phase
             const float* aQ = sQ + ((size_t)buf * QT + (size_t)(wq * QW) * 32 + l31) * kLDK + 4 * lh;
             const float* aR = sR + ((size_t)buf * RT + (size_t)(wr * RW) * 32 + l31) * kLDK + 4 * lh;
+            // fragments of k-group kg+1 are read while the 4*QW*RW MFMAs of k-group kg run
+            f4 af[2][QW], bf[2][RW];
+            auto read_frags = [&](int kg, int set) {
+#pragma unroll
+                for (int a = 0; a < QW; ++a) af[set][a] = *(const f4*)(aQ + (size_t)a * 32 * kLDK + kg * 8);
+#pragma unroll
+                for (int b = 0; b < RW; ++b) bf[set][b] = *(const f4*)(aR + (size_t)b * 32 * kLDK + kg * 8);
+            };
+            read_frags(0, 0);
 #pragma unroll
             for (int kg = 0; kg < kBK / 8; ++kg) {
-                f4 af[QW], bf[RW];
-#pragma unroll
-                for (int a = 0; a < QW; ++a) af[a] = *(const f4*)(aQ + (size_t)a * 32 * kLDK + kg * 8);
-#pragma unroll
-                for (int b = 0; b < RW; ++b) bf[b] = *(const f4*)(aR + (size_t)b * 32 * kLDK + kg * 8);
+                const int cur = kg & 1;
+                if (kg + 1 < kBK / 8) read_frags(kg + 1, cur ^ 1);
+                // the next stage's operands (loaded at the top of this stage) go to the OTHER buffer half-way
+                // through the MFMA phase, so the ds_writes issue between MFMAs instead of after them
+                if (kg == kBK / 16 && s + 1u < stages) stage_write(buf ^ 1, reg);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
 #pragma unroll
                     for (int a = 0; a < QW; ++a)
 #pragma unroll
                         for (int b = 0; b < RW; ++b)
-                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a][c], bf[b][c], acc[a][b], 0, 0, 0);
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][a][c], bf[cur][b][c], acc[a][b], 0, 0, 0);
             }
-            if (s + 1u < stages) stage_write(buf ^ 1, reg);
             __syncthreads();
         }
 

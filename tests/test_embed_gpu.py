@@ -156,3 +156,37 @@ def test_load_dir_safetensors(hip, tmp_path):
     a, b = eng.run(ids, mask), eng2.run(ids, mask)
     assert all(cos(a[i], b[i]) > 0.9999 for i in range(2))   # dense2 went through f16 on disk
     eng.close(); eng2.close()
+
+
+def test_long_sequences_and_many_rows(hip):
+    """max_seq-long inputs (2048 tokens: many key blocks, window edges on both sides, multi-tile GEMMs) and a
+    64-sequence ragged batch, against the fp32 oracle."""
+    cfg = G.GemmaConfig(vocab_size=1024, hidden=256, layers=3, heads=3, kv_heads=1, head_dim=256, intermediate=384,
+                        dense_hidden=256, sliding_window=512, sliding_pattern=3, max_seq=2048)
+    eng, w = make(cfg, seed=21)
+    ids, mask = batch(cfg, [2048, 1500], seed=22)
+    got = eng.run(ids, mask)
+    ref = G.forward(cfg, w, ids, mask)
+    for i in range(2):
+        assert cos(got[i], ref[i]) > 0.999, (i, cos(got[i], ref[i]))
+    rng = np.random.default_rng(23)
+    lens = [int(x) for x in rng.integers(1, 200, size=64)]
+    ids, mask = batch(cfg, lens, seed=24)
+    got = eng.run(ids, mask)
+    ref = G.forward(cfg, w, ids, mask)
+    cs = [cos(got[i], ref[i]) for i in range(64)]
+    assert min(cs) > 0.998, min(cs)
+    eng.close()
+
+
+def test_gqa_two_kv_heads(hip):
+    """heads / kv_heads grouping other than 3:1 (4 q-heads over 2 kv-heads)."""
+    cfg = G.GemmaConfig(vocab_size=512, hidden=256, layers=2, heads=4, kv_heads=2, head_dim=256, intermediate=256,
+                        dense_hidden=256, sliding_window=64, sliding_pattern=2, max_seq=256)
+    eng, w = make(cfg, seed=31)
+    ids, mask = batch(cfg, [130, 7, 64], seed=32)
+    got = eng.run(ids, mask)
+    ref = G.forward(cfg, w, ids, mask)
+    for i in range(3):
+        assert cos(got[i], ref[i]) > 0.999, (i, cos(got[i], ref[i]))
+    eng.close()
