@@ -7,6 +7,7 @@
 // the caller (the Rust shim), as rows are addressed by integer here.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <atomic>
 #include <cmath>
 #include <cstdio>
@@ -163,9 +164,7 @@ int32_t enqueue_search(cqs_hip_index* x, const float* d_q, uint32_t b, uint32_t 
     a.work = x->d_work;
     a.n_cu = x->n_cu;
     a.dbg = x->d_dbg;
-    // corpora that would give a CU fewer than ~8 of the 64-row tasks use 16-row tasks (and maxima groups)
-    a.group_rows = (!cqs::use_mfma(b, x->dim) && a.n_pad / cqs::kTaskRows < 8u * x->n_cu) ? cqs::kTaskRowsSmall
-                                                                                           : cqs::kTaskRows;
+    a.tiers = cqs::plan_tiers(a.n_pad, x->n_cu, cqs::use_mfma(b, x->dim));
     const bool timed = x->timing && x->ev_used + 2 <= kMaxTimingEvents;
     if (timed) {
         while (x->ev.size() < x->ev_used + 2) {
@@ -201,8 +200,8 @@ int32_t create_common(uint64_t n, uint32_t dim, uint32_t metric, int32_t device,
         return CQS_HIP_ERR_DEVICE;
     }
     if (getenv("CQS_HIP_DEBUG_STAMPS")) {
-        if (hipMalloc(&x->d_dbg, 16 * sizeof(unsigned long long)) == hipSuccess)
-            (void)hipMemset(x->d_dbg, 0, 16 * sizeof(unsigned long long));
+        const size_t bytes = (16 + 2 * cqs::kDbgWaves) * sizeof(unsigned long long);
+        if (hipMalloc(&x->d_dbg, bytes) == hipSuccess) (void)hipMemset(x->d_dbg, 0, bytes);
     }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
@@ -547,6 +546,24 @@ int32_t cqs_hip_index_search(cqs_hip_index* x, const float* queries, uint32_t b,
                 fprintf(stderr, "[cqs_hip] select_finish us: zero %.2f hist %.2f decide %.2f groups %.2f scores %.2f sort %.2f emit %.2f | groups=%llu cand=%llu\n",
                         0.0, (h[1] - h[0]) / 100.0, (h[2] - h[1]) / 100.0, (h[3] - h[2]) / 100.0, (h[4] - h[3]) / 100.0,
                         (h[5] - h[4]) / 100.0, (h[6] - h[5]) / 100.0, h[8], h[9]);
+            // scan waves: spread of start and end times relative to the first wave's start
+            std::vector<unsigned long long> w(2 * cqs::kDbgWaves);
+            if (hipMemcpy(w.data(), x->d_dbg + 16, w.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess) {
+                std::vector<double> st, en;
+                unsigned long long t0 = ~0ull;
+                for (uint32_t i = 0; i < cqs::kDbgWaves; ++i) if (w[2 * i] && w[2 * i] < t0) t0 = w[2 * i];
+                for (uint32_t i = 0; i < cqs::kDbgWaves; ++i)
+                    if (w[2 * i] && w[2 * i + 1]) { st.push_back((w[2 * i] - t0) / 100.0); en.push_back((w[2 * i + 1] - t0) / 100.0); }
+                if (!st.empty()) {
+                    std::sort(st.begin(), st.end());
+                    std::sort(en.begin(), en.end());
+                    auto pc = [](const std::vector<double>& v, double f) { return v[(size_t)(f * (v.size() - 1))]; };
+                    fprintf(stderr, "[cqs_hip] scan waves=%zu start us p0 %.1f p50 %.1f p90 %.1f p100 %.1f | end us p0 %.1f p10 %.1f p50 %.1f p90 %.1f p100 %.1f | select ends %.1f\n",
+                            st.size(), pc(st, 0), pc(st, .5), pc(st, .9), pc(st, 1), pc(en, 0), pc(en, .1), pc(en, .5), pc(en, .9), pc(en, 1),
+                            (h[6] - t0) / 100.0);
+                }
+                (void)hipMemset(x->d_dbg + 16, 0, w.size() * sizeof(unsigned long long));
+            }
         }
         for (uint32_t i = 0; i < nb; ++i) {
             const uint32_t qi = done + i;

@@ -7,15 +7,31 @@
 namespace cqs {
 
 // Geometry shared by host and device code.
-constexpr uint32_t kTaskRows = 64;        // rows one wave scores per work-queue task (large corpora; MFMA path)
-constexpr uint32_t kTaskRowsSmall = 16;   // small corpora: finer tasks so every CU gets several waves
+constexpr uint32_t kTaskRows = 64;        // rows of the largest work-queue task (= maxima group of the MFMA path)
+constexpr uint32_t kTaskRowsSmall = 16;   // rows of the smallest task (bounds the number of maxima groups)
 constexpr uint32_t kRowsPerBlock = 256;   // n_pad granule (score row stride)
 constexpr uint32_t kHistBins = 4096;      // threshold-search histogram bins
 constexpr uint32_t kCandCap = 8192;       // candidates one sort block holds in LDS
 constexpr uint32_t kMaxK = 1024;
 constexpr uint32_t kMaxGemvQ = 8;         // queries per HBM-streaming scan pass
+constexpr uint32_t kDbgWaves = 4096;      // per-wave start/end stamps kept by the scan when ScanArgs.dbg is set
 constexpr uint32_t kWorkWords = 64;       // work-queue heads (one per scan launch of a search); zero on entry,
                                           // re-zeroed by select_finish
+
+// Work-queue tasks in row order: nA tasks of 64 rows, then nB of 32, then nC of 16 (64 nA + 32 nB +
+// 16 nC = n_pad).  One task = one wave's unit of work = one group of the select's maxima index.
+struct TaskTiers {
+    uint32_t nA, nB, nC;
+    __host__ __device__ uint32_t total() const { return nA + nB + nC; }
+    // first row and row count of task t
+    __host__ __device__ uint32_t locate(uint32_t t, uint32_t& rows) const {
+        if (t < nA) { rows = 64u; return t * 64u; }
+        if (t < nA + nB) { rows = 32u; return nA * 64u + (t - nA) * 32u; }
+        rows = 16u;
+        return nA * 64u + nB * 32u + (t - nA - nB) * 16u;
+    }
+};
+TaskTiers plan_tiers(uint32_t n_pad, uint32_t n_cu, bool mfma);
 
 struct ScanArgs {
     const float* rows;      // [n, dim] f32, row-major, HBM
@@ -31,15 +47,16 @@ struct ScanArgs {
     bool nontemporal;       // stream the corpus past L2 (corpus >> Infinity Cache)
     bool linear_bins;       // scores bounded in [-1,1] (cosine / pipeline mode): linear histogram bins
     uint32_t k;
-    float* gmax;            // [b, n_pad/group_rows] per-group maxima (written by the scan)
-    uint32_t group_rows;    // kTaskRows or kTaskRowsSmall: rows per work-queue task = rows per maxima group
+    float* gmax;            // [b, tiers.total()] per-task maxima (written by the scan)
+    TaskTiers tiers;        // plan_tiers(n_pad, n_cu, use_mfma(b, dim))
     uint32_t* work;         // [kWorkWords] work-queue heads (zero on entry)
     uint32_t n_cu;          // compute units of the device
-    void* dbg;              // nullable: 16 x u64 phase stamps of select_finish (CQS_HIP_DEBUG_STAMPS=1)
+    void* dbg;              // nullable: (16 + 2 * kDbgWaves) x u64: select_finish phase stamps, then the scan's
+                            // per-wave start/end stamps (CQS_HIP_DEBUG_STAMPS=1)
 };
 
 // scores[q][row] = dot(rows[row], q) (+ mode / bitset / non-finite handling; dropped
-// entries = -inf), gmax[q][g] = max of 64-row group g.
+// entries = -inf), gmax[q][t] = max over the rows of task t (a.tiers).
 hipError_t launch_scan(const ScanArgs& a, hipStream_t stream);
 
 // Exact top-k of each query's score row (one workgroup per query; see select_finish_kernel).

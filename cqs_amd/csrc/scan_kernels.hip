@@ -1,13 +1,14 @@
 // scan_kernels.hip — gfx950 (MI355X) kernels for the cqs brute-force scan.
 //
 //  scan_gemv_kernel   HBM-streaming fp32 dot of every corpus row with 1..8 queries.
-//                     Persistent workgroups pull 64-row tasks from a global work queue
-//                     (one wave = one task); a row is read as dim/256 fully coalesced
-//                     1-KiB wave loads (16 B/lane) issued back to back, the query lives in
-//                     registers, lane partials are reduced with a transposed butterfly so
-//                     that RI rows x BQ queries cost ~1 cross-lane op per dot.  Besides the
-//                     score row it emits one maximum per 64-row group: the pruning index of
-//                     the top-k select.
+//                     One wave = one task of 64 (32, 16) rows; up to ~1.5M rows every task gets
+//                     its own wave and the hardware dispatcher does the scheduling, beyond that
+//                     a persistent grid continues from a global work queue.  A row is read as
+//                     dim/256 fully coalesced 1-KiB wave loads (16 B/lane) issued 8 rows at a
+//                     time, double-buffered; the query lives in registers; lane partials are
+//                     reduced with a transposed butterfly so that RI rows x BQ queries cost ~1
+//                     cross-lane op per dot.  Besides the score row it emits one maximum per
+//                     task: the pruning index of the top-k select.
 //                     Replaces the per-row simsimd dot of the reference's brute-force loop
 //                     (src/math.rs:11-28 called from src/search/query.rs:469-481) and
 //                     cuVS' search for the exact backend (src/cagra.rs:605).
@@ -135,17 +136,22 @@ struct ScanParams {
     uint32_t mode;
     float thr;
     uint32_t* work;     // work-queue head of this launch
-    uint32_t n_tasks;   // n_pad / TR
-    float* gmax;        // [BQ][n_tasks] maximum valid score of each 64-row group (-inf if none)
+    TaskTiers tiers;    // task t -> (first row, 64 / 32 / 16 rows)
+    uint32_t n_tasks;   // tiers.total()
+    float* gmax;        // [BQ][n_tasks] maximum valid score of each task's rows (-inf if none)
+    unsigned long long* dbg;  // CQS_HIP_DEBUG_STAMPS: [16 + 2*wave] = start / end realtime of each wave
 };
 
-// NCH = ceil(dim / 256): 1-KiB chunks per row.  BQ queries, RI rows per inner
-// iteration (RI*BQ partial sums are reduced together).  FULL: dim == NCH*256.
-// PIPE: 0 = loads then math per iteration; 1 = explicit double buffer (next iteration's
-// rows in flight while this iteration is reduced).
-// TR: rows per task (64, or 16 for corpora too small to give every CU several 64-row tasks).
-template <int NCH, int BQ, int RI, bool NT, bool FULL, int PIPE, int TR>
-__global__ __launch_bounds__(256) void scan_gemv_kernel(const ScanParams p) {
+// NCH = ceil(dim / 256): 1-KiB chunks per row.  BQ queries, RI rows per batch (RI*BQ partial
+// sums are reduced together).  FULL: dim == NCH*256.
+// PIPE: 0 = batch by batch: loads -> math (many-query variants: the register file is full of query
+//           fragments); 1 = two batches in flight while a third is reduced (tasks whose rows are partly
+//           filtered out still go batch by batch, skipping the empty ones).
+// OCC:  workgroups per CU the register allocation must leave room for.  The pipelined single-query
+//       variant wants > 256 VGPRs (one wave per SIMD); corpora with fewer tasks than 2 waves per SIMD
+//       use an OCC = 2 build instead so that every task is resident at once.
+template <int NCH, int BQ, int RI, bool NT, bool FULL, int PIPE, int OCC>
+__global__ __launch_bounds__(256, OCC) void scan_gemv_kernel(const ScanParams p) {
     constexpr int NV = RI * BQ;
     constexpr int LPV = 64 / NV;  // lanes per reduced value
     const int lane = threadIdx.x & 63;
@@ -170,102 +176,79 @@ __global__ __launch_bounds__(256) void scan_gemv_kernel(const ScanParams p) {
 
     const uint32_t last = n - 1u;
     const uint32_t nwords = (n + 31u) / 32u;
-    // First task = the wave's own index (no atomic); later tasks come from the shared queue, whose
-    // head counts from the number of waves.  A grid that covers every task never touches the queue
-    // (one queue word sustains only ~88 dequeues/us: a start-up burst from every wave costs 10-25 us).
-    const uint32_t total_waves = gridDim.x * 4u;
-    const bool use_queue = p.n_tasks > total_waves;
-    uint32_t task = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const uint32_t n_tasks = p.n_tasks;
+    const uint32_t wpb = blockDim.x >> 6;  // waves per workgroup
+    const uint32_t total_waves = gridDim.x * wpb;
+    // (readfirstlane: tell the compiler the wave index - and every task index derived from it - is uniform)
+    const uint32_t wave_id = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * wpb + (threadIdx.x >> 6)));
+    // A wave's first task is its own index (no atomic).  A one-shot grid covers every task that way and
+    // the hardware dispatcher does the scheduling; a persistent grid (huge corpora) continues from the
+    // shared queue, whose tickets count from #waves.  (One queue word sustains only ~88 dequeues/us: a
+    // start-up burst from every wave would cost 10-25 us.)
+    const bool use_queue = n_tasks > total_waves;
+    // A zero the compiler cannot see through.  With a provably uniform address hipcc rewrites the
+    // dequeue into a wave-aggregated atomic followed at once by s_waitcnt vmcnt(0) + readfirstlane,
+    // draining every row load in flight.  A "divergent" address keeps the plain returning atomic,
+    // whose ticket is only waited for where it is used.
+    uint32_t opaque_zero;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(opaque_zero));
+    if (p.dbg && lane == 0 && wave_id < kDbgWaves) p.dbg[16u + 2u * wave_id] = __builtin_amdgcn_s_memrealtime();
 
-    while (task < p.n_tasks) {
-        uint32_t next = 0;
-        const uint32_t base = task * (uint32_t)TR;
-
-        // rows this wave must score (low TR bits): inside the corpus and kept by the filter
-        constexpr uint64_t kAll = TR == 64 ? ~0ull : ((1ull << (TR & 63)) - 1ull);
-        uint64_t mask = kAll;
-        if (base + (uint32_t)TR > n) mask = (base >= n) ? 0ull : (kAll >> ((uint32_t)TR - (n - base)));
-        if (p.keep) {
-            const uint32_t w = base / 32u;
-            const uint32_t w0 = (w < nwords) ? p.keep[w] : 0u;
-            const uint32_t w1 = (w + 1u < nwords) ? p.keep[w + 1u] : 0u;
-            mask &= (((uint64_t)w1 << 32) | (uint64_t)w0) >> (base & 31u);
+    // issue the RI*NCH row loads of batch j of the task at `base` back to back (all in flight together).
+    // Address = uniform row pointer (SGPR pair, scalar ALU) + the lane's fixed 32-bit byte offset (+ the
+    // chunk as an immediate): no per-row vector address registers.
+    const char* const rows_b = (const char*)p.rows;
+    const uint32_t row_bytes = dim * 4u;
+    uint32_t lane_off[NCH];  // FULL: only [0] is used, chunks go into the immediate offset
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) lane_off[c] = coff[c] * 4u;
+    auto load_rows = [&](uint32_t base, int j, f4 (&x)[RI][NCH]) {
+#pragma unroll
+        for (int r = 0; r < RI; ++r) {
+            uint32_t row = base + (uint32_t)(RI * j + r);
+            row = row > last ? last : row;
+            const char* rp = rows_b + (uint64_t)row * row_bytes;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const f4* src = FULL ? (const f4*)(rp + lane_off[0]) + c * 64 : (const f4*)(rp + lane_off[c]);
+                if (NT) x[r][c] = __builtin_nontemporal_load(src);
+                else x[r][c] = *src;
+            }
         }
-        // wave-uniform by construction; make the loop branches scalar
-        const uint32_t mlo = __builtin_amdgcn_readfirstlane((uint32_t)mask);
-        const uint32_t mhi = __builtin_amdgcn_readfirstlane((uint32_t)(mask >> 32));
-        mask = ((uint64_t)mhi << 32) | mlo;
-
-        float sc[BQ];
+        __builtin_amdgcn_sched_barrier(0);  // keep the loads ahead of the math that follows
+    };
+    // dot the batch with the queries; lane L = RI*j + r receives row r's score of query b in sc[b]
+    auto reduce_rows = [&](int j, f4 (&x)[RI][NCH], float (&sc)[BQ]) {
+        float acc[NV];
 #pragma unroll
-        for (int b = 0; b < BQ; ++b) sc[b] = -INFINITY;
-
-        // issue the RI*NCH row loads of inner iteration j back to back (all in flight together)
-        auto load_rows = [&](int j, f4 (&x)[RI][NCH]) {
+        for (int i = 0; i < NV; ++i) acc[i] = 0.f;
 #pragma unroll
-            for (int r = 0; r < RI; ++r) {
-                uint32_t row = base + (uint32_t)(RI * j + r);
-                row = row > last ? last : row;
-                const float* rp = p.rows + (size_t)row * dim;
+        for (int r = 0; r < RI; ++r)
 #pragma unroll
-                for (int c = 0; c < NCH; ++c) {
-                    if (NT) x[r][c] = __builtin_nontemporal_load((const f4*)(rp + coff[c]));
-                    else x[r][c] = *(const f4*)(rp + coff[c]);
+            for (int c = 0; c < NCH; ++c)
+#pragma unroll
+                for (int b = 0; b < BQ; ++b) {
+                    float a = acc[b * RI + r];
+                    a = __builtin_fmaf(x[r][c].x, qv[b][c].x, a);
+                    a = __builtin_fmaf(x[r][c].y, qv[b][c].y, a);
+                    a = __builtin_fmaf(x[r][c].z, qv[b][c].z, a);
+                    a = __builtin_fmaf(x[r][c].w, qv[b][c].w, a);
+                    acc[b * RI + r] = a;
                 }
-            }
-            __builtin_amdgcn_sched_barrier(0);  // keep the loads ahead of the math that follows
-        };
-        auto reduce_rows = [&](int j, f4 (&x)[RI][NCH]) {
-            float acc[NV];
+        treduce<NV>(acc, lane);
+        // value (b, r) now sits in lanes [(b*RI+r)*LPV, +LPV); lane L = RI*j + r wants it
 #pragma unroll
-            for (int i = 0; i < NV; ++i) acc[i] = 0.f;
-#pragma unroll
-            for (int r = 0; r < RI; ++r)
-#pragma unroll
-                for (int c = 0; c < NCH; ++c)
-#pragma unroll
-                    for (int b = 0; b < BQ; ++b) {
-                        float a = acc[b * RI + r];
-                        a = __builtin_fmaf(x[r][c].x, qv[b][c].x, a);
-                        a = __builtin_fmaf(x[r][c].y, qv[b][c].y, a);
-                        a = __builtin_fmaf(x[r][c].z, qv[b][c].z, a);
-                        a = __builtin_fmaf(x[r][c].w, qv[b][c].w, a);
-                        acc[b * RI + r] = a;
-                    }
-            treduce<NV>(acc, lane);
-            // value (b, r) now sits in lanes [(b*RI+r)*LPV, +LPV); lane L = RI*j + r wants it
-#pragma unroll
-            for (int b = 0; b < BQ; ++b) {
-                const float t = __shfl(acc[0], (b * RI + (lane % RI)) * LPV, 64);
-                if (lane / RI == j) sc[b] = t;
-            }
-        };
-        if (PIPE == 1 && mask == kAll) {
-            f4 xa[RI][NCH], xb[RI][NCH];
-            load_rows(0, xa);
-            for (int j = 0; j < TR / RI; j += 2) {
-                load_rows(j + 1, xb);
-                // dequeue the next task behind the first row loads: vmcnt retires in issue
-                // order, so an atomic issued ahead of them would stall the first reduction
-                if (j == 0 && use_queue && lane == 0) next = total_waves + atomicAdd(p.work, 1u);
-                reduce_rows(j, xa);
-                if (j + 2 < TR / RI) load_rows(j + 2, xa);
-                reduce_rows(j + 1, xb);
-            }
-        } else {
-            if (use_queue && lane == 0) next = total_waves + atomicAdd(p.work, 1u);
-            for (int j = 0; j < TR / RI; ++j) {
-                const uint32_t m = (uint32_t)(mask >> (RI * j)) & ((1u << RI) - 1u);
-                if (m == 0u) continue;  // all RI rows filtered out / past the end: skip their HBM reads
-                f4 x[RI][NCH];
-                load_rows(j, x);
-                reduce_rows(j, x);
-            }
+        for (int b = 0; b < BQ; ++b) {
+            const float t = __shfl(acc[0], (b * RI + (lane % RI)) * LPV, 64);
+            if (lane / RI == j) sc[b] = t;
         }
+    };
 
-        // epilogue: lane <-> row base+lane (lanes < TR); one coalesced store per query
+    // emit the scores of task `cur` (lane <-> row base+lane, lanes < trows): one coalesced store per
+    // query and the task maximum for the select's pruning index
+    auto epilogue = [&](uint32_t cur, uint32_t base, uint32_t trows, uint64_t mask, float (&sc)[BQ]) {
         const uint32_t row = base + (uint32_t)lane;
-        const bool live = lane < TR && ((mask >> lane) & 1ull);
+        const bool live = (uint32_t)lane < trows && ((mask >> lane) & 1ull);
 #pragma unroll
         for (int b = 0; b < BQ; ++b) {
             float s = sc[b];
@@ -276,15 +259,80 @@ __global__ __launch_bounds__(256) void scan_gemv_kernel(const ScanParams p) {
                 s = s < 0.f ? 0.f : (s > 1.f ? 1.f : s);
                 if (!(s >= p.thr)) s = -INFINITY;
             }
-            if (lane < TR && row < p.n_pad) p.scores[(size_t)b * p.n_pad + row] = s;
-            // group maximum -> pruning index of the select
+            if ((uint32_t)lane < trows && row < p.n_pad) p.scores[(size_t)b * p.n_pad + row] = s;
             float gm = s;
 #pragma unroll
             for (int off = 32; off >= 1; off >>= 1) gm = fmaxf(gm, __shfl_xor(gm, off, 64));
-            if (lane == 0) p.gmax[(size_t)b * p.n_tasks + task] = gm;
+            if (lane == 0) p.gmax[(size_t)b * n_tasks + cur] = gm;
         }
-        task = use_queue ? (uint32_t)__builtin_amdgcn_readfirstlane(next) : p.n_tasks;
+    };
+    // ticket -> task index
+    auto claimed = [&](uint32_t ticket) -> uint32_t {
+        return use_queue ? total_waves + (uint32_t)__builtin_amdgcn_readfirstlane(ticket) : n_tasks;
+    };
+
+    // wave-uniform mask of the rows of a task this wave must score: inside the corpus, kept by the filter
+    auto task_mask = [&](uint32_t base, uint32_t trows) -> uint64_t {
+        const uint64_t all = trows == 64u ? ~0ull : ((1ull << trows) - 1ull);
+        uint64_t mask = all;
+        if (base + trows > n) mask = (base >= n) ? 0ull : (all >> (trows - (n - base)));
+        if (p.keep) {
+            const uint32_t w = base / 32u;
+            const uint32_t w0 = (w < nwords) ? p.keep[w] : 0u;
+            const uint32_t w1 = (w + 1u < nwords) ? p.keep[w + 1u] : 0u;
+            mask &= (((uint64_t)w1 << 32) | (uint64_t)w0) >> (base & 31u);
+        }
+        // uniform by construction; tell the compiler so the loop branches become scalar
+        const uint32_t mlo = __builtin_amdgcn_readfirstlane((uint32_t)mask);
+        const uint32_t mhi = __builtin_amdgcn_readfirstlane((uint32_t)(mask >> 32));
+        return ((uint64_t)mhi << 32) | mlo;
+    };
+    f4 xa[RI][NCH], xb[RI][NCH];
+    // batch by batch, skipping batches with no row to score
+    auto sparse_task = [&](uint32_t t, uint32_t base, uint32_t trows, uint64_t mask) {
+        float sc[BQ];
+#pragma unroll
+        for (int b = 0; b < BQ; ++b) sc[b] = -INFINITY;
+        const int nb = (int)(trows / (uint32_t)RI);
+        for (int j = 0; j < nb; ++j) {
+            const uint32_t m = (uint32_t)(mask >> (RI * j)) & ((1u << RI) - 1u);
+            if (m == 0u) continue;  // all RI rows filtered out / past the end: skip their HBM reads
+            load_rows(base, j, xb);
+            reduce_rows(j, xb, sc);
+        }
+        epilogue(t, base, trows, mask, sc);
+    };
+
+    uint32_t cur = wave_id;
+    while (cur < n_tasks) {
+        uint32_t trows;
+        const uint32_t base = p.tiers.locate(cur, trows);
+        const uint64_t mask = task_mask(base, trows);
+        const uint64_t all = trows == 64u ? ~0ull : ((1ull << trows) - 1ull);
+        uint32_t ticket = 0;  // lane 0: the dequeue drawn during this task
+        if (PIPE == 1 && mask == all) {
+            float sc[BQ];
+#pragma unroll
+            for (int b = 0; b < BQ; ++b) sc[b] = -INFINITY;
+            const int steps = (int)(trows / (2u * (uint32_t)RI));
+            load_rows(base, 0, xa);
+            for (int s = 0; s < steps; ++s) {
+                load_rows(base, 2 * s + 1, xb);
+                // the dequeue goes out behind row loads already in flight: vmcnt retires in issue
+                // order, so an atomic issued ahead of them would stall the first reduction
+                if (s == 0 && use_queue && lane == 0) ticket = atomicAdd(p.work + opaque_zero, 1u);
+                reduce_rows(2 * s, xa, sc);
+                if (s + 1 < steps) load_rows(base, 2 * s + 2, xa);
+                reduce_rows(2 * s + 1, xb, sc);
+            }
+            epilogue(cur, base, trows, mask, sc);
+        } else {
+            if (use_queue && lane == 0) ticket = atomicAdd(p.work + opaque_zero, 1u);
+            sparse_task(cur, base, trows, mask);
+        }
+        cur = claimed(ticket);
     }
+    if (p.dbg && lane == 0 && wave_id < kDbgWaves) p.dbg[17u + 2u * wave_id] = __builtin_amdgcn_s_memrealtime();
 }
 
 // ---- one-block exact select (fallback for heavy ties / crowded bins) --------
@@ -376,7 +424,7 @@ __device__ __forceinline__ void wave_slots(const bool (&take)[N], uint32_t* coun
 }
 __global__ __launch_bounds__(1024) void select_finish_kernel(const float* __restrict__ scores,
                                                              const float* __restrict__ gmax, uint32_t n_pad,
-                                                             uint32_t n_tasks, uint32_t grows_log2, uint32_t k,
+                                                             const TaskTiers tiers, uint32_t slot_log2, uint32_t k,
                                                              uint32_t row_base, uint32_t linear,
                                                              uint64_t* __restrict__ out_keys,
                                                              uint32_t* __restrict__ out_counts,
@@ -389,6 +437,7 @@ __global__ __launch_bounds__(1024) void select_finish_kernel(const float* __rest
     __shared__ uint32_t s_res[4];
     __shared__ uint32_t s_cnt, s_ng;
     const uint32_t qi = blockIdx.x;
+    const uint32_t n_tasks = tiers.total();
     const float* s = scores + (size_t)qi * n_pad;
     const float* gm = gmax + (size_t)qi * n_tasks;
     const int lane = threadIdx.x & 63;
@@ -446,18 +495,29 @@ __global__ __launch_bounds__(1024) void select_finish_kernel(const float* __rest
     uint32_t count = kCandCap + 1u;
     if (ng <= kGroupCap) {
         // phase 3: their scores (L2 / Infinity Cache hits: the scan just wrote them)
-        const uint32_t grows = 1u << grows_log2;
-        const uint32_t total = ng << grows_log2;
+        // every selected group gets 2^slot_log2 element slots (the widest tier in use); the slots
+        // past a narrower group's rows stay empty
+        const uint32_t slots = 1u << slot_log2;
+        const uint32_t total = ng << slot_log2;
         for (uint32_t e0 = 0; e0 < total; e0 += 1024u * kGB) {
             float v[kGB];
             uint32_t idx[kGB];
 #pragma unroll
             for (int u = 0; u < kGB; ++u) {
+                if (e0 + (uint32_t)u * 1024u >= total) {  // block-uniform: nothing left for this slice
+                    v[u] = -INFINITY;
+                    idx[u] = 0u;
+                    continue;
+                }
                 const uint32_t e = e0 + (uint32_t)u * 1024u + threadIdx.x;
                 const uint32_t ec = e < total ? e : total - 1u;
-                idx[u] = (s_groups[ec >> grows_log2] << grows_log2) + (ec & (grows - 1u));
+                uint32_t grows;
+                const uint32_t gbase = tiers.locate(s_groups[ec >> slot_log2], grows);
+                const uint32_t off = ec & (slots - 1u);
+                const bool in = e < total && off < grows;
+                idx[u] = gbase + (in ? off : 0u);
                 const float x = s[idx[u]];
-                v[u] = e < total ? x : -INFINITY;
+                v[u] = in ? x : -INFINITY;
             }
             bool take[kGB];
             uint32_t slot[kGB];
@@ -536,42 +596,77 @@ bool scan_dim_supported(uint32_t dim) { return dim >= 4 && dim % 4 == 0 && dim <
 #define CQS_SCAN_PIPE 1
 #endif
 #ifndef CQS_SCAN_RI1
-#define CQS_SCAN_RI1 8   // rows per inner iteration of the single-query scan
+#define CQS_SCAN_RI1 8   // rows per batch of the single-query scan
+#endif
+#ifndef CQS_SCAN_ONE_SHOT
+#define CQS_SCAN_ONE_SHOT 24u   // one task per wave up to this many tasks per SIMD; beyond: persistent grid + queue
+#endif
+#ifndef CQS_SCAN_BLOCK_WAVES
+#define CQS_SCAN_BLOCK_WAVES 2u   // waves per workgroup of the one-shot launch (64-row tasks)
+#endif
+#ifndef CQS_SCAN_BLOCK_WAVES_SMALL
+#define CQS_SCAN_BLOCK_WAVES_SMALL 1u   // ... of 16-row tasks
 #endif
 #ifndef CQS_SCAN_BLOCKS_PER_CU
-#define CQS_SCAN_BLOCKS_PER_CU 2
+#define CQS_SCAN_BLOCKS_PER_CU 2u   // persistent grid
 #endif
+#ifndef CQS_SCAN_TIER_B
+#define CQS_SCAN_TIER_B 2u   // 32-row tasks at the end of the corpus, in units of (n_cu * 4 / 2)
+#endif
+
+// Task sizes over the padded corpus (measured at 768-d, 1 query; MI355X, 256 CUs):
+//   < 8 64-row tasks per CU (<= 131k rows): 16-row tasks, so a 17.5k-row corpus still reaches every CU;
+//   otherwise 64-row tasks (8 batches of 8 rows: the double buffer's fill/drain is amortised), with the
+//   last two rounds' worth of 32-row tasks: the launch ends when its slowest wave does, and halving the
+//   final tasks halves that tail (-5 us of 460 at 1M rows).  16-row tail tasks cost more than they gain.
+TaskTiers plan_tiers(uint32_t n_pad, uint32_t n_cu, bool mfma) {
+    TaskTiers t{0u, 0u, 0u};
+    const uint32_t n64 = n_pad / 64u, waves = n_cu * 4u;
+    if (mfma) { t.nA = n64; return t; }
+    if (n64 < 8u * n_cu) { t.nC = n_pad / 16u; return t; }
+    const uint32_t nb = CQS_SCAN_TIER_B * (waves / 2u) & ~1u;
+    if (n64 >= 6u * waves && n64 > nb / 2u) { t.nA = n64 - nb / 2u; t.nB = nb; }
+    else t.nA = n64;
+    return t;
+}
+static uint32_t tier_slot_log2(const TaskTiers& t) { return t.nA ? 6u : (t.nB ? 5u : 4u); }
+
 template <int NCH, int BQ, int RI>
 static hipError_t launch_gemv(const ScanArgs& a, uint32_t q0, uint32_t work_slot, hipStream_t st) {
+    constexpr int PIPE = (BQ <= 2) ? CQS_SCAN_PIPE : 0;
     ScanParams p;
     p.rows = a.rows; p.n = a.n; p.n_pad = a.n_pad; p.dim = a.dim;
     p.q = a.q + (size_t)q0 * a.dim;
     p.scores = a.scores + (size_t)q0 * a.n_pad;
     p.keep = a.keep; p.mode = a.mode; p.thr = a.threshold;
     p.work = a.work + work_slot;
-    p.n_tasks = a.n_pad / a.group_rows;
+    p.tiers = a.tiers;
+    p.n_tasks = a.tiers.total();
     p.gmax = a.gmax + (size_t)q0 * p.n_tasks;
-    // persistent grid: enough workgroups to fill every CU at this kernel's occupancy, never
-    // more than there are 4-task rounds; a workgroup that finds the queue empty just exits.
-    uint32_t blocks = a.n_cu * CQS_SCAN_BLOCKS_PER_CU;
-    const uint32_t need = (p.n_tasks + 3u) / 4u;
-    if (blocks > need) blocks = need;
-    // small corpora: one task per wave, up to 8 workgroups per CU, no work queue at all
-    if (need <= a.n_cu * 8u) blocks = need;
-    const dim3 grid(blocks), block(256);
+    p.dbg = (unsigned long long*)a.dbg;
+    // One-shot grid (one task per wave, the hardware dispatcher schedules: beats a persistent grid up to
+    // ~1.5M rows) or, for huge corpora, a persistent grid that continues from the work queue (beats the
+    // one-shot grid by 3 % at 10M rows).
+    const bool small = a.tiers.nA == 0u && a.tiers.nB == 0u;  // 16-row tasks only
+    const bool one_shot = p.n_tasks <= a.n_cu * 4u * CQS_SCAN_ONE_SHOT;
+    uint32_t wpb = 4u, blocks = a.n_cu * CQS_SCAN_BLOCKS_PER_CU;
+    if (one_shot) {
+        wpb = small ? CQS_SCAN_BLOCK_WAVES_SMALL : CQS_SCAN_BLOCK_WAVES;
+        blocks = (p.n_tasks + wpb - 1u) / wpb;
+    }
+    const dim3 grid(blocks), block(64u * wpb);
     const bool full = (a.dim == (uint32_t)NCH * 256u);
-    // small corpora never stream past the caches, so the 16-row variant is built without nt loads only
-#define CQS_LAUNCH(NTV, FULLV, TRV) \
-    hipLaunchKernelGGL((scan_gemv_kernel<NCH, BQ, (RI < TRV / 2 ? RI : TRV / 2), NTV, FULLV, (BQ <= 2 ? CQS_SCAN_PIPE : 0), TRV>), \
-                       grid, block, 0, st, p)
 #ifdef CQS_SCAN_FORCE_NT
     const bool nt = CQS_SCAN_FORCE_NT;
 #else
     const bool nt = a.nontemporal;
 #endif
-    if (a.group_rows == kTaskRowsSmall) { if (full) CQS_LAUNCH(false, true, 16); else CQS_LAUNCH(false, false, 16); }
-    else if (nt) { if (full) CQS_LAUNCH(true, true, 64); else CQS_LAUNCH(true, false, 64); }
-    else { if (full) CQS_LAUNCH(false, true, 64); else CQS_LAUNCH(false, false, 64); }
+#define CQS_LAUNCH(NTV, FULLV, OCCV) \
+    hipLaunchKernelGGL((scan_gemv_kernel<NCH, BQ, RI, NTV, FULLV, PIPE, OCCV>), grid, block, 0, st, p)
+    // small corpora never stream past the caches: their OCC = 2 variant is built without nt loads only
+    if (small && PIPE == 1) { if (full) CQS_LAUNCH(false, true, 2); else CQS_LAUNCH(false, false, 2); }
+    else if (nt) { if (full) CQS_LAUNCH(true, true, 1); else CQS_LAUNCH(true, false, 1); }
+    else { if (full) CQS_LAUNCH(false, true, 1); else CQS_LAUNCH(false, false, 1); }
 #undef CQS_LAUNCH
     return hipGetLastError();
 }
@@ -638,7 +733,7 @@ hipError_t launch_select(const ScanArgs& a, uint32_t row_base, uint64_t* out_key
                          hipStream_t st) {
     if (a.b == 0 || a.k == 0) return hipSuccess;
     hipLaunchKernelGGL(select_finish_kernel, dim3(a.b), dim3(1024), 0, st, a.scores, a.gmax, a.n_pad,
-                       a.n_pad / a.group_rows, a.group_rows == kTaskRows ? 6u : 4u, a.k, row_base,
+                       a.tiers, tier_slot_log2(a.tiers), a.k, row_base,
                        a.linear_bins ? 1u : 0u, out_keys, out_counts, a.work,
                        (unsigned long long*)a.dbg);
     return hipGetLastError();

@@ -472,3 +472,28 @@ def test_backend_try_open_and_persistence(hip, oracle, tmp_path):
     idx4 = be.try_open(BackendContext(str(tmp_path / "b"), _FakeStore(ids, rows2), hip_threshold=1000, persist=False))
     assert len(idx4) == n - 2 and ids[5] not in idx4.id_map and ids[9] not in idx4.id_map
     idx4.close()
+
+
+@pytest.mark.parametrize("n,dim", [(400_001, 64), (150_000, 128), (2_000_003, 16)])
+def test_task_layouts_across_corpus_sizes(hip, oracle, n, dim):
+    """The scan cuts the corpus into wave tasks differently by size: 16-row tasks (small), 64-row tasks,
+    64-row tasks with a tail of 32-row tasks (>= ~393k rows), and beyond ~1.5M rows a persistent grid fed
+    by the work queue.  Full parity (ids + scores) against the oracle in each regime, with the best rows
+    planted at both ends so that every task tier holds part of the answer; single query, query pair,
+    bitset filter and k = 500."""
+    rows = synth.gaussian_unit(n, dim=dim, seed=700 + dim)
+    qs = synth.gaussian_unit(2, dim=dim, seed=701 + dim)
+    for j, r in enumerate((0, 1, 65, n // 2, n - 40_000, n - 20_001, n - 2, n - 1)):
+        v = qs[0] + 0.02 * (j + 1) * rows[r]
+        rows[r] = v / np.linalg.norm(v)
+    idx = HipIndex.build_from_flat(None, rows)
+    check(oracle, idx, rows, qs[0], 20)
+    check(oracle, idx, rows, qs, 500)
+    rng = np.random.default_rng(n)
+    keep = (rng.random(n) < 0.3)
+    keep[-3000:] = True          # the tail tasks stay (partly) selected
+    keep[n // 3: n // 3 + 5000] = False
+    bits = np.zeros((n + 31) // 32, dtype=np.uint32)
+    np.bitwise_or.at(bits, np.nonzero(keep)[0] // 32, (np.uint32(1) << (np.nonzero(keep)[0] % 32).astype(np.uint32)))
+    check(oracle, idx, rows, qs[0], 100, keep=bits)
+    idx.close()

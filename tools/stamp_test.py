@@ -3,7 +3,7 @@ os.environ["CQS_HIP_DEBUG_STAMPS"]="1"
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np, torch
 from cqs_amd import HipIndex
-n=1_000_000
+n=int(os.environ.get("ROWS","1000000"))
 g=torch.Generator(device="cuda"); g.manual_seed(1)
 rows=torch.randn((n,768),generator=g,device="cuda"); rows/=rows.norm(dim=1,keepdim=True)
 idx=HipIndex.build_from_device(None, rows.data_ptr(), n, 768, borrow=True, keepalive=rows)
