@@ -164,7 +164,7 @@ int32_t enqueue_search(cqs_hip_index* x, const float* d_q, uint32_t b, uint32_t 
     a.work = x->d_work;
     a.n_cu = x->n_cu;
     a.dbg = x->d_dbg;
-    a.tiers = cqs::plan_tiers(a.n_pad, x->n_cu, cqs::use_mfma(b, x->dim));
+    a.tiers = cqs::plan_tiers(a.n_pad, x->n_cu, cqs::uniform_groups(b, x->dim));
     const bool timed = x->timing && x->ev_used + 2 <= kMaxTimingEvents;
     if (timed) {
         while (x->ev.size() < x->ev_used + 2) {

@@ -31,7 +31,7 @@ struct TaskTiers {
         return nA * 64u + nB * 32u + (t - nA - nB) * 16u;
     }
 };
-TaskTiers plan_tiers(uint32_t n_pad, uint32_t n_cu, bool mfma);
+TaskTiers plan_tiers(uint32_t n_pad, uint32_t n_cu, bool uniform64);
 
 struct ScanArgs {
     const float* rows;      // [n, dim] f32, row-major, HBM
@@ -48,7 +48,7 @@ struct ScanArgs {
     bool linear_bins;       // scores bounded in [-1,1] (cosine / pipeline mode): linear histogram bins
     uint32_t k;
     float* gmax;            // [b, tiers.total()] per-task maxima (written by the scan)
-    TaskTiers tiers;        // plan_tiers(n_pad, n_cu, use_mfma(b, dim))
+    TaskTiers tiers;        // plan_tiers(n_pad, n_cu, uniform_groups(b, dim))
     uint32_t* work;         // [kWorkWords] work-queue heads (zero on entry)
     uint32_t n_cu;          // compute units of the device
     void* dbg;              // nullable: (16 + 2 * kDbgWaves) x u64: select_finish phase stamps, then the scan's
@@ -71,6 +71,9 @@ hipError_t launch_scan_mfma(const ScanArgs& a, uint32_t q0, uint32_t nq, uint32_
 uint32_t mfma_query_tile(uint32_t nq);
 constexpr uint32_t kMfmaMinQueries = 9;   // below this the HBM-streaming gemv passes win
 inline bool use_mfma(uint32_t b, uint32_t dim) { return b >= kMfmaMinQueries && dim % 32u == 0; }
+// 5..8 queries (dim <= 1024): the LDS-ring kernel of scan_kernels.hip; needs 64-row groups like the MFMA path
+inline bool use_coop(uint32_t b, uint32_t dim) { return !use_mfma(b, dim) && b >= 5u && b <= 8u && dim <= 1024u; }
+inline bool uniform_groups(uint32_t b, uint32_t dim) { return use_mfma(b, dim) || use_coop(b, dim); }
 
 bool scan_dim_supported(uint32_t dim);
 
