@@ -253,10 +253,11 @@ def main():
 
         def finish(lo, hi):
             torch.cuda.synchronize()
-            host = torch.stack(gathered[lo:hi]).cpu().numpy()  # [steps, world, world*bq, k+1]
-            for s in range(hi - lo):                           # host merge of this rank's own queries
-                mine = host[s][:, rank * bq:(rank + 1) * bq, :]
-                merged[lo + s] = ShardedSearch.merge_host(np.ascontiguousarray(mine), k)
+            host = torch.stack(gathered[lo:hi]).cpu().numpy()  # [steps, world, world*bq, k]
+            mine = host[:, :, rank * bq:(rank + 1) * bq, :]    # host merge of this rank's own queries, all steps at once
+            out = ShardedSearch.merge_host_many(mine, k)       # [steps, bq, k]
+            for s in range(hi - lo):
+                merged[lo + s] = [row[row != 0] for row in out[s]]
 
     for i in range(W):
         step(i)

@@ -5,8 +5,8 @@ No reference counterpart (cqs is single-GPU): the corpus is part
 contiguously by row (rowid order) into `world_size` shards, every rank scans its own shard
 with the same query block and emits its local top-k as packed keys carrying GLOBAL row ids
 (`row_base` = shard offset), one all-gather moves the `k x 8 B` candidates of every rank
-(k=20: 160 B per query per GPU - latency-, not bandwidth-bound, so ONE fused collective per
-query block), and the final k-way merge runs on the host with the same comparator
+(k=20: 160 B per query per GPU - latency-, not bandwidth-bound, so ONE collective per
+query block; zero-padded key lists carry their own length), and the final k-way merge runs on the host with the same comparator
 (score desc, row asc).  The comparator is a total order on distinct keys, so the merged
 list equals the single-GPU answer exactly.
 
@@ -49,36 +49,45 @@ class ShardedSearch:
         self._all_gather = all_gather   # optional override: f(out[world, ...], inp) (bench rehearsal mode)
 
     def gather_candidates(self, queries, k: int):
-        """Local scan + ONE all-gather of (keys, counts) -> tensors [world, b, k] / [world, b] on device."""
+        """Local scan + ONE all-gather of the packed keys -> int64 tensor [world, b, k] on device.
+
+        No separate count travels: unused key slots are zero (include/cqs_hip.h: out_keys is zero padded;
+        a valid key is never zero because every finite score has a non-zero ordered image), so the count
+        of a list is its number of non-zero keys."""
         import torch
-        keys, counts = self.local_search(queries, k)
+        keys, _counts = self.local_search(queries, k)
         b = keys.shape[0]
-        # fuse keys and counts into one buffer so the exchange is a single collective
-        payload = torch.empty((b, k + 1), dtype=torch.int64, device=keys.device)
-        payload[:, :k] = keys
-        payload[:, k] = counts.to(torch.int64)
-        out = torch.empty((self.world, b, k + 1), dtype=torch.int64, device=keys.device)
         if self.world == 1:
-            out[0] = payload
-        elif self._all_gather is not None:
-            self._all_gather(out, payload)
+            return keys.view(1, b, k)
+        out = torch.empty((self.world, b, k), dtype=torch.int64, device=keys.device)
+        if self._all_gather is not None:
+            self._all_gather(out, keys)
         else:
             try:
-                self.dist.all_gather_into_tensor(out.view(-1), payload.view(-1), group=self.group)
+                self.dist.all_gather_into_tensor(out.view(-1), keys.contiguous().view(-1), group=self.group)
             except (RuntimeError, NotImplementedError):  # backends without the fused form (older gloo)
-                self.dist.all_gather(list(out.unbind(0)), payload, group=self.group)
+                self.dist.all_gather(list(out.unbind(0)), keys.contiguous(), group=self.group)
         return out
 
     @staticmethod
     def merge_host(gathered: np.ndarray, k: int):
-        """gathered: [world, b, k+1] int64 (host).  -> list of per-query merged key arrays (uint64)."""
+        """gathered: [world, b, k] int64 (host), zero padded.  -> list of per-query merged key arrays (uint64)."""
         world, b, _ = gathered.shape
         res = []
         for q in range(b):
             lists = np.ascontiguousarray(gathered[:, q, :k]).view(np.uint64)
-            counts = gathered[:, q, k].astype(np.uint32)
+            counts = np.count_nonzero(lists, axis=1).astype(np.uint32)
             res.append(merge_keys(lists, counts, k))
         return res
+
+    @staticmethod
+    def merge_host_many(gathered: np.ndarray, k: int) -> np.ndarray:
+        """Vectorised host merge of many query blocks at once: gathered [..., world, b, k] int64 (zero padded)
+        -> uint64 [..., b, k], zero padded.  The keys of one query are distinct and totally ordered, so the
+        k-way merge of the per-shard lists equals the k largest keys of their concatenation."""
+        g = np.ascontiguousarray(np.moveaxis(gathered, -3, -2)).view(np.uint64)   # [..., b, world, k]
+        flat = g.reshape(g.shape[:-2] + (g.shape[-2] * g.shape[-1],))
+        return np.ascontiguousarray(np.sort(flat, axis=-1)[..., ::-1][..., :k])
 
     def search(self, queries, k: int):
         """Every rank gets the merged global top-k of every query (host arrays)."""

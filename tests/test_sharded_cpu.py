@@ -78,3 +78,24 @@ def test_shard_bounds_cover():
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
             assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1
+
+
+def test_merge_host_many_equals_kway_merge():
+    """The vectorised host merge (k largest keys of the concatenated lists) == cqs_hip_merge_keys per query."""
+    from cqs_amd.sharded import ShardedSearch
+    rng = np.random.default_rng(5)
+    steps, world, b, k = 7, 4, 3, 20
+    g = np.zeros((steps, world, b, k), np.uint64)
+    for s in range(steps):
+        for q in range(b):
+            keys = np.unique(rng.integers(1, 1 << 62, size=4 * world * k, dtype=np.uint64))[:world * k]
+            rng.shuffle(keys)
+            for w in range(world):
+                c = int(rng.integers(0, k + 1))
+                g[s, w, q, :c] = np.sort(keys[w * k:w * k + c])[::-1]
+    many = ShardedSearch.merge_host_many(g.view(np.int64), k)
+    for s in range(steps):
+        one = ShardedSearch.merge_host(g[s].view(np.int64), k)
+        for q in range(b):
+            got = many[s, q]
+            assert np.array_equal(got[got != 0], one[q])
