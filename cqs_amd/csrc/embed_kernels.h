@@ -44,8 +44,11 @@ hipError_t launch_qk_norm_rope(bf16_t* qkv, const int32_t* pos, const float* wq,
                                const float* cos_sin /*[max_seq][128][2]*/, float eps, float q_scale,
                                uint32_t M, uint32_t heads, uint32_t kv_heads, hipStream_t st);
 
-// vt[g][d][vt_col(m)] = v[m][g][d]  (keys contiguous per head dim: the A operand of O^T = V^T P^T)
-hipError_t launch_v_transpose(const bf16_t* qkv, bf16_t* vt, const int32_t* vt_col, uint32_t M, uint32_t heads,
+// vt[g][d][vt_start[seq] + pos] = v[token][g][d]  (keys contiguous per head dim: the A operand of
+// O^T = V^T P^T); blk / seq_* / vt_start as for launch_attention.  Columns between a sequence's end and
+// the next multiple of 32 are written as zeros.
+hipError_t launch_v_transpose(const bf16_t* qkv, bf16_t* vt, const int32_t* blk, uint32_t nblk,
+                              const int32_t* seq_start, const int32_t* seq_len, const int32_t* vt_start, uint32_t heads,
                               uint32_t kv_heads, uint32_t vt_ld, hipStream_t st);
 
 // Bidirectional (optionally windowed) attention over packed sequences.

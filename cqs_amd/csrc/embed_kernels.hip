@@ -116,69 +116,95 @@ __global__ __launch_bounds__(256) void add_norm_kernel(float* __restrict__ x, co
     }
 }
 
-// ---- q/k RMSNorm + RoPE, in place; one wave per (token, head); lane owns dims [4l, 4l+4) ----
+// ---- q/k RMSNorm + RoPE, in place; one wave per token, all its q and k heads; lane owns dims [4l, 4l+4) ----
+// (the token's cos/sin row - twice the bytes of one head - is fetched once for all heads, and the heads'
+// loads are in flight together)
+constexpr int kMaxQkHeads = 8;
 __global__ __launch_bounds__(256) void qk_norm_rope_kernel(bf16_t* __restrict__ qkv, const int32_t* __restrict__ pos,
                                                            const float* __restrict__ wq, const float* __restrict__ wk,
                                                            const float* __restrict__ cos_sin, float eps, float q_scale,
                                                            uint32_t M, uint32_t heads, uint32_t kv_heads) {
     const int lane = threadIdx.x & 63;
     const uint32_t nh = heads + kv_heads;
-    const uint32_t wv = blockIdx.x * 4u + (threadIdx.x >> 6);
-    if (wv >= M * nh) return;
-    const uint32_t m = wv / nh, h = wv % nh;
+    const uint32_t m = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (m >= M) return;
     const uint32_t ld = (heads + 2u * kv_heads) * kHD;
-    bf16_t* p = qkv + (size_t)m * ld + (size_t)h * kHD + lane * 4;
-    const bool is_q = h < heads;
-    const float* w = (is_q ? wq : wk) + lane * 4;
-    const bf4 in = *(const bf4*)p;
-    float v[4];
-    float ss = 0.f;
+    bf16_t* row = qkv + (size_t)m * ld + lane * 4;
+    bf4 in[kMaxQkHeads];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        v[i] = (float)in[i];
-        ss += v[i] * v[i];
-    }
-    const float inv = rsqrtf(wave_sum(ss) / (float)kHD + eps);
+    for (int h = 0; h < kMaxQkHeads; ++h)
+        if ((uint32_t)h < nh) in[h] = *(const bf4*)(row + (size_t)h * kHD);
     // rotate_half pairs dim d with d +/- 128: the partner lives in lane ^ 32, same element
     const float* cs = cos_sin + ((size_t)pos[m] * 128u + (uint32_t)(lane & 31) * 4u) * 2u;
     const f4 cs0 = *(const f4*)cs, cs1 = *(const f4*)(cs + 4);  // (cos,sin) x 4 dims
     const float c4[4] = {cs0[0], cs0[2], cs1[0], cs1[2]};
     const float s4[4] = {cs0[1], cs0[3], cs1[1], cs1[3]};
-    bf4 o;
+    const f4 wqv = *(const f4*)(wq + lane * 4), wkv = *(const f4*)(wk + lane * 4);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const float n = v[i] * inv * (1.0f + w[i]);
-        const float other = __shfl_xor(n, 32, 64);
-        // d < 128: n*cos - x[d+128]*sin ; d >= 128: n*cos + x[d-128]*sin
-        float r = (lane < 32) ? (n * c4[i] - other * s4[i]) : (n * c4[i] + other * s4[i]);
-        if (is_q) r *= q_scale;
-        o[i] = (bf16_t)r;
+    for (int h = 0; h < kMaxQkHeads; ++h) {
+        if ((uint32_t)h >= nh) break;
+        const bool is_q = (uint32_t)h < heads;
+        float v[4];
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[i] = (float)in[h][i];
+            ss += v[i] * v[i];
+        }
+        const float inv = rsqrtf(wave_sum(ss) / (float)kHD + eps);
+        bf4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float n = v[i] * inv * (1.0f + (is_q ? wqv[i] : wkv[i]));
+            const float other = __shfl_xor(n, 32, 64);
+            // d < 128: n*cos - x[d+128]*sin ; d >= 128: n*cos + x[d-128]*sin
+            float r = (lane < 32) ? (n * c4[i] - other * s4[i]) : (n * c4[i] + other * s4[i]);
+            if (is_q) r *= q_scale;
+            o[i] = (bf16_t)r;
+        }
+        *(bf4*)(row + (size_t)h * kHD) = o;
     }
-    *(bf4*)p = o;
 }
 
-// ---- V transpose: vt[g][d][vt_col[m]] = v[m][g][d]; block = 64 tokens x 256 dims of one kv head ----
+// ---- V transpose: vt[g][d][vt_start[seq] + pos] = v[token][g][d] -------------------------------------
+// One workgroup = 64 positions (half a 128-position super-block of the attention's blk list) x 64 head
+// dims of one kv head, through LDS.  In: 16-B loads along d.  Out: 16-B stores of 8 consecutive
+// positions of one head dim (V^T columns of a sequence start at a multiple of 32, so they are aligned);
+// 8 lanes cover one dim's 64 positions = one full 128-B line.  Positions past the sequence end are
+// written as zeros (the attention multiplies them by P = 0; they must stay finite).
 __global__ __launch_bounds__(256) void v_transpose_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ vt,
-                                                          const int32_t* __restrict__ vt_col, uint32_t M,
-                                                          uint32_t heads, uint32_t kv_heads, uint32_t vt_ld) {
-    __shared__ bf16_t tile[64][kHD + 2];
-    const uint32_t g = blockIdx.y;
-    const uint32_t m0 = blockIdx.x * 64u;
+                                                          const int32_t* __restrict__ blk,
+                                                          const int32_t* __restrict__ seq_start,
+                                                          const int32_t* __restrict__ seq_len,
+                                                          const int32_t* __restrict__ vt_start, uint32_t heads,
+                                                          uint32_t kv_heads, uint32_t vt_ld) {
+    __shared__ __attribute__((aligned(16))) bf16_t tile[64][64 + 8];
+    const uint32_t g = blockIdx.y >> 2, d0 = (blockIdx.y & 3u) * 64u;
+    const uint32_t sblk = blockIdx.x >> 1, half = blockIdx.x & 1u;
+    const uint32_t seq = (uint32_t)blk[2 * sblk], sb = (uint32_t)blk[2 * sblk + 1];
+    const uint32_t len = (uint32_t)seq_len[seq], m_seq = (uint32_t)seq_start[seq], c_seq = (uint32_t)vt_start[seq];
+    const uint32_t cols = (len + 31u) & ~31u;  // the sequence's padded V^T columns
+    const uint32_t p0 = sb * 128u + half * 64u;
+    if (p0 >= cols) return;
     const uint32_t ld = (heads + 2u * kv_heads) * kHD;
-    const uint32_t voff = (heads + kv_heads + g) * kHD;
-    for (uint32_t i = threadIdx.x; i < 64u * (kHD / 4); i += 256u) {
-        const uint32_t t = i / (kHD / 4), c = (i % (kHD / 4)) * 4u;
-        bf4 v = (bf4)(0.f);
-        if (m0 + t < M) v = *(const bf4*)(qkv + (size_t)(m0 + t) * ld + voff + c);
+    const uint32_t voff = (heads + kv_heads + g) * kHD + d0;
+    const int tid = threadIdx.x;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) tile[t][c + e] = v[e];
+    for (int u = 0; u < 2; ++u) {
+        const uint32_t i = (uint32_t)(u * 256 + tid), t = i >> 3, c = (i & 7u) * 8u;
+        bf8 v = (bf8)(0.f);
+        if (p0 + t < len) v = *(const bf8*)(qkv + (size_t)(m_seq + p0 + t) * ld + voff + c);
+        *(bf8*)&tile[t][c] = v;
     }
     __syncthreads();
-    // each thread writes one head dim for a run of tokens; tokens of one block map to
-    // consecutive vt columns except across a sequence boundary
-    for (uint32_t i = threadIdx.x; i < 64u * kHD; i += 256u) {
-        const uint32_t d = i / 64u, t = i % 64u;
-        if (m0 + t < M) vt[((size_t)g * kHD + d) * vt_ld + (uint32_t)vt_col[m0 + t]] = tile[t][d];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const uint32_t i = (uint32_t)(u * 256 + tid), d = i >> 3, t0 = (i & 7u) * 8u;
+        if (p0 + t0 >= cols) continue;
+        bf8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = tile[t0 + e][d];
+        *(bf8*)(vt + ((size_t)g * kHD + d0 + d) * vt_ld + c_seq + p0 + t0) = o;
     }
 }
 
@@ -606,17 +632,18 @@ hipError_t launch_qk_norm_rope(bf16_t* qkv, const int32_t* pos, const float* wq,
                                const float* cos_sin, float eps, float q_scale, uint32_t M, uint32_t heads,
                                uint32_t kv_heads, hipStream_t st) {
     if (M == 0) return hipSuccess;
-    const uint32_t waves = M * (heads + kv_heads);
-    hipLaunchKernelGGL(qk_norm_rope_kernel, dim3((waves + 3u) / 4u), dim3(256), 0, st, qkv, pos, wq, wk, cos_sin, eps,
+    if (heads + kv_heads > (uint32_t)kMaxQkHeads) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(qk_norm_rope_kernel, dim3((M + 3u) / 4u), dim3(256), 0, st, qkv, pos, wq, wk, cos_sin, eps,
                        q_scale, M, heads, kv_heads);
     return hipGetLastError();
 }
 
-hipError_t launch_v_transpose(const bf16_t* qkv, bf16_t* vt, const int32_t* vt_col, uint32_t M, uint32_t heads,
+hipError_t launch_v_transpose(const bf16_t* qkv, bf16_t* vt, const int32_t* blk, uint32_t nblk,
+                              const int32_t* seq_start, const int32_t* seq_len, const int32_t* vt_start, uint32_t heads,
                               uint32_t kv_heads, uint32_t vt_ld, hipStream_t st) {
-    if (M == 0) return hipSuccess;
-    hipLaunchKernelGGL(v_transpose_kernel, dim3((M + 63u) / 64u, kv_heads), dim3(256), 0, st, qkv, vt, vt_col, M, heads,
-                       kv_heads, vt_ld);
+    if (nblk == 0) return hipSuccess;
+    hipLaunchKernelGGL(v_transpose_kernel, dim3(nblk * 2u, kv_heads * 4u), dim3(256), 0, st, qkv, vt, blk, seq_start, seq_len,
+                       vt_start, heads, kv_heads, vt_ld);
     return hipGetLastError();
 }
 

@@ -82,7 +82,7 @@ struct cqs_hip_embedder {
     uint32_t tok_cap = 0, seq_cap = 0, vt_ld = 0, blk_cap = 0;
     float *x = nullptr, *hidden = nullptr, *out = nullptr;
     bf16_t *y = nullptr, *xn = nullptr, *qkv = nullptr, *vt = nullptr, *attn = nullptr, *h = nullptr, *pooled = nullptr, *d1 = nullptr;
-    int32_t *d_tok = nullptr, *d_pos = nullptr, *d_vtcol = nullptr, *d_seq_start = nullptr, *d_seq_len = nullptr,
+    int32_t *d_tok = nullptr, *d_pos = nullptr, *d_seq_start = nullptr, *d_seq_len = nullptr,
             *d_vt_start = nullptr, *d_blk = nullptr;
 
     mutable std::mutex mu;
@@ -128,7 +128,7 @@ int32_t ensure_scratch(cqs_hip_embedder* e, uint32_t M, uint32_t B, uint32_t vt_
     if (M <= e->tok_cap && B <= e->seq_cap && vt_cols <= e->vt_ld && nblk <= e->blk_cap) return CQS_HIP_OK;
     E_TRY(e, hipStreamSynchronize(e->stream));
     void* all[] = {e->x, e->y, e->hidden, e->out, e->xn, e->qkv, e->vt, e->attn, e->h, e->pooled, e->d1, e->d_tok,
-                   e->d_pos, e->d_vtcol, e->d_seq_start, e->d_seq_len, e->d_vt_start, e->d_blk};
+                   e->d_pos, e->d_seq_start, e->d_seq_len, e->d_vt_start, e->d_blk};
     for (void* p : all) (void)hipFree(p);
     const uint32_t Mc = std::max(M, e->tok_cap), Bc = std::max(B, e->seq_cap);
     const uint32_t vc = std::max(vt_cols, e->vt_ld), bc = std::max(nblk, e->blk_cap);
@@ -147,7 +147,6 @@ int32_t ensure_scratch(cqs_hip_embedder* e, uint32_t M, uint32_t B, uint32_t vt_
     E_TRY(e, dmalloc(&e->d1, (size_t)Bc * g.dense_hidden));
     E_TRY(e, dmalloc(&e->d_tok, (size_t)Mc));
     E_TRY(e, dmalloc(&e->d_pos, (size_t)Mc));
-    E_TRY(e, dmalloc(&e->d_vtcol, (size_t)Mc));
     E_TRY(e, dmalloc(&e->d_seq_start, (size_t)Bc));
     E_TRY(e, dmalloc(&e->d_seq_len, (size_t)Bc));
     E_TRY(e, dmalloc(&e->d_vt_start, (size_t)Bc));
@@ -158,7 +157,7 @@ int32_t ensure_scratch(cqs_hip_embedder* e, uint32_t M, uint32_t B, uint32_t vt_
 
 // Pack the padded [B, L] batch, run the layers, leave `hidden` (final norm, packed) on the device.
 struct Packed {
-    std::vector<int32_t> tok, pos, vtcol, seq_start, seq_len, vt_start, blk;
+    std::vector<int32_t> tok, pos, seq_start, seq_len, vt_start, blk;
     uint32_t M = 0, vt_cols = 0;
 };
 
@@ -178,7 +177,6 @@ int32_t pack(cqs_hip_embedder* e, const int64_t* ids, const int64_t* mask, uint3
             if (id < 0 || id >= (int64_t)e->g.vocab) return efail(e, CQS_HIP_ERR_INVALID, "embed: token id out of range");
             p.tok.push_back((int32_t)id);
             p.pos.push_back((int32_t)j);
-            p.vtcol.push_back((int32_t)(vcols + j));
         }
         for (uint32_t sb = 0; sb * 128u < len; ++sb) { p.blk.push_back((int32_t)b); p.blk.push_back((int32_t)sb); }
         M += len;
@@ -197,7 +195,6 @@ int32_t run_layers(cqs_hip_embedder* e, const Packed& p, uint32_t B) {
     if (rc != CQS_HIP_OK) return rc;
     E_TRY(e, hipMemcpyAsync(e->d_tok, p.tok.data(), (size_t)M * 4, hipMemcpyHostToDevice, st));
     E_TRY(e, hipMemcpyAsync(e->d_pos, p.pos.data(), (size_t)M * 4, hipMemcpyHostToDevice, st));
-    E_TRY(e, hipMemcpyAsync(e->d_vtcol, p.vtcol.data(), (size_t)M * 4, hipMemcpyHostToDevice, st));
     E_TRY(e, hipMemcpyAsync(e->d_seq_start, p.seq_start.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
     E_TRY(e, hipMemcpyAsync(e->d_seq_len, p.seq_len.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
     E_TRY(e, hipMemcpyAsync(e->d_vt_start, p.vt_start.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
@@ -211,7 +208,8 @@ int32_t run_layers(cqs_hip_embedder* e, const Packed& p, uint32_t B) {
         E_TRY(e, cqs::launch_gemm_bf16(e->xn, w.wqkv, e->qkv, M, nqkv(g), H, nqkv(g), cqs::GEMM_OUT_BF16, st));
         E_TRY(e, cqs::launch_qk_norm_rope(e->qkv, e->d_pos, w.n_q, w.n_k, full ? e->rope_global : e->rope_local,
                                           g.rms_eps, g.q_scale, M, g.heads, g.kv_heads, st));
-        E_TRY(e, cqs::launch_v_transpose(e->qkv, e->vt, e->d_vtcol, M, g.heads, g.kv_heads, e->vt_ld, st));
+        E_TRY(e, cqs::launch_v_transpose(e->qkv, e->vt, e->d_blk, nblk, e->d_seq_start, e->d_seq_len, e->d_vt_start,
+                                         g.heads, g.kv_heads, e->vt_ld, st));
         E_TRY(e, cqs::launch_attention(e->qkv, e->vt, e->attn, e->d_blk, nblk, e->d_seq_start, e->d_seq_len,
                                        e->d_vt_start, e->vt_ld, g.heads, g.kv_heads, full ? 0u : g.window, st));
         E_TRY(e, cqs::launch_gemm_bf16(e->attn, w.wo, e->y, M, H, g.heads * g.head_dim, H, cqs::GEMM_OUT_BF16, st));
@@ -381,7 +379,7 @@ int32_t cqs_hip_embedder_create(const cqs_hip_embed_config* c, int32_t device, c
     if (!c || !out) return CQS_HIP_ERR_INVALID;
     *out = nullptr;
     if (c->head_dim != 256 || c->hidden == 0 || c->hidden % 256 || c->hidden > 1024 || c->intermediate % 64 ||
-        c->dense_hidden % 128 || c->kv_heads == 0 || c->heads % c->kv_heads || c->heads / c->kv_heads > 4 ||
+        c->dense_hidden % 128 || c->kv_heads == 0 || c->heads % c->kv_heads || c->heads / c->kv_heads > 4 || c->heads + c->kv_heads > 8 ||
         c->layers == 0 || c->sliding_pattern == 0 || c->max_seq == 0 || c->vocab_size == 0 || c->hidden % 128)
         return CQS_HIP_ERR_INVALID;
     int cnt = 0;
@@ -526,7 +524,7 @@ void cqs_hip_embedder_destroy(cqs_hip_embedder* e) {
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     void* g[] = {e->emb, e->n_final, e->dense1, e->dense2, e->rope_global, e->rope_local, e->x, e->y, e->hidden, e->out,
-                 e->xn, e->qkv, e->vt, e->attn, e->h, e->pooled, e->d1, e->d_tok, e->d_pos, e->d_vtcol, e->d_seq_start,
+                 e->xn, e->qkv, e->vt, e->attn, e->h, e->pooled, e->d1, e->d_tok, e->d_pos, e->d_seq_start,
                  e->d_seq_len, e->d_vt_start, e->d_blk};
     for (void* p : g) (void)hipFree(p);
     for (LayerW& w : e->L) {

@@ -353,12 +353,18 @@ __global__ __launch_bounds__(256, OCC) void scan_gemv_kernel(const ScanParams p)
 // Filters are applied in the epilogue (no read skipping).
 template <int NCH>
 struct CoopGeom {
-    static constexpr int kRows = 8;                                  // rows per stage
+#ifndef CQS_COOP_ROWS
+#define CQS_COOP_ROWS 8
+#endif
+#ifndef CQS_COOP_STAGES2
+#define CQS_COOP_STAGES2 3
+#endif
+    static constexpr int kRows = CQS_COOP_ROWS;                      // rows per stage
 #ifndef CQS_COOP_BLOCKS_PER_CU
 #define CQS_COOP_BLOCKS_PER_CU 2
 #endif
     static constexpr int kBlocksPerCu = NCH <= 3 ? CQS_COOP_BLOCKS_PER_CU : 1;
-    static constexpr int kStages = kBlocksPerCu > 1 ? 3 : (NCH <= 3 ? 6 : 4);  // <= 144 KiB of LDS per CU
+    static constexpr int kStages = kBlocksPerCu > 1 ? CQS_COOP_STAGES2 : (NCH <= 3 ? 6 : 4);  // <= 144 KiB of LDS per CU
     static constexpr uint32_t kStageBytes = kRows * NCH * 1024u;
     static constexpr uint32_t kLdsBytes = kStages * kStageBytes;
 #ifndef CQS_COOP_QW
