@@ -890,6 +890,7 @@ static hipError_t launch_gemv(const ScanArgs& a, uint32_t q0, uint32_t work_slot
         wpb = small ? CQS_SCAN_BLOCK_WAVES_SMALL : CQS_SCAN_BLOCK_WAVES;
         blocks = (p.n_tasks + wpb - 1u) / wpb;
     }
+    if (!one_shot && PIPE == 1 && CQS_SCAN_CAP_OCCUPANCY) blocks = a.n_cu;  // (one resident workgroup per CU, see below)
     const dim3 grid(blocks), block(64u * wpb);
     // Streaming a corpus far larger than the caches runs best with ONE wave per SIMD (each with two
     // 8-row batches in flight): a second wave per SIMD costs 2-3 % of the HBM rate (DRAM page

@@ -497,3 +497,24 @@ def test_task_layouts_across_corpus_sizes(hip, oracle, n, dim):
     np.bitwise_or.at(bits, np.nonzero(keep)[0] // 32, (np.uint32(1) << (np.nonzero(keep)[0] % 32).astype(np.uint32)))
     check(oracle, idx, rows, qs[0], 100, keep=bits)
     idx.close()
+
+
+@pytest.mark.parametrize("b,n,dim", [(5, 1, 768), (6, 63, 100), (7, 4097, 384), (8, 70_000, 768), (6, 3000, 1024),
+                                     (8, 2500, 4), (7, 1500, 1280)])
+def test_five_to_eight_query_blocks(hip, oracle, b, n, dim):
+    """5..8 queries take the LDS-ring kernel (dim <= 1024; beyond that the register variants): ragged
+    corpus ends, partial 1-KiB chunks, the bitset filter (applied in its epilogue) and PIPELINE mode."""
+    rows = synth.gaussian_unit(n, dim, seed=900 + n % 97)
+    qs = synth.gaussian_unit(b, dim, seed=901 + b)
+    idx = HipIndex.build_from_flat(None, rows)
+    k = min(20, n)
+    check(oracle, idx, rows, qs, k)
+    rng = np.random.default_rng(n + b)
+    keep = rng.random(n) < 0.5
+    keep[: min(n, 100)] = True
+    bits = np.zeros((n + 31) // 32, dtype=np.uint32)
+    on = np.nonzero(keep)[0]
+    np.bitwise_or.at(bits, on // 32, np.uint32(1) << (on % 32).astype(np.uint32))
+    check(oracle, idx, rows, qs, k, keep=bits)
+    check(oracle, idx, rows, qs, k, mode=1, thr=0.02)
+    idx.close()
