@@ -71,9 +71,7 @@ hipError_t launch_scan_mfma(const ScanArgs& a, uint32_t q0, uint32_t nq, uint32_
 uint32_t mfma_query_tile(uint32_t nq);
 constexpr uint32_t kMfmaMinQueries = 9;   // below this the HBM-streaming gemv passes win
 inline bool use_mfma(uint32_t b, uint32_t dim) { return b >= kMfmaMinQueries && dim % 32u == 0; }
-// 5..8 queries (dim <= 1024): the LDS-ring kernel of scan_kernels.hip; needs 64-row groups like the MFMA path
-inline bool use_coop(uint32_t b, uint32_t dim) { return !use_mfma(b, dim) && b >= 5u && b <= 8u && dim <= 1024u; }
-inline bool uniform_groups(uint32_t b, uint32_t dim) { return use_mfma(b, dim) || use_coop(b, dim); }
+inline bool uniform_groups(uint32_t b, uint32_t dim) { return use_mfma(b, dim); }  // kernels that need 64-row groups only
 
 bool scan_dim_supported(uint32_t dim);
 

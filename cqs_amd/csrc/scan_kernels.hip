@@ -140,6 +140,7 @@ struct ScanParams {
     const uint32_t* keep;
     uint32_t mode;
     float thr;
+    uint32_t nq;        // queries actually present (<= BQ: the pass may be padded; extra slots are never stored)
     uint32_t* work;     // work-queue head of this launch
     TaskTiers tiers;    // task t -> (first row, 64 / 32 / 16 rows)
     uint32_t n_tasks;   // tiers.total()
@@ -174,7 +175,7 @@ __global__ __launch_bounds__(256, OCC) void scan_gemv_kernel(const ScanParams p)
         coff[c] = in ? idx : dim - 4u;
 #pragma unroll
         for (int b = 0; b < BQ; ++b) {
-            const f4 v = *(const f4*)(p.q + (size_t)b * dim + coff[c]);
+            const f4 v = *(const f4*)(p.q + (size_t)((uint32_t)b < p.nq ? b : 0) * dim + coff[c]);
             qv[b][c] = in ? v : (f4)(0.f);
         }
     }
@@ -264,6 +265,7 @@ __global__ __launch_bounds__(256, OCC) void scan_gemv_kernel(const ScanParams p)
                 s = s < 0.f ? 0.f : (s > 1.f ? 1.f : s);
                 if (!(s >= p.thr)) s = -INFINITY;
             }
+            if ((uint32_t)b >= p.nq) continue;  // padding slot of a 5..7-query pass
             if ((uint32_t)lane < trows && row < p.n_pad) p.scores[(size_t)b * p.n_pad + row] = s;
             float gm = s;
 #pragma unroll
@@ -338,234 +340,6 @@ __global__ __launch_bounds__(256, OCC) void scan_gemv_kernel(const ScanParams p)
         cur = claimed(ticket);
     }
     if (p.dbg && lane == 0 && wave_id < kDbgWaves) p.dbg[17u + 2u * wave_id] = __builtin_amdgcn_s_memrealtime();
-}
-
-// ---- scan, 5..8 queries: rows staged once per CU in LDS, the waves split the queries ------------
-// The register-resident multi-query variants run out of registers: 8 query fragments (96 VGPRs) leave
-// room for 6 KB of rows in flight per wave, and the scan runs on bytes in flight (4.3 TB/s at 8
-// queries).  Here the rows of a stage (8 rows) are copied global -> LDS by LDS-DMA (global_load_lds:
-// no registers), every wave reads the whole stage back (conflict-free ds_read_b128, lane = same 16 B
-// of every 1-KiB chunk as in the gemv kernel) and dots it with ITS two queries.  A workgroup walks a
-// contiguous run of 64-row tasks, so the ring never drains between tasks.  Measured at 1M x 768, 8
-// queries: 4 waves + 6-stage ring, 1 workgroup/CU 0.67 ms; 8 waves x 1 query 0.65 ms; TWO workgroups
-// per CU with 3-stage rings 0.53 ms (the per-stage barrier couples the waves of a workgroup; two
-// independent workgroups fill each other's stalls); the register kernel 0.72 ms; HBM floor 0.45 ms.
-// Filters are applied in the epilogue (no read skipping).
-template <int NCH>
-struct CoopGeom {
-#ifndef CQS_COOP_ROWS
-#define CQS_COOP_ROWS 8
-#endif
-#ifndef CQS_COOP_STAGES2
-#define CQS_COOP_STAGES2 3
-#endif
-    static constexpr int kRows = CQS_COOP_ROWS;                      // rows per stage
-#ifndef CQS_COOP_BLOCKS_PER_CU
-#define CQS_COOP_BLOCKS_PER_CU 2
-#endif
-    static constexpr int kBlocksPerCu = NCH <= 3 ? CQS_COOP_BLOCKS_PER_CU : 1;
-    static constexpr int kStages = kBlocksPerCu > 1 ? CQS_COOP_STAGES2 : (NCH <= 3 ? 6 : 4);  // <= 144 KiB of LDS per CU
-    static constexpr uint32_t kStageBytes = kRows * NCH * 1024u;
-    static constexpr uint32_t kLdsBytes = kStages * kStageBytes;
-#ifndef CQS_COOP_QW
-#define CQS_COOP_QW 2
-#endif
-    static constexpr int kQW = CQS_COOP_QW;                          // queries per wave
-    static constexpr int kWaves = 8 / kQW;                           // waves per workgroup
-    static constexpr int kRowsPerWave = kRows / kWaves;              // rows of a stage each wave copies
-    static constexpr int kLoadsPerWave = kRowsPerWave * NCH;
-};
-constexpr uint32_t kCoopQueries = 8;
-
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-
-template <int NCH, bool FULL, bool NT>
-__global__ __launch_bounds__(64 * CoopGeom<NCH>::kWaves) void scan_coop_kernel(const ScanParams p, uint32_t nq, uint32_t tasks_per_block) {
-    using G = CoopGeom<NCH>;
-    constexpr int RS = G::kRows, S = G::kStages, L = G::kLoadsPerWave, QW = G::kQW, RPW = G::kRowsPerWave;
-    static_assert(S >= 3 && (S - 2) * L <= 63, "ring depth / vmcnt field");
-    extern __shared__ __attribute__((aligned(16))) char coop_lds[];
-    const int lane = threadIdx.x & 63;
-    const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const uint32_t n = p.n, dim = p.dim;
-    const uint32_t last = n - 1u;
-    const uint32_t nwords = (n + 31u) / 32u;
-    const uint32_t n_tasks = p.n_tasks;
-
-    // this wave's queries (zero fragments past nq: their scores are never stored)
-    uint32_t lane_off[NCH];
-    f4 qv[QW][NCH];
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-        const uint32_t idx = (uint32_t)c * 256u + (uint32_t)lane * 4u;
-        const bool in = FULL || idx < dim;
-        const uint32_t off = in ? idx : dim - 4u;   // clamped in-row address against a zero fragment
-        lane_off[c] = off * 4u;
-#pragma unroll
-        for (int b = 0; b < QW; ++b) {
-            const uint32_t qi = (uint32_t)(QW * wid + b);
-            const f4 v = *(const f4*)(p.q + (size_t)(qi < nq ? qi : 0u) * dim + off);
-            qv[b][c] = (in && qi < nq) ? v : (f4)(0.f);
-        }
-    }
-
-    const uint32_t t0 = blockIdx.x * tasks_per_block;
-    const uint32_t t1 = (t0 + tasks_per_block < n_tasks) ? t0 + tasks_per_block : n_tasks;
-    if (t0 >= t1) return;
-    const uint32_t ns = (t1 - t0) * (64u / RS);  // stages of this workgroup
-    const char* const rows_b = (const char*)p.rows;
-    const uint32_t row_bytes = dim * 4u;
-
-    // LDS-DMA of stage g into ring slot g % S: this wave's two rows, one 1-KiB wave instruction per chunk
-    auto issue = [&](uint32_t g) {
-        const uint32_t slot = g % (uint32_t)S;
-#pragma unroll
-        for (int rr = 0; rr < RPW; ++rr) {
-            const uint32_t r = (uint32_t)(RPW * wid + rr);
-            uint32_t row = t0 * 64u + g * (uint32_t)RS + r;
-            row = row > last ? last : row;
-            const char* rp = rows_b + (uint64_t)row * row_bytes;
-            char* dst = coop_lds + slot * G::kStageBytes + (r * NCH) * 1024u;
-#pragma unroll
-            for (int c = 0; c < NCH; ++c)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(rp + lane_off[c]),
-                                                 (__attribute__((address_space(3))) void*)(dst + c * 1024), 16, 0,
-                                                 NT ? 2 : 0);
-        }
-    };
-#pragma unroll
-    for (int g = 0; g < S - 1; ++g)
-        if ((uint32_t)g < ns) issue((uint32_t)g);
-
-    float sc[QW];
-#pragma unroll
-    for (int b = 0; b < QW; ++b) sc[b] = -INFINITY;
-    for (uint32_t g = 0; g < ns; ++g) {
-        // this wave's share of stage g has landed once at most the loads of the younger stages are
-        // outstanding (in-order retirement; the epilogue's stores only make the wait stricter)
-        const uint32_t younger = (ns - 1u - g) < (uint32_t)(S - 2) ? (ns - 1u - g) : (uint32_t)(S - 2);
-        if (younger == (uint32_t)(S - 2)) wait_vmcnt<(S - 2) * L>();
-        else if (S > 3 && younger == (uint32_t)(S - 3)) wait_vmcnt<(S > 3 ? S - 3 : 0) * L>();
-        else if (S > 4 && younger == (uint32_t)(S - 4)) wait_vmcnt<(S > 4 ? S - 4 : 0) * L>();
-        else if (S > 5 && younger == (uint32_t)(S - 5)) wait_vmcnt<(S > 5 ? S - 5 : 0) * L>();
-        else wait_vmcnt<0>();
-        // everyone's share has landed, and everyone is done reading the slot refilled next
-        __builtin_amdgcn_s_barrier();
-        if (g + (uint32_t)(S - 1) < ns) issue(g + (uint32_t)(S - 1));
-
-        const char* src = coop_lds + (g % (uint32_t)S) * G::kStageBytes + (uint32_t)lane * 16u;
-        float acc[QW * RS];
-#pragma unroll
-        for (int i = 0; i < QW * RS; ++i) acc[i] = 0.f;
-        // row r+1 is read from LDS while row r is multiplied (two register sets; the sched_barrier keeps
-        // hipcc from pairing every read with an immediate wait)
-        f4 x[2][NCH];
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) x[0][c] = *(const f4*)(src + c * 1024);
-#pragma unroll
-        for (int r = 0; r < RS; ++r) {
-            if (r + 1 < RS) {
-#pragma unroll
-                for (int c = 0; c < NCH; ++c) x[(r + 1) & 1][c] = *(const f4*)(src + ((r + 1) * NCH + c) * 1024);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int c = 0; c < NCH; ++c)
-#pragma unroll
-                for (int b = 0; b < QW; ++b) {
-                    float a = acc[b * RS + r];
-                    a = __builtin_fmaf(x[r & 1][c].x, qv[b][c].x, a);
-                    a = __builtin_fmaf(x[r & 1][c].y, qv[b][c].y, a);
-                    a = __builtin_fmaf(x[r & 1][c].z, qv[b][c].z, a);
-                    a = __builtin_fmaf(x[r & 1][c].w, qv[b][c].w, a);
-                    acc[b * RS + r] = a;
-                }
-        }
-        treduce<QW * RS>(acc, lane);
-        // value (b, r) sits in lanes [(b*RS + r) * LPV, +LPV); lane RS*j + r of the task wants it (j = stage in task)
-        constexpr int LPV = 64 / (QW * RS);
-        const uint32_t j = g & (64u / RS - 1u);
-#pragma unroll
-        for (int b = 0; b < QW; ++b) {
-            const float t = __shfl(acc[0], (b * RS + (lane % RS)) * LPV, 64);
-            if ((uint32_t)(lane / RS) == j) sc[b] = t;
-        }
-        if (j != 64u / RS - 1u) continue;
-
-        // task complete: lane <-> row
-        const uint32_t task = t0 + g / (64u / RS);
-        const uint32_t base = task * 64u;
-        uint64_t mask = ~0ull;
-        if (base + 64u > n) mask = (base >= n) ? 0ull : (~0ull >> (64u - (n - base)));
-        if (p.keep) {
-            const uint32_t w = base / 32u;
-            const uint32_t w0 = (w < nwords) ? p.keep[w] : 0u;
-            const uint32_t w1 = (w + 1u < nwords) ? p.keep[w + 1u] : 0u;
-            mask &= ((uint64_t)w1 << 32) | (uint64_t)w0;
-        }
-        const bool live = (mask >> lane) & 1ull;
-#pragma unroll
-        for (int b = 0; b < QW; ++b) {
-            const uint32_t qi = (uint32_t)(QW * wid + b);
-            float s = sc[b];
-            sc[b] = -INFINITY;
-            if (qi >= nq) continue;
-            // non-finite scores are never emitted (src/math.rs:23-27, src/cagra.rs:649-651)
-            if (!live || !(__builtin_fabsf(s) <= 3.4028234664e38f)) s = -INFINITY;
-            else if (p.mode == 1u) {
-                // candidate.rs:550 clamp(0,1), :513-519 `>= threshold`
-                s = s < 0.f ? 0.f : (s > 1.f ? 1.f : s);
-                if (!(s >= p.thr)) s = -INFINITY;
-            }
-            const uint32_t row = base + (uint32_t)lane;
-            if (row < p.n_pad) p.scores[(size_t)qi * p.n_pad + row] = s;
-            float gm = s;
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) gm = fmaxf(gm, __shfl_xor(gm, off, 64));
-            if (lane == 0) p.gmax[(size_t)qi * n_tasks + task] = gm;
-        }
-    }
-}
-
-template <int NCH>
-static hipError_t launch_coop(const ScanArgs& a, uint32_t q0, uint32_t nq, hipStream_t st) {
-    using G = CoopGeom<NCH>;
-    ScanParams p;
-    p.rows = a.rows; p.n = a.n; p.n_pad = a.n_pad; p.dim = a.dim;
-    p.q = a.q + (size_t)q0 * a.dim;
-    p.scores = a.scores + (size_t)q0 * a.n_pad;
-    p.keep = a.keep; p.mode = a.mode; p.thr = a.threshold;
-    p.work = a.work;
-    p.tiers = a.tiers;
-    p.n_tasks = a.tiers.total();   // all 64-row tasks (plan_tiers(..., uniform64 = true))
-    p.gmax = a.gmax + (size_t)q0 * p.n_tasks;
-    p.dbg = nullptr;
-    // one workgroup per CU (the ring takes most of the LDS), each a contiguous run of tasks
-    const uint32_t slots = a.n_cu * (uint32_t)G::kBlocksPerCu;
-    uint32_t per = (p.n_tasks + slots - 1u) / slots;
-    if (per == 0u) per = 1u;
-    const uint32_t blocks = (p.n_tasks + per - 1u) / per;
-    const bool full = (a.dim == (uint32_t)NCH * 256u);
-#ifdef CQS_SCAN_FORCE_NT
-    const bool nt = CQS_SCAN_FORCE_NT;
-#else
-    const bool nt = a.nontemporal;
-#endif
-#define CQS_COOP(FULLV, NTV)                                                                                      \
-    do {                                                                                                          \
-        auto kern = scan_coop_kernel<NCH, FULLV, NTV>;                                                            \
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,         \
-                                           (int)G::kLdsBytes);                                                    \
-        if (e != hipSuccess) return e;                                                                            \
-        hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * G::kWaves), G::kLdsBytes, st, p, nq, per);                          \
-    } while (0)
-    if (full) { if (nt) CQS_COOP(true, true); else CQS_COOP(true, false); }
-    else { if (nt) CQS_COOP(false, true); else CQS_COOP(false, false); }
-#undef CQS_COOP
-    return hipGetLastError();
 }
 
 // ---- one-block exact select (fallback for heavy ties / crowded bins) --------
@@ -858,7 +632,7 @@ bool scan_dim_supported(uint32_t dim) { return dim >= 4 && dim % 4 == 0 && dim <
 TaskTiers plan_tiers(uint32_t n_pad, uint32_t n_cu, bool uniform64) {
     TaskTiers t{0u, 0u, 0u};
     const uint32_t n64 = n_pad / 64u, waves = n_cu * 4u;
-    if (uniform64) { t.nA = n64; return t; }  // matrix-core and LDS-ring kernels: 64-row groups only
+    if (uniform64) { t.nA = n64; return t; }  // matrix-core kernel: 64-row groups only
     if (n64 < 8u * n_cu) { t.nC = n_pad / 16u; return t; }
     const uint32_t nb = CQS_SCAN_TIER_B * (waves / 2u) & ~1u;
     if (n64 >= 6u * waves && n64 > nb / 2u) { t.nA = n64 - nb / 2u; t.nB = nb; }
@@ -868,13 +642,14 @@ TaskTiers plan_tiers(uint32_t n_pad, uint32_t n_cu, bool uniform64) {
 static uint32_t tier_slot_log2(const TaskTiers& t) { return t.nA ? 6u : (t.nB ? 5u : 4u); }
 
 template <int NCH, int BQ, int RI>
-static hipError_t launch_gemv(const ScanArgs& a, uint32_t q0, uint32_t work_slot, hipStream_t st) {
+static hipError_t launch_gemv(const ScanArgs& a, uint32_t q0, uint32_t nq, uint32_t work_slot, hipStream_t st) {
     constexpr int PIPE = (BQ <= 2) ? CQS_SCAN_PIPE : 0;
     ScanParams p;
     p.rows = a.rows; p.n = a.n; p.n_pad = a.n_pad; p.dim = a.dim;
     p.q = a.q + (size_t)q0 * a.dim;
     p.scores = a.scores + (size_t)q0 * a.n_pad;
     p.keep = a.keep; p.mode = a.mode; p.thr = a.threshold;
+    p.nq = nq;
     p.work = a.work + work_slot;
     p.tiers = a.tiers;
     p.n_tasks = a.tiers.total();
@@ -931,14 +706,14 @@ static hipError_t launch_gemv_groups(const ScanArgs& a, hipStream_t st) {
         uint32_t g;
         // register budget ~ 4*NCH*(BQ + RI) + BQ*RI VGPRs: wide rows take fewer queries per pass
         if constexpr (NCH <= 4) {
-            if (use_coop(a.b, a.dim)) { g = left < kCoopQueries ? left : kCoopQueries; e = launch_coop<NCH>(a, done, g, st); }
-            else if (left >= 8) { g = 8; e = launch_gemv<NCH, 8, 2>(a, done, slot, st); }
-            else if (left >= 4) { g = 4; e = launch_gemv<NCH, 4, 4>(a, done, slot, st); }
-            else if (left >= 2) { g = 2; e = launch_gemv<NCH, 2, 4>(a, done, slot, st); }
-            else { g = 1; e = launch_gemv<NCH, 1, CQS_SCAN_RI1>(a, done, slot, st); }
+            // 5..7 queries ride the 8-query pass (0.50 ms at 1M x 768; 4 + 1..3 would be two or three passes)
+            if (left >= 5) { g = left < 8u ? left : 8u; e = launch_gemv<NCH, 8, 2>(a, done, g, slot, st); }
+            else if (left >= 4) { g = 4; e = launch_gemv<NCH, 4, 4>(a, done, g, slot, st); }
+            else if (left >= 2) { g = 2; e = launch_gemv<NCH, 2, 4>(a, done, g, slot, st); }
+            else { g = 1; e = launch_gemv<NCH, 1, CQS_SCAN_RI1>(a, done, g, slot, st); }
         } else {
-            if (left >= 2) { g = 2; e = launch_gemv<NCH, 2, 2>(a, done, slot, st); }
-            else { g = 1; e = launch_gemv<NCH, 1, 2>(a, done, slot, st); }
+            if (left >= 2) { g = 2; e = launch_gemv<NCH, 2, 2>(a, done, g, slot, st); }
+            else { g = 1; e = launch_gemv<NCH, 1, 2>(a, done, g, slot, st); }
         }
         if (e != hipSuccess) return e;
         done += g;

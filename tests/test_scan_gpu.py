@@ -502,8 +502,8 @@ def test_task_layouts_across_corpus_sizes(hip, oracle, n, dim):
 @pytest.mark.parametrize("b,n,dim", [(5, 1, 768), (6, 63, 100), (7, 4097, 384), (8, 70_000, 768), (6, 3000, 1024),
                                      (8, 2500, 4), (7, 1500, 1280)])
 def test_five_to_eight_query_blocks(hip, oracle, b, n, dim):
-    """5..8 queries take the LDS-ring kernel (dim <= 1024; beyond that the register variants): ragged
-    corpus ends, partial 1-KiB chunks, the bitset filter (applied in its epilogue) and PIPELINE mode."""
+    """5..7 queries ride the 8-query pass with padded (never stored) slots (dim <= 1024; beyond that 2 + 2 +
+    ... passes): ragged corpus ends, partial 1-KiB chunks, the bitset filter and PIPELINE mode."""
     rows = synth.gaussian_unit(n, dim, seed=900 + n % 97)
     qs = synth.gaussian_unit(b, dim, seed=901 + b)
     idx = HipIndex.build_from_flat(None, rows)
