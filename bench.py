@@ -242,18 +242,29 @@ def main():
         def finish(lo, hi):
             torch.cuda.synchronize()
     else:
-        shard = ShardedSearch(hip_local_search(idx), k, all_gather=all_gather_dev)
-        qall = torch.empty((K + W, world * bq, dim), dtype=torch.float32, device=dev)
-        gathered = [None] * (K + W)
+        # One collective per step: a rank's payload = its shard's top-k keys for ALL of this step's queries
+        # followed by its OWN queries of the next step (fp32 viewed as int64), so the candidate exchange of
+        # step i also delivers the query block of step i+1.  Everything is stream-ordered; no host sync.
+        nq = world * bq
+        qw = dim // 2                                   # int64 words per query row
+        pay = nq * k + bq * qw
+        send = torch.zeros((K + W, pay), dtype=torch.int64, device=dev)
+        recv = torch.zeros((K + W, world, pay), dtype=torch.int64, device=dev)
+        qall = torch.empty((K + W + 1, nq, dim), dtype=torch.float32, device=dev)
+        counts = torch.empty((nq,), dtype=torch.int32, device=dev)
         merged = {}
+        all_gather_dev(qall[0].view(world, bq, dim), queries[0])          # prologue: the first query block
 
         def step(i):
-            all_gather_dev(qall[i].view(world, bq, dim), queries[i])               # every rank's queries
-            gathered[i] = shard.gather_candidates(qall[i], k)                     # scan + ONE all-gather
+            idx.search_device(qall[i].data_ptr(), nq, k, send[i].data_ptr(), counts.data_ptr(), stream=st)
+            if i + 1 < K + W:
+                send[i, nq * k:].view(torch.float32).view(bq, dim).copy_(queries[i + 1])
+            all_gather_dev(recv[i], send[i])
+            qall[i + 1].view(world, bq, dim).copy_(recv[i, :, nq * k:].view(torch.float32).view(world, bq, dim))
 
         def finish(lo, hi):
             torch.cuda.synchronize()
-            host = torch.stack(gathered[lo:hi]).cpu().numpy()  # [steps, world, world*bq, k]
+            host = recv[lo:hi, :, :nq * k].cpu().numpy().reshape(hi - lo, world, nq, k)
             mine = host[:, :, rank * bq:(rank + 1) * bq, :]    # host merge of this rank's own queries, all steps at once
             out = ShardedSearch.merge_host_many(mine, k)       # [steps, bq, k]
             for s in range(hi - lo):
@@ -295,7 +306,7 @@ def main():
         if not sharded_path:
             step(i)
         else:
-            shard.local_search(qall[i], k)
+            idx.search_device(qall[i].data_ptr(), nq, k, send[i].data_ptr(), counts.data_ptr(), stream=st)
     torch.cuda.synchronize()
     launches, scan_ms = idx.scan_time()
     idx.set_timing(False)

@@ -24,6 +24,7 @@
 namespace cqs {
 
 typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(1))) uint32_t gu32;
 
 // ---- ordered keys ----------------------------------------------------------
@@ -225,22 +226,28 @@ __global__ __launch_bounds__(256, OCC) void scan_gemv_kernel(const ScanParams p)
     };
     // dot the batch with the queries; lane L = RI*j + r receives row r's score of query b in sc[b]
     auto reduce_rows = [&](int j, f4 (&x)[RI][NCH], float (&sc)[BQ]) {
-        float acc[NV];
+        // packed f32 math (v_pk_fma_f32: two FMAs per instruction): every dot product keeps an (even, odd)
+        // pair of partial sums over the lane's float pairs, folded once per batch
+        f2 acc2[NV];
 #pragma unroll
-        for (int i = 0; i < NV; ++i) acc[i] = 0.f;
+        for (int i = 0; i < NV; ++i) acc2[i] = (f2)(0.f);
 #pragma unroll
         for (int r = 0; r < RI; ++r)
 #pragma unroll
-            for (int c = 0; c < NCH; ++c)
+            for (int c = 0; c < NCH; ++c) {
+                const f2 xlo = __builtin_shufflevector(x[r][c], x[r][c], 0, 1);
+                const f2 xhi = __builtin_shufflevector(x[r][c], x[r][c], 2, 3);
 #pragma unroll
                 for (int b = 0; b < BQ; ++b) {
-                    float a = acc[b * RI + r];
-                    a = __builtin_fmaf(x[r][c].x, qv[b][c].x, a);
-                    a = __builtin_fmaf(x[r][c].y, qv[b][c].y, a);
-                    a = __builtin_fmaf(x[r][c].z, qv[b][c].z, a);
-                    a = __builtin_fmaf(x[r][c].w, qv[b][c].w, a);
-                    acc[b * RI + r] = a;
+                    f2 a = acc2[b * RI + r];
+                    a = __builtin_elementwise_fma(xlo, __builtin_shufflevector(qv[b][c], qv[b][c], 0, 1), a);
+                    a = __builtin_elementwise_fma(xhi, __builtin_shufflevector(qv[b][c], qv[b][c], 2, 3), a);
+                    acc2[b * RI + r] = a;
                 }
+            }
+        float acc[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) acc[i] = acc2[i].x + acc2[i].y;
         treduce<NV>(acc, lane);
         // value (b, r) now sits in lanes [(b*RI+r)*LPV, +LPV); lane L = RI*j + r wants it
 #pragma unroll
