@@ -358,3 +358,51 @@ def test_brute_force_mt_equals_single(oracle):
     a, sa = oracle.brute_force(rows, q, 20, 0.0)
     b, sb = oracle.brute_force_mt(rows, q, 20, 0.0, 4)
     assert list(a) == list(b) and np.array_equal(sa, sb)
+
+
+# ---- tests/golden/reference_kats.json: the tabular KATs of the reference suite as data -------------------
+def _golden():
+    import json, os
+    with open(os.path.join(os.path.dirname(__file__), "golden", "reference_kats.json")) as f:
+        return json.load(f)
+
+
+def _num(x):
+    return {"nan": NAN, "inf": INF, "-inf": -INF}.get(x, x) if isinstance(x, str) else x
+
+
+def test_golden_fixture_float_functions(oracle):
+    g = _golden()
+    for c in g["full_cosine_similarity"]["cases"]:
+        got = oracle.full_cosine_similarity([_num(v) for v in c["a"]], [_num(v) for v in c["b"]])
+        if c["expect"] is None:
+            assert got is None, c
+        else:
+            assert got is not None and abs(got - c["expect"]) < c["tol"], (c, got)
+    for c in g["normalize_l2"]["cases"]:
+        got = oracle.normalize_l2(np.array([_num(v) for v in c["in"]], np.float32))
+        want = [_num(v) for v in c["expect"]]
+        assert len(got) == len(want)
+        for a, b in zip(got, want):
+            assert (math.isnan(a) and math.isnan(b)) or abs(a - b) <= c["tol"], (c, list(got))
+    L = oracle.lib()
+    for c in g["dist_dot_clamped"]["cases"]:
+        a, b = np.array(c["a"], np.float32), np.array(c["b"], np.float32)
+        d = L.cqs_oracle_dist_dot_clamped(a.ctypes.data, b.ctypes.data, len(a))
+        assert d >= 0.0 and abs(d - c["expect"]) < c["tol"], (c, d)
+
+
+def test_golden_fixture_heap_and_tables(oracle):
+    g = _golden()
+    for c in g["bounded_score_heap"]["cases"]:
+        h = oracle.BoundedScoreHeap(c["capacity"])
+        for name, score in c["push"]:
+            h.push(name, _num(score))
+        assert [x[0] for x in h.into_sorted_vec()] == c["expect_ids"], c
+    L = oracle.lib()
+    for args, want in g["dim_scaled_batch"]["cases"]:
+        assert L.cqs_oracle_dim_scaled_batch(*args) == want, args
+    for args, want in g["candidate_count_for"]["cases"]:
+        assert L.cqs_oracle_candidate_count_for(*args) == want, args
+    for args, want in g["embed_batch_size"]["cases"]:
+        assert L.cqs_oracle_embed_batch_size(*args) == want, args
