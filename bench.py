@@ -194,7 +194,10 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    # CQS_BENCH_FORCE_DIST=1 (with the torch.distributed.run env of a 1-rank launch): run the N>1 code with a
+    # real RCCL process group of size 1 - exercises the collective API calls on the one GPU a dev box has.
+    force_dist = os.environ.get("CQS_BENCH_FORCE_DIST") == "1" and "MASTER_ADDR" in os.environ
+    if world > 1 or force_dist:
         import torch.distributed as dist
         if rehearsal:
             dist.init_process_group("gloo")
@@ -231,7 +234,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    sharded_path = world > 1 or os.environ.get("CQS_BENCH_FORCE_SHARDED") == "1"   # the env knob exercises the N>1 code on 1 rank
+    sharded_path = world > 1 or force_dist or os.environ.get("CQS_BENCH_FORCE_SHARDED") == "1"   # the env knob exercises the N>1 code on 1 rank
     if not sharded_path:
         out_keys = torch.zeros((K + W, bq, k), dtype=torch.int64, device=dev)
         out_counts = torch.zeros((K + W, bq), dtype=torch.int32, device=dev)
