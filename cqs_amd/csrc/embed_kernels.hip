@@ -230,7 +230,8 @@ constexpr int kVSub = kHD * 8;              // elements per lane-group sub-tile 
 constexpr float kRescaleThr = 8.0f;  // defer the O rescale while the running max grows by < e^8 (P stays < 2981)
 typedef float f4v __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(512) void attention_kernel(const bf16_t* __restrict__ qkv,
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void attention_kernel(const bf16_t* __restrict__ qkv,
                                                         const bf16_t* __restrict__ vt,
                                                         bf16_t* __restrict__ out,
                                                         const int32_t* __restrict__ blk,
@@ -241,16 +242,20 @@ __global__ __launch_bounds__(512) void attention_kernel(const bf16_t* __restrict
     __shared__ __attribute__((aligned(16))) bf16_t smem[4 * kKSub + 4 * kVSub];
     bf16_t* sK = smem;
     bf16_t* sV = smem + 4 * kKSub;
-    constexpr int T = 512;
+    constexpr int T = 64 * WAVES;            // threads; the workgroup owns 16 * WAVES consecutive queries
+    constexpr uint32_t kParts = 8 / WAVES;   // workgroups per 128-query super-block of the blk list
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int l15 = lane & 15, lg = lane >> 4;
-    const uint32_t b = (uint32_t)blk[2 * blockIdx.x], sb = (uint32_t)blk[2 * blockIdx.x + 1];
+    const uint32_t sblk = blockIdx.x / kParts, part = blockIdx.x % kParts;
+    const uint32_t b = (uint32_t)blk[2 * sblk], sb = (uint32_t)blk[2 * sblk + 1];
     const uint32_t head = blockIdx.y;
     const uint32_t g = head / (heads / kv_heads);
     const uint32_t s0 = (uint32_t)seq_start[b], L = (uint32_t)seq_len[b], v0 = (uint32_t)vt_start[b];
     const uint32_t ld = (heads + 2u * kv_heads) * kHD;
     const uint32_t koff = (heads + g) * kHD;
-    const uint32_t q0 = sb * 128u + (uint32_t)wid * 16u;   // this wave's first query
+    const uint32_t qbase = sb * 128u + part * (16u * WAVES);  // the workgroup's first query
+    if (qbase >= L) return;                                    // (uniform: before any barrier)
+    const uint32_t q0 = qbase + (uint32_t)wid * 16u;           // this wave's first query
     const bool wave_live = q0 < L;                          // waves past the sequence only help staging
     const uint32_t qi = q0 + (uint32_t)l15;                 // this lane's query
 
@@ -269,7 +274,7 @@ __global__ __launch_bounds__(512) void attention_kernel(const bf16_t* __restrict
     const uint32_t nkb = (L + 31u) / 32u;
     uint32_t kb_lo = 0, kb_hi = nkb, wkb_lo = 0, wkb_hi = nkb;
     if (window) {
-        const uint32_t glo = sb * 128u, ghi = glo + 127u;          // workgroup's queries
+        const uint32_t glo = qbase, ghi = glo + 16u * WAVES - 1u;  // workgroup's queries
         kb_lo = (glo + 1u > window) ? (glo + 1u - window) / 32u : 0u;
         kb_hi = (ghi + window - 1u) / 32u + 1u;
         if (kb_hi > nkb) kb_hi = nkb;
@@ -278,11 +283,12 @@ __global__ __launch_bounds__(512) void attention_kernel(const bf16_t* __restrict
         wkb_hi = (qhi + window - 1u) / 32u + 1u;
     }
 
-    // K / V^T tiles go through registers one key block ahead (2 + 2 x 16 B per thread)
-    u4 rk[2], rv[2];
+    // K / V^T tiles go through registers one key block ahead (kU + kU x 16 B per thread)
+    constexpr int kU = 1024 / T;
+    u4 rk[kU], rv[kU];
     auto stage_load = [&](uint32_t kb) {
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < kU; ++u) {
             const int i = u * T + tid;
             const uint32_t kr = (uint32_t)i / (kHD / 8), c = ((uint32_t)i % (kHD / 8)) * 8u;
             uint32_t key = kb * 32u + kr;
@@ -294,7 +300,7 @@ __global__ __launch_bounds__(512) void attention_kernel(const bf16_t* __restrict
     };
     auto stage_write = [&]() {
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < kU; ++u) {
             const int i = u * T + tid;
             // K: 16-B chunk cc of key row kr = dims 8cc..8cc+7 = k-step cc/4, lane group cc%4
             const uint32_t kr = (uint32_t)i / (kHD / 8), cc = (uint32_t)i % (kHD / 8);
@@ -652,8 +658,15 @@ hipError_t launch_attention(const bf16_t* qkv, const bf16_t* vt, bf16_t* out, co
                             uint32_t heads, uint32_t kv_heads, uint32_t window, hipStream_t st) {
     if (nblk == 0) return hipSuccess;
     if (kv_heads == 0 || heads % kv_heads) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(attention_kernel, dim3(nblk, heads), dim3(512), 0, st, qkv, vt, out, blk, seq_start, seq_len,
-                       vt_start, vt_ld, heads, kv_heads, window);
+#ifndef CQS_ATT_WAVES
+#define CQS_ATT_WAVES 8
+#endif
+    // 128-query workgroups (8 waves).  64-query ones (4 waves) would make 32 x 512-token sequences x 3 heads
+    // 768 workgroups, all resident at once instead of 384 = one and a half rounds - measured 8 % SLOWER
+    // end to end: every workgroup stages the sequence's whole K / V^T, so halving it doubles that traffic.
+    constexpr int kW = CQS_ATT_WAVES;
+    hipLaunchKernelGGL(attention_kernel<kW>, dim3(nblk * (8 / kW), heads), dim3(64 * kW), 0, st, qkv, vt, out, blk,
+                       seq_start, seq_len, vt_start, vt_ld, heads, kv_heads, window);
     return hipGetLastError();
 }
 
