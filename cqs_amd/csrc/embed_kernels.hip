@@ -230,7 +230,7 @@ constexpr int kVSub = kHD * 8;              // elements per lane-group sub-tile 
 constexpr float kRescaleThr = 8.0f;  // defer the O rescale while the running max grows by < e^8 (P stays < 2981)
 typedef float f4v __attribute__((ext_vector_type(4)));
 
-template <int WAVES>
+template <int WAVES, int G>
 __global__ __launch_bounds__(64 * WAVES) void attention_kernel(const bf16_t* __restrict__ qkv,
                                                         const bf16_t* __restrict__ vt,
                                                         bf16_t* __restrict__ out,
@@ -242,20 +242,23 @@ __global__ __launch_bounds__(64 * WAVES) void attention_kernel(const bf16_t* __r
     __shared__ __attribute__((aligned(16))) bf16_t smem[4 * kKSub + 4 * kVSub];
     bf16_t* sK = smem;
     bf16_t* sV = smem + 4 * kKSub;
-    constexpr int T = 64 * WAVES;            // threads; the workgroup owns 16 * WAVES consecutive queries
-    constexpr uint32_t kParts = 8 / WAVES;   // workgroups per 128-query super-block of the blk list
+    // The workgroup owns TQ = WAVES / G tiles of 16 consecutive queries for ALL G q-heads of one kv head:
+    // wave -> (query tile wid / G, head wid % G), so one staged K / V^T tile serves G heads.
+    constexpr int T = 64 * WAVES;                   // threads
+    constexpr int TQ = WAVES / G;                   // query tiles
+    constexpr uint32_t kParts = 128 / (16 * TQ);    // workgroups per 128-query super-block of the blk list
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int l15 = lane & 15, lg = lane >> 4;
     const uint32_t sblk = blockIdx.x / kParts, part = blockIdx.x % kParts;
     const uint32_t b = (uint32_t)blk[2 * sblk], sb = (uint32_t)blk[2 * sblk + 1];
-    const uint32_t head = blockIdx.y;
-    const uint32_t g = head / (heads / kv_heads);
+    const uint32_t g = blockIdx.y;
+    const uint32_t head = g * (uint32_t)G + (uint32_t)(wid % G);
     const uint32_t s0 = (uint32_t)seq_start[b], L = (uint32_t)seq_len[b], v0 = (uint32_t)vt_start[b];
     const uint32_t ld = (heads + 2u * kv_heads) * kHD;
     const uint32_t koff = (heads + g) * kHD;
-    const uint32_t qbase = sb * 128u + part * (16u * WAVES);  // the workgroup's first query
+    const uint32_t qbase = sb * 128u + part * (16u * TQ);      // the workgroup's first query
     if (qbase >= L) return;                                    // (uniform: before any barrier)
-    const uint32_t q0 = qbase + (uint32_t)wid * 16u;           // this wave's first query
+    const uint32_t q0 = qbase + (uint32_t)(wid / G) * 16u;     // this wave's first query
     const bool wave_live = q0 < L;                          // waves past the sequence only help staging
     const uint32_t qi = q0 + (uint32_t)l15;                 // this lane's query
 
@@ -274,7 +277,7 @@ __global__ __launch_bounds__(64 * WAVES) void attention_kernel(const bf16_t* __r
     const uint32_t nkb = (L + 31u) / 32u;
     uint32_t kb_lo = 0, kb_hi = nkb, wkb_lo = 0, wkb_hi = nkb;
     if (window) {
-        const uint32_t glo = qbase, ghi = glo + 16u * WAVES - 1u;  // workgroup's queries
+        const uint32_t glo = qbase, ghi = glo + 16u * TQ - 1u;     // workgroup's queries
         kb_lo = (glo + 1u > window) ? (glo + 1u - window) / 32u : 0u;
         kb_hi = (ghi + window - 1u) / 32u + 1u;
         if (kb_hi > nkb) kb_hi = nkb;
@@ -284,12 +287,13 @@ __global__ __launch_bounds__(64 * WAVES) void attention_kernel(const bf16_t* __r
     }
 
     // K / V^T tiles go through registers one key block ahead (kU + kU x 16 B per thread)
-    constexpr int kU = 1024 / T;
+    constexpr int kU = (1024 + T - 1) / T;
     u4 rk[kU], rv[kU];
     auto stage_load = [&](uint32_t kb) {
 #pragma unroll
         for (int u = 0; u < kU; ++u) {
             const int i = u * T + tid;
+            if (1024 % T != 0 && i >= 1024) break;
             const uint32_t kr = (uint32_t)i / (kHD / 8), c = ((uint32_t)i % (kHD / 8)) * 8u;
             uint32_t key = kb * 32u + kr;
             key = key < L ? key : L - 1u;   // rows past the sequence: any finite row, masked later
@@ -302,6 +306,7 @@ __global__ __launch_bounds__(64 * WAVES) void attention_kernel(const bf16_t* __r
 #pragma unroll
         for (int u = 0; u < kU; ++u) {
             const int i = u * T + tid;
+            if (1024 % T != 0 && i >= 1024) break;
             // K: 16-B chunk cc of key row kr = dims 8cc..8cc+7 = k-step cc/4, lane group cc%4
             const uint32_t kr = (uint32_t)i / (kHD / 8), cc = (uint32_t)i % (kHD / 8);
             *(u4*)(sK + (cc & 3u) * kKSub + kr * kKRow + (cc >> 2) * 8u) = rk[u];
@@ -658,15 +663,25 @@ hipError_t launch_attention(const bf16_t* qkv, const bf16_t* vt, bf16_t* out, co
                             uint32_t heads, uint32_t kv_heads, uint32_t window, hipStream_t st) {
     if (nblk == 0) return hipSuccess;
     if (kv_heads == 0 || heads % kv_heads) return hipErrorInvalidValue;
-#ifndef CQS_ATT_WAVES
-#define CQS_ATT_WAVES 8
+#ifndef CQS_ATT_TQ
+#define CQS_ATT_TQ 4
 #endif
-    // 128-query workgroups (8 waves).  64-query ones (4 waves) would make 32 x 512-token sequences x 3 heads
-    // 768 workgroups, all resident at once instead of 384 = one and a half rounds - measured 8 % SLOWER
-    // end to end: every workgroup stages the sequence's whole K / V^T, so halving it doubles that traffic.
-    constexpr int kW = CQS_ATT_WAVES;
-    hipLaunchKernelGGL(attention_kernel<kW>, dim3(nblk * (8 / kW), heads), dim3(64 * kW), 0, st, qkv, vt, out, blk,
-                       seq_start, seq_len, vt_start, vt_ld, heads, kv_heads, window);
+    // One workgroup = CQS_ATT_TQ tiles of 16 queries x all q-heads of a kv head (EmbeddingGemma: 4 x 3 = 12
+    // waves, 64 queries): the staged K / V^T tiles serve 192 query-heads instead of 128 (8 waves x 1 head),
+    // and 32 x 512-token sequences make 256 workgroups = one per CU in one round instead of 384.
+    // (4 q-heads per kv head: 2 tiles, or the 16 waves would be held to 128 VGPRs and spill)
+#define CQS_ATT(GV, TQV)                                                                                           \
+    hipLaunchKernelGGL((attention_kernel<TQV * GV, GV>), dim3(nblk * (128 / (16 * TQV)), kv_heads),               \
+                       dim3(64 * TQV * GV), 0, st, qkv, vt, out, blk, seq_start, seq_len, vt_start, vt_ld, heads,   \
+                       kv_heads, window)
+    switch (heads / kv_heads) {
+        case 1: CQS_ATT(1, 8); break;
+        case 2: CQS_ATT(2, 4); break;
+        case 3: CQS_ATT(3, CQS_ATT_TQ); break;
+        case 4: CQS_ATT(4, 2); break;
+        default: return hipErrorInvalidValue;
+    }
+#undef CQS_ATT
     return hipGetLastError();
 }
 
