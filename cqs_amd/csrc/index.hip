@@ -44,7 +44,7 @@ struct cqs_hip_index {
     uint32_t* d_work = nullptr;   // scan work-queue heads
     unsigned long long* d_dbg = nullptr;  // CQS_HIP_DEBUG_STAMPS=1: select_finish phase stamps
     uint32_t n_cu = 256;
-    float* d_gmax = nullptr;      // [q_cap, n_pad/64] group maxima
+    float* d_gmax = nullptr;      // [q_cap, <= n_pad/16] per-task maxima (stride = tiers.total())
     uint64_t* d_out_keys = nullptr;
     uint32_t* d_out_counts = nullptr;
     uint32_t* d_keep = nullptr;

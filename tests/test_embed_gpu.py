@@ -190,3 +190,21 @@ def test_gqa_two_kv_heads(hip):
     for i in range(3):
         assert cos(got[i], ref[i]) > 0.999, (i, cos(got[i], ref[i]))
     eng.close()
+
+
+@pytest.mark.parametrize("layout,heads,kv", [("shared", 3, 1), ("per-head", 3, 1), ("shared", 4, 2), ("shared", 4, 1)])
+def test_attention_workgroup_layouts(hip, layout, heads, kv, monkeypatch):
+    """The attention kernel has two workgroup layouts (all q-heads of a kv head share one staged K / V^T tile
+    when the batch is large enough to fill the chip; one q-head per workgroup otherwise).  Both against the
+    fp32 oracle on the real head geometry (3 q-heads, 1 kv head) and the 2:1 / 4:1 sharing variants,
+    sliding + full layers, ragged lengths."""
+    monkeypatch.setenv("CQS_HIP_ATT_LAYOUT", layout)
+    cfg = G.GemmaConfig(vocab_size=512, hidden=256, layers=3, heads=heads, kv_heads=kv, head_dim=256, intermediate=256,
+                        dense_hidden=256, sliding_window=64, sliding_pattern=3, max_seq=512)
+    eng, w = make(cfg, seed=41)
+    ids, mask = batch(cfg, [300, 65, 64, 1, 129, 200], seed=42)
+    got = eng.run(ids, mask)
+    ref = G.forward(cfg, w, ids, mask)
+    for i in range(len(ids)):
+        assert cos(got[i], ref[i]) > 0.999, (layout, heads, kv, i, cos(got[i], ref[i]))
+    eng.close()
