@@ -439,7 +439,10 @@ __global__ __launch_bounds__(64 * WAVES) void attention_kernel(const bf16_t* __r
 // Measured alternatives at M=16384 (tools/gemm_bench.py), all 620-730 TF like this one: register-staged
 // operands (ds_write_b128), a 256x128 tile with 4 waves of 128x64 and a 3-slot DMA ring (1 wave/SIMD: the
 // ~100-cycle DMA issue cannot overlap the wave's own MFMAs: 1.5x slower), the same tile with 8 waves and
-// staggered DMA issue (equal).  The remaining gap to the matrix-core peak is per-K-step latency exposure
+// staggered DMA issue (equal), BK = 32 with three workgroups per CU (620-670 TF: twice the barriers cost more than
+// the third wave per SIMD gives back).  PMC on this kernel: waves issue 35 % of their cycles, are issue-stalled 41 %
+// (mostly behind the other wave's MFMA) and parked at a waitcnt / barrier 24 %; the MFMA pipe is busy 36 %.
+// The remaining gap to the matrix-core peak is per-K-step latency exposure
 // (barrier + first fragment reads); closing it needs the phase-interleaved 256x256 schedule.
 // LDS tile [128 rows][64 k] bf16, 16-B chunk c of row r stored at chunk c ^ ((r >> 1) & 7): the 16
 // rows one ds_read_b128 lane group touches then hit 16 distinct 16-B slots of the 256-B bank row.
