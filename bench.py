@@ -245,27 +245,42 @@ def main():
         def finish(lo, hi):
             torch.cuda.synchronize()
     else:
-        # One collective per step: a rank's payload = its shard's top-k keys for ALL of this step's queries
-        # followed by its OWN queries of the next step (fp32 viewed as int64), so the candidate exchange of
-        # step i also delivers the query block of step i+1.  Everything is stream-ordered; no host sync.
+        # One collective per step, off the critical path: a rank's payload = its shard's top-k keys for ALL of
+        # this step's queries followed by its OWN queries of step i+2 (fp32 viewed as int64).  The exchange of
+        # step i therefore delivers the query block of step i+2, and - issued asynchronously on RCCL's stream -
+        # runs under the scan of step i+1, which only needs the exchange of step i-1.  No host sync.
         nq = world * bq
         qw = dim // 2                                   # int64 words per query row
         pay = nq * k + bq * qw
         send = torch.zeros((K + W, pay), dtype=torch.int64, device=dev)
         recv = torch.zeros((K + W, world, pay), dtype=torch.int64, device=dev)
-        qall = torch.empty((K + W + 1, nq, dim), dtype=torch.float32, device=dev)
+        qall = torch.empty((K + W + 2, nq, dim), dtype=torch.float32, device=dev)
         counts = torch.empty((nq,), dtype=torch.int32, device=dev)
+        works = [None] * (K + W)
         merged = {}
-        all_gather_dev(qall[0].view(world, bq, dim), queries[0])          # prologue: the first query block
+        for j0 in range(min(2, K + W)):                                    # prologue: the first two query blocks
+            all_gather_dev(qall[j0].view(world, bq, dim), queries[j0])
+
+        def exchange(i):
+            if dist is None or rehearsal:
+                all_gather_dev(recv[i], send[i])
+                return None
+            return dist.all_gather_into_tensor(recv[i].view(-1), send[i].view(-1), async_op=True)
 
         def step(i):
+            if i >= 2:
+                if works[i - 2] is not None:
+                    works[i - 2].wait()                 # the compute stream waits; the host does not
+                qall[i].view(world, bq, dim).copy_(recv[i - 2, :, nq * k:].view(torch.float32).view(world, bq, dim))
             idx.search_device(qall[i].data_ptr(), nq, k, send[i].data_ptr(), counts.data_ptr(), stream=st)
-            if i + 1 < K + W:
-                send[i, nq * k:].view(torch.float32).view(bq, dim).copy_(queries[i + 1])
-            all_gather_dev(recv[i], send[i])
-            qall[i + 1].view(world, bq, dim).copy_(recv[i, :, nq * k:].view(torch.float32).view(world, bq, dim))
+            if i + 2 < K + W:
+                send[i, nq * k:].view(torch.float32).view(bq, dim).copy_(queries[i + 2])
+            works[i] = exchange(i)
 
         def finish(lo, hi):
+            for wk in works[lo:hi]:
+                if wk is not None:
+                    wk.wait()
             torch.cuda.synchronize()
             host = recv[lo:hi, :, :nq * k].cpu().numpy().reshape(hi - lo, world, nq, k)
             mine = host[:, :, rank * bq:(rank + 1) * bq, :]    # host merge of this rank's own queries, all steps at once
