@@ -568,21 +568,31 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
         }
 }
 
-// ---- masked mean pool: block = (sequence, 256 hidden dims); 4 waves split the tokens ----
-__global__ __launch_bounds__(256) void mean_pool_kernel(const float* __restrict__ hidden,
-                                                        const int32_t* __restrict__ seq_start,
-                                                        const int32_t* __restrict__ seq_len,
-                                                        bf16_t* __restrict__ pooled, uint32_t H) {
-    __shared__ f4 part[4][64];
-    const uint32_t b = blockIdx.x, col = blockIdx.y * 256u + (threadIdx.x & 63u) * 4u;
+// ---- masked mean pool: block = (sequence, 256 hidden dims); 16 waves split the tokens, 4 loads in flight each ----
+// (96 workgroups for 32 sequences x 768 dims: the parallelism has to come from inside the workgroup)
+__global__ __launch_bounds__(1024) void mean_pool_kernel(const float* __restrict__ hidden,
+                                                         const int32_t* __restrict__ seq_start,
+                                                         const int32_t* __restrict__ seq_len,
+                                                         bf16_t* __restrict__ pooled, uint32_t H) {
+    __shared__ f4 part[16][64];
+    const uint32_t b = blockIdx.x, lane = threadIdx.x & 63u, col = blockIdx.y * 256u + lane * 4u;
     const uint32_t s0 = (uint32_t)seq_start[b], L = (uint32_t)seq_len[b];
     const uint32_t w = threadIdx.x >> 6;
+    const float* base = hidden + (size_t)s0 * H + col;
     f4 acc = (f4)(0.f);
-    for (uint32_t t = w; t < L; t += 4u) acc += *(const f4*)(hidden + (size_t)(s0 + t) * H + col);
-    part[w][threadIdx.x & 63u] = acc;
+    uint32_t t = w;
+    for (; t + 48u < L; t += 64u) {   // 4 independent loads per trip
+        const f4 a0 = *(const f4*)(base + (size_t)t * H), a1 = *(const f4*)(base + (size_t)(t + 16u) * H);
+        const f4 a2 = *(const f4*)(base + (size_t)(t + 32u) * H), a3 = *(const f4*)(base + (size_t)(t + 48u) * H);
+        acc += (a0 + a1) + (a2 + a3);
+    }
+    for (; t < L; t += 16u) acc += *(const f4*)(base + (size_t)t * H);
+    part[w][lane] = acc;
     __syncthreads();
     if (w == 0) {
-        const f4 sum = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+        f4 sum = part[0][lane];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) sum += part[i][lane];
         const float inv = L ? 1.0f / (float)L : 0.f;   // zero mask -> zero vector (src/embedder/pooling.rs:113-119)
         bf4 o;
 #pragma unroll
@@ -709,7 +719,7 @@ hipError_t launch_attention(const bf16_t* qkv, const bf16_t* vt, bf16_t* out, co
 hipError_t launch_mean_pool(const float* hidden, const int32_t* seq_start, const int32_t* seq_len, bf16_t* pooled,
                             uint32_t B, uint32_t H, hipStream_t st) {
     if (B == 0) return hipSuccess;
-    hipLaunchKernelGGL(mean_pool_kernel, dim3(B, H / 256u), dim3(256), 0, st, hidden, seq_start, seq_len, pooled, H);
+    hipLaunchKernelGGL(mean_pool_kernel, dim3(B, H / 256u), dim3(1024), 0, st, hidden, seq_start, seq_len, pooled, H);
     return hipGetLastError();
 }
 
