@@ -224,3 +224,25 @@ def test_full_depth_full_geometry(hip):
     print("cosines", cs)
     assert min(cs) > 0.999, cs
     eng.close()
+
+
+@pytest.mark.parametrize("tile", ["wide", "small"])
+def test_gemm_tile_kernels(hip, tile, monkeypatch):
+    """The forward has two GEMM kernels (128 x 128 tiles; 256 x 192 tiles for N = 768 when the batch fills whole
+    rounds of CUs).  Small test batches never pick the wide one by themselves: force each and compare with the
+    fp32 oracle at hidden = 768 (ragged M: the last 256-row tile is partly empty)."""
+    monkeypatch.setenv("CQS_HIP_GEMM_TILE", tile)
+    cfg = G.GemmaConfig(vocab_size=1024, hidden=768, layers=4, heads=3, kv_heads=1, head_dim=256, intermediate=1152,
+                        dense_hidden=768, sliding_window=128, sliding_pattern=2, max_seq=512)
+    eng, w = make(cfg, seed=61)
+    ids, mask = batch(cfg, [257, 300, 31, 200], seed=62)
+    got = eng.run(ids, mask)
+    ref = G.forward(cfg, w, ids, mask)
+    for i in range(len(ids)):
+        assert cos(got[i], ref[i]) > 0.999, (tile, i, cos(got[i], ref[i]))
+    hid = eng.run_hidden(ids, mask)
+    href = G.forward(cfg, w, ids, mask, return_hidden=True)
+    live = mask.astype(bool)
+    err = np.abs(hid[live] - href[live])
+    assert err.mean() / np.abs(href[live]).mean() < 0.02
+    eng.close()
