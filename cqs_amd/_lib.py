@@ -25,6 +25,7 @@ METRIC_DOT = 1
 MODE_RAW = 0
 MODE_PIPELINE = 1
 MAX_K = 1024
+NEIGHBORS_MAX = 100
 
 _c_idx = C.c_void_p
 _pp = C.POINTER
@@ -56,6 +57,7 @@ SIGNATURES = [
     ("cqs_hip_index_search_device", C.c_int32,
      [_c_idx, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_float,
       C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("cqs_hip_index_neighbors", C.c_int32, [_c_idx, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, _pp(C.c_uint32)]),
     ("cqs_hip_unpack_keys", None, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     ("cqs_hip_merge_keys", C.c_size_t,
      [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p]),

@@ -18,6 +18,8 @@
 #include <string>
 #include <vector>
 
+#include <sys/stat.h>
+
 #include "../../include/cqs_hip.h"
 #include "embed_kernels.h"
 
@@ -123,15 +125,22 @@ int32_t upload_f32(cqs_hip_embedder* e, float* dst, const float* src, size_t cou
     return CQS_HIP_OK;
 }
 
+void free_scratch(cqs_hip_embedder* e) {
+    void** all[] = {(void**)&e->x, (void**)&e->y, (void**)&e->hidden, (void**)&e->out, (void**)&e->xn, (void**)&e->qkv,
+                    (void**)&e->vt, (void**)&e->attn, (void**)&e->h, (void**)&e->pooled, (void**)&e->d1, (void**)&e->d_tok,
+                    (void**)&e->d_pos, (void**)&e->d_seq_start, (void**)&e->d_seq_len, (void**)&e->d_vt_start,
+                    (void**)&e->d_blk};
+    for (void** p : all) { (void)hipFree(*p); *p = nullptr; }
+    e->tok_cap = e->seq_cap = e->vt_ld = e->blk_cap = 0;
+}
+
 int32_t ensure_scratch(cqs_hip_embedder* e, uint32_t M, uint32_t B, uint32_t vt_cols, uint32_t nblk) {
     const cqs::EmbedGeom& g = e->g;
     if (M <= e->tok_cap && B <= e->seq_cap && vt_cols <= e->vt_ld && nblk <= e->blk_cap) return CQS_HIP_OK;
     E_TRY(e, hipStreamSynchronize(e->stream));
-    void* all[] = {e->x, e->y, e->hidden, e->out, e->xn, e->qkv, e->vt, e->attn, e->h, e->pooled, e->d1, e->d_tok,
-                   e->d_pos, e->d_seq_start, e->d_seq_len, e->d_vt_start, e->d_blk};
-    for (void* p : all) (void)hipFree(p);
     const uint32_t Mc = std::max(M, e->tok_cap), Bc = std::max(B, e->seq_cap);
     const uint32_t vc = std::max(vt_cols, e->vt_ld), bc = std::max(nblk, e->blk_cap);
+    free_scratch(e);   // pointers nulled, capacities zeroed: a failed hipMalloc below leaves a consistent (empty) scratch
     const size_t H = g.hidden;
     E_TRY(e, dmalloc(&e->x, (size_t)Mc * H));
     E_TRY(e, dmalloc(&e->y, (size_t)Mc * H));
@@ -336,6 +345,8 @@ int32_t load_safetensors(cqs_hip_embedder* e, const std::string& path, const std
     if (fread(&js[0], 1, hl, f) != hl) { fclose(f); return efail(e, CQS_HIP_ERR_INVALID, "load_dir: truncated header in " + path); }
     std::map<std::string, StEntry> ents;
     if (!parse_safetensors_header(js, ents)) { fclose(f); return efail(e, CQS_HIP_ERR_INVALID, "load_dir: cannot parse header of " + path); }
+    struct stat fst;
+    const uint64_t file_size = fstat(fileno(f), &fst) == 0 ? (uint64_t)fst.st_size : 0;
     std::vector<uint8_t> raw;
     std::vector<float> vals;
     for (auto& kv : ents) {
@@ -343,9 +354,13 @@ int32_t load_safetensors(cqs_hip_embedder* e, const std::string& path, const std
         if (name.empty()) continue;
         const StEntry& en = kv.second;
         uint64_t count = 1;
-        for (uint64_t d : en.shape) count *= d;
+        bool sane = en.lo <= en.hi && en.hi <= file_size - std::min<uint64_t>(file_size, 8 + hl);   // offsets inside the file
+        for (uint64_t d : en.shape) {
+            if (d != 0 && count > (1ull << 40) / d) { sane = false; break; }   // untrusted dims: no overflow, no absurd resize
+            count *= d;
+        }
         const uint64_t esz = en.dtype == "F32" ? 4 : ((en.dtype == "BF16" || en.dtype == "F16") ? 2 : 0);
-        if (!esz || en.hi - en.lo != count * esz) { fclose(f); return efail(e, CQS_HIP_ERR_INVALID, "load_dir: unsupported dtype/shape for " + kv.first); }
+        if (!sane || !esz || en.hi - en.lo != count * esz) { fclose(f); return efail(e, CQS_HIP_ERR_INVALID, "load_dir: unsupported dtype/shape for " + kv.first); }
         raw.resize(count * esz);
         if (fseek(f, (long)(8 + hl + en.lo), SEEK_SET) != 0 || fread(raw.data(), 1, raw.size(), f) != raw.size()) {
             fclose(f);

@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <cerrno>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -17,6 +18,11 @@
 #include <new>
 #include <string>
 #include <vector>
+
+#include <fcntl.h>
+#include <libgen.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include "../../include/cqs_hip.h"
 #include "scan_kernels.h"
@@ -53,6 +59,12 @@ struct cqs_hip_index {
     float* h_q = nullptr;
     uint64_t* h_out_keys = nullptr;
     uint32_t* h_out_counts = nullptr;
+
+    // Searches share one scratch (d_scores, d_gmax, d_work, d_q): the handle orders them across streams.
+    // Every enqueue records `done` on its stream; an enqueue on a DIFFERENT stream first waits on it.
+    hipEvent_t done = nullptr;
+    hipStream_t done_stream = nullptr;
+    bool done_valid = false;
 
     bool timing = false;
     std::vector<hipEvent_t> ev;  // pairs: [2i] before, [2i+1] after the scan launches
@@ -139,6 +151,8 @@ uint32_t max_query_block(const cqs_hip_index* x) {
 // Enqueue scan + select for queries already on the device.  Caller holds mu.
 int32_t enqueue_search(cqs_hip_index* x, const float* d_q, uint32_t b, uint32_t k, const uint32_t* d_keep,
                        uint32_t mode, float thr, uint64_t* d_out_keys, uint32_t* d_out_counts, hipStream_t st) {
+    // the previous search may still be running on another stream and owns the same scratch
+    if (x->done_valid && x->done_stream != st) HIP_TRY(x, hipStreamWaitEvent(st, x->done, 0));
     if (cqs::use_mfma(b, x->dim)) {
         // the matrix-core path reads whole query tiles: stage the block in d_q with a zero tail
         const size_t qbytes = (size_t)b * x->dim * sizeof(float);
@@ -180,7 +194,17 @@ int32_t enqueue_search(cqs_hip_index* x, const float* d_q, uint32_t b, uint32_t 
         x->ev_used += 2;
     }
     HIP_TRY(x, cqs::launch_select(a, (uint32_t)x->row_base, d_out_keys, d_out_counts, st));
+    HIP_TRY(x, hipEventRecord(x->done, st));
+    x->done_stream = st;
+    x->done_valid = true;
     return CQS_HIP_OK;
+}
+
+// Wait (host) for the last enqueued search, whatever stream it ran on.  Caller holds mu.
+hipError_t quiesce(cqs_hip_index* x) {
+    hipError_t e = x->stream ? hipStreamSynchronize(x->stream) : hipSuccess;
+    if (e == hipSuccess && x->done_valid) e = hipEventSynchronize(x->done);
+    return e;
 }
 
 int32_t create_common(uint64_t n, uint32_t dim, uint32_t metric, int32_t device, uint64_t row_base,
@@ -195,7 +219,9 @@ int32_t create_common(uint64_t n, uint32_t dim, uint32_t metric, int32_t device,
     cqs_hip_index* x = new (std::nothrow) cqs_hip_index();
     if (!x) return CQS_HIP_ERR_NOMEM;
     x->device = device; x->n = n; x->dim = dim; x->metric = metric; x->row_base = row_base;
-    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&x->stream, hipStreamNonBlocking) != hipSuccess) {
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&x->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&x->done, hipEventDisableTiming) != hipSuccess) {
+        if (x->stream) hipStreamDestroy(x->stream);
         delete x;
         return CQS_HIP_ERR_DEVICE;
     }
@@ -285,7 +311,7 @@ int32_t cqs_hip_index_extend(cqs_hip_index* x, const float* rows, uint64_t n_new
     if (!rows) return fail(x, CQS_HIP_ERR_INVALID, "extend: null rows");
     if (x->n + n_new + x->row_base > 0xFFFFFFFEull) return fail(x, CQS_HIP_ERR_INVALID, "extend: row id overflow");
     HIP_TRY(x, hipSetDevice(x->device));
-    HIP_TRY(x, hipStreamSynchronize(x->stream));
+    HIP_TRY(x, quiesce(x));   // a search enqueued on a caller stream may still read d_rows
     const size_t row_bytes = (size_t)x->dim * sizeof(float);
     if (x->n + n_new > x->cap_rows) {  // grow geometrically, copy device-to-device
         uint64_t cap = x->cap_rows * 2;
@@ -318,83 +344,193 @@ struct FlatHeader {
 static_assert(sizeof(FlatHeader) == 64, "header is 64 bytes");
 const char kFlatMagic[8] = {'C', 'Q', 'S', 'H', 'I', 'P', 'F', '1'};
 
-uint64_t content_checksum(const void* data, size_t bytes) {  // 64-bit multiply-rotate hash over 8-byte words
-    const uint64_t P1 = 0x9E3779B185EBCA87ull, P2 = 0xC2B2AE3D27D4EB4Full;
-    uint64_t h = 0x27D4EB2F165667C5ull ^ (uint64_t)bytes;
-    const uint8_t* p = (const uint8_t*)data;
-    size_t i = 0;
-    for (; i + 8 <= bytes; i += 8) {
-        uint64_t w;
-        memcpy(&w, p + i, 8);
-        h ^= w * P1;
-        h = ((h << 31) | (h >> 33)) * P2;
+// 64-bit multiply-rotate hash over the 8-byte words of the content, computable in pieces: every piece
+// but the last must be a multiple of 8 bytes (the streaming save / load use 64 MiB pieces).
+struct Checksum {
+    static constexpr uint64_t P1 = 0x9E3779B185EBCA87ull, P2 = 0xC2B2AE3D27D4EB4Full;
+    uint64_t h;
+    explicit Checksum(uint64_t total_bytes) : h(0x27D4EB2F165667C5ull ^ total_bytes) {}
+    void update(const void* data, size_t bytes, bool last) {
+        const uint8_t* p = (const uint8_t*)data;
+        size_t i = 0;
+        for (; i + 8 <= bytes; i += 8) {
+            uint64_t w;
+            memcpy(&w, p + i, 8);
+            h ^= w * P1;
+            h = ((h << 31) | (h >> 33)) * P2;
+        }
+        if (last) {
+            uint64_t tail = 0;
+            if (i < bytes) memcpy(&tail, p + i, bytes - i);
+            h ^= tail * P1;
+        }
     }
-    uint64_t tail = 0;
-    if (i < bytes) memcpy(&tail, p + i, bytes - i);
-    h ^= tail * P1;
-    h ^= h >> 29;
-    h *= P2;
-    h ^= h >> 32;
-    return h;
+    uint64_t finish() {
+        h ^= h >> 29;
+        h *= P2;
+        h ^= h >> 32;
+        return h;
+    }
+};
+
+constexpr size_t kIoPiece = 64ull << 20;   // pinned staging piece (x2: copy of piece i+1 overlaps file I/O of piece i)
+
+bool write_all(int fd, const void* data, size_t bytes) {
+    const uint8_t* p = (const uint8_t*)data;
+    while (bytes) {
+        const ssize_t w = write(fd, p, bytes);
+        if (w < 0) { if (errno == EINTR) continue; return false; }
+        p += w; bytes -= (size_t)w;
+    }
+    return true;
 }
+bool read_all(int fd, void* data, size_t bytes) {
+    uint8_t* p = (uint8_t*)data;
+    while (bytes) {
+        const ssize_t r = read(fd, p, bytes);
+        if (r < 0) { if (errno == EINTR) continue; return false; }
+        if (r == 0) return false;
+        p += r; bytes -= (size_t)r;
+    }
+    return true;
+}
+void fsync_parent(const std::string& path) {   // make a rename durable (src/cagra.rs:1526-1537)
+    std::string tmp = path;
+    const char* dir = dirname(&tmp[0]);
+    const int fd = open(dir, O_RDONLY | O_DIRECTORY);
+    if (fd >= 0) { (void)fsync(fd); close(fd); }
+}
+bool exists(const std::string& p) { struct stat st; return stat(p.c_str(), &st) == 0; }
 }  // namespace
 
+// Blob write = `save_blob_atomic_with_rollback` (src/cagra.rs:1468-1592): refuse on a stale `.bak`; stream the rows
+// HBM -> pinned pieces -> `<path>.tmp` (checksummed on the way, fsync); move a live blob to `.bak`; rename tmp ->
+// live; on failure restore `.bak`; on success drop it.  Host memory: two 64 MiB pinned pieces, whatever the corpus.
 int32_t cqs_hip_index_save(cqs_hip_index* x, const char* path, uint64_t* out_checksum) {
     if (!x || !path) return CQS_HIP_ERR_INVALID;
     std::lock_guard<std::mutex> g(x->mu);
     if (x->poisoned.load(std::memory_order_acquire)) return CQS_HIP_ERR_POISONED;  // src/cagra.rs:1103-1107
     HIP_TRY(x, hipSetDevice(x->device));
+    const std::string live(path), bak = live + ".bak", tmp = live + ".tmp";
+    if (exists(bak)) return fail(x, CQS_HIP_ERR_INVALID, "save: stale .bak from a prior failed save; manual recovery required");
     const size_t bytes = (size_t)x->n * x->dim * sizeof(float);
-    std::vector<float> host((size_t)x->n * x->dim);
-    if (bytes) HIP_TRY(x, hipMemcpy(host.data(), x->d_rows, bytes, hipMemcpyDeviceToHost));
+    uint8_t* pin[2] = {nullptr, nullptr};
+    const size_t piece = bytes < kIoPiece ? (bytes ? bytes : 8) : kIoPiece;
+    for (int i = 0; i < 2; ++i) {
+        hipError_t e = hipHostMalloc((void**)&pin[i], piece, hipHostMallocDefault);
+        if (e != hipSuccess) { if (pin[0]) hipHostFree(pin[0]); return fail(x, CQS_HIP_ERR_NOMEM, "save: pinned staging", e); }
+    }
+    auto release = [&]() { hipHostFree(pin[0]); hipHostFree(pin[1]); };
+    const int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    if (fd < 0) { release(); return fail(x, CQS_HIP_ERR_INVALID, "save: cannot create temp file"); }
     FlatHeader h{};
     memcpy(h.magic, kFlatMagic, 8);
     h.version = 1; h.dim = x->dim; h.metric = x->metric; h.rows = x->n;
-    h.checksum = content_checksum(host.data(), bytes);
-    const std::string tmp = std::string(path) + ".tmp";
-    FILE* f = fopen(tmp.c_str(), "wb");
-    if (!f) return fail(x, CQS_HIP_ERR_INVALID, "save: cannot create temp file");
-    const bool ok = fwrite(&h, sizeof h, 1, f) == 1 && (bytes == 0 || fwrite(host.data(), 1, bytes, f) == bytes) &&
-                    fflush(f) == 0;
-    fclose(f);
-    if (!ok || rename(tmp.c_str(), path) != 0) {
-        remove(tmp.c_str());
-        return fail(x, CQS_HIP_ERR_INVALID, "save: write / rename failed");
+    bool ok = write_all(fd, &h, sizeof h);   // checksum patched in below
+    Checksum ck(bytes);
+    hipError_t he = hipSuccess;
+    const uint8_t* src = (const uint8_t*)x->d_rows;
+    const size_t n_pieces = (bytes + piece - 1) / piece;
+    if (ok && n_pieces) he = hipMemcpyAsync(pin[0], src, bytes < piece ? bytes : piece, hipMemcpyDeviceToHost, x->stream);
+    for (size_t i = 0; ok && he == hipSuccess && i < n_pieces; ++i) {
+        const size_t off = i * piece, len = bytes - off < piece ? bytes - off : piece;
+        he = hipStreamSynchronize(x->stream);            // piece i is in pin[i & 1]
+        if (he != hipSuccess) break;
+        if (i + 1 < n_pieces) {
+            const size_t off2 = off + piece, len2 = bytes - off2 < piece ? bytes - off2 : piece;
+            he = hipMemcpyAsync(pin[(i + 1) & 1], src + off2, len2, hipMemcpyDeviceToHost, x->stream);
+            if (he != hipSuccess) break;
+        }
+        ck.update(pin[i & 1], len, i + 1 == n_pieces);
+        ok = write_all(fd, pin[i & 1], len);
     }
+    if (n_pieces == 0) ck.update(nullptr, 0, true);
+    if (he != hipSuccess) (void)hipStreamSynchronize(x->stream);
+    release();
+    h.checksum = ck.finish();
+    ok = ok && he == hipSuccess && lseek(fd, 0, SEEK_SET) == 0 && write_all(fd, &h, sizeof h) && fsync(fd) == 0;
+    close(fd);
+    if (!ok) {
+        unlink(tmp.c_str());
+        return he != hipSuccess ? fail(x, CQS_HIP_ERR_DEVICE, "save: device copy", he) : fail(x, CQS_HIP_ERR_INVALID, "save: write failed");
+    }
+    const bool backed_up = exists(live);
+    if (backed_up) {
+        if (rename(live.c_str(), bak.c_str()) != 0) { unlink(tmp.c_str()); return fail(x, CQS_HIP_ERR_INVALID, "save: cannot back up the live blob"); }
+        fsync_parent(live);
+    }
+    if (rename(tmp.c_str(), live.c_str()) != 0) {
+        unlink(tmp.c_str());
+        if (backed_up) {
+            if (rename(bak.c_str(), live.c_str()) != 0) return fail(x, CQS_HIP_ERR_INVALID, "save failed and rollback failed: rename .bak back by hand");
+            fsync_parent(live);
+        }
+        return fail(x, CQS_HIP_ERR_INVALID, "save: rename failed");
+    }
+    if (backed_up) unlink(bak.c_str());
+    fsync_parent(live);
     if (out_checksum) *out_checksum = h.checksum;
     return CQS_HIP_OK;
 }
 
+// `CagraIndex::load` (src/cagra.rs:1174-1330): header / size checks first, then the rows stream file -> pinned
+// pieces -> HBM while the checksum is recomputed; a mismatch discards the half-built index.
 int32_t cqs_hip_index_load(const char* path, uint32_t expected_dim, uint64_t expected_rows, int32_t device,
                            uint64_t row_base, cqs_hip_index** out) {
     if (!path || !out) return CQS_HIP_ERR_INVALID;
     *out = nullptr;
-    FILE* f = fopen(path, "rb");
-    if (!f) return CQS_HIP_ERR_INVALID;
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return CQS_HIP_ERR_INVALID;
     FlatHeader h{};
-    bool ok = fread(&h, sizeof h, 1, f) == 1 && memcmp(h.magic, kFlatMagic, 8) == 0 && h.version == 1 &&
-              h.dim == expected_dim && (expected_rows == 0 || h.rows == expected_rows) && h.metric <= CQS_HIP_METRIC_DOT;
-    std::vector<float> host;
-    if (ok) {
-        const size_t bytes = (size_t)h.rows * h.dim * sizeof(float);
-        host.resize((size_t)h.rows * h.dim);
-        ok = (bytes == 0 || fread(host.data(), 1, bytes, f) == bytes) && fgetc(f) == EOF &&
-             content_checksum(host.data(), bytes) == h.checksum;
+    struct stat st;
+    bool ok = read_all(fd, &h, sizeof h) && memcmp(h.magic, kFlatMagic, 8) == 0 && h.version == 1 &&
+              h.dim == expected_dim && (expected_rows == 0 || h.rows == expected_rows) && h.metric <= CQS_HIP_METRIC_DOT &&
+              fstat(fd, &st) == 0 && h.dim != 0 && h.rows <= (UINT64_MAX - sizeof h) / ((uint64_t)h.dim * 4u) &&
+              (uint64_t)st.st_size == sizeof h + h.rows * h.dim * 4u;
+    if (!ok) { close(fd); return CQS_HIP_ERR_INVALID; }
+    cqs_hip_index* x = nullptr;
+    int32_t rc = create_common(h.rows, h.dim, h.metric, device, row_base, out, &x);
+    if (rc != CQS_HIP_OK) { close(fd); return rc; }
+    const size_t bytes = (size_t)h.rows * h.dim * sizeof(float);
+    x->cap_rows = h.rows ? h.rows : 1;
+    const size_t piece = bytes < kIoPiece ? (bytes ? bytes : 8) : kIoPiece;
+    uint8_t* pin[2] = {nullptr, nullptr};
+    hipError_t he = hipMalloc(&x->d_rows, (size_t)x->cap_rows * h.dim * sizeof(float));
+    for (int i = 0; he == hipSuccess && i < 2; ++i) he = hipHostMalloc((void**)&pin[i], piece, hipHostMallocDefault);
+    Checksum ck(bytes);
+    const size_t n_pieces = (bytes + piece - 1) / piece;
+    for (size_t i = 0; ok && he == hipSuccess && i < n_pieces; ++i) {
+        const size_t off = i * piece, len = bytes - off < piece ? bytes - off : piece;
+        ok = read_all(fd, pin[i & 1], len);              // overlaps the H2D copy of piece i-1
+        if (!ok) break;
+        ck.update(pin[i & 1], len, i + 1 == n_pieces);
+        if (i >= 1) he = hipStreamSynchronize(x->stream);  // pin[(i+1)&1] is reused by the next read
+        if (he == hipSuccess) he = hipMemcpyAsync((uint8_t*)x->d_rows + off, pin[i & 1], len, hipMemcpyHostToDevice, x->stream);
     }
-    fclose(f);
-    if (!ok) return CQS_HIP_ERR_INVALID;
-    return cqs_hip_index_create(host.data(), h.rows, h.dim, h.metric, device, row_base, out);
+    if (n_pieces == 0) ck.update(nullptr, 0, true);
+    hipError_t hs = hipStreamSynchronize(x->stream);
+    if (he == hipSuccess) he = hs;
+    if (pin[0]) hipHostFree(pin[0]);
+    if (pin[1]) hipHostFree(pin[1]);
+    close(fd);
+    if (he != hipSuccess || !ok || ck.finish() != h.checksum) {
+        cqs_hip_index_destroy(x);
+        return he == hipErrorOutOfMemory ? CQS_HIP_ERR_NOMEM : (he != hipSuccess ? CQS_HIP_ERR_DEVICE : CQS_HIP_ERR_INVALID);
+    }
+    *out = x;
+    return CQS_HIP_OK;
 }
 
 void cqs_hip_index_destroy(cqs_hip_index* x) {
     if (!x) return;
     hipSetDevice(x->device);
-    if (x->stream) hipStreamSynchronize(x->stream);  // src/cagra.rs:289-302
+    (void)quiesce(x);  // src/cagra.rs:289-302 (incl. searches enqueued on caller streams)
     free_scratch(x);
     hipFree(x->d_keep);
     hipFree(x->d_dbg);
     if (!x->borrow) hipFree(x->d_rows);
     for (hipEvent_t e : x->ev) hipEventDestroy(e);
+    if (x->done) hipEventDestroy(x->done);
     if (x->stream) hipStreamDestroy(x->stream);
     delete x;
 }
@@ -490,6 +626,8 @@ int32_t cqs_hip_index_search(cqs_hip_index* x, const float* queries, uint32_t b,
     if (!out_rows || !out_scores) return fail(x, CQS_HIP_ERR_INVALID, "search: null output buffer");
 
     HIP_TRY(x, hipSetDevice(x->device));
+    // a device-API search on a caller stream may still use the shared scratch this call is about to overwrite
+    if (x->done_valid && x->done_stream != x->stream) HIP_TRY(x, hipStreamWaitEvent(x->stream, x->done, 0));
     // bitset: count kept rows on the host (src/cagra.rs:747-775)
     const uint32_t* d_keep = nullptr;
     uint32_t k_eff = k;
@@ -505,9 +643,8 @@ int32_t cqs_hip_index_search(cqs_hip_index* x, const float* queries, uint32_t b,
         if (included < x->n) {                                  // all-pass == unfiltered, :760-762
             if (included < k_eff) k_eff = (uint32_t)included;   // :775
             if (words > x->keep_words_cap) {
-                HIP_TRY(x, hipStreamSynchronize(x->stream));
+                HIP_TRY(x, quiesce(x));
                 hipFree(x->d_keep);
-    hipFree(x->d_dbg);
                 x->d_keep = nullptr;
                 x->keep_words_cap = 0;
                 HIP_TRY(x, hipMalloc(&x->d_keep, words * sizeof(uint32_t)));
@@ -575,6 +712,47 @@ int32_t cqs_hip_index_search(cqs_hip_index* x, const float* queries, uint32_t b,
         }
         done += nb;
     }
+    return CQS_HIP_OK;
+}
+
+// `find_neighbors` (src/cli/commands/search/neighbors.rs:86-132) for a row of this index: the query is the
+// target row where it already lies in HBM (no H2D), the scan asks for limit + 1 and the target itself is
+// dropped from the answer: top-(limit+1) of all rows minus the target = top-limit of all rows but the target
+// under the same total order (score desc, row asc; neighbors.rs:131), duplicates of the target included.
+int32_t cqs_hip_index_neighbors(cqs_hip_index* x, uint64_t target_row, uint32_t limit, uint64_t* out_rows,
+                                float* out_scores, uint32_t* out_count) {
+    if (!x || !out_count) return CQS_HIP_ERR_INVALID;
+    std::lock_guard<std::mutex> g(x->mu);
+    *out_count = 0;
+    if (x->poisoned.load(std::memory_order_acquire)) return CQS_HIP_ERR_POISONED;
+    if (!out_rows || !out_scores) return fail(x, CQS_HIP_ERR_INVALID, "neighbors: null output buffer");
+    if (target_row < x->row_base || target_row - x->row_base >= x->n)
+        return fail(x, CQS_HIP_ERR_INVALID, "neighbors: target row not in this index");   // get_chunk_with_embedding fails, :98-106
+    if (limit < 1u) limit = 1u;                      // limit.clamp(1, SIMILAR_LIMIT_MAX), neighbors.rs:95, cli/limits.rs:40
+    if (limit > CQS_HIP_NEIGHBORS_MAX) limit = CQS_HIP_NEIGHBORS_MAX;
+    if (x->n <= 1) return CQS_HIP_OK;
+    const uint32_t k = (uint64_t)limit + 1u < x->n ? limit + 1u : (uint32_t)x->n;
+    HIP_TRY(x, hipSetDevice(x->device));
+    if (x->done_valid && x->done_stream != x->stream) HIP_TRY(x, hipStreamWaitEvent(x->stream, x->done, 0));
+    int32_t rc = ensure_scratch(x, 1, k);
+    if (rc != CQS_HIP_OK) return rc;
+    const float* d_target = x->d_rows + (size_t)(target_row - x->row_base) * x->dim;
+    rc = enqueue_search(x, d_target, 1, k, nullptr, CQS_HIP_MODE_RAW, 0.f, x->d_out_keys, x->d_out_counts, x->stream);
+    if (rc != CQS_HIP_OK) return rc;
+    HIP_TRY(x, hipMemcpyAsync(x->h_out_keys, x->d_out_keys, (size_t)k * sizeof(uint64_t), hipMemcpyDeviceToHost, x->stream));
+    HIP_TRY(x, hipMemcpyAsync(x->h_out_counts, x->d_out_counts, sizeof(uint32_t), hipMemcpyDeviceToHost, x->stream));
+    HIP_TRY(x, hipStreamSynchronize(x->stream));
+    uint32_t c = x->h_out_counts[0] < k ? x->h_out_counts[0] : k, outc = 0;
+    for (uint32_t i = 0; i < c && outc < limit; ++i) {
+        uint64_t row;
+        float score;
+        cqs_hip_unpack_keys(x->h_out_keys + i, 1, &row, &score);
+        if (row == target_row) continue;             // neighbors.rs:116-118 (exclude self)
+        out_rows[outc] = row;
+        out_scores[outc] = score;
+        ++outc;
+    }
+    *out_count = outc;
     return CQS_HIP_OK;
 }
 

@@ -170,9 +170,10 @@ __global__ __launch_bounds__(256, 1) void scan_mfma_kernel(const MfmaParams p) {
             }
 #pragma unroll
             for (int a = 0; a < QW; ++a) {
-                // 32-bit element offsets from the uniform base keep one VGPR per store address
+                // 64-bit addressing (a 256-query block of a > 16.7M-row shard passes 2^32 score elements): the
+                // per-lane part is one pointer, the per-register part (dq * n_pad) is wave-uniform
                 const uint32_t q_lo = (uint32_t)((wq * QW + a) * 32 + 4 * lh);
-                const uint32_t off0 = q_lo * p.n_pad + row;
+                float* const sp = p.scores + (size_t)q_lo * p.n_pad + row;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const uint32_t dq = (uint32_t)((r & 3) + 8 * (r >> 2));
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(256, 1) void scan_mfma_kernel(const MfmaParams p) {
                         if (!(s >= p.thr)) s = -INFINITY;
                     }
                     acc[a][b][r] = s;
-                    if (q_lo + dq < p.b) p.scores[off0 + dq * p.n_pad] = s;
+                    if (q_lo + dq < p.b) sp[(size_t)dq * p.n_pad] = s;
                 }
             }
         }
@@ -199,7 +200,7 @@ __global__ __launch_bounds__(256, 1) void scan_mfma_kernel(const MfmaParams p) {
                     for (int off = 16; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
                     const uint32_t qi = (uint32_t)((wq * QW + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh);
                     if (l31 == 0 && qi < p.b)
-                        p.gmax[qi * (p.n_pad / 64u) + task * gpt + (uint32_t)(wr * (RW / 2) + g)] = m;
+                        p.gmax[(size_t)qi * (p.n_pad / 64u) + task * gpt + (uint32_t)(wr * (RW / 2) + g)] = m;
                 }
         __syncthreads();   // everyone is done with s_task / the tile before the next dequeue
         if (tid == 0) s_task = gridDim.x + atomicAdd(p.work, 1u);

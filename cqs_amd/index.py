@@ -375,6 +375,34 @@ class HipIndex(VectorIndex):
         c = int(counts[0])
         return [IndexResult(self._id(int(rows[0, i])), float(scores[0, i])) for i in range(c)]
 
+    def neighbors_rows(self, target_row: int, limit: int):
+        """`cqs_hip_index_neighbors`: (rows u64, scores f32) of the stored row's nearest neighbours, itself excluded."""
+        rows = np.zeros((_lib.NEIGHBORS_MAX,), dtype=np.uint64)
+        scores = np.zeros((_lib.NEIGHBORS_MAX,), dtype=np.float32)
+        c = C.c_uint32()
+        rc = self._lib.cqs_hip_index_neighbors(self._h, target_row, max(0, min(int(limit), 2**32 - 1)), _ptr(rows), _ptr(scores), C.byref(c))
+        if rc != _lib.OK:
+            raise HipError(rc, self.last_error())
+        return rows[:c.value], scores[:c.value]
+
+    def find_neighbors(self, target_id: str, limit: int) -> List[IndexResult]:
+        """`find_neighbors(store, target, limit)` (src/cli/commands/search/neighbors.rs:86-132) on the resident
+        corpus: ids instead of `ChunkSummary`s (hydration stays with the store, :139-146).  Raises `KeyError`
+        when the target is not indexed (the reference: "Could not load embedding for ..."), :98-106."""
+        base = int(self._lib.cqs_hip_index_row_base(self._h))
+        if self.id_map is None:
+            row = int(target_id)
+            if not (base <= row < base + len(self)):
+                raise KeyError(target_id)
+        else:
+            if not hasattr(self, "_row_of") or len(self._row_of) != len(self.id_map):
+                self._row_of = {cid: i for i, cid in enumerate(self.id_map)}
+            if target_id not in self._row_of:
+                raise KeyError(target_id)
+            row = base + self._row_of[target_id]
+        rows, scores = self.neighbors_rows(row, limit)
+        return [IndexResult(self._id(int(r)), float(s)) for r, s in zip(rows, scores)]
+
     # ---- device-resident path (bench, sharded search) ---------------------------
     def search_device(self, d_queries: int, b: int, k: int, d_out_keys: int, d_out_counts: int,
                       d_keep: int = 0, mode: int = _lib.MODE_RAW, threshold: float = 0.0, stream: int = 0) -> None:

@@ -156,6 +156,19 @@ int32_t cqs_hip_index_search_device(cqs_hip_index* idx, const float* d_queries, 
                                     const uint32_t* d_keep_bitset, uint32_t mode, float threshold,
                                     uint64_t* d_out_keys, uint32_t* d_out_counts, void* stream);
 
+/* ---- neighbours of a stored row ----------------------------------------------
+ * `find_neighbors` (src/cli/commands/search/neighbors.rs:86-132): exact kNN of a row that is already in the
+ * index, the row itself excluded (:116-118), ordered (score desc, row asc) (:131), limit clamped to
+ * [1, SIMILAR_LIMIT_MAX = 100] (:95, src/cli/limits.rs:40).  target_row is a GLOBAL row id (row_base + local).
+ * out_rows / out_scores hold at least min(limit, 100) slots; *out_count <= min(limit, 100, len - 1).
+ * target_row outside the index -> CQS_HIP_ERR_INVALID (the reference fails to load the target's embedding,
+ * :98-106).  Scores are raw dots (the reference sums f32 left to right: equal to 1e-6 on unit vectors).
+ * Rows with a non-finite score are dropped as in every search of this library; an index built through
+ * `prepare_index_data` holds none. */
+#define CQS_HIP_NEIGHBORS_MAX 100u
+int32_t cqs_hip_index_neighbors(cqs_hip_index* idx, uint64_t target_row, uint32_t limit, uint64_t* out_rows,
+                                float* out_scores, uint32_t* out_count);
+
 /* Host helpers for packed candidate keys (see above). */
 void cqs_hip_unpack_keys(const uint64_t* keys, size_t count, uint64_t* rows, float* scores);
 /* Final host-side k-way merge of per-shard candidate lists for one query

@@ -40,9 +40,20 @@ static inline float rust_clamp(float x, float lo, float hi) {
  * lanes) = fmadd(a_vec, b_vec, ab_vec) per 8 elements; a partial tail is loaded
  * zero-filled; the 8 lanes are reduced after widening to f64: lanes i and i+4
  * are added first (low/high 128-bit halves), then the 4 f64 sums pairwise.
- * Called from src/math.rs:15-16. */
-__attribute__((target_clones("arch=haswell", "default")))
-double cqs_oracle_dot_simsimd(const float* a, const float* b, size_t n) {
+ * Called from src/math.rs:15-16.
+ *
+ * Two bodies with the SAME arithmetic (one fused multiply-add per lane per 8
+ * elements, same reduction): a scalar one (fmaf) and an AVX2+FMA one
+ * (_mm256_fmadd_ps).  Results are bit-identical; the body is chosen once from
+ * the CPU's feature bits (NOT from its model: `target_clones("arch=haswell")`
+ * resolves to the vector clone on Intel Haswell parts only). */
+static double reduce8_f64(const float* acc) {
+    double s[4];
+    for (int l = 0; l < 4; ++l) s[l] = (double)acc[l] + (double)acc[l + 4];
+    double lo = s[0] + s[2], hi = s[1] + s[3];
+    return lo + hi;
+}
+static double dot_haswell_scalar(const float* a, const float* b, size_t n) {
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     size_t i = 0;
     for (; i + 8 <= n; i += 8)
@@ -54,10 +65,85 @@ double cqs_oracle_dot_simsimd(const float* a, const float* b, size_t n) {
             acc[l] = fmaf(av, bv, acc[l]);
         }
     }
-    double s[4];
-    for (int l = 0; l < 4; ++l) s[l] = (double)acc[l] + (double)acc[l + 4];
-    double lo = s[0] + s[2], hi = s[1] + s[3];
-    return lo + hi;
+    return reduce8_f64(acc);
+}
+#if defined(__x86_64__)
+#include <immintrin.h>
+__attribute__((target("avx2,fma")))
+static double dot_haswell_avx2(const float* a, const float* b, size_t n) {
+    __m256 ab = _mm256_setzero_ps();
+    size_t i = 0;
+    for (; i + 8 <= n; i += 8) ab = _mm256_fmadd_ps(_mm256_loadu_ps(a + i), _mm256_loadu_ps(b + i), ab);
+    if (i < n) {
+        float ta[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tb[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (size_t l = 0; i + l < n; ++l) { ta[l] = a[i + l]; tb[l] = b[i + l]; }
+        ab = _mm256_fmadd_ps(_mm256_loadu_ps(ta), _mm256_loadu_ps(tb), ab);
+    }
+    float acc[8];
+    _mm256_storeu_ps(acc, ab);
+    return reduce8_f64(acc);
+}
+/* simsimd_dot_f32_skylake (AVX-512F; what simsimd's run-time dispatch takes on AVX-512 hosts): one
+ * 16-lane fmadd accumulator, masked zero-filled tail, f32 tree reduction (512 -> 256 -> 128 -> hadd x2).
+ * Used only as the timed CPU baseline on such hosts (cqs_oracle_dot_simsimd_native); parity and KATs
+ * stay on the haswell order above, which is the same on every host. */
+__attribute__((target("avx512f")))
+static double dot_skylake_avx512(const float* a, const float* b, size_t n) {
+    __m512 ab = _mm512_setzero_ps();
+    size_t i = 0;
+    for (; i + 16 <= n; i += 16) ab = _mm512_fmadd_ps(_mm512_loadu_ps(a + i), _mm512_loadu_ps(b + i), ab);
+    if (i < n) {
+        const __mmask16 m = (__mmask16)((1u << (n - i)) - 1u);
+        ab = _mm512_fmadd_ps(_mm512_maskz_loadu_ps(m, a + i), _mm512_maskz_loadu_ps(m, b + i), ab);
+    }
+    __m512 x = _mm512_add_ps(ab, _mm512_shuffle_f32x4(ab, ab, _MM_SHUFFLE(0, 0, 3, 2)));
+    __m128 r = _mm512_castps512_ps128(_mm512_add_ps(x, _mm512_shuffle_f32x4(x, x, _MM_SHUFFLE(0, 0, 0, 1))));
+    r = _mm_hadd_ps(r, r);
+    return (double)_mm_cvtss_f32(_mm_hadd_ps(r, r));
+}
+#endif
+
+typedef double (*dot_fn)(const float*, const float*, size_t);
+static dot_fn g_dot_haswell = 0, g_dot_native = 0;
+static const char* g_isa_haswell = "scalar-fmaf";
+static const char* g_isa_native = "scalar-fmaf";
+static int g_force_scalar = 0;
+static void dot_resolve(void) {
+    dot_fn h = dot_haswell_scalar, nat = dot_haswell_scalar;
+    const char *ih = "scalar-fmaf", *in = "scalar-fmaf";
+#if defined(__x86_64__)
+    __builtin_cpu_init();
+    if (!g_force_scalar && __builtin_cpu_supports("avx2") && __builtin_cpu_supports("fma")) {
+        h = nat = dot_haswell_avx2;
+        ih = in = "avx2+fma";
+    }
+    if (!g_force_scalar && __builtin_cpu_supports("avx512f")) {
+        nat = dot_skylake_avx512;
+        in = "avx512f";
+    }
+#endif
+    g_isa_haswell = ih; g_isa_native = in;
+    g_dot_native = nat;
+    __atomic_store_n(&g_dot_haswell, h, __ATOMIC_RELEASE);
+}
+double cqs_oracle_dot_simsimd(const float* a, const float* b, size_t n) {
+    dot_fn f = __atomic_load_n(&g_dot_haswell, __ATOMIC_ACQUIRE);
+    if (!f) { dot_resolve(); f = g_dot_haswell; }
+    return f(a, b, n);
+}
+double cqs_oracle_dot_simsimd_native(const float* a, const float* b, size_t n) {
+    if (!__atomic_load_n(&g_dot_haswell, __ATOMIC_ACQUIRE)) dot_resolve();
+    return g_dot_native(a, b, n);
+}
+/* ISA of the body behind cqs_oracle_dot_simsimd (which = 0) / _native (which = 1) on this host. */
+const char* cqs_oracle_dot_isa(int which) {
+    if (!__atomic_load_n(&g_dot_haswell, __ATOMIC_ACQUIRE)) dot_resolve();
+    return which ? g_isa_native : g_isa_haswell;
+}
+/* Test hook: 1 = pin the scalar body (bit-identity check of the two bodies), 0 = re-detect. */
+void cqs_oracle_dot_force_scalar(int on) {
+    g_force_scalar = on;
+    dot_resolve();
 }
 
 /* src/math.rs:18-22: `.map(|(&x,&y)| (x as f64)*(y as f64)).sum::<f64>()`. */
@@ -82,6 +168,7 @@ static double dot_by_kind(const float* a, const float* b, size_t n, int kind) {
     switch (kind) {
         case 1: return cqs_oracle_dot_f64(a, b, n);
         case 2: return (double)cqs_oracle_dot_seq_f32(a, b, n);
+        case 3: return cqs_oracle_dot_simsimd_native(a, b, n);
         default: return cqs_oracle_dot_simsimd(a, b, n);
     }
 }
@@ -455,7 +542,7 @@ void cqs_oracle_last_token_pool(const float* hidden, const int64_t* mask, size_t
 
 /* ---- multi-threaded baseline --------------------------------------------- */
 typedef struct {
-    const float* rows; size_t lo, hi, dim; const float* query; size_t limit; float threshold;
+    const float* rows; size_t lo, hi, dim; const float* query; size_t limit; float threshold; int dot_kind;
     uint64_t* ids; float* scores; size_t count;
 } mt_job;
 static void* mt_worker(void* p) {
@@ -463,7 +550,7 @@ static void* mt_worker(void* p) {
     cqs_oracle_heap* h = cqs_oracle_heap_new(j->limit);
     for (size_t r = j->lo; r < j->hi; ++r) {
         float base, score;
-        if (!cosine_kind(j->query, j->dim, j->rows + r * j->dim, j->dim, 0, &base)) continue;
+        if (!cosine_kind(j->query, j->dim, j->rows + r * j->dim, j->dim, j->dot_kind, &base)) continue;
         if (!cqs_oracle_apply_scoring_default(base, j->threshold, &score)) continue;
         cqs_oracle_heap_push_u64(h, (uint64_t)r, score);
     }
@@ -472,7 +559,7 @@ static void* mt_worker(void* p) {
     return NULL;
 }
 size_t cqs_oracle_brute_force_mt(const float* rows, size_t n, size_t dim, const float* query,
-                                 size_t limit, float threshold, int threads,
+                                 size_t limit, float threshold, int threads, int dot_kind,
                                  uint64_t* ids_out, float* scores_out) {
     if (threads < 1) threads = 1;
     mt_job* jobs = (mt_job*)calloc((size_t)threads, sizeof(mt_job));
@@ -482,7 +569,7 @@ size_t cqs_oracle_brute_force_mt(const float* rows, size_t n, size_t dim, const 
         size_t lo = per * (size_t)t, hi = lo + per;
         if (lo > n) lo = n;
         if (hi > n) hi = n;
-        jobs[t] = (mt_job){rows, lo, hi, dim, query, limit, threshold,
+        jobs[t] = (mt_job){rows, lo, hi, dim, query, limit, threshold, dot_kind,
                            (uint64_t*)malloc(sizeof(uint64_t) * (limit ? limit : 1)),
                            (float*)malloc(sizeof(float) * (limit ? limit : 1)), 0};
         pthread_create(&th[t], NULL, mt_worker, &jobs[t]);

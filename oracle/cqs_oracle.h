@@ -32,8 +32,17 @@ extern "C" {
 #endif
 
 /* ---- A1: dot products ---------------------------------------------------- */
-/* simsimd-style 8-lane f32 FMA dot, f64 horizontal reduce (src/math.rs:15-16). */
+/* simsimd-style 8-lane f32 FMA dot, f64 horizontal reduce (src/math.rs:15-16): the haswell kernel's
+ * arithmetic on every host (AVX2+FMA body when the CPU has both features, else scalar fmaf;
+ * bit-identical).  This is the parity oracle's dot. */
 double cqs_oracle_dot_simsimd(const float* a, const float* b, size_t n);
+/* What simsimd's run-time dispatch would run on THIS host: the AVX-512 (skylake) kernel where
+ * available, else the haswell one.  Timing baseline only (dot_kind 3). */
+double cqs_oracle_dot_simsimd_native(const float* a, const float* b, size_t n);
+/* "scalar-fmaf" / "avx2+fma" / "avx512f": the body behind _simsimd (which=0) / _native (which=1). */
+const char* cqs_oracle_dot_isa(int which);
+/* Test hook: pin the scalar bodies (1) / re-detect (0). */
+void cqs_oracle_dot_force_scalar(int on);
 /* f64-accumulate fallback (src/math.rs:18-22). */
 double cqs_oracle_dot_f64(const float* a, const float* b, size_t n);
 /* strict left-to-right f32 multiply-then-add (neighbors.rs:82, hnsw/mod.rs:291). */
@@ -74,7 +83,8 @@ size_t cqs_oracle_heap_into_sorted(cqs_oracle_heap*, uint64_t* ids_out, float* s
 /* ---- A5: brute-force scan (search/query.rs:348-510 minus SQLite) ----------
  * corpus rows [n*dim] in RAM, ids = row index.  Per row: cosine (A1) -> None
  * skip -> clamp/threshold (A3) -> heap push (A4); then into_sorted_vec.
- * dot_kind: 0 simsimd-style, 1 f64 fallback, 2 sequential f32. */
+ * dot_kind: 0 simsimd-style (haswell order), 1 f64 fallback, 2 sequential f32,
+ *           3 simsimd as dispatched on this host (timing baseline). */
 size_t cqs_oracle_brute_force(const float* rows, size_t n, size_t dim, const float* query, size_t qdim,
                               size_t limit, float threshold, int dot_kind,
                               uint64_t* ids_out, float* scores_out);
@@ -119,7 +129,7 @@ void cqs_oracle_last_token_pool(const float* hidden, const int64_t* mask, size_t
  * a final merge by the same comparator (the reference itself is single-
  * threaded per query, search/query.rs:362).  Uses pthreads. */
 size_t cqs_oracle_brute_force_mt(const float* rows, size_t n, size_t dim, const float* query,
-                                 size_t limit, float threshold, int threads,
+                                 size_t limit, float threshold, int threads, int dot_kind,
                                  uint64_t* ids_out, float* scores_out);
 
 #ifdef __cplusplus

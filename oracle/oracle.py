@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcqs_oracle.so")
 _lib = None
 
-DOT_SIMSIMD, DOT_F64, DOT_SEQ = 0, 1, 2
+DOT_SIMSIMD, DOT_F64, DOT_SEQ, DOT_NATIVE = 0, 1, 2, 3
 
 
 def build() -> None:
@@ -32,6 +32,9 @@ def lib() -> C.CDLL:
         vp, sz, f, d, i = C.c_void_p, C.c_size_t, C.c_float, C.c_double, C.c_int
         sig = {
             "cqs_oracle_dot_simsimd": (d, [vp, vp, sz]),
+            "cqs_oracle_dot_simsimd_native": (d, [vp, vp, sz]),
+            "cqs_oracle_dot_isa": (C.c_char_p, [i]),
+            "cqs_oracle_dot_force_scalar": (None, [i]),
             "cqs_oracle_dot_f64": (d, [vp, vp, sz]),
             "cqs_oracle_dot_seq_f32": (f, [vp, vp, sz]),
             "cqs_oracle_cosine_similarity": (i, [vp, sz, vp, sz, vp]),
@@ -58,7 +61,7 @@ def lib() -> C.CDLL:
             "cqs_oracle_mean_pool": (None, [vp, vp, sz, sz, sz, vp]),
             "cqs_oracle_cls_pool": (None, [vp, sz, sz, sz, vp]),
             "cqs_oracle_last_token_pool": (None, [vp, vp, sz, sz, sz, vp]),
-            "cqs_oracle_brute_force_mt": (sz, [vp, sz, sz, vp, sz, f, i, vp, vp]),
+            "cqs_oracle_brute_force_mt": (sz, [vp, sz, sz, vp, sz, f, i, i, vp, vp]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(L, name)
@@ -82,6 +85,8 @@ def dot(a, b, kind=DOT_SIMSIMD) -> float:
         return L.cqs_oracle_dot_f64(_p(a), _p(b), a.size)
     if kind == DOT_SEQ:
         return L.cqs_oracle_dot_seq_f32(_p(a), _p(b), a.size)
+    if kind == DOT_NATIVE:
+        return L.cqs_oracle_dot_simsimd_native(_p(a), _p(b), a.size)
     return L.cqs_oracle_dot_simsimd(_p(a), _p(b), a.size)
 
 
@@ -158,13 +163,22 @@ def brute_force(rows, query, limit, threshold=0.0, kind=DOT_SIMSIMD):
     return ids[:c], sc[:c]
 
 
-def brute_force_mt(rows, query, limit, threshold, threads):
+def brute_force_mt(rows, query, limit, threshold, threads, kind=DOT_SIMSIMD):
     rows, query = _f32(rows), _f32(query)
     n, dim = rows.shape
     ids = np.zeros((max(limit, 1),), dtype=np.uint64)
     sc = np.zeros((max(limit, 1),), dtype=np.float32)
-    c = lib().cqs_oracle_brute_force_mt(_p(rows), n, dim, _p(query), limit, threshold, threads, _p(ids), _p(sc))
+    c = lib().cqs_oracle_brute_force_mt(_p(rows), n, dim, _p(query), limit, threshold, threads, kind, _p(ids), _p(sc))
     return ids[:c], sc[:c]
+
+
+def dot_isa(native: bool = False) -> str:
+    """ISA of the dot body in use on this host ("scalar-fmaf" / "avx2+fma" / "avx512f")."""
+    return lib().cqs_oracle_dot_isa(1 if native else 0).decode()
+
+
+def dot_force_scalar(on: bool) -> None:
+    lib().cqs_oracle_dot_force_scalar(1 if on else 0)
 
 
 def find_neighbors(rows, target_row, limit):

@@ -86,6 +86,41 @@ def test_dot_kinds_agree(oracle):
     assert abs(oracle.dot(a, b, 0) - float(np.dot(a.astype(np.float64), b.astype(np.float64)))) < 1e-5
 
 
+def test_dot_body_is_chosen_by_cpu_features_and_bit_identical(oracle):
+    """The timed CPU baseline runs the vector body wherever the CPU has AVX2 + FMA (feature bits, not the
+    CPU model: round 1's `target_clones("arch=haswell")` fell to one `fmaf` call per element everywhere but
+    on Intel Haswell), and both bodies give bit-identical dots, so the KATs do not depend on the host."""
+    flags = set()
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("flags"):
+                    flags = set(line.split(":", 1)[1].split())
+                    break
+    except OSError:
+        pass
+    isa = oracle.dot_isa()
+    if {"avx2", "fma"} <= flags:
+        assert isa == "avx2+fma", isa
+        assert oracle.dot_isa(native=True) == ("avx512f" if "avx512f" in flags else "avx2+fma")
+    else:
+        assert isa == "scalar-fmaf"
+    rng = np.random.default_rng(11)
+    try:
+        for n in (1, 7, 8, 9, 15, 16, 17, 31, 100, 768, 769, 2048):
+            a = rng.standard_normal(n).astype(np.float32)
+            b = rng.standard_normal(n).astype(np.float32)
+            oracle.dot_force_scalar(False)
+            v_vec, v_nat = oracle.dot(a, b, 0), oracle.dot(a, b, 3)
+            oracle.dot_force_scalar(True)
+            assert oracle.dot_isa() == "scalar-fmaf"
+            assert oracle.dot(a, b, 0) == v_vec, n              # bit-identical
+            ref = float(np.dot(a.astype(np.float64), b.astype(np.float64)))
+            assert abs(v_nat - ref) <= 2e-6 * max(1.0, float(np.sum(np.abs(a * b)))), n
+    finally:
+        oracle.dot_force_scalar(False)
+
+
 # ---- src/embedder/core.rs normalize_l2 KATs ---------------------------------------
 def test_normalize_l2_kats(oracle):
     v = oracle.normalize_l2([3.0, 4.0])  # core.rs:1484-1494

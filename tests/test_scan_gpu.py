@@ -518,3 +518,267 @@ def test_five_to_eight_query_blocks(hip, oracle, b, n, dim):
     check(oracle, idx, rows, qs, k, keep=bits)
     check(oracle, idx, rows, qs, k, mode=1, thr=0.02)
     idx.close()
+
+
+# ---- round 2: regimes bench.py times but nothing verified -------------------------
+def _bits(keep):
+    bits = np.zeros((len(keep) + 31) // 32, dtype=np.uint32)
+    on = np.nonzero(keep)[0]
+    np.bitwise_or.at(bits, on // 32, np.uint32(1) << (on % 32).astype(np.uint32))
+    return bits
+
+
+@pytest.mark.parametrize("b", [20, 64, 128, 256])
+def test_mfma_work_queue_regime(hip, oracle, b):
+    """scan_mfma_kernel continues from its work queue once a launch has more row tiles than workgroups
+    (n_pad / RT > CUs: 80 000 rows = 313 tiles of 256 rows for the 32/64-query configs, 625 tiles of 128 rows for the
+    128/256-query ones, on 256 CUs): dequeue, the s_task broadcast and tiles 2..3 of a workgroup.  Every query
+    of the block against the oracle, with the best rows planted in the FIRST and the LAST tiles."""
+    n = 80_000
+    rows = synth.gaussian_unit(n, seed=2000 + b)
+    qs = synth.gaussian_unit(b, seed=2001 + b)
+    for j, r in enumerate((0, 255, 256, 40_000, n - 257, n - 129, n - 1)):     # first / queue-fed / last tiles
+        v = qs[j % b] + 0.03 * (j + 1) * rows[r]
+        rows[r] = v / np.linalg.norm(v)
+    idx = HipIndex.build_from_flat(None, rows)
+    check(oracle, idx, rows, qs, 20)
+    idx.close()
+
+
+def test_mfma_work_queue_filter_pipeline_and_second_slot(hip, oracle):
+    """Queue regime with (a) a keep-bitset that empties whole tiles, (b) PIPELINE mode, (c) b = 300 = two
+    launches (256 + 44 queries: the second launch uses its own work-queue slot and another tile config)."""
+    n = 80_000
+    rows = synth.gaussian_unit(n, seed=2100)
+    qs = synth.gaussian_unit(300, seed=2101)
+    idx = HipIndex.build_from_flat(None, rows)
+    rng = np.random.default_rng(21)
+    keep = rng.random(n) < 0.4
+    keep[1000:9000] = False                   # several consecutive tiles fully filtered
+    keep[-300:] = True
+    check(oracle, idx, rows, qs[:40], 20, keep=_bits(keep))
+    check(oracle, idx, rows, qs[:130], 30, mode=_lib.MODE_PIPELINE, thr=0.05)
+    # b = 300: check a spread of queries from both launches (incl. the block edges 255 / 256 / 299)
+    got_rows, got_scores, counts = idx.search_batch(qs, 20)
+    for i in (0, 1, 127, 128, 254, 255, 256, 257, 280, 298, 299):
+        ext_ids, ext_scores = oracle.index_search(rows, qs[i], 20 + MARGIN)
+        assert_topk_parity(got_rows[i, :counts[i]], got_scores[i, :counts[i]], ext_ids, ext_scores, 20)
+    idx.close()
+
+
+def _property_check(torch, rows, q, r, s, k, planted=None):
+    """Size-independent properties of one query's top-k (rows / q on the device; r, s host arrays)."""
+    assert len(r) == k
+    assert np.all(np.diff(s) <= 0), "not sorted by score"
+    for i in range(k - 1):
+        assert s[i] > s[i + 1] or r[i] < r[i + 1], "exact ties not ordered by row"
+    if planted is not None:
+        assert list(r[:len(planted)]) == list(planted), (list(r[:len(planted)]), planted)
+    direct = (rows[torch.from_numpy(r.astype(np.int64)).to(rows.device)].double() @ q.double()).cpu().numpy()
+    assert np.max(np.abs(direct - s)) <= 1e-5, float(np.max(np.abs(direct - s)))
+
+
+def test_full_size_properties_1m_x_256_queries(hip):
+    """BASELINE configs[2] at full size (1M x 768, 256-query block = 7 813 row tiles through the matrix-core
+    kernel's work queue): for every query sortedness + direct fp64 dot of the returned rows <= 1e-5; planted rows
+    first for a spread of queries; exhaustive threshold count (nothing outside the list beats the k-th score by
+    more than 2e-6) for all 256 queries; and the block equals 256 single-query searches (other kernel, same ids)."""
+    import torch
+    n, dim, k, b = 1_000_000, 768, 20, 256
+    g = torch.Generator(device="cuda"); g.manual_seed(4321)
+    rows = torch.empty((n, dim), device="cuda", dtype=torch.float32)
+    for lo in range(0, n, 1 << 18):
+        hi = min(n, lo + (1 << 18))
+        x = torch.randn((hi - lo, dim), generator=g, device="cuda"); x /= x.norm(dim=1, keepdim=True); rows[lo:hi] = x
+    qs = torch.randn((b, dim), generator=g, device="cuda"); qs /= qs.norm(dim=1, keepdim=True)
+    planted = {}
+    for qi, slots in ((0, [0, 999_999, 500_000]), (100, [127, 128, 999_872]), (255, [999_999, 0, 12_345])):
+        for j, r in enumerate(slots):
+            noise = torch.randn((dim,), generator=g, device="cuda")
+            noise -= (noise @ qs[qi]) * qs[qi]; noise /= noise.norm()
+            c = 0.95 - 0.05 * j - 0.001 * qi / 255
+            rows[r] = c * qs[qi] + (1 - c * c) ** 0.5 * noise
+        planted[qi] = slots
+    idx = HipIndex.build_from_device(None, rows.data_ptr(), n, dim, borrow=True, keepalive=rows)
+    keys = torch.zeros((b, k), dtype=torch.int64, device="cuda")
+    counts = torch.zeros((b,), dtype=torch.int32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    idx.search_device(qs.data_ptr(), b, k, keys.data_ptr(), counts.data_ptr(), stream=st)
+    torch.cuda.synchronize()
+    assert bool((counts == k).all())
+    hk = keys.cpu().numpy().view(np.uint64)
+    allsc = rows @ qs.T                                            # [n, b] f32, 1 GB
+    kth = []
+    for qi in range(b):
+        r, s = unpack_keys(hk[qi])
+        _property_check(torch, rows, qs[qi], r, s, k, planted.get(qi))
+        kth.append(float(s[-1]))
+    beat = (allsc > (torch.tensor(kth, device="cuda") + 2e-6)[None, :]).sum(dim=0).cpu().numpy()
+    assert np.all(beat <= k - 1), beat.max()
+    del allsc
+    # the same queries one at a time (HBM-streaming kernel): identical ids wherever scores are > 2e-6 apart
+    k1 = torch.zeros((1, k), dtype=torch.int64, device="cuda"); c1 = torch.zeros((1,), dtype=torch.int32, device="cuda")
+    for qi in (0, 100, 255, 17):
+        idx.search_device(qs[qi].data_ptr(), 1, k, k1.data_ptr(), c1.data_ptr(), stream=st)
+        torch.cuda.synchronize()
+        r1, s1 = unpack_keys(k1.cpu().numpy().view(np.uint64)[0])
+        rb, sb = unpack_keys(hk[qi])
+        assert np.max(np.abs(s1 - sb)) <= 2e-6
+        gaps = np.abs(np.diff(sb)) > 4e-6
+        if np.all(gaps):
+            assert list(r1) == list(rb)
+        else:
+            assert set(r1[:k - 1]) <= set(rb) | set(r1) and len(set(r1) & set(rb)) >= k - 2
+    idx.close()
+
+
+def test_full_size_properties_10m_and_8_shards(hip):
+    """BASELINE configs[4] size on ONE GPU: 10M x 768 fp32 (30.7 GB) through the persistent-grid scan, k = 20 and
+    k = 500; properties as above + the corpus cut into 8 row shards with row_base, per-shard top-k merged on the
+    host == the whole-corpus answer, key for key (what the 8-GPU all-gather + merge computes)."""
+    import torch
+    n, dim = 10_000_000, 768
+    free, _total = torch.cuda.mem_get_info()
+    if free < 40 * (1 << 30):
+        pytest.skip("needs ~36 GB of free HBM")
+    g = torch.Generator(device="cuda"); g.manual_seed(777)
+    rows = torch.empty((n, dim), device="cuda", dtype=torch.float32)
+    for lo in range(0, n, 1 << 18):
+        hi = min(n, lo + (1 << 18))
+        x = torch.randn((hi - lo, dim), generator=g, device="cuda"); x /= x.norm(dim=1, keepdim=True); rows[lo:hi] = x
+    q = torch.randn((dim,), generator=g, device="cuda"); q /= q.norm()
+    planted = [9_999_999, 0, 1_250_000, 1_249_999, 8_750_001]      # ends of the corpus and both sides of shard cuts
+    for j, r in enumerate(planted):
+        noise = torch.randn((dim,), generator=g, device="cuda")
+        noise -= (noise @ q) * q; noise /= noise.norm()
+        c = 0.9 - 0.05 * j
+        rows[r] = c * q + (1 - c * c) ** 0.5 * noise
+    idx = HipIndex.build_from_device(None, rows.data_ptr(), n, dim, borrow=True, keepalive=rows)
+    st = torch.cuda.current_stream().cuda_stream
+    allsc = rows @ q
+    whole = {}
+    for k in (20, 500):
+        keys = torch.zeros((1, k), dtype=torch.int64, device="cuda"); cnt = torch.zeros((1,), dtype=torch.int32, device="cuda")
+        idx.search_device(q.data_ptr(), 1, k, keys.data_ptr(), cnt.data_ptr(), stream=st)
+        torch.cuda.synchronize()
+        assert cnt.item() == k
+        hk = keys.cpu().numpy().view(np.uint64)[0]
+        r, s = unpack_keys(hk)
+        _property_check(torch, rows, q, r, s, k, planted)
+        assert int((allsc > float(s[-1]) + 2e-6).sum().item()) <= k - 1
+        whole[k] = hk
+    idx.close()
+    k, shards = 20, 8
+    per = n // shards
+    ks = torch.zeros((shards, k), dtype=torch.int64, device="cuda"); cs = torch.zeros((shards,), dtype=torch.int32, device="cuda")
+    parts = []
+    for sidx in range(shards):
+        lo = sidx * per
+        part = HipIndex.build_from_device(None, rows[lo:].data_ptr(), per, dim, borrow=True, row_base=lo)
+        part.search_device(q.data_ptr(), 1, k, ks[sidx].data_ptr(), cs[sidx:].data_ptr(), stream=st)
+        parts.append(part)
+    torch.cuda.synchronize()
+    merged = merge_keys(ks.cpu().numpy().view(np.uint64), cs.cpu().numpy().astype(np.uint32), k)
+    assert list(merged) == list(whole[20])
+    for p in parts:
+        p.close()
+
+
+def test_two_streams_share_one_handle(hip, oracle):
+    """include/cqs_hip.h: searches on one handle share one scratch; the handle orders searches enqueued on
+    DIFFERENT streams (event wait), so back-to-back device-API calls on two streams and a host-API call right
+    behind them all return the right answers (this used to race silently)."""
+    import torch
+    n, k = 300_000, 20
+    rows = synth.gaussian_unit(n, seed=2300)
+    qs = synth.gaussian_unit(6, seed=2301)
+    d_rows = torch.from_numpy(rows).cuda()
+    idx = HipIndex.build_from_device(None, d_rows.data_ptr(), n, 768, borrow=True, keepalive=d_rows)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    d_q = torch.from_numpy(qs).cuda()
+    keys = torch.zeros((6, k), dtype=torch.int64, device="cuda")
+    counts = torch.zeros((6,), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    for rep in range(3):
+        for i in range(6):
+            st = (s1, s2)[i & 1]
+            idx.search_device(d_q[i].data_ptr(), 1, k, keys[i].data_ptr(), counts[i:].data_ptr(), stream=st.cuda_stream)
+        hr, hs, hc = idx.search_batch(qs[0], k)        # host API on the handle's own stream, right behind
+        torch.cuda.synchronize()
+        hk = keys.cpu().numpy().view(np.uint64)
+        for i in range(6):
+            r, s = unpack_keys(hk[i])
+            ext_ids, ext_scores = oracle.index_search(rows, qs[i], k + MARGIN)
+            assert_topk_parity(r, s, ext_ids, ext_scores, k)
+        ext_ids, ext_scores = oracle.index_search(rows, qs[0], k + MARGIN)
+        assert_topk_parity(hr[0, :hc[0]], hs[0, :hc[0]], ext_ids, ext_scores, k)
+    idx.close()
+
+
+def test_debug_stamps_mode_with_filter_and_k500(hip, oracle, monkeypatch):
+    """CQS_HIP_DEBUG_STAMPS=1 (diagnostic build of the handle): a filtered search used to free the stamp buffer
+    (stray hipFree in the bitset-grow branch) and later searches wrote through the dangling pointer."""
+    monkeypatch.setenv("CQS_HIP_DEBUG_STAMPS", "1")
+    n = 20_000
+    rows = synth.gaussian_unit(n, seed=2400)
+    q = synth.gaussian_unit(1, seed=2401)[0]
+    idx = HipIndex.build_from_flat(None, rows)
+    rng = np.random.default_rng(24)
+    keep = _bits(rng.random(n) < 0.5)
+    check(oracle, idx, rows, q, 20, keep=keep)
+    check(oracle, idx, rows, q, 500)
+    check(oracle, idx, rows, q, 20, keep=keep)
+    check(oracle, idx, rows, q, 20)
+    idx.close()
+
+
+# ---- A6: find_neighbors (src/cli/commands/search/neighbors.rs:86-132) ------------------------------------
+@pytest.mark.parametrize("n,limit", [(3000, 5), (3000, 0), (3000, 1), (3000, 100), (3000, 500), (40, 100), (2, 10), (1, 10)])
+def test_find_neighbors_matches_oracle(hip, oracle, n, limit):
+    """Exact kNN of a stored row, itself excluded, limit clamped to [1, 100]; the oracle restates the reference's
+    sequential-f32 dot + full sort (ids exact outside 2e-6 near-ties, scores to 1e-5)."""
+    rows = synth.gaussian_unit(n, seed=3000 + n)
+    idx = HipIndex.build_from_flat(None, rows)
+    want = min(max(limit, 1), 100, n - 1)
+    for t in sorted({0, n // 2, n - 1}):
+        r, s = idx.neighbors_rows(t, limit)
+        assert len(r) == want and t not in set(int(x) for x in r)
+        if n > 1:
+            # extended oracle list = the same restatement with a larger limit is capped at 100, so rank against
+            # the exact index search (k + margin, target removed) and pin scores to the sequential-f32 sums
+            ext_ids, ext_scores = oracle.index_search(rows, rows[t], min(n, want + MARGIN + 1), None, 0, 0.0, 2)
+            sel = ext_ids != t
+            assert_topk_parity(r, s, ext_ids[sel], ext_scores[sel], want)
+            ref_ids, ref_scores = oracle.find_neighbors(rows, t, limit)
+            assert len(ref_ids) == want
+            assert np.max(np.abs(np.sort(ref_scores)[::-1] - s)) <= 1e-5
+    idx.close()
+
+
+def test_find_neighbors_duplicates_row_base_and_ids(hip, oracle):
+    """Duplicates of the target tie with it and order by row asc (neighbors.rs:131); a sharded index addresses
+    the target by its GLOBAL row; the trait-side mirror maps chunk ids; bad targets are errors."""
+    base = synth.gaussian_unit(300, seed=3100)
+    rows = np.concatenate([base[:10], np.tile(base[7], (150, 1)), base[10:]])      # rows 10..159 duplicate row 7
+    idx = HipIndex.build_from_flat(None, rows)
+    r, s = idx.neighbors_rows(100, 100)                                            # target inside the duplicate run
+    ref_ids, ref_scores = oracle.find_neighbors(rows, 100, 100)
+    assert list(r) == list(ref_ids) and 100 not in r
+    assert list(r[:3]) == [7, 10, 11]
+    r, s = idx.neighbors_rows(7, 3)
+    assert list(r) == [10, 11, 12]
+    idx.close()
+    rows = synth.gaussian_unit(2000, seed=3101)
+    ids = [f"src/m{i % 5}.rs:{i}:beef" for i in range(2000)]
+    idx = HipIndex.build_from_flat(ids, rows, row_base=5000)
+    res = idx.find_neighbors(ids[42], 10)
+    ref_ids, ref_scores = oracle.find_neighbors(rows, 42, 10)
+    assert [x.id for x in res] == [ids[int(i)] for i in ref_ids]
+    assert np.allclose([x.score for x in res], ref_scores, atol=1e-5)
+    with pytest.raises(KeyError):
+        idx.find_neighbors("nope", 5)
+    with pytest.raises(Exception):
+        idx.neighbors_rows(42, 5)                    # local row id on a row_base index: not in [5000, 7000)
+    r, s = idx.neighbors_rows(5042, 5)
+    assert list(r) == [5000 + int(i) for i in ref_ids[:5]]
+    idx.close()
