@@ -39,6 +39,13 @@ SIGNATURES = [
      [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int32, C.c_uint64, _pp(_c_idx)]),
     ("cqs_hip_index_create_device", C.c_int32,
      [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int32, C.c_uint64, C.c_int32, _pp(_c_idx)]),
+    ("cqs_hip_index_create_sharded", C.c_int32,
+     [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint64, _pp(_c_idx)]),
+    ("cqs_hip_index_load_sharded", C.c_int32,
+     [C.c_char_p, C.c_uint32, C.c_uint64, C.c_void_p, C.c_uint32, C.c_uint64, _pp(_c_idx)]),
+    ("cqs_hip_index_shards", C.c_uint32, [_c_idx]),
+    ("cqs_hip_index_shard_info", C.c_int32,
+     [_c_idx, C.c_uint32, _pp(C.c_int32), _pp(C.c_uint64), _pp(C.c_uint64), _pp(C.c_int32)]),
     ("cqs_hip_index_extend", C.c_int32, [_c_idx, C.c_void_p, C.c_uint64]),
     ("cqs_hip_index_destroy", None, [_c_idx]),
     ("cqs_hip_index_save", C.c_int32, [_c_idx, C.c_char_p, _pp(C.c_uint64)]),

@@ -24,65 +24,16 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
-#include "../../include/cqs_hip.h"
-#include "scan_kernels.h"
+#include "index_internal.h"
 
 using cqs::kMaxK;
 using cqs::kRowsPerBlock;
 
-struct cqs_hip_index {
-    int device = 0;
-    uint64_t n = 0;         // rows
-    uint64_t cap_rows = 0;  // allocated rows (owning index)
-    uint32_t dim = 0;
-    uint32_t metric = 0;
-    uint64_t row_base = 0;
-    bool borrow = false;
-    float* d_rows = nullptr;
-    hipStream_t stream = nullptr;
-
-    // scratch, grown on demand (never inside an enqueue-only path once warm)
-    uint32_t q_cap = 0;        // queries the scratch can hold
-    uint64_t scr_n_pad = 0;    // score-row stride the scratch was sized for
-    uint32_t k_cap = 0;
-    float* d_q = nullptr;
-    float* d_scores = nullptr;
-    uint32_t* d_work = nullptr;   // scan work-queue heads
-    unsigned long long* d_dbg = nullptr;  // CQS_HIP_DEBUG_STAMPS=1: select_finish phase stamps
-    uint32_t n_cu = 256;
-    float* d_gmax = nullptr;      // [q_cap, <= n_pad/16] per-task maxima (stride = tiers.total())
-    uint64_t* d_out_keys = nullptr;
-    uint32_t* d_out_counts = nullptr;
-    uint32_t* d_keep = nullptr;
-    uint64_t keep_words_cap = 0;
-    // pinned host staging
-    float* h_q = nullptr;
-    uint64_t* h_out_keys = nullptr;
-    uint32_t* h_out_counts = nullptr;
-
-    // Searches share one scratch (d_scores, d_gmax, d_work, d_q): the handle orders them across streams.
-    // Every enqueue records `done` on its stream; an enqueue on a DIFFERENT stream first waits on it.
-    hipEvent_t done = nullptr;
-    hipStream_t done_stream = nullptr;
-    bool done_valid = false;
-
-    bool timing = false;
-    std::vector<hipEvent_t> ev;  // pairs: [2i] before, [2i+1] after the scan launches
-    size_t ev_used = 0;          // events recorded since the last read
-
-    mutable std::mutex mu;
-    std::atomic<bool> poisoned{false};
-    std::string last_error;
-};
-
-namespace {
-
-constexpr size_t kMaxTimingEvents = 8192;
-constexpr uint64_t kNtBytes = 200ull << 20;  // corpus larger than this streams past L2/MALL
+namespace cqs_idx {
 
 uint64_t pad_rows(uint64_t n) { return (n + kRowsPerBlock - 1) / kRowsPerBlock * kRowsPerBlock; }
 
-int32_t fail(cqs_hip_index* idx, int32_t code, const char* what, hipError_t e = hipSuccess) {
+int32_t fail(cqs_hip_index* idx, int32_t code, const char* what, hipError_t e) {
     char buf[512];
     if (e != hipSuccess)
         snprintf(buf, sizeof buf, "%s: %s (%s)", what, hipGetErrorString(e), hipGetErrorName(e));
@@ -94,13 +45,6 @@ int32_t fail(cqs_hip_index* idx, int32_t code, const char* what, hipError_t e = 
     }
     return code;
 }
-
-#define HIP_TRY(idx, expr)                                                        \
-    do {                                                                          \
-        hipError_t _e = (expr);                                                   \
-        if (_e != hipSuccess)                                                     \
-            return fail((idx), _e == hipErrorOutOfMemory ? CQS_HIP_ERR_NOMEM : CQS_HIP_ERR_DEVICE, #expr, _e); \
-    } while (0)
 
 void free_scratch(cqs_hip_index* x) {
     hipFree(x->d_q); hipFree(x->d_scores); hipFree(x->d_gmax); hipFree(x->d_work);
@@ -207,6 +151,20 @@ hipError_t quiesce(cqs_hip_index* x) {
     return e;
 }
 
+// Copy a host keep-bitset (`words` u32) into the handle's device copy on its stream.  Caller holds mu.
+int32_t stage_keep(cqs_hip_index* x, const uint32_t* host_words, uint64_t words) {
+    if (words > x->keep_words_cap) {
+        HIP_TRY(x, quiesce(x));
+        hipFree(x->d_keep);
+        x->d_keep = nullptr;
+        x->keep_words_cap = 0;
+        HIP_TRY(x, hipMalloc(&x->d_keep, words * sizeof(uint32_t)));
+        x->keep_words_cap = words;
+    }
+    HIP_TRY(x, hipMemcpyAsync(x->d_keep, host_words, words * sizeof(uint32_t), hipMemcpyHostToDevice, x->stream));
+    return CQS_HIP_OK;
+}
+
 int32_t create_common(uint64_t n, uint32_t dim, uint32_t metric, int32_t device, uint64_t row_base,
                       cqs_hip_index** out, cqs_hip_index** made) {
     if (!out) return CQS_HIP_ERR_INVALID;
@@ -236,7 +194,9 @@ int32_t create_common(uint64_t n, uint32_t dim, uint32_t metric, int32_t device,
     return CQS_HIP_OK;
 }
 
-}  // namespace
+}  // namespace cqs_idx
+
+using namespace cqs_idx;
 
 extern "C" {
 
@@ -304,6 +264,7 @@ int32_t cqs_hip_index_create_device(const void* d_rows, uint64_t n, uint32_t dim
 
 int32_t cqs_hip_index_extend(cqs_hip_index* x, const float* rows, uint64_t n_new) {
     if (!x) return CQS_HIP_ERR_INVALID;
+    if (x->sh) return cqs_sharded::extend(x, rows, n_new);
     std::lock_guard<std::mutex> g(x->mu);
     if (x->poisoned.load(std::memory_order_acquire)) return CQS_HIP_ERR_POISONED;
     if (x->borrow) return fail(x, CQS_HIP_ERR_INVALID, "extend: index borrows its rows");
@@ -334,6 +295,8 @@ int32_t cqs_hip_index_extend(cqs_hip_index* x, const float* rows, uint64_t n_new
     return CQS_HIP_OK;
 }
 
+}  // extern "C"
+
 namespace {
 struct FlatHeader {
     char magic[8];
@@ -345,7 +308,7 @@ static_assert(sizeof(FlatHeader) == 64, "header is 64 bytes");
 const char kFlatMagic[8] = {'C', 'Q', 'S', 'H', 'I', 'P', 'F', '1'};
 
 // 64-bit multiply-rotate hash over the 8-byte words of the content, computable in pieces: every piece
-// but the last must be a multiple of 8 bytes (the streaming save / load use 64 MiB pieces).
+// but the last must be a multiple of 8 bytes (the streaming save / load use <= 64 MiB pieces of whole rows).
 struct Checksum {
     static constexpr uint64_t P1 = 0x9E3779B185EBCA87ull, P2 = 0xC2B2AE3D27D4EB4Full;
     uint64_t h;
@@ -401,52 +364,69 @@ void fsync_parent(const std::string& path) {   // make a rename durable (src/cag
     if (fd >= 0) { (void)fsync(fd); close(fd); }
 }
 bool exists(const std::string& p) { struct stat st; return stat(p.c_str(), &st) == 0; }
+
+// The rows of one or more device segments (row order) cut into pieces of <= 64 MiB that never straddle a segment.
+struct Piece { const cqs_idx::Segment* seg; size_t off, len; };
+std::vector<Piece> cut_pieces(const std::vector<cqs_idx::Segment>& segs, uint32_t dim) {
+    std::vector<Piece> out;
+    for (const cqs_idx::Segment& sg : segs) {
+        const size_t bytes = (size_t)sg.rows * dim * sizeof(float);
+        for (size_t off = 0; off < bytes; off += kIoPiece) out.push_back({&sg, off, bytes - off < kIoPiece ? bytes - off : kIoPiece});
+    }
+    return out;
+}
+struct PinPair {
+    uint8_t* p[2] = {nullptr, nullptr};
+    hipError_t alloc(size_t bytes) {
+        for (int i = 0; i < 2; ++i) {
+            hipError_t e = hipHostMalloc((void**)&p[i], bytes ? bytes : 8, hipHostMallocPortable);
+            if (e != hipSuccess) return e;
+        }
+        return hipSuccess;
+    }
+    ~PinPair() { if (p[0]) hipHostFree(p[0]); if (p[1]) hipHostFree(p[1]); }
+};
 }  // namespace
+
+namespace cqs_idx {
 
 // Blob write = `save_blob_atomic_with_rollback` (src/cagra.rs:1468-1592): refuse on a stale `.bak`; stream the rows
 // HBM -> pinned pieces -> `<path>.tmp` (checksummed on the way, fsync); move a live blob to `.bak`; rename tmp ->
 // live; on failure restore `.bak`; on success drop it.  Host memory: two 64 MiB pinned pieces, whatever the corpus.
-int32_t cqs_hip_index_save(cqs_hip_index* x, const char* path, uint64_t* out_checksum) {
-    if (!x || !path) return CQS_HIP_ERR_INVALID;
-    std::lock_guard<std::mutex> g(x->mu);
-    if (x->poisoned.load(std::memory_order_acquire)) return CQS_HIP_ERR_POISONED;  // src/cagra.rs:1103-1107
-    HIP_TRY(x, hipSetDevice(x->device));
+int32_t save_segments(cqs_hip_index* x, const std::vector<Segment>& segs, uint32_t dim, uint32_t metric, const char* path,
+                      uint64_t* out_checksum) {
     const std::string live(path), bak = live + ".bak", tmp = live + ".tmp";
     if (exists(bak)) return fail(x, CQS_HIP_ERR_INVALID, "save: stale .bak from a prior failed save; manual recovery required");
-    const size_t bytes = (size_t)x->n * x->dim * sizeof(float);
-    uint8_t* pin[2] = {nullptr, nullptr};
-    const size_t piece = bytes < kIoPiece ? (bytes ? bytes : 8) : kIoPiece;
-    for (int i = 0; i < 2; ++i) {
-        hipError_t e = hipHostMalloc((void**)&pin[i], piece, hipHostMallocDefault);
-        if (e != hipSuccess) { if (pin[0]) hipHostFree(pin[0]); return fail(x, CQS_HIP_ERR_NOMEM, "save: pinned staging", e); }
-    }
-    auto release = [&]() { hipHostFree(pin[0]); hipHostFree(pin[1]); };
+    uint64_t rows = 0;
+    for (const Segment& sg : segs) rows += sg.rows;
+    const size_t bytes = (size_t)rows * dim * sizeof(float);
+    const std::vector<Piece> pieces = cut_pieces(segs, dim);
+    PinPair pin;
+    hipError_t he = pin.alloc(bytes < kIoPiece ? bytes : kIoPiece);
+    if (he != hipSuccess) return fail(x, CQS_HIP_ERR_NOMEM, "save: pinned staging", he);
     const int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
-    if (fd < 0) { release(); return fail(x, CQS_HIP_ERR_INVALID, "save: cannot create temp file"); }
+    if (fd < 0) return fail(x, CQS_HIP_ERR_INVALID, "save: cannot create temp file");
     FlatHeader h{};
     memcpy(h.magic, kFlatMagic, 8);
-    h.version = 1; h.dim = x->dim; h.metric = x->metric; h.rows = x->n;
+    h.version = 1; h.dim = dim; h.metric = metric; h.rows = rows;
     bool ok = write_all(fd, &h, sizeof h);   // checksum patched in below
     Checksum ck(bytes);
-    hipError_t he = hipSuccess;
-    const uint8_t* src = (const uint8_t*)x->d_rows;
-    const size_t n_pieces = (bytes + piece - 1) / piece;
-    if (ok && n_pieces) he = hipMemcpyAsync(pin[0], src, bytes < piece ? bytes : piece, hipMemcpyDeviceToHost, x->stream);
-    for (size_t i = 0; ok && he == hipSuccess && i < n_pieces; ++i) {
-        const size_t off = i * piece, len = bytes - off < piece ? bytes - off : piece;
-        he = hipStreamSynchronize(x->stream);            // piece i is in pin[i & 1]
+    auto issue = [&](size_t i) -> hipError_t {
+        const Piece& pc = pieces[i];
+        hipError_t e = hipSetDevice(pc.seg->device);
+        if (e != hipSuccess) return e;
+        return hipMemcpyAsync(pin.p[i & 1], (const uint8_t*)pc.seg->d_rows + pc.off, pc.len, hipMemcpyDeviceToHost, pc.seg->stream);
+    };
+    if (ok && !pieces.empty()) he = issue(0);
+    for (size_t i = 0; ok && he == hipSuccess && i < pieces.size(); ++i) {
+        he = hipStreamSynchronize(pieces[i].seg->stream);            // piece i is in pin[i & 1]
         if (he != hipSuccess) break;
-        if (i + 1 < n_pieces) {
-            const size_t off2 = off + piece, len2 = bytes - off2 < piece ? bytes - off2 : piece;
-            he = hipMemcpyAsync(pin[(i + 1) & 1], src + off2, len2, hipMemcpyDeviceToHost, x->stream);
-            if (he != hipSuccess) break;
-        }
-        ck.update(pin[i & 1], len, i + 1 == n_pieces);
-        ok = write_all(fd, pin[i & 1], len);
+        if (i + 1 < pieces.size() && (he = issue(i + 1)) != hipSuccess) break;
+        ck.update(pin.p[i & 1], pieces[i].len, i + 1 == pieces.size());
+        ok = write_all(fd, pin.p[i & 1], pieces[i].len);
     }
-    if (n_pieces == 0) ck.update(nullptr, 0, true);
-    if (he != hipSuccess) (void)hipStreamSynchronize(x->stream);
-    release();
+    if (pieces.empty()) ck.update(nullptr, 0, true);
+    for (const Segment& sg : segs) (void)hipStreamSynchronize(sg.stream);
     h.checksum = ck.finish();
     ok = ok && he == hipSuccess && lseek(fd, 0, SEEK_SET) == 0 && write_all(fd, &h, sizeof h) && fsync(fd) == 0;
     close(fd);
@@ -473,56 +453,94 @@ int32_t cqs_hip_index_save(cqs_hip_index* x, const char* path, uint64_t* out_che
     return CQS_HIP_OK;
 }
 
-// `CagraIndex::load` (src/cagra.rs:1174-1330): header / size checks first, then the rows stream file -> pinned
-// pieces -> HBM while the checksum is recomputed; a mismatch discards the half-built index.
-int32_t cqs_hip_index_load(const char* path, uint32_t expected_dim, uint64_t expected_rows, int32_t device,
-                           uint64_t row_base, cqs_hip_index** out) {
-    if (!path || !out) return CQS_HIP_ERR_INVALID;
-    *out = nullptr;
+// `CagraIndex::load` (src/cagra.rs:1174-1330), part 1: header / size checks.  Leaves the file open at the rows.
+int32_t open_blob(const char* path, uint32_t expected_dim, uint64_t expected_rows, int* fd_out, uint64_t* rows,
+                  uint32_t* metric, uint64_t* checksum) {
     const int fd = open(path, O_RDONLY);
     if (fd < 0) return CQS_HIP_ERR_INVALID;
     FlatHeader h{};
     struct stat st;
-    bool ok = read_all(fd, &h, sizeof h) && memcmp(h.magic, kFlatMagic, 8) == 0 && h.version == 1 &&
-              h.dim == expected_dim && (expected_rows == 0 || h.rows == expected_rows) && h.metric <= CQS_HIP_METRIC_DOT &&
-              fstat(fd, &st) == 0 && h.dim != 0 && h.rows <= (UINT64_MAX - sizeof h) / ((uint64_t)h.dim * 4u) &&
-              (uint64_t)st.st_size == sizeof h + h.rows * h.dim * 4u;
+    const bool ok = read_all(fd, &h, sizeof h) && memcmp(h.magic, kFlatMagic, 8) == 0 && h.version == 1 &&
+                    h.dim == expected_dim && (expected_rows == 0 || h.rows == expected_rows) && h.metric <= CQS_HIP_METRIC_DOT &&
+                    fstat(fd, &st) == 0 && h.dim != 0 && h.rows <= (UINT64_MAX - sizeof h) / ((uint64_t)h.dim * 4u) &&
+                    (uint64_t)st.st_size == sizeof h + h.rows * h.dim * 4u;
     if (!ok) { close(fd); return CQS_HIP_ERR_INVALID; }
-    cqs_hip_index* x = nullptr;
-    int32_t rc = create_common(h.rows, h.dim, h.metric, device, row_base, out, &x);
-    if (rc != CQS_HIP_OK) { close(fd); return rc; }
-    const size_t bytes = (size_t)h.rows * h.dim * sizeof(float);
-    x->cap_rows = h.rows ? h.rows : 1;
-    const size_t piece = bytes < kIoPiece ? (bytes ? bytes : 8) : kIoPiece;
-    uint8_t* pin[2] = {nullptr, nullptr};
-    hipError_t he = hipMalloc(&x->d_rows, (size_t)x->cap_rows * h.dim * sizeof(float));
-    for (int i = 0; he == hipSuccess && i < 2; ++i) he = hipHostMalloc((void**)&pin[i], piece, hipHostMallocDefault);
+    *fd_out = fd; *rows = h.rows; *metric = h.metric; *checksum = h.checksum;
+    return CQS_HIP_OK;
+}
+
+// part 2: the rows stream file -> pinned pieces -> HBM (the segments' buffers are allocated by the caller) while
+// the checksum is recomputed.  Closes fd.  A mismatch returns CQS_HIP_ERR_INVALID and the caller discards the index.
+int32_t read_blob_into(int fd, uint64_t checksum, uint32_t dim, const std::vector<Segment>& segs) {
+    uint64_t rows = 0;
+    for (const Segment& sg : segs) rows += sg.rows;
+    const size_t bytes = (size_t)rows * dim * sizeof(float);
+    const std::vector<Piece> pieces = cut_pieces(segs, dim);
+    PinPair pin;
+    hipError_t he = pin.alloc(bytes < kIoPiece ? bytes : kIoPiece);
     Checksum ck(bytes);
-    const size_t n_pieces = (bytes + piece - 1) / piece;
-    for (size_t i = 0; ok && he == hipSuccess && i < n_pieces; ++i) {
-        const size_t off = i * piece, len = bytes - off < piece ? bytes - off : piece;
-        ok = read_all(fd, pin[i & 1], len);              // overlaps the H2D copy of piece i-1
+    bool ok = true;
+    for (size_t i = 0; ok && he == hipSuccess && i < pieces.size(); ++i) {
+        const Piece& pc = pieces[i];
+        if (i >= 2) he = hipStreamSynchronize(pieces[i - 2].seg->stream);   // pin[i & 1] was the source of piece i-2's copy
+        if (he != hipSuccess) break;
+        ok = read_all(fd, pin.p[i & 1], pc.len);                            // overlaps the H2D copy of piece i-1
         if (!ok) break;
-        ck.update(pin[i & 1], len, i + 1 == n_pieces);
-        if (i >= 1) he = hipStreamSynchronize(x->stream);  // pin[(i+1)&1] is reused by the next read
-        if (he == hipSuccess) he = hipMemcpyAsync((uint8_t*)x->d_rows + off, pin[i & 1], len, hipMemcpyHostToDevice, x->stream);
+        ck.update(pin.p[i & 1], pc.len, i + 1 == pieces.size());
+        he = hipSetDevice(pc.seg->device);
+        if (he == hipSuccess) he = hipMemcpyAsync((uint8_t*)pc.seg->d_rows + pc.off, pin.p[i & 1], pc.len, hipMemcpyHostToDevice, pc.seg->stream);
     }
-    if (n_pieces == 0) ck.update(nullptr, 0, true);
-    hipError_t hs = hipStreamSynchronize(x->stream);
-    if (he == hipSuccess) he = hs;
-    if (pin[0]) hipHostFree(pin[0]);
-    if (pin[1]) hipHostFree(pin[1]);
+    if (pieces.empty()) ck.update(nullptr, 0, true);
+    for (const Segment& sg : segs) {
+        const hipError_t hs = hipStreamSynchronize(sg.stream);
+        if (he == hipSuccess) he = hs;
+    }
     close(fd);
-    if (he != hipSuccess || !ok || ck.finish() != h.checksum) {
+    if (he != hipSuccess) return he == hipErrorOutOfMemory ? CQS_HIP_ERR_NOMEM : CQS_HIP_ERR_DEVICE;
+    return ok && ck.finish() == checksum ? CQS_HIP_OK : CQS_HIP_ERR_INVALID;
+}
+
+}  // namespace cqs_idx
+
+extern "C" {
+
+int32_t cqs_hip_index_save(cqs_hip_index* x, const char* path, uint64_t* out_checksum) {
+    if (!x || !path) return CQS_HIP_ERR_INVALID;
+    if (x->sh) return cqs_sharded::save(x, path, out_checksum);
+    std::lock_guard<std::mutex> g(x->mu);
+    if (x->poisoned.load(std::memory_order_acquire)) return CQS_HIP_ERR_POISONED;  // src/cagra.rs:1103-1107
+    HIP_TRY(x, hipSetDevice(x->device));
+    HIP_TRY(x, quiesce(x));
+    return save_segments(x, {Segment{x->device, x->d_rows, x->n, x->stream}}, x->dim, x->metric, path, out_checksum);
+}
+
+int32_t cqs_hip_index_load(const char* path, uint32_t expected_dim, uint64_t expected_rows, int32_t device,
+                           uint64_t row_base, cqs_hip_index** out) {
+    if (!path || !out) return CQS_HIP_ERR_INVALID;
+    *out = nullptr;
+    int fd = -1;
+    uint64_t rows = 0, checksum = 0;
+    uint32_t metric = 0;
+    int32_t rc = open_blob(path, expected_dim, expected_rows, &fd, &rows, &metric, &checksum);
+    if (rc != CQS_HIP_OK) return rc;
+    cqs_hip_index* x = nullptr;
+    rc = create_common(rows, expected_dim, metric, device, row_base, out, &x);
+    if (rc != CQS_HIP_OK) { close(fd); return rc; }
+    x->cap_rows = rows ? rows : 1;
+    if (hipMalloc(&x->d_rows, (size_t)x->cap_rows * expected_dim * sizeof(float)) != hipSuccess) {
+        close(fd);
         cqs_hip_index_destroy(x);
-        return he == hipErrorOutOfMemory ? CQS_HIP_ERR_NOMEM : (he != hipSuccess ? CQS_HIP_ERR_DEVICE : CQS_HIP_ERR_INVALID);
+        return CQS_HIP_ERR_NOMEM;
     }
+    rc = read_blob_into(fd, checksum, expected_dim, {Segment{device, x->d_rows, rows, x->stream}});
+    if (rc != CQS_HIP_OK) { cqs_hip_index_destroy(x); return rc; }
     *out = x;
     return CQS_HIP_OK;
 }
 
 void cqs_hip_index_destroy(cqs_hip_index* x) {
     if (!x) return;
+    if (x->sh) { cqs_sharded::destroy(x); return; }
     hipSetDevice(x->device);
     (void)quiesce(x);  // src/cagra.rs:289-302 (incl. searches enqueued on caller streams)
     free_scratch(x);
@@ -535,16 +553,20 @@ void cqs_hip_index_destroy(cqs_hip_index* x) {
     delete x;
 }
 
-uint64_t cqs_hip_index_len(const cqs_hip_index* x) { return x ? x->n : 0; }
+uint64_t cqs_hip_index_len(const cqs_hip_index* x) { return x ? (x->sh ? cqs_sharded::len(x) : x->n) : 0; }
 uint32_t cqs_hip_index_dim(const cqs_hip_index* x) { return x ? x->dim : 0; }
 uint32_t cqs_hip_index_metric(const cqs_hip_index* x) { return x ? x->metric : 0; }
 uint32_t cqs_hip_index_max_k(const cqs_hip_index* x) { (void)x; return kMaxK; }
-int32_t cqs_hip_index_poisoned(const cqs_hip_index* x) { return x && x->poisoned.load(std::memory_order_acquire) ? 1 : 0; }
+int32_t cqs_hip_index_poisoned(const cqs_hip_index* x) {
+    if (x && x->sh) return cqs_sharded::poisoned(x);
+    return x && x->poisoned.load(std::memory_order_acquire) ? 1 : 0;
+}
 int32_t cqs_hip_index_device(const cqs_hip_index* x) { return x ? x->device : -1; }
 uint64_t cqs_hip_index_row_base(const cqs_hip_index* x) { return x ? x->row_base : 0; }
 
 size_t cqs_hip_index_last_error(const cqs_hip_index* x, char* buf, size_t cap) {
     if (!x || !buf || cap == 0) return 0;
+    if (x->sh) return cqs_sharded::last_error(x, buf, cap);
     std::lock_guard<std::mutex> g(x->mu);
     size_t m = x->last_error.size() < cap - 1 ? x->last_error.size() : cap - 1;
     memcpy(buf, x->last_error.data(), m);
@@ -589,6 +611,7 @@ int32_t cqs_hip_index_search_device(cqs_hip_index* x, const float* d_queries, ui
                                     const uint32_t* d_keep_bitset, uint32_t mode, float threshold,
                                     uint64_t* d_out_keys, uint32_t* d_out_counts, void* stream) {
     if (!x) return CQS_HIP_ERR_INVALID;
+    if (x->sh) return CQS_HIP_ERR_INVALID;   // a row-sharded handle spans devices: host-buffer API only
     std::lock_guard<std::mutex> g(x->mu);
     if (x->poisoned.load(std::memory_order_acquire)) return CQS_HIP_ERR_POISONED;
     if (b == 0) return CQS_HIP_OK;
@@ -611,6 +634,7 @@ int32_t cqs_hip_index_search(cqs_hip_index* x, const float* queries, uint32_t b,
                              const uint32_t* keep_bitset, uint32_t mode, float threshold, uint64_t* out_rows,
                              float* out_scores, uint32_t* out_counts) {
     if (!x) return CQS_HIP_ERR_INVALID;
+    if (x->sh) return cqs_sharded::search(x, queries, b, query_dim, k, keep_bitset, mode, threshold, out_rows, out_scores, out_counts);
     std::lock_guard<std::mutex> g(x->mu);
     if (x->poisoned.load(std::memory_order_acquire)) return CQS_HIP_ERR_POISONED;  // src/cagra.rs:486-490
     if (b == 0) return CQS_HIP_OK;
@@ -642,15 +666,8 @@ int32_t cqs_hip_index_search(cqs_hip_index* x, const float* queries, uint32_t b,
         if (included == 0) return CQS_HIP_OK;                   // src/cagra.rs:765-767
         if (included < x->n) {                                  // all-pass == unfiltered, :760-762
             if (included < k_eff) k_eff = (uint32_t)included;   // :775
-            if (words > x->keep_words_cap) {
-                HIP_TRY(x, quiesce(x));
-                hipFree(x->d_keep);
-                x->d_keep = nullptr;
-                x->keep_words_cap = 0;
-                HIP_TRY(x, hipMalloc(&x->d_keep, words * sizeof(uint32_t)));
-                x->keep_words_cap = words;
-            }
-            HIP_TRY(x, hipMemcpyAsync(x->d_keep, keep_bitset, words * sizeof(uint32_t), hipMemcpyHostToDevice, x->stream));
+            int32_t rck = stage_keep(x, keep_bitset, words);
+            if (rck != CQS_HIP_OK) return rck;
             d_keep = x->d_keep;
         }
     }
@@ -722,6 +739,7 @@ int32_t cqs_hip_index_search(cqs_hip_index* x, const float* queries, uint32_t b,
 int32_t cqs_hip_index_neighbors(cqs_hip_index* x, uint64_t target_row, uint32_t limit, uint64_t* out_rows,
                                 float* out_scores, uint32_t* out_count) {
     if (!x || !out_count) return CQS_HIP_ERR_INVALID;
+    if (x->sh) return cqs_sharded::neighbors(x, target_row, limit, out_rows, out_scores, out_count);
     std::lock_guard<std::mutex> g(x->mu);
     *out_count = 0;
     if (x->poisoned.load(std::memory_order_acquire)) return CQS_HIP_ERR_POISONED;
@@ -758,6 +776,7 @@ int32_t cqs_hip_index_neighbors(cqs_hip_index* x, uint64_t target_row, uint32_t 
 
 void cqs_hip_index_set_timing(cqs_hip_index* x, int32_t enable) {
     if (!x) return;
+    if (x->sh) { cqs_sharded::set_timing(x, enable); return; }
     std::lock_guard<std::mutex> g(x->mu);
     x->timing = enable != 0;
     x->ev_used = 0;
@@ -765,6 +784,7 @@ void cqs_hip_index_set_timing(cqs_hip_index* x, int32_t enable) {
 
 int32_t cqs_hip_index_scan_time(cqs_hip_index* x, uint32_t* launches, double* total_ms) {
     if (!x || !launches || !total_ms) return CQS_HIP_ERR_INVALID;
+    if (x->sh) return cqs_sharded::scan_time(x, launches, total_ms);
     std::lock_guard<std::mutex> g(x->mu);
     *launches = 0;
     *total_ms = 0.0;

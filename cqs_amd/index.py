@@ -166,6 +166,34 @@ class HipIndex(VectorIndex):
         return cls(h.value, id_map, metric)
 
     @classmethod
+    def build_sharded(cls, id_map: Optional[List[str]], flat: np.ndarray, devices: Sequence[int],
+                      metric: DistanceMetric = DistanceMetric.Cosine, row_base: int = 0) -> "HipIndex":
+        """`cqs_hip_index_create_sharded`: ONE process, the rows cut over `devices` (rowid order); the handle
+        behaves like any other (`search`, `search_with_filter`, `find_neighbors`, `extend`, `save`)."""
+        lib = _lib.load()
+        flat = np.ascontiguousarray(flat, dtype=np.float32)
+        if flat.ndim != 2:
+            raise ValueError("flat must be [n, dim]")
+        n, dim = flat.shape
+        if id_map is not None and len(id_map) != n:
+            raise ValueError("id_map length != rows")
+        devs = np.ascontiguousarray(list(devices), dtype=np.int32)
+        h = C.c_void_p()
+        rc = lib.cqs_hip_index_create_sharded(_ptr(flat), n, dim, metric.value, _ptr(devs), len(devs), row_base, C.byref(h))
+        if rc != _lib.OK:
+            raise HipError(rc, "cqs_hip_index_create_sharded failed")
+        return cls(h.value, id_map, metric)
+
+    def shards(self):
+        """[(device, first_row, rows, gathers_with_rccl)] per shard (one entry for a single-device index)."""
+        out = []
+        for s in range(int(self._lib.cqs_hip_index_shards(self._h))):
+            dev, first, rows, rc = C.c_int32(), C.c_uint64(), C.c_uint64(), C.c_int32()
+            if self._lib.cqs_hip_index_shard_info(self._h, s, C.byref(dev), C.byref(first), C.byref(rows), C.byref(rc)) == _lib.OK:
+                out.append((dev.value, first.value, rows.value, bool(rc.value)))
+        return out
+
+    @classmethod
     def build_from_device(cls, id_map: Optional[List[str]], d_ptr: int, n: int, dim: int,
                           metric: DistanceMetric = DistanceMetric.Cosine, device: int = 0,
                           row_base: int = 0, borrow: bool = True, keepalive=None) -> "HipIndex":
@@ -227,7 +255,8 @@ class HipIndex(VectorIndex):
             raise
 
     @classmethod
-    def load(cls, path: str, dim: int, chunk_count: int, device: int = 0) -> "HipIndex":
+    def load(cls, path: str, dim: int, chunk_count: int, device: int = 0,
+             devices: Optional[Sequence[int]] = None) -> "HipIndex":
         """`CagraIndex::load`: sidecar magic / version / dim / chunk_count must match the store, the blob's
         checksum must match the sidecar; anything else raises ValueError (caller deletes + rebuilds)."""
         import json
@@ -254,7 +283,11 @@ class HipIndex(VectorIndex):
         if magic != b"CQSHIPF1" or meta.get("checksum") != f"{blob_ck:016x}":
             raise ValueError("HIP index sidecar does not match the blob (checksum)")
         h = C.c_void_p()
-        rc = lib.cqs_hip_index_load(path.encode(), dim, chunk_count, device, 0, C.byref(h))   # verifies the content
+        if devices is not None:
+            devs = np.ascontiguousarray(list(devices), dtype=np.int32)
+            rc = lib.cqs_hip_index_load_sharded(path.encode(), dim, chunk_count, _ptr(devs), len(devs), 0, C.byref(h))
+        else:
+            rc = lib.cqs_hip_index_load(path.encode(), dim, chunk_count, device, 0, C.byref(h))   # verifies the content
         if rc != _lib.OK:
             raise ValueError(f"HIP index blob rejected (rc={rc})")
         return cls(h.value, ids, DistanceMetric.parse(meta.get("metric", "cosine")))
@@ -456,6 +489,7 @@ class BackendContext:
     hip_threshold: int = 5000  # same gate as CQS_CAGRA_THRESHOLD (src/cagra.rs:1683-1690)
     device: int = 0
     persist: bool = True       # CQS_CAGRA_PERSIST analogue (src/cagra.rs:1013)
+    devices: Optional[Sequence[int]] = None   # CQS_HIP_DEVICES: shard the corpus over these GPUs (one process)
 
 
 def dim_scaled_batch(baseline: int, dim: int, lo: int, hi: int) -> int:
@@ -487,14 +521,15 @@ class HipBackend:
         free, total = C.c_uint64(), C.c_uint64()
         if lib.cqs_hip_device_mem(ctx.device, C.byref(free), C.byref(total)) != _lib.OK:
             return None
-        if n * dim * 4 * 1.25 > free.value:  # gpu_available_for (src/cagra.rs:336-376)
+        n_dev = len(ctx.devices) if ctx.devices else 1
+        if n * dim * 4 * 1.25 / n_dev > free.value:  # gpu_available_for (src/cagra.rs:336-376), per shard
             log.warning("HIP backend: corpus does not fit device memory, falling through")
             return None
         import os
         path = os.path.join(ctx.cqs_dir, "index.hipflat")
         if ctx.persist and os.path.exists(path):           # persisted first (src/cagra.rs:1726-1752)
             try:
-                idx = HipIndex.load(path, dim, n, ctx.device)
+                idx = HipIndex.load(path, dim, n, ctx.device, devices=ctx.devices)
                 log.info("Vector index backend selected backend=hip source=persisted vectors=%d", len(idx))
                 return idx
             except ValueError as e:
@@ -504,7 +539,11 @@ class HipBackend:
         for batch in ctx.store.embedding_batches(dim_scaled_batch(10_000, dim, 500, 50_000)):
             embeddings.extend(batch)
         try:
-            idx = HipIndex.build_from_embeddings(embeddings, dim, DistanceMetric.Cosine, ctx.device)
+            if ctx.devices:
+                id_map, flat, _ = prepare_index_data(embeddings, dim)
+                idx = HipIndex.build_sharded(id_map, flat, ctx.devices, DistanceMetric.Cosine)
+            else:
+                idx = HipIndex.build_from_embeddings(embeddings, dim, DistanceMetric.Cosine, ctx.device)
         except (ValueError, HipError) as e:
             log.warning("HIP backend build failed, falling through: %s", e)
             return None

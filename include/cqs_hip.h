@@ -12,7 +12,11 @@
  *
  * Threading: every entry point is safe to call concurrently on one handle
  * (the handle serialises device work behind an internal mutex, like
- * `CagraIndex.gpu: Mutex<GpuState>`, src/cagra.rs:263).  Device failures never
+ * `CagraIndex.gpu: Mutex<GpuState>`, src/cagra.rs:263).  Searches of one handle share
+ * one device scratch: `cqs_hip_index_search_device` returns with its kernels still in
+ * flight, and the handle orders the NEXT search (any entry point, any stream) behind
+ * them with an event, so calls on different streams serialise on the device instead of
+ * racing; extend / save / destroy wait for the last enqueued search first.  Device failures never
  * abort: they return a negative status, set the handle's poisoned flag
  * (src/index.rs:203-205, src/cagra.rs:472-489) and leave a message for
  * cqs_hip_index_last_error.
@@ -83,6 +87,29 @@ int32_t cqs_hip_index_create(const float* rows, uint64_t n, uint32_t dim, uint32
 int32_t cqs_hip_index_create_device(const void* d_rows, uint64_t n, uint32_t dim, uint32_t metric,
                                     int32_t device, uint64_t row_base, int32_t borrow,
                                     cqs_hip_index** out);
+/* Row-sharded index over several GPUs of ONE process (north_star): the reference's daemon is
+ * one process holding an `Arc<dyn VectorIndex>` (src/cli/batch/context.rs:157, GPU state behind one mutex
+ * src/cagra.rs:263), so the multi-GPU path sits behind the SAME handle type.  The n rows are cut in rowid order
+ * into n_devices near-equal contiguous shards (shard starts are multiples of 256 rows), shard s lives on
+ * devices[s]; every other entry point accepts the returned handle: `cqs_hip_index_search` broadcasts the query
+ * block to every device, scans the shards concurrently, moves the per-shard packed (score,row) candidates with
+ * ONE RCCL all-gather over xGMI (ncclGroupStart/End, communicators from ncclCommInitAll) and merges them on the
+ * host with cqs_hip_merge_keys - the result contract is exactly the single-device one.  RCCL is bound at run time
+ * (dlopen "librccl.so.1"); n_devices == 1 needs none.  A device may be named more than once (test hook for
+ * one-GPU boxes): such a list cannot form an RCCL clique and gathers by device-to-device copies instead.
+ * `cqs_hip_index_search_device` is not available on a sharded handle (-> CQS_HIP_ERR_INVALID); extend appends to
+ * the last shard that holds rows; save writes one blob (rows of all shards in order), which either loader reads. */
+int32_t cqs_hip_index_create_sharded(const float* rows, uint64_t n, uint32_t dim, uint32_t metric,
+                                     const int32_t* devices, uint32_t n_devices, uint64_t row_base,
+                                     cqs_hip_index** out);
+int32_t cqs_hip_index_load_sharded(const char* path, uint32_t expected_dim, uint64_t expected_rows,
+                                   const int32_t* devices, uint32_t n_devices, uint64_t row_base, cqs_hip_index** out);
+/* Number of shards (1 for a single-device handle) and, per shard: its device, first global row, row count, and
+ * whether its gathers go through RCCL (1) or device-to-device copies (0). */
+uint32_t cqs_hip_index_shards(const cqs_hip_index* idx);
+int32_t cqs_hip_index_shard_info(const cqs_hip_index* idx, uint32_t shard, int32_t* device, uint64_t* first_row,
+                                 uint64_t* rows, int32_t* gathers_with_rccl);
+
 /* Append rows (host) to an owning index — incremental add, the contract the
  * tiered backend's extend() exposes (src/tiered.rs:1-43).  Not valid on a
  * borrowing index. */

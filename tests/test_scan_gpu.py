@@ -592,7 +592,7 @@ def test_full_size_properties_1m_x_256_queries(hip):
         x = torch.randn((hi - lo, dim), generator=g, device="cuda"); x /= x.norm(dim=1, keepdim=True); rows[lo:hi] = x
     qs = torch.randn((b, dim), generator=g, device="cuda"); qs /= qs.norm(dim=1, keepdim=True)
     planted = {}
-    for qi, slots in ((0, [0, 999_999, 500_000]), (100, [127, 128, 999_872]), (255, [999_999, 0, 12_345])):
+    for qi, slots in ((0, [0, 999_999, 500_000]), (100, [127, 128, 999_872]), (255, [999_998, 1, 12_345])):
         for j, r in enumerate(slots):
             noise = torch.randn((dim,), generator=g, device="cuda")
             noise -= (noise @ qs[qi]) * qs[qi]; noise /= noise.norm()
