@@ -3,16 +3,19 @@
 
   python bench.py --gpus N --steps K --warmup W        (N=1 default; N>1 under torch.distributed.run)
 
-Workload (BASELINE.json configs[1]): synthetic 1 000 000 x 768 fp32 unit vectors per GPU,
-single-query brute-force cosine top-20.  A "step" is one pass of the hot path over one
-batch: at N=1 one query scanned against the 1M-row corpus (3.072 GB of HBM reads); at N>1
-the corpus is row-sharded (1M rows per GPU, N x 1M rows in total - weak scaling), every
-rank contributes one query per step, the N queries are all-gathered, each rank scans its
-shard ONCE for all N queries, per-shard (score,row) candidates are exchanged with one RCCL
-all-gather and merged on the host (north_star).  value = whole-job queries/s.
+N = 1 (BASELINE.json configs[1], what the metric is quoted on): synthetic 1 000 000 x 768 fp32 unit vectors
+resident in HBM, single-query brute-force cosine top-20.  A "step" = one query scanned against the corpus
+(3.072 GB of HBM reads) + the exact top-k.  value = queries/s.
 
-Inputs (corpus, queries) are resident in HBM before the timed region.  Rank 0 prints ONE
-JSON line with the driver's contract fields plus `roofline` and `cpu_baseline`.
+N > 1 (BASELINE.json configs[4], `--mode strong`, the default): ONE fixed corpus of 10 000 000 x 768 rows cut
+row-wise over the N ranks (10M / N rows per GPU), one query per step scanned by every shard, ONE RCCL all-gather
+of the per-shard k x u64 candidates, host merge (north_star).  "scaling": "strong".  `--mode weak` keeps round 1's
+variant (1M rows per GPU, N queries per step) for comparison.
+
+Inputs (corpus, queries) are resident in HBM before the timed region.  Rank 0 prints ONE JSON line with the
+driver's contract fields plus `roofline`, `cpu_baseline`, `latency_host_api`, `other_configs` (the remaining
+BASELINE / SURVEY §8d configurations, each CHECKED outside its timed region), `embed` (index-build leg, with its
+own cpu_baseline) and `e2e` (configs[3]: chunks -> embed -> index -> k-NN with R@K against the CPU oracle).
 """
 import argparse
 import json
@@ -32,16 +35,22 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=30)
-    ap.add_argument("--rows", type=int, default=1_000_000, help="corpus rows per GPU")
+    ap.add_argument("--mode", choices=["auto", "single", "strong", "weak"], default="auto",
+                    help="auto: single at N=1, strong (configs[4]) at N>1")
+    ap.add_argument("--rows", type=int, default=1_000_000, help="corpus rows per GPU (single / weak modes)")
+    ap.add_argument("--total-rows", type=int, default=10_000_000, help="whole-corpus rows (strong mode)")
     ap.add_argument("--dim", type=int, default=768)
     ap.add_argument("--k", type=int, default=20)
-    ap.add_argument("--batch", type=int, default=1, help="queries per rank per step")
+    ap.add_argument("--batch", type=int, default=1, help="queries per step (per rank in weak mode)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of each cpu_baseline leg (0 = skip)")
-    ap.add_argument("--extras", type=int, default=1, help="N=1 only: also time the other BASELINE configs (k=500, 17.5k rows, "
-                    "256-query blocks, 10M rows) into `other_configs` (0 = skip)")
+    ap.add_argument("--extras", type=int, default=1, help="N=1 only: also time + check the other BASELINE configs "
+                    "(k=500, 17.5k rows, 256-query blocks, 10M rows) into `other_configs` (0 = skip)")
     ap.add_argument("--embed-steps", type=int, default=8, help="timed embedding batches per rank (0 = skip the embed leg)")
     ap.add_argument("--embed-batch", type=int, default=32, help="sequences per embedding batch (reference: embed_batch_size() = 32)")
     ap.add_argument("--embed-len", type=int, default=512, help="tokens per sequence of the fixed-length embed leg")
+    ap.add_argument("--e2e-chunks", type=int, default=100_000, help="configs[3]: chunks embedded + indexed end to end (0 = skip)")
+    ap.add_argument("--abi-devices", type=str, default="", help="N=1 only: also run the single-process sharded index "
+                    "(cqs_hip_index_create_sharded) over this comma-separated device list, e.g. 0,1,2,3 (or 0,0 on one GPU)")
     return ap.parse_args()
 
 
@@ -58,85 +67,149 @@ def make_unit_rows(torch, n, dim, seed, device):
     return rows
 
 
+def check_topk(torch, np, rows, q, keys_u64, count, k, row_base=0, exhaustive=True, what=""):
+    """Size-independent properties of one query's answer (outside any timed region): full count, sorted by
+    (score desc, row asc), scores equal a direct fp64 dot of the returned rows to 1e-5, and - exhaustively -
+    no more than k-1 rows of the corpus beat the k-th score by more than 2e-6."""
+    from cqs_amd import unpack_keys
+    r, s = unpack_keys(np.ascontiguousarray(keys_u64))
+    assert int(count) == k and len(r) == k, f"{what}: count {count} != {k}"
+    assert np.all(np.diff(s) <= 0), f"{what}: not sorted"
+    assert all(s[i] > s[i + 1] or r[i] < r[i + 1] for i in range(k - 1)), f"{what}: ties not ordered by row"
+    local = torch.from_numpy((r.astype(np.int64) - row_base)).to(rows.device)
+    direct = (rows[local].double() @ q.double()).cpu().numpy()
+    err = float(np.max(np.abs(direct - s)))
+    assert err <= 1e-5, f"{what}: scores differ from a direct fp64 dot by {err}"
+    if exhaustive:
+        beat = int(((rows @ q) > float(s[-1]) + 2e-6).sum().item())
+        assert beat <= k - 1, f"{what}: {beat} rows beat the k-th score"
+    return r, s
+
+
 def cpu_baseline(rows_host, queries_host, k, seconds):
-    """The oracle (C restatement of the reference CPU scan, search/query.rs:453-482 minus SQLite)
-    timed on this host: single-threaded = the reference's per-query behaviour; plus one thread
-    per core over row shards.  Reported baseline only - never part of `value`."""
+    """The oracle (C restatement of the reference CPU scan, search/query.rs:453-482 minus SQLite) timed on this
+    host with the dot body simsimd's run-time dispatch would take here (AVX-512 / AVX2+FMA / scalar - the ISA
+    that ran is in `isa`): single-threaded = the reference's per-query behaviour; plus one thread per core over
+    row shards.  Reported baseline only - never part of `value`."""
     from oracle import oracle
     n = rows_host.shape[0]
-    out = {"unit": "queries/s", "kind": "port", "cores": 1}
+    out = {"unit": "queries/s", "kind": "port", "cores": 1, "isa": oracle.dot_isa(native=True)}
     t0 = time.perf_counter()
     done = 0
     while True:
-        oracle.brute_force(rows_host, queries_host[done % len(queries_host)], k, 0.0)
+        oracle.brute_force(rows_host, queries_host[done % len(queries_host)], k, 0.0, oracle.DOT_NATIVE)
         done += 1
         el = time.perf_counter() - t0
         if el >= seconds and done >= 2:
             break
-    out["value"] = done / el
+    out["value"] = round(done / el, 3)
     cores = os.cpu_count() or 1
     threads = min(cores, 64)
     t0 = time.perf_counter()
     done_mt = 0
     while True:
-        oracle.brute_force_mt(rows_host, queries_host[done_mt % len(queries_host)], k, 0.0, threads)
+        oracle.brute_force_mt(rows_host, queries_host[done_mt % len(queries_host)], k, 0.0, threads, oracle.DOT_NATIVE)
         done_mt += 1
         el = time.perf_counter() - t0
         if el >= seconds and done_mt >= 2:
             break
-    out["mt_value"] = done_mt / el
+    out["mt_value"] = round(done_mt / el, 3)
     out["mt_cores"] = threads
     out["host_cores"] = cores
     out["sample"] = (f"{done} single-thread + {done_mt} {threads}-thread queries, each a full scan of the same "
-                     f"{n}x{rows_host.shape[1]} fp32 corpus held in RAM, k={k}, threshold 0.0 (oracle: "
-                     "simsimd-style AVX2 dot + clamp + BoundedScoreHeap)")
+                     f"{n}x{rows_host.shape[1]} fp32 corpus held in RAM, k={k}, threshold 0.0 (oracle: simsimd "
+                     f"dot restated, body that ran: {out['isa']}; + clamp + BoundedScoreHeap)")
     return out
 
 
-def embed_leg(a, rank, world, dist, torch, np, dev, all_reduce_max):
-    """Index-build leg of the metric ("index embed chunks/sec"): EmbeddingGemma-300m geometry with seeded
-    random weights (no network for the real checkpoint), synthetic token ids, batch = the reference's
-    embed_batch_size() (32), (a) fixed L and (b) log-normal lengths ("few hundred tokens").
-    Data-parallel over ranks: replicated weights, no collective."""
-    from cqs_amd.embedder import HipEmbedEngine, default_config
-    cfg = default_config()
-    eng = HipEmbedEngine(cfg, device=dev.index)
+# ---------------------------------------------------------------------------------------------------------
+# embedding leg
+# ---------------------------------------------------------------------------------------------------------
+def seeded_embed_weights(np, cfg):
+    """EmbeddingGemma-300m geometry, seeded random weights (no network for the real checkpoint)."""
     rng = np.random.default_rng(0xC950003)
-    H, D, I, V, NL = 768, 256, 1152, cfg.vocab_size, cfg.layers
+    H, D, I, V, NL = cfg.hidden, cfg.head_dim, cfg.intermediate, cfg.vocab_size, cfg.layers
 
     def lin(n, k):
         return rng.standard_normal((n, k), dtype=np.float32) * np.float32(1.0 / np.sqrt(k))
 
-    eng.set_tensor("embed_tokens.weight", rng.standard_normal((V, H), dtype=np.float32) * np.float32(0.05))
+    w = {"embed_tokens.weight": rng.standard_normal((V, H), dtype=np.float32) * np.float32(0.05)}
     for l in range(NL):
         p = f"layers.{l}."
         for nme in ("input_layernorm", "post_attention_layernorm", "pre_feedforward_layernorm", "post_feedforward_layernorm"):
-            eng.set_tensor(p + nme + ".weight", rng.standard_normal(H, dtype=np.float32) * np.float32(0.1))
-        eng.set_tensor(p + "self_attn.q_norm.weight", rng.standard_normal(D, dtype=np.float32) * np.float32(0.1))
-        eng.set_tensor(p + "self_attn.k_norm.weight", rng.standard_normal(D, dtype=np.float32) * np.float32(0.1))
-        eng.set_tensor(p + "self_attn.q_proj.weight", lin(3 * D, H))
-        eng.set_tensor(p + "self_attn.k_proj.weight", lin(D, H))
-        eng.set_tensor(p + "self_attn.v_proj.weight", lin(D, H))
-        eng.set_tensor(p + "self_attn.o_proj.weight", lin(H, 3 * D))
-        eng.set_tensor(p + "mlp.gate_proj.weight", lin(I, H))
-        eng.set_tensor(p + "mlp.up_proj.weight", lin(I, H))
-        eng.set_tensor(p + "mlp.down_proj.weight", lin(H, I))
-    eng.set_tensor("norm.weight", rng.standard_normal(H, dtype=np.float32) * np.float32(0.1))
-    eng.set_tensor("dense1.weight", lin(3072, H))
-    eng.set_tensor("dense2.weight", lin(H, 3072))
-    eng.set_weights({})
+            w[p + nme + ".weight"] = rng.standard_normal(H, dtype=np.float32) * np.float32(0.1)
+        w[p + "self_attn.q_norm.weight"] = rng.standard_normal(D, dtype=np.float32) * np.float32(0.1)
+        w[p + "self_attn.k_norm.weight"] = rng.standard_normal(D, dtype=np.float32) * np.float32(0.1)
+        w[p + "self_attn.q_proj.weight"] = lin(cfg.heads * D, H)
+        w[p + "self_attn.k_proj.weight"] = lin(cfg.kv_heads * D, H)
+        w[p + "self_attn.v_proj.weight"] = lin(cfg.kv_heads * D, H)
+        w[p + "self_attn.o_proj.weight"] = lin(H, cfg.heads * D)
+        w[p + "mlp.gate_proj.weight"] = lin(I, H)
+        w[p + "mlp.up_proj.weight"] = lin(I, H)
+        w[p + "mlp.down_proj.weight"] = lin(H, I)
+    w["norm.weight"] = rng.standard_normal(H, dtype=np.float32) * np.float32(0.1)
+    w["dense1.weight"] = lin(cfg.dense_hidden, H)
+    w["dense2.weight"] = lin(H, cfg.dense_hidden)
+    return w
 
-    def flops_of(lens):
-        gemm = 2.0 * NL * (H * 1280 + H * H + H * 2 * I + I * H)           # per token (SURVEY §8d: 0.203 GFLOP)
-        att = 0.0
-        W = cfg.sliding_window // 2 + 1
-        for L in lens:
-            pos = np.arange(L)
-            local = np.minimum(pos + W, L) - np.maximum(pos - W + 1, 0)    # keys with |q-k| < W
-            n_full = NL // cfg.sliding_pattern
-            att += 4.0 * 3 * D * (n_full * L * L + (NL - n_full) * float(local.sum()))
-        head = 2.0 * 2 * H * 3072 * len(lens)
-        return gemm * float(np.sum(lens)) + att + head
+
+def embed_flops(np, cfg, lens):
+    """2 x 101.5 M non-embedding parameters per token + attention + the dense head per sequence."""
+    H, D, I, NL = cfg.hidden, cfg.head_dim, cfg.intermediate, cfg.layers
+    nq = (cfg.heads + 2 * cfg.kv_heads) * D
+    gemm = 2.0 * NL * (H * nq + H * cfg.heads * D + H * 2 * I + I * H)
+    att = 0.0
+    W = cfg.sliding_window // 2 + 1
+    n_full = NL // cfg.sliding_pattern
+    for L in lens:
+        pos = np.arange(L)
+        local = np.minimum(pos + W, L) - np.maximum(pos - W + 1, 0)    # keys with |q-k| < W
+        att += 4.0 * cfg.heads * D * (n_full * L * L + (NL - n_full) * float(local.sum()))
+    head = 2.0 * 2 * H * cfg.dense_hidden * len(lens)
+    return gemm * float(np.sum(lens)) + att + head
+
+
+def embed_cpu_baseline(np, cfg, weights, seconds, L):
+    """"PyTorch-CPU Gemma3 (same seeded weights) sequences/sec".  oracle/gemma3_ref.forward (fp32, torch
+    CPU, padded batch like ORT) on a bounded sample: a 2-sequence probe sizes one batch of up to 32 x L tokens."""
+    import torch
+    from oracle import gemma3_ref as G
+    gc = G.GemmaConfig(vocab_size=cfg.vocab_size, hidden=cfg.hidden, layers=cfg.layers, heads=cfg.heads, kv_heads=cfg.kv_heads,
+                       head_dim=cfg.head_dim, intermediate=cfg.intermediate, sliding_window=cfg.sliding_window,
+                       sliding_pattern=cfg.sliding_pattern, dense_hidden=cfg.dense_hidden, max_seq=cfg.max_seq)
+    rng = np.random.default_rng(0xC950007)
+
+    def run(B):
+        ids = rng.integers(1, cfg.vocab_size, size=(B, L)).astype(np.int64)
+        mask = np.ones((B, L), np.int64)
+        t0 = time.perf_counter()
+        out = G.forward(gc, weights, ids, mask)
+        assert np.all(np.isfinite(out))
+        return time.perf_counter() - t0
+
+    t2 = run(2)
+    B = int(max(2, min(32, (seconds / max(t2 / 2, 1e-6)) // 1)))
+    tb = run(B) if B > 2 else t2
+    return {"kind": "port", "what": "oracle/gemma3_ref.forward (torch CPU fp32, same seeded weights, padded batch)",
+            "chunks_per_sec": round(B / tb, 3), "tokens_per_sec": round(B * L / tb, 1), "cores": torch.get_num_threads(),
+            "host_cores": os.cpu_count(), "sample": f"one batch of {B} x {L} tokens ({tb:.1f} s) after a 2-sequence probe",
+            "tflops": round(embed_flops(np, gc, [L] * B) / tb / 1e12, 3)}
+
+
+def embed_leg(a, rank, world, dist, torch, np, dev, all_reduce_max):
+    """Index-build leg of the metric ("index embed chunks/sec"): EmbeddingGemma-300m geometry with seeded
+    random weights, synthetic token ids, batch = the reference's embed_batch_size() (32), (a) fixed L and
+    (b) log-normal lengths ("few hundred tokens").  Data-parallel over ranks: replicated weights,
+    no collective."""
+    from cqs_amd.embedder import HipEmbedEngine, default_config
+    cfg = default_config()
+    eng = HipEmbedEngine(cfg, device=dev.index)
+    weights = seeded_embed_weights(np, cfg)
+    for name, t in weights.items():
+        eng.set_tensor(name, t)
+    eng.set_weights({})
+    rng = np.random.default_rng(0xC950004)
+    V = cfg.vocab_size
 
     def run(lens, steps):
         B, L = len(lens), int(max(lens))
@@ -159,7 +232,7 @@ def embed_leg(a, rank, world, dist, torch, np, dev, all_reduce_max):
         if dist is not None:
             el = all_reduce_max(el)
         toks = int(np.sum(lens))
-        tf = flops_of(lens) * steps / (dev_ms / 1e3) / 1e12
+        tf = embed_flops(np, cfg, lens) * steps / (dev_ms / 1e3) / 1e12
         return {"chunks_per_sec": round(B * steps * world / el, 1), "tokens_per_sec": round(toks * steps * world / el, 1),
                 "ms_per_batch": round(el / steps * 1e3, 3), "device_ms_per_batch": round(dev_ms / steps, 3),
                 "batch": B, "tokens_per_batch": toks,
@@ -171,7 +244,7 @@ def embed_leg(a, rank, world, dist, torch, np, dev, all_reduce_max):
     ragged = run(list(lens), a.embed_steps)
     # SURVEY §8d asks for "a tuned larger batch" beside the reference's 32, and for the measured GEMM ceiling
     # of the bf16 kernel the forward is built on (a big square GEMM through the same kernel)
-    big = run([a.embed_len] * (4 * a.embed_batch), max(2, a.embed_steps // 4)) if rank == 0 or dist is not None else None
+    big = run([a.embed_len] * (4 * a.embed_batch), max(2, a.embed_steps // 4))
     ceiling = None
     try:
         import ctypes as C
@@ -183,17 +256,111 @@ def embed_leg(a, rank, world, dist, torch, np, dev, all_reduce_max):
         ceiling = round(2.0 * 8192 * 4096 * 4096 / ms / 1e9, 1) if ms > 0 else None
     except Exception:
         ceiling = None
-    eng.close()
-    return {"model": "EmbeddingGemma-300m geometry (24 x [768 | 3x256 q, 1 kv | 1152], vocab 262144), seeded weights",
-            "steps": a.embed_steps, "fixed_len_%d" % a.embed_len: fixed, "lognormal_len": ragged,
-            "fixed_len_%d_batch%d" % (a.embed_len, 4 * a.embed_batch): big,
-            "gemm_kernel_ceiling_tflops": ceiling,
-            "note": "host-buffer API (ids in, embeddings out per batch, PCIe-inclusive); timed wall-clock, max over ranks"}
+    cpu = None
+    if rank == 0 and world == 1 and a.cpu_seconds > 0:
+        cpu = embed_cpu_baseline(np, cfg, weights, a.cpu_seconds, a.embed_len)
+    out = {"model": "EmbeddingGemma-300m geometry (24 x [768 | 3x256 q, 1 kv | 1152], vocab 262144), seeded weights",
+           "steps": a.embed_steps, "fixed_len_%d" % a.embed_len: fixed, "lognormal_len": ragged,
+           "fixed_len_%d_batch%d" % (a.embed_len, 4 * a.embed_batch): big,
+           "gemm_kernel_ceiling_tflops": ceiling, "cpu_baseline": cpu,
+           "note": "host-buffer API (ids in, embeddings out per batch, PCIe-inclusive); timed wall-clock, max over ranks"}
+    return out, eng, cfg, weights
 
 
-def other_configs(torch, np, HipIndex, make_unit_rows, idx, rows, queries, dim, dev, st):
+def e2e_leg(a, torch, np, dev, eng, cfg, weights):
+    """BASELINE configs[3]: synthetic code chunks (log-normal token lengths) -> GPU EmbeddingGemma forward through the
+    index pipeline (length-sorted batches, cqs_amd.pipeline) -> L2 normalise -> HIP index -> 256 queries k-NN.
+    R@5 / R@20: the CPU-oracle pipeline (fp32 forward + oracle scan) on a sub-sample at the real geometry."""
+    try:
+        from cqs_amd.pipeline import EmbedPipeline
+    except Exception as e:  # pipeline module not built yet
+        return {"skipped": f"pipeline unavailable: {e}"}
+    from cqs_amd import HipIndex
+    rng = np.random.default_rng(0xC950008)
+    n = a.e2e_chunks
+    lens = np.clip(np.exp(rng.normal(np.log(300.0), 0.6, size=n)).astype(int), 8, cfg.max_seq)
+    V = cfg.vocab_size
+    chunks = [rng.integers(1, V, size=int(L)).astype(np.int64) for L in lens]
+    pipe = EmbedPipeline(eng)
+    pipe.embed_token_lists(chunks[:256])             # warm-up (scratch sizes)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    emb = pipe.embed_token_lists(chunks)             # [n, 768] f32, L2-normalised, input order
+    t_embed = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    idx = HipIndex.build_from_flat(None, emb[:4096])
+    for lo in range(4096, n, 32768):
+        idx.extend(None, emb[lo:lo + 32768])
+    nq, k = 256, 20
+    qrows = rng.choice(n, size=nq, replace=False)
+    noise = rng.standard_normal((nq, emb.shape[1])).astype(np.float32) * np.float32(0.02)
+    queries = emb[qrows] + noise
+    queries /= np.linalg.norm(queries, axis=1, keepdims=True)
+    got_rows, got_scores, counts = idx.search_batch(queries.astype(np.float32), k)
+    t_index = time.perf_counter() - t1
+    total = time.perf_counter() - t0
+    assert bool(np.all(counts == k)) and np.all(np.isfinite(got_scores))
+    hit1 = float(np.mean(got_rows[:, 0] == qrows))   # a query is its chunk's embedding + 2 % noise
+    out = {"workload": f"configs[3]: {n} synthetic chunks (log-normal lengths, median ~300 tokens) -> HIP embed pipeline -> "
+                       f"extend -> {nq} queries top-{k}",
+           "chunks_per_sec_e2e": round(n / total, 1), "embed_chunks_per_sec": round(n / t_embed, 1),
+           "embed_tokens_per_sec": round(float(lens.sum()) / t_embed, 1), "embed_s": round(t_embed, 2),
+           "index_and_query_s": round(t_index, 3), "self_hit_at_1": round(hit1, 4), "pipeline": pipe.stats()}
+    idx.close()
+    # recall against the CPU-oracle pipeline on a sub-sample (the fp32 CPU forward is ~1e4 x slower)
+    if a.cpu_seconds > 0:
+        from oracle import gemma3_ref as G
+        from oracle import oracle
+        gc = G.GemmaConfig(vocab_size=cfg.vocab_size, hidden=cfg.hidden, layers=cfg.layers, heads=cfg.heads,
+                           kv_heads=cfg.kv_heads, head_dim=cfg.head_dim, intermediate=cfg.intermediate,
+                           sliding_window=cfg.sliding_window, sliding_pattern=cfg.sliding_pattern,
+                           dense_hidden=cfg.dense_hidden, max_seq=cfg.max_seq)
+        budget = max(20.0, 6 * a.cpu_seconds)
+        order = np.argsort(lens)[: max(64, n // 4)]           # short chunks first: most chunks per CPU-second
+        sub, t_cpu0, ref = [], time.perf_counter(), []
+        for lo in range(0, len(order), 16):
+            sel = order[lo:lo + 16]
+            L = int(max(lens[sel]))
+            ids = np.zeros((len(sel), L), np.int64)
+            mask = np.zeros((len(sel), L), np.int64)
+            for i, c in enumerate(sel):
+                ids[i, :lens[c]] = chunks[c]
+                mask[i, :lens[c]] = 1
+            ref.append(G.forward(gc, weights, ids, mask))
+            sub.extend(int(c) for c in sel)
+            if time.perf_counter() - t_cpu0 > budget and len(sub) >= 64:
+                break
+        ref = np.concatenate(ref)
+        ref /= np.linalg.norm(ref, axis=1, keepdims=True)
+        ref = ref.astype(np.float32)
+        sub = np.array(sub)
+        hip_sub = np.ascontiguousarray(emb[sub])
+        cs = np.sum(hip_sub * ref, axis=1)
+        nqs = min(64, len(sub) // 2)
+        sidx = HipIndex.build_from_flat(None, hip_sub)
+        r5 = r20 = 0.0
+        kk = min(20, len(sub) - 1)
+        gr, _, gc_ = sidx.search_batch(hip_sub[:nqs], kk)
+        for qi in range(nqs):
+            ref_ids, _ = oracle.index_search(ref, ref[qi], kk)
+            got = [int(x) for x in gr[qi, :int(gc_[qi])]]
+            r5 += len(set(ref_ids[:5]) & set(got[:5])) / 5.0
+            r20 += len(set(ref_ids[:kk]) & set(got[:kk])) / float(kk)
+        sidx.close()
+        out["recall_vs_cpu_oracle"] = {"sample_chunks": int(len(sub)), "queries": int(nqs), "R@5": round(r5 / nqs, 4),
+                                       "R@20": round(r20 / nqs, 4), "min_cosine_hip_vs_fp32": round(float(cs.min()), 6),
+                                       "cpu_forward_s": round(time.perf_counter() - t_cpu0, 1),
+                                       "note": "seeded weights: parity unpinned w.r.t. the real checkpoint (no weights offline)"}
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------
+# scan legs
+# ---------------------------------------------------------------------------------------------------------
+def other_configs(torch, np, HipIndex, idx, rows, queries, dim, dev, st):
     """The other BASELINE / SURVEY §8d configurations, timed the same way (inputs resident in HBM, device API,
-    steps enqueued back to back).  Reported beside the headline, never instead of it."""
+    steps enqueued back to back) and CHECKED outside the timed region (check_topk).  Reported beside the headline,
+    never instead of it."""
     def timed(index, q, b, k, steps, warm):
         keys = torch.zeros((b, k), dtype=torch.int64, device=dev)
         cnt = torch.zeros((b,), dtype=torch.int32, device=dev)
@@ -204,40 +371,83 @@ def other_configs(torch, np, HipIndex, make_unit_rows, idx, rows, queries, dim, 
         for _ in range(steps):
             index.search_device(q.data_ptr(), b, k, keys.data_ptr(), cnt.data_ptr(), stream=st)
         torch.cuda.synchronize()
-        return (time.perf_counter() - t0) / steps
+        return (time.perf_counter() - t0) / steps, keys.cpu().numpy().view(np.uint64), cnt.cpu().numpy()
 
     out = {}
     n = rows.shape[0]
-    q1 = queries[0].contiguous()
-    t = timed(idx, q1, 1, 500, 100, 10)                       # what production asks for (src/limits.rs:315-320)
-    out["k500_1M"] = {"queries_per_sec": round(1.0 / t, 1), "ms_per_query": round(t * 1e3, 4)}
+    q1 = queries[0, 0].contiguous()
+    t, hk, hc = timed(idx, q1, 1, 500, 100, 10)               # what production asks for (src/limits.rs:315-320)
+    check_topk(torch, np, rows, q1, hk[0], hc[0], 500, what="k500_1M")
+    out["k500_1M"] = {"queries_per_sec": round(1.0 / t, 1), "ms_per_query": round(t * 1e3, 4), "checked": True}
     qb = make_unit_rows(torch, 256, dim, 0xC950003, dev)
-    t = timed(idx, qb, 256, 20, 10, 2)                        # configs[2]: 256-query blocks on the f32 matrix cores
+    t, hk, hc = timed(idx, qb, 256, 20, 10, 2)                # configs[2]: 256-query blocks on the f32 matrix cores
+    allsc = rows @ qb.T                                       # exhaustive threshold count for all 256 queries at once
+    kth = torch.empty((256,), device=dev)
+    for qi in range(256):
+        _, s = check_topk(torch, np, rows, qb[qi], hk[qi], hc[qi], 20, exhaustive=False, what="batch256_1M[%d]" % qi)
+        kth[qi] = float(s[-1])
+    beat = (allsc > (kth + 2e-6)[None, :]).sum(dim=0)
+    assert int(beat.max().item()) <= 19, "batch256_1M: rows beat the k-th score"
+    del allsc
     tf = 2.0 * 256 * n * dim / t / 1e12
-    out["batch256_1M"] = {"queries_per_sec": round(256 / t, 1), "ms_per_batch": round(t * 1e3, 3),
+    out["batch256_1M"] = {"queries_per_sec": round(256 / t, 1), "ms_per_batch": round(t * 1e3, 3), "checked": True,
                           "roofline": {"bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                                        "frac": round(tf / MFMA_F32_PEAK_TF, 4), "dtype": "f32"}}
     small = make_unit_rows(torch, 17523, dim, 0xC950004, dev)  # configs[0] shape (cache resident: not judged against HBM)
     si = HipIndex.build_from_device(None, small.data_ptr(), 17523, dim, device=dev.index or 0, borrow=True, keepalive=small)
-    t = timed(si, q1, 1, 20, 500, 50)
-    out["rows17523"] = {"queries_per_sec": round(1.0 / t, 1), "ms_per_query": round(t * 1e3, 4)}
+    t, hk, hc = timed(si, q1, 1, 20, 500, 50)
+    check_topk(torch, np, small, q1, hk[0], hc[0], 20, what="rows17523")
+    out["rows17523"] = {"queries_per_sec": round(1.0 / t, 1), "ms_per_query": round(t * 1e3, 4), "checked": True}
     si.close()
     del small
     try:
         big_n = 10_000_000
         big = make_unit_rows(torch, big_n, dim, 0xC950005, dev)
         bi = HipIndex.build_from_device(None, big.data_ptr(), big_n, dim, device=dev.index or 0, borrow=True, keepalive=big)
-        t = timed(bi, q1, 1, 20, 20, 3)
+        t, hk, hc = timed(bi, q1, 1, 20, 20, 3)
+        check_topk(torch, np, big, q1, hk[0], hc[0], 20, what="rows10M")
         gbs = big_n * dim * 4 / t / 1e9
-        out["rows10M"] = {"queries_per_sec": round(1.0 / t, 2), "ms_per_query": round(t * 1e3, 3),
+        out["rows10M"] = {"queries_per_sec": round(1.0 / t, 2), "ms_per_query": round(t * 1e3, 3), "checked": True,
                           "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                        "frac": round(gbs / HBM_PEAK_GBS, 4), "note": "whole step incl. select"}}
         bi.close()
         del big
+    except AssertionError:
+        raise
     except Exception as e:  # e.g. not enough free HBM beside another tenant
         out["rows10M"] = {"skipped": str(e)[:120]}
     torch.cuda.empty_cache()
     return out
+
+
+def abi_sharded_leg(a, torch, np, rows, queries, k, dim):
+    """Single-process multi-GPU path behind the C ABI (cqs_hip_index_create_sharded): synchronous host-API queries
+    on the same corpus, checked against the single-device answer."""
+    from cqs_amd import HipIndex
+    devs = [int(x) for x in a.abi_devices.split(",") if x != ""]
+    host = rows.cpu().numpy()
+    t0 = time.perf_counter()
+    sh = HipIndex.build_sharded(None, host, devs)
+    t_build = time.perf_counter() - t0
+    qh = queries[:, 0].cpu().numpy()
+    nq = min(200, qh.shape[0])
+    for i in range(min(10, nq)):
+        sh.search_batch(qh[i], k)
+    t0 = time.perf_counter()
+    res = [sh.search_batch(qh[i], k) for i in range(nq)]
+    el = time.perf_counter() - t0
+    single = HipIndex.build_from_device(None, rows.data_ptr(), rows.shape[0], dim, borrow=True, keepalive=rows)
+    for i in (0, nq // 2, nq - 1):
+        r1, s1, c1 = single.search_batch(qh[i], k)
+        assert c1[0] == res[i][2][0] and np.max(np.abs(s1 - res[i][1])) <= 2e-6
+        if np.all(np.abs(np.diff(s1[0])) > 4e-6):
+            assert np.array_equal(r1, res[i][0])
+    info = sh.shards()
+    single.close()
+    sh.close()
+    return {"devices": devs, "shards": [{"device": d, "rows": r, "rccl": rc} for d, _f, r, rc in info],
+            "queries_per_sec_host_api": round(nq / el, 1), "ms_per_query": round(el / nq * 1e3, 4),
+            "build_s": round(t_build, 2), "checked_vs_single_device": True}
 
 
 def main():
@@ -245,7 +455,7 @@ def main():
     import numpy as np
     import torch
     from cqs_amd import HipIndex, unpack_keys
-    from cqs_amd.sharded import ShardedSearch, hip_local_search
+    from cqs_amd.sharded import ShardedSearch, shard_bounds
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -270,6 +480,11 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
+    mode = a.mode
+    if mode == "auto":
+        mode = "strong" if (world > 1 or force_dist) else "single"
+    if mode == "single" and world > 1:
+        raise SystemExit("--mode single needs --gpus 1")
 
     def all_gather_dev(out, inp):
         """One fused all-gather of a device tensor (RCCL over xGMI; host-staged gloo in rehearsal mode)."""
@@ -283,16 +498,30 @@ def main():
         else:
             dist.all_gather_into_tensor(out.view(-1), inp.contiguous().view(-1))
 
-    def all_reduce_max(x):
+    def all_reduce(x, op):
         t = torch.tensor([x], dtype=torch.float64, device="cpu" if rehearsal else dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=op)
         return float(t.item())
 
-    n, dim, k, bq = a.rows, a.dim, a.k, a.batch
+    def all_reduce_max(x):
+        return all_reduce(x, dist.ReduceOp.MAX)
+
+    dim, k, bq = a.dim, a.k, a.batch
     K, W = a.steps, a.warmup
+    if mode == "strong":
+        total_rows = a.total_rows
+        lo, hi = shard_bounds(total_rows, world, rank)
+        n = hi - lo
+        row_base = lo
+        # every rank holds the SAME query stream (resident in HBM before the timed region), its own row shard
+        queries = make_unit_rows(torch, (K + W) * bq, dim, 0xC950002, dev).view(K + W, bq, dim)
+    else:
+        n = a.rows
+        total_rows = n * world
+        row_base = rank * n
+        queries = make_unit_rows(torch, (K + W) * bq, dim, 0xC950002 + 7919 * rank, dev).view(K + W, bq, dim)
     rows = make_unit_rows(torch, n, dim, 0xC950001 + rank, dev)
-    queries = make_unit_rows(torch, (K + W) * bq, dim, 0xC950002 + 7919 * rank, dev).view(K + W, bq, dim)
-    idx = HipIndex.build_from_device(None, rows.data_ptr(), n, dim, device=local_rank, row_base=rank * n,
+    idx = HipIndex.build_from_device(None, rows.data_ptr(), n, dim, device=local_rank, row_base=row_base,
                                      borrow=True, keepalive=rows)
     st = torch.cuda.current_stream().cuda_stream
 
@@ -301,22 +530,55 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    sharded_path = world > 1 or force_dist or os.environ.get("CQS_BENCH_FORCE_SHARDED") == "1"   # the env knob exercises the N>1 code on 1 rank
-    if not sharded_path:
+    merged = {}
+    if mode == "single":
+        nq_scan = bq
         out_keys = torch.zeros((K + W, bq, k), dtype=torch.int64, device=dev)
         out_counts = torch.zeros((K + W, bq), dtype=torch.int32, device=dev)
 
         def step(i):
             idx.search_device(queries[i].data_ptr(), bq, k, out_keys[i].data_ptr(), out_counts[i].data_ptr(), stream=st)
 
-        def finish(lo, hi):
+        def finish(lo_, hi_):
             torch.cuda.synchronize()
+
+        def scan_only(i):
+            step(i)
+    elif mode == "strong":
+        # configs[4]: step i = every shard scans the SAME query block; ONE all-gather of the shards' [bq, k] packed
+        # keys, issued asynchronously on RCCL's stream so that it runs under the scan of step i+1; the host merge of
+        # all steps closes the timed region.  No host sync inside a step.
+        nq_scan = bq
+        send = torch.zeros((K + W, bq * k), dtype=torch.int64, device=dev)
+        recv = torch.zeros((K + W, world, bq * k), dtype=torch.int64, device=dev)
+        counts = torch.empty((bq,), dtype=torch.int32, device=dev)
+        works = [None] * (K + W)
+
+        def step(i):
+            idx.search_device(queries[i].data_ptr(), bq, k, send[i].data_ptr(), counts.data_ptr(), stream=st)
+            if dist is None or rehearsal:
+                all_gather_dev(recv[i], send[i])
+            else:
+                works[i] = dist.all_gather_into_tensor(recv[i].view(-1), send[i].view(-1), async_op=True)
+
+        def finish(lo_, hi_):
+            for wk in works[lo_:hi_]:
+                if wk is not None:
+                    wk.wait()
+            torch.cuda.synchronize()
+            host = recv[lo_:hi_].cpu().numpy().reshape(hi_ - lo_, world, bq, k)
+            out = ShardedSearch.merge_host_many(host, k)       # [steps, bq, k]: the host-side merge (north_star)
+            for s in range(hi_ - lo_):
+                merged[lo_ + s] = [row[row != 0] for row in out[s]]
+
+        def scan_only(i):
+            idx.search_device(queries[i].data_ptr(), bq, k, send[i].data_ptr(), counts.data_ptr(), stream=st)
     else:
-        # One collective per step, off the critical path: a rank's payload = its shard's top-k keys for ALL of
-        # this step's queries followed by its OWN queries of step i+2 (fp32 viewed as int64).  The exchange of
-        # step i therefore delivers the query block of step i+2, and - issued asynchronously on RCCL's stream -
-        # runs under the scan of step i+1, which only needs the exchange of step i-1.  No host sync.
+        # weak (round 1): a rank's payload = its shard's top-k keys for ALL of this step's queries followed by its OWN
+        # queries of step i+2 (fp32 viewed as int64): the exchange of step i delivers the query block of step i+2 and
+        # runs under the scan of step i+1.
         nq = world * bq
+        nq_scan = nq
         qw = dim // 2                                   # int64 words per query row
         pay = nq * k + bq * qw
         send = torch.zeros((K + W, pay), dtype=torch.int64, device=dev)
@@ -324,15 +586,8 @@ def main():
         qall = torch.empty((K + W + 2, nq, dim), dtype=torch.float32, device=dev)
         counts = torch.empty((nq,), dtype=torch.int32, device=dev)
         works = [None] * (K + W)
-        merged = {}
         for j0 in range(min(2, K + W)):                                    # prologue: the first two query blocks
             all_gather_dev(qall[j0].view(world, bq, dim), queries[j0])
-
-        def exchange(i):
-            if dist is None or rehearsal:
-                all_gather_dev(recv[i], send[i])
-                return None
-            return dist.all_gather_into_tensor(recv[i].view(-1), send[i].view(-1), async_op=True)
 
         def step(i):
             if i >= 2:
@@ -342,18 +597,24 @@ def main():
             idx.search_device(qall[i].data_ptr(), nq, k, send[i].data_ptr(), counts.data_ptr(), stream=st)
             if i + 2 < K + W:
                 send[i, nq * k:].view(torch.float32).view(bq, dim).copy_(queries[i + 2])
-            works[i] = exchange(i)
+            if dist is None or rehearsal:
+                all_gather_dev(recv[i], send[i])
+            else:
+                works[i] = dist.all_gather_into_tensor(recv[i].view(-1), send[i].view(-1), async_op=True)
 
-        def finish(lo, hi):
-            for wk in works[lo:hi]:
+        def finish(lo_, hi_):
+            for wk in works[lo_:hi_]:
                 if wk is not None:
                     wk.wait()
             torch.cuda.synchronize()
-            host = recv[lo:hi, :, :nq * k].cpu().numpy().reshape(hi - lo, world, nq, k)
+            host = recv[lo_:hi_, :, :nq * k].cpu().numpy().reshape(hi_ - lo_, world, nq, k)
             mine = host[:, :, rank * bq:(rank + 1) * bq, :]    # host merge of this rank's own queries, all steps at once
             out = ShardedSearch.merge_host_many(mine, k)       # [steps, bq, k]
-            for s in range(hi - lo):
-                merged[lo + s] = [row[row != 0] for row in out[s]]
+            for s in range(hi_ - lo_):
+                merged[lo_ + s] = [row[row != 0] for row in out[s]]
+
+        def scan_only(i):
+            idx.search_device(qall[i].data_ptr(), nq, k, send[i].data_ptr(), counts.data_ptr(), stream=st)
 
     for i in range(W):
         step(i)
@@ -368,48 +629,44 @@ def main():
     if dist is not None:
         elapsed = all_reduce_max(elapsed)
 
-    # ---- sanity of the last step's answer (outside the timed region) ----
+    # ---- the last step's answer, checked outside the timed region ----
     i = W + K - 1
-    if not sharded_path:
-        r, s = unpack_keys(out_keys[i, 0].cpu().numpy().view(np.uint64))
-        assert int(out_counts[i, 0].item()) == k
+    q_last = queries[i, 0]
+    if mode == "single":
+        check_topk(torch, np, rows, q_last, out_keys[i, 0].cpu().numpy().view(np.uint64), int(out_counts[i, 0].item()), k,
+                   what="headline")
     else:
         r, s = unpack_keys(merged[i][0])
-        assert len(r) == k
-    assert np.all(np.diff(s) <= 0), "top-k not sorted"
-    local = [(int(x) - rank * n) for x in r if rank * n <= int(x) < (rank + 1) * n]
-    if local:
-        direct = (rows[torch.tensor(local, device=dev)].double() @ queries[i, 0].double()).cpu().numpy()
-        mine = np.array([float(sv) for x, sv in zip(r, s) if rank * n <= int(x) < (rank + 1) * n])
-        assert np.max(np.abs(direct - mine)) <= 1e-5, (
-            "scores differ from a direct fp64 dot: rank %d max|d|=%g rows=%s got=%s want=%s"
-            % (rank, float(np.max(np.abs(direct - mine))), list(r[:6]), list(mine[:4]), list(direct[:4])))
+        assert len(r) == k and np.all(np.diff(s) <= 0), "merged top-k not sorted / short"
+        mine = [(int(x) - row_base, float(sv)) for x, sv in zip(r, s) if row_base <= int(x) < row_base + n]
+        if mine:
+            loc = torch.tensor([m[0] for m in mine], device=dev)
+            direct = (rows[loc].double() @ q_last.double()).cpu().numpy()
+            err = float(np.max(np.abs(direct - np.array([m[1] for m in mine]))))
+            assert err <= 1e-5, "rank %d: merged scores differ from a direct fp64 dot by %g" % (rank, err)
+        # exhaustive over ALL shards: at most k-1 rows of the whole corpus beat the merged k-th score of each rank's
+        # query (strong mode: every rank holds the same query; weak mode: one query per rank)
+        q_all = torch.empty((world, dim), dtype=torch.float32, device=dev)
+        kth_all = torch.empty((world,), dtype=torch.float32, device=dev)
+        all_gather_dev(q_all, q_last.contiguous())
+        all_gather_dev(kth_all, torch.tensor([float(s[-1])], dtype=torch.float32, device=dev))
+        beat = ((rows @ q_all.T) > (kth_all + 2e-6)[None, :]).sum(dim=0).to(torch.float64)
+        if dist is not None:
+            bt = beat.cpu() if rehearsal else beat
+            dist.all_reduce(bt, op=dist.ReduceOp.SUM)
+            beat = bt
+        assert float(beat[rank].item()) <= k - 1, "%d rows of the sharded corpus beat the merged k-th score" % int(beat[rank].item())
 
     # ---- roofline: the scan kernel's own duration, HIP events on the launch stream ----
     idx.set_timing(True)
     for i in range(W, W + K):
-        if not sharded_path:
-            step(i)
-        else:
-            idx.search_device(qall[i].data_ptr(), nq, k, send[i].data_ptr(), counts.data_ptr(), stream=st)
+        scan_only(i)
     torch.cuda.synchronize()
     launches, scan_ms = idx.scan_time()
     idx.set_timing(False)
     avg_s = scan_ms / max(launches, 1) / 1e3
     alg_bytes = n * dim * 4  # algorithmic bytes per launch = shard rows x dim x 4 B (corpus read once)
     achieved = alg_bytes / avg_s / 1e9
-    traffic = None
-    nq_scan_probe = bq * world
-    tpath = os.path.join(ROOT, "profiles", "r01_scan_traffic.json")
-    if os.path.exists(tpath):
-        try:
-            tj = json.load(open(tpath))
-            # PMC traffic was measured on the default workload only (rocprofv3 --pmc passes, profiles/)
-            if tj.get("alg_bytes_per_launch") == alg_bytes and nq_scan_probe == 1:
-                traffic = tj.get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
-    nq_scan = bq * world
     if nq_scan >= 9 and dim % 32 == 0:
         # query blocks >= 9 run on the f32 matrix cores: compute-bound (2*B*n*dim flops per launch)
         flops = 2.0 * nq_scan * n * dim
@@ -418,28 +675,72 @@ def main():
                     "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TF, 4), "traffic": None,
                     "alg_flops_per_launch": flops, "avg_launch_ms": round(avg_s * 1e3, 5), "launches": launches}
     else:
+        # traffic: NOT measured in this run (PMC needs rocprofv3 passes of their own).  The committed counter
+        # summary for this exact workload, if any, is quoted with its source; otherwise null.
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, "profiles", "scan_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                if tj.get("alg_bytes_per_launch") == alg_bytes and nq_scan == 1:
+                    traffic, traffic_src = tj.get("hbm_bytes_per_launch"), tj.get("source")
+            except Exception:
+                traffic = None
         roofline = {"bound": "hbm", "kernel": "scan_gemv_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": round(avg_s * 1e3, 5), "launches": launches}
+                    "traffic_source": traffic_src, "alg_bytes_per_launch": alg_bytes,
+                    "avg_launch_ms": round(avg_s * 1e3, 5), "launches": launches}
+
+    # ---- what `VectorIndex::search` sees: the synchronous host-buffer entry point (query H2D + results D2H + sync) ----
+    latency = None
+    if rank == 0 and world == 1 and mode == "single":
+        qh = queries[W:W + min(K, 200), 0].cpu().numpy()
+        for j in range(min(10, len(qh))):
+            idx.search_batch(qh[j], k)
+        t1 = time.perf_counter()
+        for j in range(len(qh)):
+            idx.search_batch(qh[j], k)
+        el = time.perf_counter() - t1
+        latency = {"queries_per_sec": round(len(qh) / el, 1), "ms_per_query": round(el / len(qh) * 1e3, 4),
+                   "what": "cqs_hip_index_search, host query in / host results out, one call at a time"}
 
     cpu = None
     if rank == 0 and world == 1 and a.cpu_seconds > 0:
-        nq = min(8, K)
-        cpu = cpu_baseline(rows.cpu().numpy(), queries[W:W + nq, 0].cpu().numpy(), k, a.cpu_seconds)
+        nqc = min(8, K)
+        cpu = cpu_baseline(rows.cpu().numpy(), queries[W:W + nqc, 0].cpu().numpy(), k, a.cpu_seconds)
 
     other = None
-    if rank == 0 and world == 1 and not sharded_path and a.extras:
-        other = other_configs(torch, np, HipIndex, make_unit_rows, idx, rows, queries, dim, dev, st)
+    if rank == 0 and world == 1 and mode == "single" and a.extras:
+        other = other_configs(torch, np, HipIndex, idx, rows, queries, dim, dev, st)
 
-    embed = None
+    abi = None
+    if rank == 0 and world == 1 and mode == "single" and a.abi_devices:
+        abi = abi_sharded_leg(a, torch, np, rows, queries[W:], k, dim)
+
+    embed = e2e = None
     if a.embed_steps > 0:
         idx.close()
         del rows
         torch.cuda.empty_cache()
-        embed = embed_leg(a, rank, world, dist, torch, np, dev, all_reduce_max)
+        embed, eng, ecfg, eweights = embed_leg(a, rank, world, dist, torch, np, dev, all_reduce_max)
+        if rank == 0 and world == 1 and a.e2e_chunks > 0:
+            e2e = e2e_leg(a, torch, np, dev, eng, ecfg, eweights)
+        eng.close()
 
     if rank == 0:
-        total_q = K * bq * world
+        if mode == "weak":
+            total_q = K * bq * world
+            workload = ("weak scaling (round-1 variant): %d x %d fp32 unit vectors per GPU, %d quer%s per rank per step, "
+                        "brute-force cosine top-%d" % (n, dim, bq, "y" if bq == 1 else "ies", k))
+        elif mode == "strong":
+            total_q = K * bq
+            workload = ("BASELINE configs[4]: %d x %d fp32 unit vectors row-sharded over %d GPU%s, %d quer%s per step scanned "
+                        "by every shard, one RCCL all-gather of per-shard top-%d, host merge"
+                        % (total_rows, dim, world, "" if world == 1 else "s", bq, "y" if bq == 1 else "ies", k))
+        else:
+            total_q = K * bq
+            workload = ("BASELINE configs[1]: %d x %d fp32 unit vectors, %d quer%s per step, brute-force cosine top-%d"
+                        % (n, dim, bq, "y" if bq == 1 else "ies", k))
         line = {
             "metric": "queries/sec @k=%d (brute-force cosine scan + top-k, 768-d fp32)" % k,
             "value": round(total_q / elapsed, 2),
@@ -449,19 +750,21 @@ def main():
             "warmup": W,
             "ms_per_step": round(elapsed / K * 1e3, 5),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "weak" if mode in ("weak", "single") else "strong",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: %d x %d fp32 unit vectors per GPU, %d quer%s per rank per step, "
-                                   "brute-force cosine top-%d" % (n, dim, bq, "y" if bq == 1 else "ies", k),
-                       "rows_per_gpu": n, "total_rows": n * world, "dim": dim, "k": k, "queries_per_step": bq * world,
+            "config": {"workload": workload, "mode": mode, "rows_per_gpu": n, "total_rows": total_rows, "dim": dim, "k": k,
+                       "queries_per_step": bq * (world if mode == "weak" else 1),
                        "parallelism": "row-sharded x%d, RCCL all-gather of per-shard candidates, host merge" % world
                        if world > 1 else "single GPU"},
             "roofline": roofline,
             "cpu_baseline": cpu,
+            "latency_host_api": latency,
             "other_configs": other,
+            "abi_sharded": abi,
             "embed": embed,
+            "e2e": e2e,
         }
         print(json.dumps(line), flush=True)
     if a.embed_steps <= 0:

@@ -79,6 +79,10 @@ SIGNATURES = [
     ("cqs_hip_embedder_poisoned", C.c_int32, [_c_idx]),
     ("cqs_hip_embedder_last_error", C.c_size_t, [_c_idx, C.c_char_p, C.c_size_t]),
     ("cqs_hip_embed", C.c_int32, [_c_idx, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
+    ("cqs_hip_embed_submit", C.c_int32, [_c_idx, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, _pp(C.c_uint64)]),
+    ("cqs_hip_embed_submit_ragged", C.c_int32, [_c_idx, C.c_void_p, C.c_void_p, C.c_uint32, _pp(C.c_uint64)]),
+    ("cqs_hip_embed_collect", C.c_int32, [_c_idx, C.c_uint64, C.c_void_p]),
+    ("cqs_hip_normalize_l2_rows", None, [C.c_void_p, C.c_uint64, C.c_uint32]),
     ("cqs_hip_embed_hidden", C.c_int32, [_c_idx, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
     ("cqs_hip_embedder_last_ms", C.c_float, [_c_idx]),
     ("cqs_hip_index_set_timing", None, [_c_idx, C.c_int32]),

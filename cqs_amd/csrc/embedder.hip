@@ -69,7 +69,6 @@ struct cqs_hip_embedder {
     cqs_hip_embed_config cfg{};
     cqs::EmbedGeom g{};
     hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
     float last_ms = -1.f;
 
     bf16_t* emb = nullptr;
@@ -84,8 +83,28 @@ struct cqs_hip_embedder {
     uint32_t tok_cap = 0, seq_cap = 0, vt_ld = 0, blk_cap = 0;
     float *x = nullptr, *hidden = nullptr, *out = nullptr;
     bf16_t *y = nullptr, *xn = nullptr, *qkv = nullptr, *vt = nullptr, *attn = nullptr, *h = nullptr, *pooled = nullptr, *d1 = nullptr;
+    // per-batch integer tables in ONE device block (one H2D per batch from the slot's pinned twin):
+    // [tok M][pos M][seq_start B][seq_len B][vt_start B][blk 2 nblk]; the pointers are carved per batch
+    int32_t* d_meta = nullptr;
+    size_t meta_cap = 0;   // int32 elements
     int32_t *d_tok = nullptr, *d_pos = nullptr, *d_seq_start = nullptr, *d_seq_len = nullptr,
             *d_vt_start = nullptr, *d_blk = nullptr;
+
+    // Submission slots (pinned host staging + events): batch i+1 is packed and enqueued while batch i computes;
+    // results come back through the slot's pinned `out` (cqs_hip_embed_submit / _collect).
+    struct Slot {
+        int32_t* meta = nullptr;   // pinned, same layout as d_meta
+        size_t meta_cap = 0;
+        float* out = nullptr;      // pinned [B, hidden]
+        size_t out_cap = 0;        // floats
+        uint32_t B = 0, M = 0, vt_cols = 0, nblk = 0;
+        hipEvent_t ev0 = nullptr, ev1 = nullptr;   // forward start / end (timing), ev_done after the D2H
+        hipEvent_t done = nullptr;
+        uint64_t ticket = 0;       // 0 = free
+    };
+    static constexpr int kSlots = 3;
+    Slot slot[kSlots];
+    uint64_t next_ticket = 1;
 
     mutable std::mutex mu;
     std::atomic<bool> poisoned{false};
@@ -127,11 +146,11 @@ int32_t upload_f32(cqs_hip_embedder* e, float* dst, const float* src, size_t cou
 
 void free_scratch(cqs_hip_embedder* e) {
     void** all[] = {(void**)&e->x, (void**)&e->y, (void**)&e->hidden, (void**)&e->out, (void**)&e->xn, (void**)&e->qkv,
-                    (void**)&e->vt, (void**)&e->attn, (void**)&e->h, (void**)&e->pooled, (void**)&e->d1, (void**)&e->d_tok,
-                    (void**)&e->d_pos, (void**)&e->d_seq_start, (void**)&e->d_seq_len, (void**)&e->d_vt_start,
-                    (void**)&e->d_blk};
+                    (void**)&e->vt, (void**)&e->attn, (void**)&e->h, (void**)&e->pooled, (void**)&e->d1, (void**)&e->d_meta};
     for (void** p : all) { (void)hipFree(*p); *p = nullptr; }
+    e->d_tok = e->d_pos = e->d_seq_start = e->d_seq_len = e->d_vt_start = e->d_blk = nullptr;
     e->tok_cap = e->seq_cap = e->vt_ld = e->blk_cap = 0;
+    e->meta_cap = 0;
 }
 
 int32_t ensure_scratch(cqs_hip_embedder* e, uint32_t M, uint32_t B, uint32_t vt_cols, uint32_t nblk) {
@@ -154,25 +173,77 @@ int32_t ensure_scratch(cqs_hip_embedder* e, uint32_t M, uint32_t B, uint32_t vt_
     E_TRY(e, dmalloc(&e->h, (size_t)Mc * g.inter));
     E_TRY(e, dmalloc(&e->pooled, (size_t)Bc * H));
     E_TRY(e, dmalloc(&e->d1, (size_t)Bc * g.dense_hidden));
-    E_TRY(e, dmalloc(&e->d_tok, (size_t)Mc));
-    E_TRY(e, dmalloc(&e->d_pos, (size_t)Mc));
-    E_TRY(e, dmalloc(&e->d_seq_start, (size_t)Bc));
-    E_TRY(e, dmalloc(&e->d_seq_len, (size_t)Bc));
-    E_TRY(e, dmalloc(&e->d_vt_start, (size_t)Bc));
-    E_TRY(e, dmalloc(&e->d_blk, (size_t)bc * 2));
+    e->meta_cap = (size_t)2 * Mc + (size_t)3 * Bc + (size_t)2 * bc;
+    E_TRY(e, dmalloc(&e->d_meta, e->meta_cap));
     e->tok_cap = Mc; e->seq_cap = Bc; e->vt_ld = vc; e->blk_cap = bc;
     return CQS_HIP_OK;
 }
 
-// Pack the padded [B, L] batch, run the layers, leave `hidden` (final norm, packed) on the device.
-struct Packed {
-    std::vector<int32_t> tok, pos, seq_start, seq_len, vt_start, blk;
-    uint32_t M = 0, vt_cols = 0;
-};
+// ---- batch packing into a submission slot ------------------------------------------------------------------
+using Slot = cqs_hip_embedder::Slot;
 
-int32_t pack(cqs_hip_embedder* e, const int64_t* ids, const int64_t* mask, uint32_t B, uint32_t L, Packed& p) {
-    p.seq_start.resize(B); p.seq_len.resize(B); p.vt_start.resize(B);
-    uint32_t M = 0, vcols = 0;
+int32_t slot_reserve(cqs_hip_embedder* e, Slot& sl, uint32_t B, uint32_t M, uint32_t nblk) {
+    const size_t need = (size_t)2 * M + (size_t)3 * B + (size_t)2 * nblk;
+    if (need > sl.meta_cap) {
+        if (sl.meta) (void)hipHostFree(sl.meta);
+        sl.meta = nullptr; sl.meta_cap = 0;
+        const size_t cap = need + need / 4 + 64;
+        E_TRY(e, hipHostMalloc((void**)&sl.meta, cap * sizeof(int32_t), hipHostMallocDefault));
+        sl.meta_cap = cap;
+    }
+    const size_t out_need = (size_t)B * e->g.hidden;
+    if (out_need > sl.out_cap) {
+        if (sl.out) (void)hipHostFree(sl.out);
+        sl.out = nullptr; sl.out_cap = 0;
+        E_TRY(e, hipHostMalloc((void**)&sl.out, (out_need + out_need / 4 + 64) * sizeof(float), hipHostMallocDefault));
+        sl.out_cap = out_need + out_need / 4 + 64;
+    }
+    if (!sl.ev0) {
+        E_TRY(e, hipEventCreate(&sl.ev0));
+        E_TRY(e, hipEventCreate(&sl.ev1));
+        E_TRY(e, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+    }
+    sl.B = B; sl.M = M; sl.nblk = nblk;
+    return CQS_HIP_OK;
+}
+
+// Fill the slot's tables from per-sequence lengths + a token fetcher; lens already validated (<= max_seq).
+template <class TokAt>
+int32_t slot_fill(cqs_hip_embedder* e, Slot& sl, const uint32_t* lens, uint32_t B, TokAt tok_at) {
+    uint64_t M64 = 0, nblk64 = 0;
+    for (uint32_t b = 0; b < B; ++b) { M64 += lens[b]; nblk64 += (lens[b] + 127u) / 128u; }
+    if (M64 > 0x7FFFFFFFull) return efail(e, CQS_HIP_ERR_INVALID, "embed: batch holds too many tokens");
+    int32_t rc = slot_reserve(e, sl, B, (uint32_t)M64, (uint32_t)nblk64);
+    if (rc != CQS_HIP_OK) return rc;
+    const uint32_t M = sl.M;
+    int32_t* tok = sl.meta;
+    int32_t* pos = tok + M;
+    int32_t* seq_start = pos + M;
+    int32_t* seq_len = seq_start + B;
+    int32_t* vt_start = seq_len + B;
+    int32_t* blk = vt_start + B;
+    uint32_t m = 0, vcols = 0, nb = 0;
+    const int64_t vocab = (int64_t)e->g.vocab;
+    for (uint32_t b = 0; b < B; ++b) {
+        const uint32_t len = lens[b];
+        seq_start[b] = (int32_t)m; seq_len[b] = (int32_t)len; vt_start[b] = (int32_t)vcols;
+        for (uint32_t j = 0; j < len; ++j) {
+            const int64_t id = tok_at(b, j);
+            if (id < 0 || id >= vocab) return efail(e, CQS_HIP_ERR_INVALID, "embed: token id out of range");
+            tok[m + j] = (int32_t)id;
+            pos[m + j] = (int32_t)j;
+        }
+        for (uint32_t sb = 0; sb * 128u < len; ++sb) { blk[2 * nb] = (int32_t)b; blk[2 * nb + 1] = (int32_t)sb; ++nb; }
+        m += len;
+        vcols += (len + 31u) / 32u * 32u;
+    }
+    sl.vt_cols = vcols + 32u;
+    return CQS_HIP_OK;
+}
+
+// The padded [B, L] contract of `session.run` (src/embedder/core.rs:1031-1035): mask rows are 1...10...0.
+int32_t pack_padded(cqs_hip_embedder* e, Slot& sl, const int64_t* ids, const int64_t* mask, uint32_t B, uint32_t L) {
+    std::vector<uint32_t> lens(B);
     for (uint32_t b = 0; b < B; ++b) {
         uint32_t len = 0;
         while (len < L && mask[(size_t)b * L + len] != 0) ++len;
@@ -180,36 +251,39 @@ int32_t pack(cqs_hip_embedder* e, const int64_t* ids, const int64_t* mask, uint3
             if (mask[(size_t)b * L + j] != 0)
                 return efail(e, CQS_HIP_ERR_INVALID, "embed: attention_mask must be a right-padded prefix mask");
         if (len > e->g.max_seq) return efail(e, CQS_HIP_ERR_INVALID, "embed: sequence longer than max_seq");
-        p.seq_start[b] = (int32_t)M; p.seq_len[b] = (int32_t)len; p.vt_start[b] = (int32_t)vcols;
-        for (uint32_t j = 0; j < len; ++j) {
-            const int64_t id = ids[(size_t)b * L + j];
-            if (id < 0 || id >= (int64_t)e->g.vocab) return efail(e, CQS_HIP_ERR_INVALID, "embed: token id out of range");
-            p.tok.push_back((int32_t)id);
-            p.pos.push_back((int32_t)j);
-        }
-        for (uint32_t sb = 0; sb * 128u < len; ++sb) { p.blk.push_back((int32_t)b); p.blk.push_back((int32_t)sb); }
-        M += len;
-        vcols += (len + 31u) / 32u * 32u;
+        lens[b] = len;
     }
-    p.M = M;
-    p.vt_cols = vcols + 32u;
-    return CQS_HIP_OK;
+    return slot_fill(e, sl, lens.data(), B, [&](uint32_t b, uint32_t j) { return ids[(size_t)b * L + j]; });
 }
 
-int32_t run_layers(cqs_hip_embedder* e, const Packed& p, uint32_t B) {
+int32_t pack_ragged(cqs_hip_embedder* e, Slot& sl, const int32_t* tokens, const uint32_t* lens, uint32_t B) {
+    std::vector<size_t> start(B);
+    size_t off = 0;
+    for (uint32_t b = 0; b < B; ++b) {
+        if (lens[b] > e->g.max_seq) return efail(e, CQS_HIP_ERR_INVALID, "embed: sequence longer than max_seq");
+        start[b] = off;
+        off += lens[b];
+    }
+    return slot_fill(e, sl, lens, B, [&](uint32_t b, uint32_t j) { return (int64_t)tokens[start[b] + j]; });
+}
+
+// Enqueue: tables H2D (one copy), the layers; leaves `hidden` (final norm, packed) on the device.
+int32_t run_layers(cqs_hip_embedder* e, Slot& sl) {
     const cqs::EmbedGeom& g = e->g;
-    const uint32_t M = p.M, H = g.hidden;
+    const uint32_t M = sl.M, H = g.hidden, B = sl.B;
     hipStream_t st = e->stream;
-    int32_t rc = ensure_scratch(e, M, B, p.vt_cols, (uint32_t)p.blk.size() / 2u);
+    int32_t rc = ensure_scratch(e, M, B, sl.vt_cols, sl.nblk);
     if (rc != CQS_HIP_OK) return rc;
-    E_TRY(e, hipMemcpyAsync(e->d_tok, p.tok.data(), (size_t)M * 4, hipMemcpyHostToDevice, st));
-    E_TRY(e, hipMemcpyAsync(e->d_pos, p.pos.data(), (size_t)M * 4, hipMemcpyHostToDevice, st));
-    E_TRY(e, hipMemcpyAsync(e->d_seq_start, p.seq_start.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
-    E_TRY(e, hipMemcpyAsync(e->d_seq_len, p.seq_len.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
-    E_TRY(e, hipMemcpyAsync(e->d_vt_start, p.vt_start.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
-    E_TRY(e, hipMemcpyAsync(e->d_blk, p.blk.data(), p.blk.size() * 4, hipMemcpyHostToDevice, st));
-    E_TRY(e, hipEventRecord(e->ev0, st));
-    const uint32_t nblk = (uint32_t)p.blk.size() / 2u;
+    e->d_tok = e->d_meta;
+    e->d_pos = e->d_tok + M;
+    e->d_seq_start = e->d_pos + M;
+    e->d_seq_len = e->d_seq_start + B;
+    e->d_vt_start = e->d_seq_len + B;
+    e->d_blk = e->d_vt_start + B;
+    const size_t words = (size_t)2 * M + (size_t)3 * B + (size_t)2 * sl.nblk;
+    E_TRY(e, hipMemcpyAsync(e->d_meta, sl.meta, words * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    E_TRY(e, hipEventRecord(sl.ev0, st));
+    const uint32_t nblk = sl.nblk;
     E_TRY(e, cqs::launch_embed_norm(e->d_tok, e->emb, sqrtf((float)H), e->L[0].n_in, g.rms_eps, e->x, e->xn, M, H, st));
     for (uint32_t l = 0; l < g.layers; ++l) {
         const LayerW& w = e->L[l];
@@ -411,8 +485,7 @@ int32_t cqs_hip_embedder_create(const cqs_hip_embed_config* c, int32_t device, c
     g.sliding_pattern = c->sliding_pattern; g.max_seq = c->max_seq; g.rms_eps = c->rms_eps;
     g.theta_global = c->rope_theta_global; g.theta_local = c->rope_theta_local;
     g.q_scale = 1.0f / sqrtf(c->query_pre_attn_scalar);
-    bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) == hipSuccess &&
-              hipEventCreate(&e->ev0) == hipSuccess && hipEventCreate(&e->ev1) == hipSuccess;
+    bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) == hipSuccess;
     const size_t H = g.hidden, D = g.head_dim;
     e->L.resize(g.layers);
     ok = ok && dmalloc(&e->emb, (size_t)g.vocab * H) == hipSuccess && dmalloc(&e->n_final, H) == hipSuccess &&
@@ -538,16 +611,20 @@ void cqs_hip_embedder_destroy(cqs_hip_embedder* e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
-    void* g[] = {e->emb, e->n_final, e->dense1, e->dense2, e->rope_global, e->rope_local, e->x, e->y, e->hidden, e->out,
-                 e->xn, e->qkv, e->vt, e->attn, e->h, e->pooled, e->d1, e->d_tok, e->d_pos, e->d_seq_start,
-                 e->d_seq_len, e->d_vt_start, e->d_blk};
+    void* g[] = {e->emb, e->n_final, e->dense1, e->dense2, e->rope_global, e->rope_local};
     for (void* p : g) (void)hipFree(p);
+    free_scratch(e);
+    for (cqs_hip_embedder::Slot& sl : e->slot) {
+        if (sl.meta) (void)hipHostFree(sl.meta);
+        if (sl.out) (void)hipHostFree(sl.out);
+        if (sl.ev0) (void)hipEventDestroy(sl.ev0);
+        if (sl.ev1) (void)hipEventDestroy(sl.ev1);
+        if (sl.done) (void)hipEventDestroy(sl.done);
+    }
     for (LayerW& w : e->L) {
         void* ws[] = {w.wqkv, w.wo, w.wgu, w.wd, w.n_in, w.n_post_attn, w.n_pre_ffw, w.n_post_ffw, w.n_q, w.n_k};
         for (void* p : ws) (void)hipFree(p);
     }
-    if (e->ev0) (void)hipEventDestroy(e->ev0);
-    if (e->ev1) (void)hipEventDestroy(e->ev1);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -565,46 +642,155 @@ size_t cqs_hip_embedder_last_error(const cqs_hip_embedder* e, char* buf, size_t 
     return m;
 }
 
-static int32_t embed_common(cqs_hip_embedder* e, const int64_t* ids, const int64_t* mask, uint32_t B, uint32_t L,
-                            float* out, bool want_hidden) {
+// ---- submit / collect ---------------------------------------------------------------------------------------
+// submit: validate + pack into a free slot's pinned tables (host work), enqueue H2D + forward + pool / dense +
+// D2H on the engine's stream, return a ticket; nothing waits for the device.  collect: wait for that slot's
+// event, hand the rows out.  With kSlots tickets in flight the host packs batch i+1 (and the caller tokenises
+// batch i+2) while the device runs batch i - the overlap the reference gets from its parse -> embed -> write
+// channel pipeline (src/cli/pipeline/mod.rs:61-244), moved under the `session.run` seam.
+namespace {
+
+int32_t submit_locked(cqs_hip_embedder* e, uint32_t B, const std::function<int32_t(cqs_hip_embedder::Slot&)>& pack,
+                      uint64_t* ticket) {
+    if (e->poisoned.load(std::memory_order_acquire)) return CQS_HIP_ERR_POISONED;
+    if (!e->finalized) return efail(e, CQS_HIP_ERR_INVALID, "embed: weights not finalized");
+    if (!ticket) return efail(e, CQS_HIP_ERR_INVALID, "embed: null ticket");
+    *ticket = 0;
+    if (B == 0) return efail(e, CQS_HIP_ERR_INVALID, "embed: empty batch");
+    cqs_hip_embedder::Slot* sl = nullptr;
+    for (cqs_hip_embedder::Slot& c : e->slot)
+        if (c.ticket == 0) { sl = &c; break; }
+    if (!sl) return efail(e, CQS_HIP_ERR_INVALID, "embed: every submission slot is in flight (collect a ticket first)");
+    E_TRY(e, hipSetDevice(e->device));
+    int32_t rc = pack(*sl);
+    if (rc != CQS_HIP_OK) return rc;
+    hipStream_t st = e->stream;
+    const uint32_t H = e->g.hidden;
+    if (sl->M == 0) {
+        // every row empty: zero vectors (src/embedder/pooling.rs:113-119); still a ticket, nothing enqueued
+        memset(sl->out, 0, (size_t)B * H * sizeof(float));
+        E_TRY(e, hipEventRecord(sl->ev0, st));
+        E_TRY(e, hipEventRecord(sl->ev1, st));
+        E_TRY(e, hipEventRecord(sl->done, st));
+    } else {
+        rc = run_layers(e, *sl);
+        if (rc != CQS_HIP_OK) return rc;
+        const cqs::EmbedGeom& g = e->g;
+        E_TRY(e, cqs::launch_mean_pool(e->hidden, e->d_seq_start, e->d_seq_len, e->pooled, B, H, st));
+        E_TRY(e, cqs::launch_gemm_bf16(e->pooled, e->dense1, e->d1, B, g.dense_hidden, H, g.dense_hidden, cqs::GEMM_OUT_BF16, st));
+        E_TRY(e, cqs::launch_gemm_bf16(e->d1, e->dense2, e->out, B, H, g.dense_hidden, H, cqs::GEMM_OUT_F32, st));
+        E_TRY(e, hipEventRecord(sl->ev1, st));
+        E_TRY(e, hipMemcpyAsync(sl->out, e->out, (size_t)B * H * sizeof(float), hipMemcpyDeviceToHost, st));
+        E_TRY(e, hipEventRecord(sl->done, st));
+    }
+    sl->ticket = e->next_ticket++;
+    *ticket = sl->ticket;
+    return CQS_HIP_OK;
+}
+
+}  // namespace
+
+int32_t cqs_hip_embed_submit(cqs_hip_embedder* e, const int64_t* ids, const int64_t* mask, uint32_t B, uint32_t L,
+                             uint64_t* ticket) {
+    if (!e) return CQS_HIP_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (!ids || !mask || L == 0) return efail(e, CQS_HIP_ERR_INVALID, "embed: null buffer / empty sequence");
+    return submit_locked(e, B, [&](cqs_hip_embedder::Slot& sl) { return pack_padded(e, sl, ids, mask, B, L); }, ticket);
+}
+
+int32_t cqs_hip_embed_submit_ragged(cqs_hip_embedder* e, const int32_t* tokens, const uint32_t* lens, uint32_t B,
+                                    uint64_t* ticket) {
+    if (!e) return CQS_HIP_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (!lens || (!tokens && B)) return efail(e, CQS_HIP_ERR_INVALID, "embed: null buffer");
+    return submit_locked(e, B, [&](cqs_hip_embedder::Slot& sl) { return pack_ragged(e, sl, tokens, lens, B); }, ticket);
+}
+
+int32_t cqs_hip_embed_collect(cqs_hip_embedder* e, uint64_t ticket, float* out) {
+    if (!e) return CQS_HIP_ERR_INVALID;
+    cqs_hip_embedder::Slot* sl = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(e->mu);
+        if (!out || ticket == 0) return efail(e, CQS_HIP_ERR_INVALID, "collect: null buffer / ticket");
+        for (cqs_hip_embedder::Slot& c : e->slot)
+            if (c.ticket == ticket) { sl = &c; break; }
+        if (!sl) return efail(e, CQS_HIP_ERR_INVALID, "collect: unknown ticket");
+    }
+    // wait outside the lock: other threads may submit meanwhile; the slot stays ours until its ticket is cleared
+    (void)hipSetDevice(e->device);
+    const hipError_t he = hipEventSynchronize(sl->done);
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (he != hipSuccess) { sl->ticket = 0; return efail(e, CQS_HIP_ERR_DEVICE, "collect: device failure", he); }
+    const uint32_t H = e->g.hidden, B = sl->B;
+    memcpy(out, sl->out, (size_t)B * H * sizeof(float));
+    const int32_t* seq_len = sl->meta + (size_t)2 * sl->M + B;
+    for (uint32_t b = 0; b < B; ++b)   // empty rows: exact zeros, like the reference's zero-mask pooling
+        if (seq_len[b] == 0) memset(out + (size_t)b * H, 0, (size_t)H * sizeof(float));
+    float ms = -1.f;
+    if (hipEventElapsedTime(&ms, sl->ev0, sl->ev1) == hipSuccess) e->last_ms = ms;
+    sl->ticket = 0;
+    return CQS_HIP_OK;
+}
+
+// `session.run` (src/embedder/core.rs:1097): submit + collect.
+int32_t cqs_hip_embed(cqs_hip_embedder* e, const int64_t* ids, const int64_t* mask, uint32_t B, uint32_t L, float* out) {
+    if (!e) return CQS_HIP_ERR_INVALID;
+    if (B == 0) return CQS_HIP_OK;
+    if (!out) { std::lock_guard<std::mutex> lk(e->mu); return efail(e, CQS_HIP_ERR_INVALID, "embed: null buffer / empty sequence"); }
+    uint64_t t = 0;
+    const int32_t rc = cqs_hip_embed_submit(e, ids, mask, B, L, &t);
+    if (rc != CQS_HIP_OK) return rc;
+    return cqs_hip_embed_collect(e, t, out);
+}
+
+// Diagnostic twin (synchronous): final-norm hidden states [B, L, hidden], zeros at padded positions.
+int32_t cqs_hip_embed_hidden(cqs_hip_embedder* e, const int64_t* ids, const int64_t* mask, uint32_t B, uint32_t L, float* out) {
     if (!e) return CQS_HIP_ERR_INVALID;
     std::lock_guard<std::mutex> lk(e->mu);
     if (e->poisoned.load(std::memory_order_acquire)) return CQS_HIP_ERR_POISONED;
     if (!e->finalized) return efail(e, CQS_HIP_ERR_INVALID, "embed: weights not finalized");
     if (B == 0) return CQS_HIP_OK;
     if (!ids || !mask || !out || L == 0) return efail(e, CQS_HIP_ERR_INVALID, "embed: null buffer / empty sequence");
+    cqs_hip_embedder::Slot* sl = nullptr;
+    for (cqs_hip_embedder::Slot& c : e->slot)
+        if (c.ticket == 0) { sl = &c; break; }
+    if (!sl) return efail(e, CQS_HIP_ERR_INVALID, "embed: every submission slot is in flight (collect a ticket first)");
     E_TRY(e, hipSetDevice(e->device));
-    const uint32_t H = e->g.hidden;
-    Packed p;
-    int32_t rc = pack(e, ids, mask, B, L, p);
+    int32_t rc = pack_padded(e, *sl, ids, mask, B, L);
     if (rc != CQS_HIP_OK) return rc;
-    if (want_hidden) memset(out, 0, (size_t)B * L * H * sizeof(float));
-    else memset(out, 0, (size_t)B * H * sizeof(float));
-    if (p.M == 0) return CQS_HIP_OK;  // every mask row empty: zero vectors (src/embedder/pooling.rs:113-119)
-    rc = run_layers(e, p, B);
+    const uint32_t H = e->g.hidden;
+    memset(out, 0, (size_t)B * L * H * sizeof(float));
+    if (sl->M == 0) return CQS_HIP_OK;
+    rc = run_layers(e, *sl);
     if (rc != CQS_HIP_OK) return rc;
     hipStream_t st = e->stream;
-    if (want_hidden) {
-        E_TRY(e, hipEventRecord(e->ev1, st));
-        std::vector<float> packed((size_t)p.M * H);
-        E_TRY(e, hipMemcpyAsync(packed.data(), e->hidden, packed.size() * 4, hipMemcpyDeviceToHost, st));
-        E_TRY(e, hipStreamSynchronize(st));
-        for (uint32_t b = 0; b < B; ++b)
-            memcpy(out + (size_t)b * L * H, packed.data() + (size_t)p.seq_start[b] * H, (size_t)p.seq_len[b] * H * 4);
-    } else {
-        const cqs::EmbedGeom& g = e->g;
-        E_TRY(e, cqs::launch_mean_pool(e->hidden, e->d_seq_start, e->d_seq_len, e->pooled, B, H, st));
-        E_TRY(e, cqs::launch_gemm_bf16(e->pooled, e->dense1, e->d1, B, g.dense_hidden, H, g.dense_hidden, cqs::GEMM_OUT_BF16, st));
-        E_TRY(e, cqs::launch_gemm_bf16(e->d1, e->dense2, e->out, B, H, g.dense_hidden, H, cqs::GEMM_OUT_F32, st));
-        E_TRY(e, hipEventRecord(e->ev1, st));
-        E_TRY(e, hipMemcpyAsync(out, e->out, (size_t)B * H * 4, hipMemcpyDeviceToHost, st));
-        E_TRY(e, hipStreamSynchronize(st));
-        for (uint32_t b = 0; b < B; ++b)  // empty rows: exact zeros, like the reference's zero-mask pooling
-            if (p.seq_len[b] == 0) memset(out + (size_t)b * H, 0, (size_t)H * 4);
-    }
+    E_TRY(e, hipEventRecord(sl->ev1, st));
+    std::vector<float> packed((size_t)sl->M * H);
+    E_TRY(e, hipMemcpyAsync(packed.data(), e->hidden, packed.size() * 4, hipMemcpyDeviceToHost, st));
+    E_TRY(e, hipStreamSynchronize(st));
+    const int32_t* seq_start = sl->meta + (size_t)2 * sl->M;
+    const int32_t* seq_len = seq_start + B;
+    for (uint32_t b = 0; b < B; ++b)
+        memcpy(out + (size_t)b * L * H, packed.data() + (size_t)seq_start[b] * H, (size_t)seq_len[b] * H * 4);
     float ms = -1.f;
-    if (hipEventElapsedTime(&ms, e->ev0, e->ev1) == hipSuccess) e->last_ms = ms;
+    if (hipEventElapsedTime(&ms, sl->ev0, sl->ev1) == hipSuccess) e->last_ms = ms;
     return CQS_HIP_OK;
+}
+
+// `normalize_l2` (src/embedder/pooling.rs:60-67) over the rows of a host matrix: norm_sq folded left to right in
+// f32, scaled by 1/sqrt when > 0, zero rows stay zero.  Host helper for callers that keep embeddings in one array.
+void cqs_hip_normalize_l2_rows(float* rows, uint64_t n, uint32_t dim) {
+#pragma clang fp contract(off)   // Rust does not fuse x * x + acc: keep the reference's roundings
+    if (!rows) return;
+    for (uint64_t r = 0; r < n; ++r) {
+        float* v = rows + r * dim;
+        float norm_sq = 0.f;
+        for (uint32_t i = 0; i < dim; ++i) norm_sq += v[i] * v[i];
+        if (norm_sq > 0.f) {
+            const float inv = 1.0f / sqrtf(norm_sq);
+            for (uint32_t i = 0; i < dim; ++i) v[i] *= inv;
+        }
+    }
 }
 
 // Tuning aid (not part of the public header): average milliseconds of one C[M,N] = A[M,K] W[N,K]^T
@@ -633,13 +819,6 @@ float cqs_hip_debug_gemm_ms(uint32_t M, uint32_t N, uint32_t K, uint32_t iters, 
     (void)hipFree(A); (void)hipFree(W); (void)hipFree(C);
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     return ms / (float)iters;
-}
-
-int32_t cqs_hip_embed(cqs_hip_embedder* e, const int64_t* ids, const int64_t* mask, uint32_t B, uint32_t L, float* out) {
-    return embed_common(e, ids, mask, B, L, out, false);
-}
-int32_t cqs_hip_embed_hidden(cqs_hip_embedder* e, const int64_t* ids, const int64_t* mask, uint32_t B, uint32_t L, float* out) {
-    return embed_common(e, ids, mask, B, L, out, true);
 }
 
 }  // extern "C"

@@ -87,8 +87,6 @@ struct ShardSet {
 
 namespace {
 
-size_t n_shards(const cqs_hip_index* p) { return p->sh->shard.size(); }
-
 int32_t pfail(cqs_hip_index* p, int32_t code, const std::string& what) {
     p->last_error = what;
     if (code == CQS_HIP_ERR_DEVICE) p->poisoned.store(true, std::memory_order_release);

@@ -134,6 +134,42 @@ class HipEmbedEngine:
             raise EmbedderError(f"InferenceFailed: {self.last_error()} ({rc})")
         return out
 
+    def submit(self, input_ids: np.ndarray, attention_mask: np.ndarray) -> int:
+        """`cqs_hip_embed_submit`: enqueue a padded [B, L] batch, return its ticket (no device wait)."""
+        ids = np.ascontiguousarray(input_ids, dtype=np.int64)
+        mask = np.ascontiguousarray(attention_mask, dtype=np.int64)
+        if ids.shape != mask.shape or ids.ndim != 2:
+            raise EmbedderError("InferenceFailed: input_ids / attention_mask shape mismatch")
+        t = C.c_uint64()
+        rc = self._lib.cqs_hip_embed_submit(self._h, ids.ctypes.data_as(C.c_void_p), mask.ctypes.data_as(C.c_void_p),
+                                            ids.shape[0], ids.shape[1], C.byref(t))
+        if rc != _lib.OK:
+            raise EmbedderError(f"InferenceFailed: {self.last_error()} ({rc})")
+        return int(t.value)
+
+    def submit_ragged(self, tokens: np.ndarray, lens: np.ndarray) -> int:
+        """`cqs_hip_embed_submit_ragged`: sequences back to back (i32) + their lengths (u32)."""
+        tok = np.ascontiguousarray(tokens, dtype=np.int32)
+        ln = np.ascontiguousarray(lens, dtype=np.uint32)
+        if int(ln.sum()) != tok.size:
+            raise EmbedderError("InferenceFailed: lens do not add up to the token count")
+        t = C.c_uint64()
+        rc = self._lib.cqs_hip_embed_submit_ragged(self._h, tok.ctypes.data_as(C.c_void_p), ln.ctypes.data_as(C.c_void_p),
+                                                   ln.size, C.byref(t))
+        if rc != _lib.OK:
+            raise EmbedderError(f"InferenceFailed: {self.last_error()} ({rc})")
+        return int(t.value)
+
+    def collect(self, ticket: int, batch: int, out: Optional[np.ndarray] = None) -> np.ndarray:
+        """`cqs_hip_embed_collect`: wait for `ticket`, return its f32 [batch, dim] rows (not normalised)."""
+        if out is None:
+            out = np.empty((batch, self.dim()), dtype=np.float32)
+        assert out.flags["C_CONTIGUOUS"] and out.dtype == np.float32 and out.shape == (batch, self.dim())
+        rc = self._lib.cqs_hip_embed_collect(self._h, ticket, out.ctypes.data_as(C.c_void_p))
+        if rc != _lib.OK:
+            raise EmbedderError(f"InferenceFailed: {self.last_error()} ({rc})")
+        return out
+
     def run_hidden(self, input_ids: np.ndarray, attention_mask: np.ndarray) -> np.ndarray:
         ids = np.ascontiguousarray(input_ids, dtype=np.int64)
         mask = np.ascontiguousarray(attention_mask, dtype=np.int64)

@@ -276,6 +276,22 @@ size_t   cqs_hip_embedder_last_error(const cqs_hip_embedder* e, char* buf, size_
  * of range -> CQS_HIP_ERR_INVALID (`EmbedderError::InferenceFailed` in the shim). */
 int32_t cqs_hip_embed(cqs_hip_embedder* e, const int64_t* input_ids, const int64_t* attention_mask,
                       uint32_t batch, uint32_t seq_len, float* out);
+/* Asynchronous form of the same call, for the index pipeline (the embed stage is its bottleneck when the cache is
+ * cold, src/cli/pipeline/embedding.rs:226-421): submit validates and packs the batch into pinned staging, enqueues
+ * tables H2D + forward + D2H on the engine's stream and returns a ticket without waiting; collect waits for that
+ * ticket and copies its [batch, hidden] rows out.  Up to 3 tickets may be in flight: while the device runs batch i
+ * the host packs batch i+1 and the caller tokenises batch i+2.  A 4th submit without a collect ->
+ * CQS_HIP_ERR_INVALID.  Tickets may be collected in any order; results do not depend on what else is in flight.
+ * submit_ragged takes the batch without padding: `tokens` = the sequences' ids back to back (i32), lens[b] = length
+ * of sequence b (0 allowed -> zero vector) - what a length-sorted scheduler holds anyway. */
+int32_t cqs_hip_embed_submit(cqs_hip_embedder* e, const int64_t* input_ids, const int64_t* attention_mask,
+                             uint32_t batch, uint32_t seq_len, uint64_t* ticket);
+int32_t cqs_hip_embed_submit_ragged(cqs_hip_embedder* e, const int32_t* tokens, const uint32_t* lens, uint32_t batch,
+                                    uint64_t* ticket);
+int32_t cqs_hip_embed_collect(cqs_hip_embedder* e, uint64_t ticket, float* out);
+/* `normalize_l2` (src/embedder/pooling.rs:60-67) applied to each row of a host [n, dim] matrix, in place: f32
+ * left-to-right sum of squares, scale by 1/sqrt when > 0, zero rows stay zero.  Host code (no device work). */
+void cqs_hip_normalize_l2_rows(float* rows, uint64_t n, uint32_t dim);
 /* Diagnostic twin: final-norm hidden states f32 [batch, seq_len, hidden] (zeros at padded positions). */
 int32_t cqs_hip_embed_hidden(cqs_hip_embedder* e, const int64_t* input_ids, const int64_t* attention_mask,
                              uint32_t batch, uint32_t seq_len, float* out_hidden);
