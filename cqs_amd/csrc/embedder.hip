@@ -22,6 +22,7 @@
 
 #include "../../include/cqs_hip.h"
 #include "embed_kernels.h"
+#include "onnx_reader.h"
 
 using cqs::bf16_t;
 
@@ -453,6 +454,19 @@ int32_t load_safetensors(cqs_hip_embedder* e, const std::string& path, const std
     return CQS_HIP_OK;
 }
 
+// Is `name` one of the tensors cqs_hip_embedder_set_tensor accepts for this geometry?
+bool known_tensor(const cqs_hip_embedder* e, const std::string& name) {
+    if (name == "embed_tokens.weight" || name == "norm.weight" || name == "dense1.weight" || name == "dense2.weight") return true;
+    if (name.rfind("layers.", 0) != 0) return false;
+    const size_t dot = name.find('.', 7);
+    if (dot == std::string::npos) return false;
+    for (size_t i = 7; i < dot; ++i) if (name[i] < '0' || name[i] > '9') return false;
+    if ((uint32_t)atoi(name.substr(7, dot - 7).c_str()) >= e->g.layers) return false;
+    const std::string t = name.substr(dot + 1);
+    for (const char* k : kLayerTensors) if (t == k) return true;
+    return false;
+}
+
 }  // namespace
 
 extern "C" {
@@ -592,11 +606,29 @@ int32_t cqs_hip_embedder_load_dir(const char* dir, const cqs_hip_embed_config* c
         if (n.rfind("model.", 0) == 0) return n.substr(6);
         return n;
     };
-    rc = load_safetensors(e, d + "/model.safetensors", strip);
-    if (rc == CQS_HIP_OK)
-        rc = load_safetensors(e, d + "/2_Dense/model.safetensors", [](const std::string& n) { return n == "linear.weight" ? std::string("dense1.weight") : std::string(); });
-    if (rc == CQS_HIP_OK)
-        rc = load_safetensors(e, d + "/3_Dense/model.safetensors", [](const std::string& n) { return n == "linear.weight" ? std::string("dense2.weight") : std::string(); });
+    // What the reference's local-model hook holds (CQS_ONNX_DIR, src/embedder/download.rs:12-41): the structured
+    // layout `onnx/model.onnx` (src/embedder/models.rs:455-457) or the flat `model.onnx`, each with its external-data
+    // sidecar next to it (download.rs:82).  A Hugging Face checkpoint directory (model.safetensors + 2_Dense/ +
+    // 3_Dense/) is read too.
+    struct stat stt;
+    std::string onnx;
+    for (const char* cand : {"/onnx/model.onnx", "/model.onnx"})
+        if (onnx.empty() && stat((d + cand).c_str(), &stt) == 0) onnx = d + cand;
+    if (!onnx.empty()) {
+        std::string err;
+        const int fed = cqs_onnx::load(onnx, e->g.hidden, e->g.dense_hidden,
+            [&](const std::string& name, const float* data, uint64_t count, const std::vector<uint64_t>&) -> int {
+                if (!known_tensor(e, name)) return 0;                      // graph constants etc.
+                return cqs_hip_embedder_set_tensor(e, name.c_str(), data, count) == CQS_HIP_OK ? 1 : -1;
+            }, err);
+        if (fed < 0) rc = efail(e, CQS_HIP_ERR_INVALID, "load_dir: " + err + (e->last_error.empty() ? "" : " (" + e->last_error + ")"));
+    } else {
+        rc = load_safetensors(e, d + "/model.safetensors", strip);
+        if (rc == CQS_HIP_OK)
+            rc = load_safetensors(e, d + "/2_Dense/model.safetensors", [](const std::string& n) { return n == "linear.weight" ? std::string("dense1.weight") : std::string(); });
+        if (rc == CQS_HIP_OK)
+            rc = load_safetensors(e, d + "/3_Dense/model.safetensors", [](const std::string& n) { return n == "linear.weight" ? std::string("dense2.weight") : std::string(); });
+    }
     if (rc == CQS_HIP_OK) rc = cqs_hip_embedder_finalize(e);
     if (rc != CQS_HIP_OK) {
         fprintf(stderr, "[cqs_hip] embedder load_dir failed: %s\n", e->last_error.c_str());

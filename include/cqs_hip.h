@@ -256,10 +256,14 @@ void cqs_hip_embed_config_default(cqs_hip_embed_config* cfg);
 int32_t cqs_hip_embedder_create(const cqs_hip_embed_config* cfg, int32_t device, cqs_hip_embedder** out);
 int32_t cqs_hip_embedder_set_tensor(cqs_hip_embedder* e, const char* name, const float* data, uint64_t count);
 int32_t cqs_hip_embedder_finalize(cqs_hip_embedder* e);
-/* Convenience loader replacing `create_session(model_path, ..)` (src/embedder/provider.rs:349-447):
- * reads `model.safetensors` (+ `2_Dense/model.safetensors`, `3_Dense/model.safetensors`, tensor
- * `linear.weight`) from a local model directory — the hook the reference exposes for local files
- * is CQS_ONNX_DIR (src/embedder/download.rs:12-41).  F32 / BF16 / F16 tensors. */
+/* Loader replacing `create_session(model_path, ..)` (src/embedder/provider.rs:349-447).  Reads what the reference's
+ * local-model hook holds (CQS_ONNX_DIR, src/embedder/download.rs:12-41): `<dir>/onnx/model.onnx` (structured layout,
+ * src/embedder/models.rs:455-457) or `<dir>/model.onnx` (flat layout), with the external-data sidecar
+ * `model.onnx_data` beside it (download.rs:82) - the float initialisers are parsed straight from the protobuf wire
+ * format (no ONNX Runtime, no protobuf library): named parameters keep their names, `Linear` weights folded into
+ * transposed MatMul initialisers are resolved through the consuming node's module path, the two Dense layers by
+ * shape.  Without an ONNX file, a Hugging Face checkpoint directory is read instead: `model.safetensors`
+ * (+ `2_Dense/model.safetensors`, `3_Dense/model.safetensors`, tensor `linear.weight`).  F32 / BF16 / F16 tensors. */
 int32_t cqs_hip_embedder_load_dir(const char* model_dir, const cqs_hip_embed_config* cfg, int32_t device,
                                   cqs_hip_embedder** out);
 void cqs_hip_embedder_destroy(cqs_hip_embedder* e);

@@ -158,6 +158,110 @@ def test_load_dir_safetensors(hip, tmp_path):
     eng.close(); eng2.close()
 
 
+def _write_onnx_dir(root, w, cfg, flat):
+    """The reference's local artefact (CQS_ONNX_DIR, download.rs:12-41) in the shape exporters produce: named
+    parameters for the embedding table and the norm scales, `Linear` weights folded into anonymous TRANSPOSED MatMul
+    initialisers found through the consuming node's name, big tensors in the `model.onnx_data` sidecar."""
+    import onnx_bytes as ob
+    d = root if flat else root / "onnx"
+    d.mkdir(parents=True, exist_ok=True)
+    side = bytearray(b"\0" * 24)                      # offsets do not start at 0
+    nodes, inits, n_anon = [], [], [0]
+
+    def ext(arr, dtype=ob.FLOAT):
+        raw = ob.encode_values(arr, dtype)
+        off = len(side)
+        side.extend(raw)
+        side.extend(b"\0" * ((-len(side)) % 16))
+        return ("model.onnx_data", off, len(raw))
+
+    def linear(path, wt, dtype=ob.FLOAT, external=False, name_hint=None):
+        n_anon[0] += 1
+        iname = f"onnx::MatMul_{1000 + n_anon[0]}"
+        t = np.ascontiguousarray(wt.T)                # [in, out]: the MatMul operand
+        nodes.append(ob.node("MatMul", f"/model/{path.replace('.', '/', 9).replace('layers/', 'layers.')}/MatMul" if name_hint is None else name_hint,
+                             [f"h{n_anon[0]}", iname], [f"o{n_anon[0]}"]))
+        inits.append(ob.tensor(iname, t, dtype, "external" if external else "raw", external=ext(t, dtype) if external else None))
+
+    inits.append(ob.tensor("model.embed_tokens.weight", w["embed_tokens.weight"], ob.FLOAT, "external",
+                           external=ext(w["embed_tokens.weight"])))
+    nodes.append(ob.node("Gather", "/model/embed_tokens/Gather", ["model.embed_tokens.weight", "input_ids"], ["emb"]))
+    for l in range(cfg.layers):
+        p = f"layers.{l}."
+        for nm in ("input_layernorm", "post_attention_layernorm", "pre_feedforward_layernorm", "post_feedforward_layernorm"):
+            inits.append(ob.tensor("model." + p + nm + ".weight", w[p + nm + ".weight"], ob.FLOAT,
+                                   "float_data" if l == 0 else "raw", packed_dims=(l != 1)))
+        for nm in ("q_norm", "k_norm"):
+            inits.append(ob.tensor("model." + p + "self_attn." + nm + ".weight", w[p + "self_attn." + nm + ".weight"],
+                                   ob.BFLOAT16 if nm == "k_norm" else ob.FLOAT))
+        for nm in ("q_proj", "k_proj", "v_proj", "o_proj"):
+            wt = w[p + "self_attn." + nm + ".weight"]
+            linear(None, wt, ob.FLOAT16 if (nm == "v_proj" and l == 0) else ob.FLOAT, external=(nm == "q_proj"),
+                   name_hint=f"/model/layers.{l}/self_attn/{nm}/MatMul")
+        for nm in ("gate_proj", "up_proj", "down_proj"):
+            linear(None, w[p + "mlp." + nm + ".weight"], external=(nm == "down_proj"), name_hint=f"/model/layers.{l}/mlp/{nm}/MatMul")
+    inits.append(ob.tensor("model.norm.weight", w["norm.weight"]))
+    linear(None, w["dense1.weight"], name_hint="/dense/linear/MatMul")             # recognised by shape
+    linear(None, w["dense2.weight"], name_hint="/dense_1/linear/MatMul", external=True)
+    # things a real graph also holds and the reader must ignore
+    inits.append(ob.tensor("onnx::Reshape_77", np.array([1, -1, 256]), ob.INT64))
+    inits.append(ob.tensor("scalar_eps", np.float32(1e-6).reshape(()), ob.FLOAT))
+    nodes.append(ob.node("MatMul", "/model/rotary/MatMul", ["a", "b_not_an_initialiser"], ["c"]))
+    (d / "model.onnx").write_bytes(ob.model(nodes, inits))
+    (d / "model.onnx_data").write_bytes(bytes(side))
+    return d
+
+
+@pytest.mark.parametrize("flat", [False, True])
+def test_load_dir_onnx_initialisers(hip, tmp_path, flat):
+    """cqs_hip_embedder_load_dir on `onnx/model.onnx` (+ `model.onnx_data`) - what CQS_ONNX_DIR holds for the
+    reference (src/embedder/download.rs:12-41,82) - gives the same embeddings as the same weights set tensor by
+    tensor.  The file is written by the byte-level encoder in tests/onnx_bytes.py (no `onnx` package)."""
+    w = G.seeded_weights(SMALL, seed=21)
+    _write_onnx_dir(tmp_path, w, SMALL, flat)
+    eng, _ = make(SMALL, seed=21)
+    eng2 = HipEmbedEngine.load_dir(str(tmp_path), eng.cfg)
+    ids, mask = batch(SMALL, [40, 17, 3], seed=22)
+    a, b = eng.run(ids, mask), eng2.run(ids, mask)
+    # f16 on disk for one v_proj; everything else is bit-identical after the bf16 conversion
+    assert all(cos(a[i], b[i]) > 0.9999 for i in range(3))
+    assert np.max(np.abs(a - b)) <= 2e-2 * np.abs(a).max()
+    eng.close(); eng2.close()
+
+
+def test_load_dir_onnx_rejects_broken_files(hip, tmp_path):
+    import onnx_bytes as ob
+    w = G.seeded_weights(SMALL, seed=23)
+    cfg = default_config()
+    c = make(SMALL, seed=23)[0]
+    d = _write_onnx_dir(tmp_path / "ok", w, SMALL, flat=True)
+    # truncated sidecar -> error, not a crash
+    side = (d / "model.onnx_data").read_bytes()
+    (d / "model.onnx_data").write_bytes(side[: len(side) // 2])
+    with pytest.raises(Exception):
+        HipEmbedEngine.load_dir(str(d), c.cfg)
+    # a tensor missing -> finalize names it
+    d2 = tmp_path / "missing"
+    d2.mkdir()
+    (d2 / "model.onnx").write_bytes(ob.model([], [ob.tensor("model.norm.weight", w["norm.weight"])]))
+    with pytest.raises(Exception):
+        HipEmbedEngine.load_dir(str(d2), c.cfg)
+    # garbage bytes
+    d3 = tmp_path / "garbage"
+    d3.mkdir()
+    (d3 / "model.onnx").write_bytes(b"\xff" * 100)
+    with pytest.raises(Exception):
+        HipEmbedEngine.load_dir(str(d3), c.cfg)
+    # an external location that climbs out of the directory is refused (download.rs:17-29)
+    d4 = tmp_path / "escape"
+    d4.mkdir()
+    t = ob.tensor("model.norm.weight", w["norm.weight"], ob.FLOAT, "external", external=("../ok/model.onnx_data", 0, None))
+    (d4 / "model.onnx").write_bytes(ob.model([], [t]))
+    with pytest.raises(Exception):
+        HipEmbedEngine.load_dir(str(d4), c.cfg)
+    c.close()
+
+
 def test_long_sequences_and_many_rows(hip):
     """max_seq-long inputs (2048 tokens: many key blocks, window edges on both sides, multi-tile GEMMs) and a
     64-sequence ragged batch, against the fp32 oracle."""
