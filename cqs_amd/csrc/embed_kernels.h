@@ -38,6 +38,12 @@ enum GemmOut { GEMM_OUT_BF16 = 0, GEMM_OUT_F32 = 1, GEMM_OUT_GEGLU = 2 };
 hipError_t launch_gemm_bf16(const bf16_t* A, const bf16_t* W, void* C, uint32_t M, uint32_t N, uint32_t K,
                             uint32_t ldc, GemmOut out, hipStream_t st);
 
+// Second-generation kernel (gemm_kernels.hip): 256 x (64 tn) x 64 tiles, 8 waves in two rows that alternate load and
+// multiply intervals, counted-vmcnt LDS-DMA.  tn in {3, 4, 5} (GeGLU: 4 only); N % (64 tn) == 0, K % 64 == 0.
+// launch_gemm_bf16 picks between it and the 128 x 128 kernel by shape.
+hipError_t launch_gemm_p8(const bf16_t* A, const bf16_t* W, void* C, uint32_t M, uint32_t N, uint32_t K,
+                          uint32_t ldc, GemmOut out, int tn, hipStream_t st);
+
 // In place on qkv [M, (heads + 2 kv) * 256] bf16: per-head RMSNorm * (1 + w), RoPE from the
 // cos/sin table of the layer type, q additionally scaled by q_scale.  pos[m] = position in sequence.
 hipError_t launch_qk_norm_rope(bf16_t* qkv, const int32_t* pos, const float* wq, const float* wk,

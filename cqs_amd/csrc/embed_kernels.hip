@@ -435,7 +435,8 @@ __global__ __launch_bounds__(64 * WAVES) void attention_kernel(const bf16_t* __r
     }
 }
 
-// ---- GEMM: C[M,N] = A[M,K] W[N,K]^T, 128x128x64 tiles, 4 waves (2x2) of 64x64, 32x32x16 bf16 MFMA ----
+// ---- GEMM (first generation; gemm_kernels.hip holds the 256-row ping-pong kernel that takes the full rounds) ----
+// C[M,N] = A[M,K] W[N,K]^T, 128x128x64 tiles, 4 waves (2x2) of 64x64, 32x32x16 bf16 MFMA
 // Measured alternatives at M=16384 (tools/gemm_bench.py), all 620-730 TF like this one: register-staged
 // operands (ds_write_b128), a 256x128 tile with 4 waves of 128x64 and a 3-slot DMA ring (1 wave/SIMD: the
 // ~100-cycle DMA issue cannot overlap the wave's own MFMAs: 1.5x slower), the same tile with 8 waves and
@@ -568,130 +569,6 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
         }
 }
 
-// ---- wide-tile GEMM: 256 x TN x 64 tiles (TN = 192), 8 waves of 32 rows x TN columns -----------------------
-// One workgroup per CU (112 KiB of LDS).  Per flop it moves ~0.6x the L2 -> LDS bytes of the 128 x 128 tile, and
-// at M = 16384, N = 768 its 64 x 4 = 256 tiles are ONE round of the 256 CUs (the 128 x 128 kernel: 768 tiles =
-// three half-rounds).  Every wave owns whole 64-column gate|up groups, so a GeGLU epilogue would stay in
-// registers (implemented and tested, but N = 2304 runs 2 % faster on the 128 x 128 kernel).
-constexpr int kWM = 256;
-template <int OUT, int TN>
-__global__ __launch_bounds__(512) void gemm_bf16_wide_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
-                                                             void* __restrict__ Cv, uint32_t M, uint32_t N, uint32_t K,
-                                                             uint32_t ldc) {
-    extern __shared__ __attribute__((aligned(16))) bf16_t wsmem[];   // [buf][A 256 x 64 | B TN x 64]
-    constexpr int NT = TN / 32;                     // 32-column MFMA tiles per wave
-    constexpr int kBI = TN / 8;                     // 8-row DMA instructions for the B tile
-    constexpr uint32_t kStage = (kWM + TN) * 64;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int l31 = lane & 31, lh = lane >> 5;
-
-    const uint32_t nt = N / TN, mt = (M + kWM - 1) / kWM, total = nt * mt;
-    const uint32_t bid = blockIdx.x, xcd = bid % 8u, q = total / 8u, r = total % 8u;
-    const uint32_t tile = (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + bid / 8u;
-    const uint32_t m0 = (tile / nt) * kWM, n0 = (tile % nt) * TN;
-
-    // LDS-DMA staging (swizzle on the source address as in the 128 x 128 kernel): wave w copies A rows
-    // [32w, 32w + 32) (4 instructions of 8 rows) and the B instructions w, w + 8, w + 16 (< kBI)
-    constexpr int kBW = (kBI + 7) / 8;
-    const bf16_t* ga[4];
-    const bf16_t* gb[kBW];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const uint32_t row = (uint32_t)(wid * 32 + u * 8 + (lane >> 3));
-        const uint32_t c = (uint32_t)(lane & 7) ^ ((row >> 1) & 7u);
-        uint32_t ar = m0 + row;
-        ar = ar < M ? ar : M - 1u;
-        ga[u] = A + (size_t)ar * K + c * 8u;
-    }
-#pragma unroll
-    for (int u = 0; u < kBW; ++u) {
-        uint32_t row = (uint32_t)((u * 8 + wid) * 8 + (lane >> 3));
-        row = row < (uint32_t)TN ? row : (uint32_t)TN - 1u;
-        const uint32_t c = (uint32_t)(lane & 7) ^ ((row >> 1) & 7u);
-        gb[u] = W + (size_t)(n0 + row) * K + c * 8u;
-    }
-    auto stage = [&](uint32_t kt, int buf) {
-        bf16_t* dA = wsmem + (size_t)buf * kStage + (size_t)(wid * 32) * 64;
-        bf16_t* dB = wsmem + (size_t)buf * kStage + kWM * 64;
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ga[u] + (size_t)kt * 64u),
-                                             (__attribute__((address_space(3))) void*)(dA + u * 8 * 64), 16, 0, 0);
-#pragma unroll
-        for (int u = 0; u < kBW; ++u)
-            if (u * 8 + wid < kBI)   // wave-uniform
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gb[u] + (size_t)kt * 64u),
-                                                 (__attribute__((address_space(3))) void*)(dB + (u * 8 + wid) * 8 * 64), 16,
-                                                 0, 0);
-    };
-    f16v acc[NT];
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
-
-    const uint32_t nk = K / 64u;
-    stage(0, 0);
-    for (uint32_t kt = 0; kt < nk; ++kt) {
-        const int buf = (int)(kt & 1u);
-        __syncthreads();   // drains this wave's DMA (tile kt landed for everyone); the other buffer is free
-        if (kt + 1u < nk) stage(kt + 1u, buf ^ 1);
-        const bf16_t* sA = wsmem + (size_t)buf * kStage;
-        const bf16_t* sB = sA + kWM * 64;
-        bf8 af[2], bfr[2][NT];
-        auto read_frags = [&](int ks, int set) {
-            af[set] = *(const bf8*)(sA + swz((uint32_t)(wid * 32 + l31), (uint32_t)(2 * ks + lh)));
-#pragma unroll
-            for (int j = 0; j < NT; ++j)
-                bfr[set][j] = *(const bf8*)(sB + swz((uint32_t)(j * 32 + l31), (uint32_t)(2 * ks + lh)));
-        };
-        read_frags(0, 0);
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const int cur = ks & 1;
-            if (ks + 1 < 4) read_frags(ks + 1, cur ^ 1);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int j = 0; j < NT; ++j)
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cur], bfr[cur][j], acc[j], 0, 0, 0);
-        }
-    }
-    // epilogue: C tile element (row = (e&3) + 8(e>>2) + 4lh, col = l31) of acc[j]
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        const uint32_t row = m0 + (uint32_t)(wid * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh);
-        if (row >= M) continue;
-        if (OUT == GEMM_OUT_GEGLU) {
-            // columns come in groups of 64 = 32 gate channels + the same channels' up
-#pragma unroll
-            for (int j = 0; j < NT; j += 2) {
-                const uint32_t ch = (n0 + (uint32_t)(j * 32)) / 2u + (uint32_t)l31;
-                const float v = gelu_tanh(acc[j][e]) * acc[j + 1][e];
-                ((bf16_t*)Cv)[(size_t)row * ldc + ch] = (bf16_t)v;
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const uint32_t col = n0 + (uint32_t)(j * 32 + l31);
-                if (OUT == GEMM_OUT_F32) ((float*)Cv)[(size_t)row * ldc + col] = acc[j][e];
-                else ((bf16_t*)Cv)[(size_t)row * ldc + col] = (bf16_t)acc[j][e];
-            }
-        }
-    }
-}
-
-template <int OUT, int TN>
-static hipError_t launch_wide(const bf16_t* A, const bf16_t* W, void* C, uint32_t M, uint32_t N, uint32_t K, uint32_t ldc,
-                              hipStream_t st) {
-    const dim3 grid((N / TN) * ((M + kWM - 1) / kWM));
-    const size_t lds = (size_t)2 * (kWM + TN) * 64 * sizeof(bf16_t);
-    auto kern = gemm_bf16_wide_kernel<OUT, TN>;
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, A, W, C, M, N, K, ldc);
-    return hipGetLastError();
-}
-
 // ---- masked mean pool: block = (sequence, 256 hidden dims); 16 waves split the tokens, 4 loads in flight each ----
 // (96 workgroups for 32 sequences x 768 dims: the parallelism has to come from inside the workgroup)
 __global__ __launch_bounds__(1024) void mean_pool_kernel(const float* __restrict__ hidden,
@@ -770,14 +647,6 @@ hipError_t launch_gemm_bf16(const bf16_t* A, const bf16_t* W, void* C, uint32_t 
                             uint32_t ldc, GemmOut out, hipStream_t st) {
     if (M == 0) return hipSuccess;
     if (N % 128u || K % 64u) return hipErrorInvalidValue;
-#ifndef CQS_GEMM_WIDE
-#define CQS_GEMM_WIDE 1
-#endif
-    // The wide tile wins where it turns one and a half rounds of 128 x 128 tiles into one (N = 768: o_proj and
-    // down, +8..9 %).  Measured and left on the 128 x 128 kernel: the GeGLU GEMM (N = 2304: -2 %) and, with
-    // TN = 160, the QKV GEMM (N = 1280: +2.5 %, not worth a second instantiation).
-    // ... and only when its rounds beat the small tile's: a wide tile costs 2.64 small-tile rounds (measured), so
-    // e.g. 8.7k tokens x N = 768 (140 wide tiles = 1 round vs 414 small tiles = 2) stay on the 128 x 128 kernel.
     static int n_cu = 0;
     if (n_cu == 0) {
         int dev = 0;
@@ -785,18 +654,29 @@ hipError_t launch_gemm_bf16(const bf16_t* A, const bf16_t* W, void* C, uint32_t 
             hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
             n_cu = 256;
     }
-    const uint32_t cu = (uint32_t)n_cu;
-    const uint32_t wide_rounds = ((N / 192u) * ((M + 255u) / 256u) + cu - 1u) / cu;
-    const uint32_t small_rounds = ((N / 128u) * ((M + 127u) / 128u) + cu - 1u) / cu;
-    bool wide_pays = N % 192u == 0 && (float)wide_rounds * 2.64f < (float)small_rounds;
-    if (const char* f = getenv("CQS_HIP_GEMM_TILE")) {  // test hook: "wide" / "small" force one kernel
-        if (f[0] == 'w') wide_pays = N % 192u == 0;
-        else if (f[0] == 's') wide_pays = false;
+    // Kernel choice by rounds x measured cost of one round of tiles (microseconds at K = 768 on an MI355X, launch to
+    // launch; a round of the 256-row kernels costs ~8 us of prologue + epilogue on top of its K-steps, so they only
+    // pay when their rounds are well filled):  128 x 128: 9 | 256 x 192: 24 | 256 x 256: 25.5 | 256 x 320: 32.5.
+    // GeGLU pairs gate / up columns inside 64-column groups: 256 x 256 only.
+    const float kscale = (float)K / 768.f;
+    auto rounds = [&](uint32_t bm, uint32_t bn) { return (float)(((N / bn) * ((M + bm - 1u) / bm) + (uint32_t)n_cu - 1u) / (uint32_t)n_cu); };
+    int tn = 0;                                              // 0 = the 128 x 128 kernel
+    float best = rounds(128u, 128u) * (3.f + 6.f * kscale);
+    const bool fits = (uint64_t)M * K < (1ull << 31) && (uint64_t)N * K < (1ull << 31);
+    const float cost[6] = {0.f, 0.f, 0.f, 24.f, 25.5f, 32.5f};
+    for (int t = 3; t <= 5 && fits; ++t) {
+        if (N % (64u * (uint32_t)t) || (out == GEMM_OUT_GEGLU && t != 4)) continue;
+        const float c = rounds(256u, 64u * (uint32_t)t) * (8.f + (cost[t] - 8.f) * kscale);
+        if (c < best) { best = c; tn = t; }
     }
-    if (CQS_GEMM_WIDE && wide_pays && N <= 1152u && out != GEMM_OUT_GEGLU) {
-        if (out == GEMM_OUT_F32) return launch_wide<GEMM_OUT_F32, 192>(A, W, C, M, N, K, ldc, st);
-        return launch_wide<GEMM_OUT_BF16, 192>(A, W, C, M, N, K, ldc, st);
+    if (const char* f = getenv("CQS_HIP_GEMM_TILE")) {  // test hook: "small" / "pp:<tn>" force one kernel
+        if (f[0] == 's') tn = 0;
+        else if (f[0] == 'p') {
+            const int t = f[2] == ':' ? atoi(f + 3) : 4;
+            tn = (t >= 3 && t <= 5 && fits && N % (64u * (uint32_t)t) == 0 && (out != GEMM_OUT_GEGLU || t == 4)) ? t : 0;
+        }
     }
+    if (tn) return launch_gemm_p8(A, W, C, M, N, K, ldc, out, tn, st);
     const dim3 grid((N / 128u) * ((M + 127u) / 128u)), block(256);
     switch (out) {
         case GEMM_OUT_BF16: hipLaunchKernelGGL(gemm_bf16_kernel<GEMM_OUT_BF16>, grid, block, 0, st, A, W, C, M, N, K, ldc); break;

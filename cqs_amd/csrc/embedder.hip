@@ -825,6 +825,16 @@ void cqs_hip_normalize_l2_rows(float* rows, uint64_t n, uint32_t dim) {
     }
 }
 
+// Test / tuning aid (not part of the public header): one GEMM launch on caller-provided device buffers
+// (bf16 A [M,K], bf16 W [N,K], C per out_kind) on `stream`; the kernel is chosen like in the forward
+// (CQS_HIP_GEMM_TILE forces one).
+int32_t cqs_hip_debug_gemm_run(const void* A, const void* W, void* C, uint32_t M, uint32_t N, uint32_t K, uint32_t ldc,
+                               int32_t out_kind, void* stream) {
+    const hipError_t e = cqs::launch_gemm_bf16((const bf16_t*)A, (const bf16_t*)W, C, M, N, K, ldc, (cqs::GemmOut)out_kind,
+                                               (hipStream_t)stream);
+    return e == hipSuccess ? CQS_HIP_OK : CQS_HIP_ERR_DEVICE;
+}
+
 // Tuning aid (not part of the public header): average milliseconds of one C[M,N] = A[M,K] W[N,K]^T
 // launch over `iters` back-to-back launches on random bf16 operands.
 float cqs_hip_debug_gemm_ms(uint32_t M, uint32_t N, uint32_t K, uint32_t iters, int32_t out_kind) {

@@ -1,0 +1,334 @@
+// gemm_kernels.hip — bf16 GEMM for the embedding forward, second generation: C[M,N] = A[M,K] W[N,K]^T on
+// 256 x (64 TN) x 64 tiles, 8 waves (2 per SIMD, one workgroup per CU), v_mfma_f32_16x16x32_bf16.
+//
+// Why a second kernel (gemm_bf16_kernel in embed_kernels.hip stays for small / odd shapes and partly filled rounds):
+// a 128 x 128 tile moves 32 KB of operands L2 -> LDS per 64-deep K-step for 512 MFMA cycles per SIMD - 64 B/clk/CU
+// against the ~56 B/clk/CU an XCD's L2 delivers - and re-reads the A panel once per 128 output columns (PMC, round 2:
+// 169 MB fetched by the GeGLU GEMM against 28 MB of operands).  A 256 x 256 tile needs half of both.
+//   * wave grid 2 (M) x 4 (N): a wave owns 128 rows x 16 TN columns = 8 x TN accumulator tiles (128 regs at TN = 4);
+//     per 32-deep k-step 8 + TN fragment reads feed 8 TN MFMAs;
+//   * operands by LDS-DMA (global_load_lds_dwordx4, 16 B per lane, full 128-B lines, bank swizzle on the SOURCE
+//     address), counted `s_waitcnt vmcnt(N)` (never 0 in the main loop) + raw `s_barrier`: the DMA stays in flight
+//     across barriers (a __syncthreads() would drain it);
+//   * operand roles swapped: W rows are the MFMA's A operand, activation rows its B operand, so a lane ends up
+//     with 4 CONSECUTIVE output columns of one row (GeGLU pairs stay in-lane);
+//   * PING-PONG time structure (see gemm_pp_kernel) and an LDS-staged epilogue that stores whole rows.
+// History (measured on 4096^3, random operands): all waves in lock-step with fragments read in the phase that uses
+// them 1058-1150 TF; the same with fragments prefetched one phase ahead 1030-1070 TF (ablations: MFMA alone half the
+// time, DMA alone the other half, nothing overlapped because every wave did the same thing at the same time);
+// ping-pong 1290-1360 TF.
+#include "embed_kernels.h"
+
+#include <cstdlib>
+#include <type_traits>
+
+namespace cqs {
+
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int kP8M = 256;                 // tile rows
+constexpr int kARegion = 256 * 64;        // elements of the A tile per LDS buffer (32 KB)
+
+__device__ __forceinline__ float p8_gelu_tanh(float x) {
+    const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+    const float u2 = 2.0f * k0 * (x + k1 * x * x * x);
+    return x * __frcp_rn(1.0f + __expf(-u2));
+}
+
+#define P8_WAIT_VM(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
+// the LDS reads a phase issued have long returned by its end; the explicit wait makes the refill of their slot
+// (issued by other waves right after the barrier) safe by construction
+#ifdef P8_ABLATE_NOBAR
+#define P8_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#else
+#define P8_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#endif
+
+// LDS image of one buffer: [A: 256 rows][B: 64 TN rows], 128 B (64 bf16) per row, 16-B chunk c of row R stored at
+// chunk c ^ ((R >> 1) & 7) (conflict-free 16 x 32 fragment reads, see embed_kernels.hip swz()).  Row order:
+//   A region row R: piece h = R / 128, m-tile t = (R % 128) / 32, wave row wm = (R / 16) % 2, r = R % 16
+//                   -> tile row m = wm * 128 + (4 h + t) * 16 + r
+//   B region row R: n-tile t = R / 64 (tiles [0, TN0) = piece B0, the rest B1), wn = (R / 16) % 4, r = R % 16
+//                   -> tile column n = wn * 16 TN + t * 16 + r
+// ---- the kernel: ping-pong time structure -------------------------------------------------------------------------
+// With all eight waves in lock-step (issue DMA, read fragments, wait, multiply - everybody at the same time) the matrix
+// pipe idles while a wave does anything else.  Here the workgroup's two wave rows run ONE INTERVAL apart (waves 0-3 start, waves 4-7 take one extra barrier first
+// and one fewer at the end): every wave alternates a LOAD interval (fragment reads for its next multiply, DMA refills,
+// counted DMA wait) with an MMA interval (32 MFMAs, nothing else), and on every SIMD one wave multiplies while its
+// partner loads.  A K-tile is two phases (A half h x the whole B tile); pieces A0 | B | A1:
+//   LOAD(kt,0): read A0(kt), B(kt)   | refill A1's slot of buffer kt+1 (last read in phase (kt-1,1)) | wait A1(kt)
+//   LOAD(kt,1): read A1(kt)          | refill A0 and B of K-tile kt+2 (read in phase (kt,0))         | wait A0,B(kt+1)
+// A piece read by both wave rows is dead one interval after the later row's LOAD; the refill sits one phase later, so
+// the same program is hazard-free for both rows.  DMA flight time: two phases (four intervals).
+template <int TN, int OUT>
+__global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
+                                                         void* __restrict__ Cv, uint32_t M, uint32_t N, uint32_t K,
+                                                         uint32_t ldc) {
+    constexpr int BN = 64 * TN;
+    constexpr int kBuf = (kP8M + BN) * 64;                      // elements per LDS buffer
+    constexpr int PA = 2, PB = TN;                              // DMA instructions per wave: an A half / the B tile
+    extern __shared__ __attribute__((aligned(16))) bf16_t p8smem[];   // [2][A 256 x 64 | B BN x 64]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 2, wn = wid & 3;
+    const int l15 = lane & 15, lg = lane >> 4;
+
+    const uint32_t nt = N / BN, mt = (M + kP8M - 1) / kP8M, total = nt * mt;
+    const uint32_t bid = blockIdx.x, xcd = bid % 8u, q8 = total / 8u, r8 = total % 8u;
+    const uint32_t tile = (xcd < r8 ? xcd * (q8 + 1u) : r8 * (q8 + 1u) + (xcd - r8) * q8) + bid / 8u;
+    const uint32_t m0 = (tile / nt) * kP8M, n0 = (tile % nt) * BN;
+
+    // DMA sources.  Instruction i of a piece covers 8 LDS rows: lane -> row (lane >> 3), physical chunk (lane & 7) ->
+    // logical chunk (lane & 7) ^ ((R >> 1) & 7).  For the A piece h, instruction j of wave w (i = w + 8 j):
+    //   tile row m = ((w >> 1) & 1) * 128 + (4 h + (w >> 2) + 2 j) * 16 + (w & 1) * 8 + (lane >> 3)
+    // and for n-tile t of the B tile: column n = (w >> 1) * 16 TN + t * 16 + (w & 1) * 8 + (lane >> 3); the swizzle term
+    // depends on (w & 1, lane) only.  So ONE per-lane byte offset per operand lives in a VGPR; the (h, j) / t parts are
+    // wave-uniform and go into the scalar base.  In the last, partial M tile the lanes whose row is >= M read row M - 1
+    // instead (any finite row: their outputs are never stored).
+    const uint32_t rr = (uint32_t)((wid & 1) * 8 + (lane >> 3));
+    const uint32_t lcw = (uint32_t)(lane & 7) ^ ((rr >> 1) & 7u);
+    const uint32_t offA0 = ((((uint32_t)(wid >> 1) & 1u) * 128u + (uint32_t)(wid >> 2) * 16u + rr) * K + lcw * 8u) * 2u;
+    const uint32_t offB0 = (((uint32_t)(wid >> 1) * (uint32_t)(16 * TN) + rr) * K + lcw * 8u) * 2u;
+    const size_t rowK = (size_t)K * 32u;        // bytes of 16 rows
+    const char* const gA = (const char*)(A + (size_t)m0 * K);
+    const char* const gW = (const char*)(W + (size_t)n0 * K);
+    // LDS-DMA by hand (global_load_lds_dwordx4 with a scalar base + one 32-bit lane offset): through the builtin hipcc
+    // hoists one 64-bit VGPR address per instruction out of the K loop (18-22 VGPRs this kernel does not have).  M0 =
+    // LDS byte address of the wave's 1 KiB; nothing else in this kernel uses M0.  The statement is invisible to hipcc's
+    // waitcnt bookkeeping, which is what the counted vmcnt scheme wants anyway.
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) bf16_t*)p8smem;
+    auto dma = [&](const char* sbase, uint32_t voff, uint32_t lds_elem) {
+        const uint32_t m0v = lds0 + lds_elem * 2u;
+        asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                     :: "s"(m0v), "v"(voff), "s"(sbase) : "memory");
+    };
+    const uint32_t rows_left = M - m0;           // >= 1
+    const uint32_t offClamp = ((rows_left - 1u) * K + lcw * 8u) * 2u;
+    auto stage_a = [&](int h, uint32_t kt, int par) {
+#pragma unroll
+        for (int j = 0; j < PA; ++j) {
+            const uint32_t lds_elem = (uint32_t)(par * kBuf + (h * 128 + (wid + 8 * j) * 8) * 64);
+            const uint32_t row0 = ((uint32_t)(wid >> 1) & 1u) * 128u + (uint32_t)(4 * h + (wid >> 2) + 2 * j) * 16u;   // of rr = 0
+            if (row0 + 16u <= rows_left) {           // wave-uniform: the whole instruction is inside the matrix
+                dma(gA + ((size_t)kt * 128u + (size_t)(4 * h + 2 * j) * rowK), offA0, lds_elem);
+            } else {
+                const uint32_t voff = (row0 + rr < rows_left) ? offA0 + (uint32_t)(4 * h + 2 * j) * (uint32_t)rowK : offClamp;
+                dma(gA + (size_t)kt * 128u, voff, lds_elem);
+            }
+        }
+    };
+    auto stage_b = [&](uint32_t kt, int par) {
+#pragma unroll
+        for (int t = 0; t < TN; ++t)
+            dma(gW + ((size_t)kt * 128u + (size_t)t * rowK), offB0, (uint32_t)(par * kBuf + kARegion + (t * 64 + wid * 8) * 64));
+    };
+
+    const uint32_t sw = (uint32_t)(lane >> 1) & 7u;
+    const bf16_t* la[2];
+    const bf16_t* lb[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const uint32_t f = (uint32_t)l15 * 64u + (((uint32_t)(4 * s + lg)) ^ sw) * 8u;
+        la[s] = p8smem + (uint32_t)(wm * 16) * 64u + f;
+        lb[s] = p8smem + (uint32_t)kARegion + (uint32_t)(wn * 16) * 64u + f;
+    }
+
+    f4 acc[8][TN];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f4)(0.f);
+    bf8 xa[4][2];           // the current A half: [m-tile][k-sub]
+    bf8 wb[TN][2];          // the K-tile's W fragments (read in phase 0, kept for phase 1)
+
+    auto read_a = [&](int par, int h) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) xa[t][s] = *(const bf8*)(la[s] + (par * kBuf + h * 128 * 64 + t * 32 * 64));
+    };
+    auto read_b = [&](int par) {
+#pragma unroll
+        for (int t = 0; t < TN; ++t)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) wb[t][s] = *(const bf8*)(lb[s] + (par * kBuf + t * 64 * 64));
+    };
+    auto mma = [&](int h) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[4 * h + t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[j][s], xa[t][s], acc[4 * h + t][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    // DMA pieces in issue order: A0 B A1 of K-tile 0, 1, 2, ... (index 3 kt + pos; PA / PB / PA instructions per wave).
+    const uint32_t nk = K / 64u;
+    const uint32_t n_pieces = 3u * nk;
+    constexpr int kCnt[3] = {PA, PB, PA};
+    auto wait_tail = [&](auto pos_c, uint32_t needed_idx) {   // fewer than three younger pieces exist
+        constexpr int pos = decltype(pos_c)::value;
+        if (needed_idx >= n_pieces) return;
+        switch (n_pieces - 1u - needed_idx) {
+            case 0: P8_WAIT_VM(0); break;
+            case 1: P8_WAIT_VM(kCnt[(pos + 1) % 3]); break;
+            case 2: P8_WAIT_VM(kCnt[(pos + 1) % 3] + kCnt[(pos + 2) % 3]); break;
+            default: P8_WAIT_VM(PA + PB + PA); break;
+        }
+    };
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    constexpr int kAll = PA + PB + PA;
+
+    // prologue (all waves together): A0 B A1 of K-tile 0, A0 B of K-tile 1; A0 / B of K-tile 0 must have landed
+    stage_a(0, 0u, 0); stage_b(0u, 0); stage_a(1, 0u, 0);
+    if (nk > 1u) { stage_a(0, 1u, 1); stage_b(1u, 1); }
+    if (nk > 1u) P8_WAIT_VM(kAll); else P8_WAIT_VM(PA);       // younger than B(0): A1(0) | A0(1) B(1)
+    P8_BARRIER();
+    if (wm == 1) P8_BARRIER();                                 // wave row 1 runs one interval behind
+
+    auto tile_body = [&](uint32_t kt, auto par_c) {
+        constexpr int par = decltype(par_c)::value;
+        const bool steady = kt + 2u < nk;                      // every piece up to B (kt+2) exists
+        // LOAD (kt, 0)
+        read_a(par, 0);
+        read_b(par);
+        if (kt + 1u < nk) stage_a(1, kt + 1u, par ^ 1);
+        if (steady) P8_WAIT_VM(kAll); else wait_tail(I2{}, 3u * kt + 2u);        // A1 (kt); younger: A0 B A1 (kt+1)
+        P8_BARRIER();
+        mma(0);
+        P8_BARRIER();
+        // LOAD (kt, 1)
+        read_a(par, 1);
+        if (kt + 2u < nk) { stage_a(0, kt + 2u, par); stage_b(kt + 2u, par); }
+        if (steady) P8_WAIT_VM(kAll); else wait_tail(I1{}, 3u * kt + 4u);        // B (kt+1); younger: A1 (kt+1) A0 B (kt+2)
+        P8_BARRIER();
+        mma(1);
+        P8_BARRIER();
+    };
+    for (uint32_t kt = 0; kt < nk; kt += 2u) {
+        tile_body(kt, P0{});
+        if (kt + 1u < nk) tile_body(kt + 1u, P1{});
+    }
+    if (wm == 0) P8_BARRIER();                                 // wave row 0 waits for row 1's last interval
+
+    // ---- epilogue: acc[i][j][r] = C[m = wm*128 + i*16 + l15][n = wn*16TN + j*16 + 4 lg + r]
+    if (OUT == GEMM_OUT_F32) {           // (only the two tiny Dense GEMMs of the head: direct 16-byte stores)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const uint32_t row = m0 + (uint32_t)(wm * 128 + i * 16 + l15);
+            if (row >= M) continue;
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                *(f4*)((float*)Cv + (size_t)row * ldc + n0 + (uint32_t)(wn * 16 * TN + j * 16 + 4 * lg)) = acc[i][j];
+        }
+        return;
+    }
+    // bf16 / GeGLU: through LDS, so that the workgroup writes WHOLE rows of its tile (a lane's 8 bytes of a 16 x 16
+    // accumulator tile are a quarter of a 32-byte segment: stored directly, every 128-byte line is written in four
+    // pieces by four instructions - measured: the store phase was 25-35 % of these K = 768 GEMMs).  Two passes of 128
+    // rows (m-tiles 4p .. 4p+3 of both wave rows); LDS row = OC output columns + 8 bytes (bank shift 2 dwords / row).
+    {
+        constexpr int OC = OUT == GEMM_OUT_GEGLU ? BN / 2 : BN;     // output columns of the workgroup tile
+        constexpr int kStride = OC + 4;                             // elements
+        constexpr int kCPR = OC / 4;                                // 8-byte chunks per row
+        bf16_t* const stage = p8smem;                               // 128 x kStride elements <= 80 KiB + pad
+        const uint32_t oc0 = OUT == GEMM_OUT_GEGLU ? n0 / 2u : n0;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int i = 4 * p + t;
+                bf16_t* rowp = stage + (size_t)(wm * 64 + t * 16 + l15) * kStride;
+                if (OUT == GEMM_OUT_GEGLU) {
+                    static_assert(OUT != GEMM_OUT_GEGLU || TN == 4, "GeGLU epilogue needs 64 columns per wave");
+                    // W rows interleaved per 64: 32 gate rows then the same channels' 32 up rows (embedder.hip)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        bf4 o;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) o[r] = (bf16_t)(p8_gelu_tanh(acc[i][j][r]) * acc[i][(j + 2) % TN][r]);
+                        *(bf4*)(rowp + wn * 32 + j * 16 + 4 * lg) = o;
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        bf4 o;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) o[r] = (bf16_t)acc[i][j][r];
+                        *(bf4*)(rowp + wn * 16 * TN + j * 16 + 4 * lg) = o;
+                    }
+                }
+            }
+            __syncthreads();
+            for (uint32_t c = (uint32_t)tid; c < 128u * (uint32_t)kCPR; c += 512u) {
+                const uint32_t r = c / (uint32_t)kCPR, cc = c % (uint32_t)kCPR;
+                const uint32_t row = m0 + (r >> 6) * 128u + (uint32_t)(4 * p) * 16u + (r & 63u);
+                if (row < M) {
+#ifdef P8_ABLATE_NOSTORE
+                    if (acc[0][0][0] != 12345.678f) continue;
+#endif
+                    *(bf4*)((bf16_t*)Cv + (size_t)row * ldc + oc0 + cc * 4u) = *(const bf4*)(stage + (size_t)r * kStride + cc * 4u);
+                }
+            }
+            if (p == 0) __syncthreads();
+        }
+    }
+}
+
+template <int TN, int OUT>
+hipError_t launch_p8(const bf16_t* A, const bf16_t* W, void* C, uint32_t M, uint32_t N, uint32_t K, uint32_t ldc,
+                     hipStream_t st) {
+    constexpr int BN = 64 * TN;
+    const dim3 grid((N / BN) * ((M + kP8M - 1) / kP8M));
+    const size_t lds = (size_t)2 * (kP8M + BN) * 64 * sizeof(bf16_t);
+    auto kern = gemm_pp_kernel<TN, OUT>;
+    static bool attr_set = false;   // per instantiation
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, A, W, C, M, N, K, ldc);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+// tn: n-tiles per wave (tile width 64 tn: 192 / 256 / 320); N % (64 tn) == 0, K % 64 == 0, M * K < 2^31 elements;
+// GeGLU: tn = 4 only.
+hipError_t launch_gemm_p8(const bf16_t* A, const bf16_t* W, void* C, uint32_t M, uint32_t N, uint32_t K, uint32_t ldc,
+                          GemmOut out, int tn, hipStream_t st) {
+    if (M == 0) return hipSuccess;
+    if (K % 64u || K < 64u || tn < 3 || tn > 5 || N % (64u * (uint32_t)tn) || (uint64_t)M * K >= (1ull << 31) ||
+        (uint64_t)N * K >= (1ull << 31))
+        return hipErrorInvalidValue;
+#define P8_CASE(TNV)                                                                                      \
+    case TNV:                                                                                             \
+        if (out == GEMM_OUT_BF16) return launch_p8<TNV, GEMM_OUT_BF16>(A, W, C, M, N, K, ldc, st);        \
+        if (out == GEMM_OUT_F32) return launch_p8<TNV, GEMM_OUT_F32>(A, W, C, M, N, K, ldc, st);          \
+        break;
+    switch (tn) {
+        P8_CASE(3)
+        P8_CASE(5)
+        case 4:
+            if (out == GEMM_OUT_BF16) return launch_p8<4, GEMM_OUT_BF16>(A, W, C, M, N, K, ldc, st);
+            if (out == GEMM_OUT_F32) return launch_p8<4, GEMM_OUT_F32>(A, W, C, M, N, K, ldc, st);
+            return launch_p8<4, GEMM_OUT_GEGLU>(A, W, C, M, N, K, ldc, st);
+        default: break;
+    }
+#undef P8_CASE
+    return hipErrorInvalidValue;
+}
+
+}  // namespace cqs

@@ -280,7 +280,9 @@ int load(const std::string& model_path, uint32_t hidden, uint32_t dense_hidden, 
                 else vals[i] = f16_to_f32(h);
             }
         }
-        std::string name;
+        // candidate names, most specific first: the consumer's module path / the tensor's own name, then the
+        // sentence-transformers Dense layers by shape (their node names vary by exporter)
+        std::vector<std::string> names;
         const float* out = vals.data();
         std::vector<uint64_t> dims = t.dims;
         const auto mm = matmul_of.find(t.name);
@@ -292,19 +294,17 @@ int load(const std::string& model_path, uint32_t hidden, uint32_t dense_hidden, 
                 for (uint64_t n = 0; n < N; ++n) tr[n * K + k] = vals[k * N + n];
             out = tr.data();
             dims = {N, K};
-            if (K == hidden && N == dense_hidden) name = "dense1.weight";
-            else if (K == dense_hidden && N == hidden) name = "dense2.weight";
-            else name = mm->second;
+            if (!mm->second.empty()) names.push_back(mm->second);
         } else {
-            name = strip_model(t.name);
-            // sentence-transformers Dense modules exported with their parameter names
-            if (t.dims.size() == 2 && t.dims[0] == dense_hidden && t.dims[1] == hidden && name.find("linear.weight") != std::string::npos) name = "dense1.weight";
-            else if (t.dims.size() == 2 && t.dims[0] == hidden && t.dims[1] == dense_hidden && name.find("linear.weight") != std::string::npos) name = "dense2.weight";
+            names.push_back(strip_model(t.name));
         }
-        if (name.empty()) continue;
-        const int rc = sink(name, out, count, dims);
-        if (rc < 0) { err = "tensor " + t.name + " (as " + name + ") rejected"; return -1; }
-        fed += rc;
+        if (dims.size() == 2 && dims[0] == dense_hidden && dims[1] == hidden) names.push_back("dense1.weight");
+        if (dims.size() == 2 && dims[0] == hidden && dims[1] == dense_hidden) names.push_back("dense2.weight");
+        for (const std::string& name : names) {
+            const int rc = sink(name, out, count, dims);
+            if (rc < 0) { err = "tensor " + t.name + " (as " + name + ") rejected"; return -1; }
+            if (rc > 0) { fed += rc; break; }
+        }
     }
     return fed;
 }

@@ -330,10 +330,10 @@ def test_full_depth_full_geometry(hip):
     eng.close()
 
 
-@pytest.mark.parametrize("tile", ["wide", "small"])
+@pytest.mark.parametrize("tile", ["small", "pp:3", "pp:4", "pp:5"])
 def test_gemm_tile_kernels(hip, tile, monkeypatch):
-    """The forward has two GEMM kernels (128 x 128 tiles; 256 x 192 tiles for N = 768 when the batch fills whole
-    rounds of CUs).  Small test batches never pick the wide one by themselves: force each and compare with the
+    """The forward has two GEMM kernels (128 x 128 tiles; the 256 x {192, 256, 320} ping-pong kernel where it fills whole
+    rounds of CUs).  Small test batches never pick the big tiles by themselves: force each and compare with the
     fp32 oracle at hidden = 768 (ragged M: the last 256-row tile is partly empty)."""
     monkeypatch.setenv("CQS_HIP_GEMM_TILE", tile)
     cfg = G.GemmaConfig(vocab_size=1024, hidden=768, layers=4, heads=3, kv_heads=1, head_dim=256, intermediate=1152,
@@ -350,3 +350,40 @@ def test_gemm_tile_kernels(hip, tile, monkeypatch):
     err = np.abs(hid[live] - href[live])
     assert err.mean() / np.abs(href[live]).mean() < 0.02
     eng.close()
+
+
+@pytest.mark.parametrize("tile", ["small", "pp:3", "pp:4", "pp:5"])
+def test_gemm_kernels_exact_integer_data(hip, tile, monkeypatch):
+    """Each GEMM kernel alone against torch on small-integer bf16 operands (every product and partial sum is exact in
+    f32, so the comparison is bit-exact and a transposed / permuted fragment cannot hide): asymmetric operands,
+    ragged M, the three epilogues, K from one K-tile (64) up to 1152."""
+    import ctypes as C
+    import torch
+    monkeypatch.setenv("CQS_HIP_GEMM_TILE", tile)
+    f = _lib.load().cqs_hip_debug_gemm_run
+    f.restype = C.c_int32
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_uint32] * 4 + [C.c_int32, C.c_void_p]
+    g = torch.Generator(device="cuda"); g.manual_seed(7)
+    shapes = [(256, 768, 64), (1, 768, 128), (300, 1280, 768), (1000, 2304, 768), (513, 768, 1152), (2048, 3840, 192), (255, 3840, 320)]
+    for M, N, K in shapes:
+        A = torch.randint(-4, 5, (M, K), generator=g, device="cuda").to(torch.bfloat16)
+        W = torch.randint(-3, 4, (N, K), generator=g, device="cuda").to(torch.bfloat16)
+        ref = A.float() @ W.float().T                                      # exact: |sum| < 2^24
+        for kind in (0, 1, 2):
+            if kind == 2:
+                out = torch.full((M, N // 2), 7.0, device="cuda", dtype=torch.bfloat16)
+                ldc = N // 2
+            else:
+                out = torch.full((M, N), 7.0, device="cuda", dtype=torch.float32 if kind == 1 else torch.bfloat16)
+                ldc = N
+            assert f(A.data_ptr(), W.data_ptr(), out.data_ptr(), M, N, K, ldc, kind, None) == 0
+            torch.cuda.synchronize()
+            if kind == 1:
+                assert torch.equal(out, ref), (tile, M, N, K, float((out - ref).abs().max()))
+            elif kind == 0:
+                assert torch.equal(out, ref.to(torch.bfloat16)), (tile, M, N, K)
+            else:
+                r = ref.view(M, N // 64, 2, 32)                             # per 64 columns: 32 gate | 32 up
+                want = (torch.nn.functional.gelu(r[:, :, 0], approximate="tanh") * r[:, :, 1]).reshape(M, N // 2)
+                err = (out.float() - want).abs().max().item()
+                assert err <= 0.02 * want.abs().max().item() + 1e-3, (tile, M, N, K, err)
