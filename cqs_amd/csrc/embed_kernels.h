@@ -39,16 +39,17 @@ hipError_t launch_gemm_bf16(const bf16_t* A, const bf16_t* W, void* C, uint32_t 
                             uint32_t ldc, GemmOut out, hipStream_t st);
 
 // Second-generation kernel (gemm_kernels.hip): 256 x (64 tn) x 64 tiles, 8 waves in two rows that alternate load and
-// multiply intervals, counted-vmcnt LDS-DMA.  tn in {3, 4, 5} (GeGLU: 4 only); N % (64 tn) == 0, K % 64 == 0.
+// multiply intervals, counted-vmcnt LDS-DMA.  tn in {3, 4, 5}; N % (64 tn) == 0, K % 64 == 0.
 // launch_gemm_bf16 picks between it and the 128 x 128 kernel by shape.
 hipError_t launch_gemm_p8(const bf16_t* A, const bf16_t* W, void* C, uint32_t M, uint32_t N, uint32_t K,
                           uint32_t ldc, GemmOut out, int tn, hipStream_t st);
 
 // In place on qkv [M, (heads + 2 kv) * 256] bf16: per-head RMSNorm * (1 + w), RoPE from the
 // cos/sin table of the layer type, q additionally scaled by q_scale.  pos[m] = position in sequence.
+// k_only != 0: the k heads only (launch_attention then does the same for its own Q fragments, q_norm_w != NULL).
 hipError_t launch_qk_norm_rope(bf16_t* qkv, const int32_t* pos, const float* wq, const float* wk,
                                const float* cos_sin /*[max_seq][128][2]*/, float eps, float q_scale,
-                               uint32_t M, uint32_t heads, uint32_t kv_heads, hipStream_t st);
+                               uint32_t M, uint32_t heads, uint32_t kv_heads, int k_only, hipStream_t st);
 
 // vt[g][d][vt_start[seq] + pos] = v[token][g][d]  (keys contiguous per head dim: the A operand of
 // O^T = V^T P^T); blk / seq_* / vt_start as for launch_attention.  Columns between a sequence's end and
@@ -63,7 +64,8 @@ hipError_t launch_v_transpose(const bf16_t* qkv, bf16_t* vt, const int32_t* blk,
 hipError_t launch_attention(const bf16_t* qkv, const bf16_t* vt, bf16_t* out, const int32_t* blk /*[nblk][2]*/,
                             uint32_t nblk, const int32_t* seq_start, const int32_t* seq_len,
                             const int32_t* vt_start, uint32_t vt_ld, uint32_t heads, uint32_t kv_heads,
-                            uint32_t window /*0 = full*/, hipStream_t st);
+                            uint32_t window /*0 = full*/, const float* q_norm_w /*nullable: q already normalised + rotated*/,
+                            const float* cos_sin, float eps, float q_scale, hipStream_t st);
 
 // pooled[b] = bf16(mean over the sequence's tokens of hidden[m]) (masked mean pool)
 hipError_t launch_mean_pool(const float* hidden, const int32_t* seq_start, const int32_t* seq_len, bf16_t* pooled,

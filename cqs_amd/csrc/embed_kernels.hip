@@ -125,13 +125,15 @@ constexpr int kMaxQkHeads = 8;
 __global__ __launch_bounds__(256) void qk_norm_rope_kernel(bf16_t* __restrict__ qkv, const int32_t* __restrict__ pos,
                                                            const float* __restrict__ wq, const float* __restrict__ wk,
                                                            const float* __restrict__ cos_sin, float eps, float q_scale,
-                                                           uint32_t M, uint32_t heads, uint32_t kv_heads) {
+                                                           uint32_t M, uint32_t heads, uint32_t kv_heads, uint32_t h_first) {
+    // heads [h_first, heads + kv_heads) of the fused q | k | v row: h_first = 0 -> q and k heads, h_first = heads -> the
+    // k heads only (the attention kernel then normalises / rotates its own Q fragments)
     const int lane = threadIdx.x & 63;
-    const uint32_t nh = heads + kv_heads;
+    const uint32_t nh = heads + kv_heads - h_first;
     const uint32_t m = blockIdx.x * 4u + (threadIdx.x >> 6);
     if (m >= M) return;
     const uint32_t ld = (heads + 2u * kv_heads) * kHD;
-    bf16_t* row = qkv + (size_t)m * ld + lane * 4;
+    bf16_t* row = qkv + (size_t)m * ld + (size_t)h_first * kHD + lane * 4;
     bf4 in[kMaxQkHeads];
 #pragma unroll
     for (int h = 0; h < kMaxQkHeads; ++h)
@@ -145,7 +147,7 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(bf16_t* __restrict__ 
 #pragma unroll
     for (int h = 0; h < kMaxQkHeads; ++h) {
         if ((uint32_t)h >= nh) break;
-        const bool is_q = (uint32_t)h < heads;
+        const bool is_q = (uint32_t)h + h_first < heads;
         float v[4];
         float ss = 0.f;
 #pragma unroll
@@ -240,7 +242,9 @@ __global__ __launch_bounds__(64 * WAVES) void attention_kernel(const bf16_t* __r
                                                         const int32_t* __restrict__ seq_start,
                                                         const int32_t* __restrict__ seq_len,
                                                         const int32_t* __restrict__ vt_start, uint32_t vt_ld,
-                                                        uint32_t heads, uint32_t kv_heads, uint32_t window) {
+                                                        uint32_t heads, uint32_t kv_heads, uint32_t window,
+                                                        const float* __restrict__ q_norm_w,
+                                                        const float* __restrict__ cos_sin, float eps, float q_scale) {
     __shared__ __attribute__((aligned(16))) bf16_t smem[4 * kKSub + 4 * kVSub];
     bf16_t* sK = smem;
     bf16_t* sV = smem + 4 * kKSub;
@@ -270,6 +274,41 @@ __global__ __launch_bounds__(64 * WAVES) void attention_kernel(const bf16_t* __r
     bf8 qf[8];
 #pragma unroll
     for (int s = 0; s < 8; ++s) qf[s] = *(const bf8*)(qkv + (size_t)qtok * ld + head * kHD + 32 * s + 8 * lg);
+    if (q_norm_w) {
+        // q-head RMSNorm * (1 + w), RoPE and the 1/sqrt(query_pre_attn_scalar) scale on the wave's own fragments (what
+        // qk_norm_rope_kernel does for the k heads): the query's 256 dims live in this lane (64 of them) and in lanes
+        // ^16, ^32, ^48; rotate_half pairs dim d with d +/- 128 = fragments s and s + 4 of the SAME lane.
+        float ss = 0.f;
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float v = (float)qf[s][j]; ss += v * v; }
+        ss += __shfl_xor(ss, 16, 64);
+        ss += __shfl_xor(ss, 32, 64);
+        const float inv = rsqrtf(ss / (float)kHD + eps);
+        const uint32_t qpos = qi < L ? qi : L - 1u;           // position in the sequence
+        const float* cs = cos_sin + (size_t)qpos * 256u;       // [128][2] (cos, sin)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const uint32_t d0 = (uint32_t)(32 * s + 8 * lg);    // dims d0 .. d0+7 (< 128) and their partners d0 + 128
+            f4 c[4], wlo[2], whi[2];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) c[u] = *(const f4*)(cs + 2u * d0 + 4u * (uint32_t)u);   // (cos,sin) x 2 dims each
+#pragma unroll
+            for (int u = 0; u < 2; ++u) { wlo[u] = *(const f4*)(q_norm_w + d0 + 4 * u); whi[u] = *(const f4*)(q_norm_w + 128u + d0 + 4 * u); }
+            bf8 lo, hi;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float co = c[j >> 1][2 * (j & 1)], si = c[j >> 1][2 * (j & 1) + 1];
+                const float nlo = (float)qf[s][j] * inv * (1.0f + wlo[j >> 2][j & 3]);
+                const float nhi = (float)qf[s + 4][j] * inv * (1.0f + whi[j >> 2][j & 3]);
+                lo[j] = (bf16_t)((nlo * co - nhi * si) * q_scale);      // d < 128: n cos - x[d+128] sin
+                hi[j] = (bf16_t)((nhi * co + nlo * si) * q_scale);      // d >= 128: n cos + x[d-128] sin
+            }
+            qf[s] = lo;
+            qf[s + 4] = hi;
+        }
+    }
 
     f4v o[16];
 #pragma unroll
@@ -340,19 +379,22 @@ __global__ __launch_bounds__(64 * WAVES) void attention_kernel(const bf16_t* __r
         f4v sc[2];
         sc[0] = (f4v)(0.f);
         sc[1] = (f4v)(0.f);
+        // kRA fragment reads in flight ahead of their MFMAs: 8 with two waves per SIMD; 4 for the 12-wave layout
+        // (three waves per SIMD hide the rest, and 8 spilled 13 registers to scratch at its 168-VGPR budget)
+        constexpr int kRA = WAVES >= 12 ? 4 : 8;
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            bf8 kf[8];
+        for (int grp = 0; grp < 16 / kRA; ++grp) {
+            bf8 kf[kRA];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int st = half * 4 + (i >> 1), kt = i & 1;
-                kf[i] = *(const bf8*)(sK + lg * kKSub + (kt * 16 + l15) * kKRow + 8 * st);
+            for (int u = 0; u < kRA; ++u) {
+                const int i = grp * kRA + u, st = i >> 1, kt = i & 1;
+                kf[u] = *(const bf8*)(sK + lg * kKSub + (kt * 16 + l15) * kKRow + 8 * st);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int st = half * 4 + (i >> 1), kt = i & 1;
-                sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[i], qf[st], sc[kt], 0, 0, 0);
+            for (int u = 0; u < kRA; ++u) {
+                const int i = grp * kRA + u, st = i >> 1, kt = i & 1;
+                sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[u], qf[st], sc[kt], 0, 0, 0);
             }
         }
         // mask (only on blocks that touch the sequence end or the window edge) + online softmax over this
@@ -408,16 +450,16 @@ __global__ __launch_bounds__(64 * WAVES) void attention_kernel(const bf16_t* __r
         lsum += __shfl_xor(lsum, 32, 64);
         l_run += lsum;
         // slots 0..3 = keys 4lg + 0..3, slots 4..7 = keys 16 + 4lg + 0..3: one 16-B read per dim tile,
-        // again 8 reads ahead of their 8 MFMAs
+        // again kRA reads ahead of their MFMAs
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            bf8 vf[8];
+        for (int grp = 0; grp < 16 / kRA; ++grp) {
+            bf8 vf[kRA];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) vf[i] = *(const bf8*)(sV + lg * kVSub + ((half * 8 + i) * 16 + l15) * 8);
+            for (int u = 0; u < kRA; ++u) vf[u] = *(const bf8*)(sV + lg * kVSub + ((grp * kRA + u) * 16 + l15) * 8);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
-                o[half * 8 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[i], pf, o[half * 8 + i], 0, 0, 0);
+            for (int u = 0; u < kRA; ++u)
+                o[grp * kRA + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[u], pf, o[grp * kRA + u], 0, 0, 0);
         }
     }
 
@@ -657,7 +699,6 @@ hipError_t launch_gemm_bf16(const bf16_t* A, const bf16_t* W, void* C, uint32_t 
     // Kernel choice by rounds x measured cost of one round of tiles (microseconds at K = 768 on an MI355X, launch to
     // launch; a round of the 256-row kernels costs ~8 us of prologue + epilogue on top of its K-steps, so they only
     // pay when their rounds are well filled):  128 x 128: 9 | 256 x 192: 24 | 256 x 256: 25.5 | 256 x 320: 32.5.
-    // GeGLU pairs gate / up columns inside 64-column groups: 256 x 256 only.
     const float kscale = (float)K / 768.f;
     auto rounds = [&](uint32_t bm, uint32_t bn) { return (float)(((N / bn) * ((M + bm - 1u) / bm) + (uint32_t)n_cu - 1u) / (uint32_t)n_cu); };
     int tn = 0;                                              // 0 = the 128 x 128 kernel
@@ -665,7 +706,7 @@ hipError_t launch_gemm_bf16(const bf16_t* A, const bf16_t* W, void* C, uint32_t 
     const bool fits = (uint64_t)M * K < (1ull << 31) && (uint64_t)N * K < (1ull << 31);
     const float cost[6] = {0.f, 0.f, 0.f, 24.f, 25.5f, 32.5f};
     for (int t = 3; t <= 5 && fits; ++t) {
-        if (N % (64u * (uint32_t)t) || (out == GEMM_OUT_GEGLU && t != 4)) continue;
+        if (N % (64u * (uint32_t)t)) continue;
         const float c = rounds(256u, 64u * (uint32_t)t) * (8.f + (cost[t] - 8.f) * kscale);
         if (c < best) { best = c; tn = t; }
     }
@@ -673,7 +714,7 @@ hipError_t launch_gemm_bf16(const bf16_t* A, const bf16_t* W, void* C, uint32_t 
         if (f[0] == 's') tn = 0;
         else if (f[0] == 'p') {
             const int t = f[2] == ':' ? atoi(f + 3) : 4;
-            tn = (t >= 3 && t <= 5 && fits && N % (64u * (uint32_t)t) == 0 && (out != GEMM_OUT_GEGLU || t == 4)) ? t : 0;
+            tn = (t >= 3 && t <= 5 && fits && N % (64u * (uint32_t)t) == 0) ? t : 0;
         }
     }
     if (tn) return launch_gemm_p8(A, W, C, M, N, K, ldc, out, tn, st);
@@ -688,11 +729,11 @@ hipError_t launch_gemm_bf16(const bf16_t* A, const bf16_t* W, void* C, uint32_t 
 
 hipError_t launch_qk_norm_rope(bf16_t* qkv, const int32_t* pos, const float* wq, const float* wk,
                                const float* cos_sin, float eps, float q_scale, uint32_t M, uint32_t heads,
-                               uint32_t kv_heads, hipStream_t st) {
+                               uint32_t kv_heads, int k_only, hipStream_t st) {
     if (M == 0) return hipSuccess;
     if (heads + kv_heads > (uint32_t)kMaxQkHeads) return hipErrorInvalidValue;
     hipLaunchKernelGGL(qk_norm_rope_kernel, dim3((M + 3u) / 4u), dim3(256), 0, st, qkv, pos, wq, wk, cos_sin, eps,
-                       q_scale, M, heads, kv_heads);
+                       q_scale, M, heads, kv_heads, k_only ? heads : 0u);
     return hipGetLastError();
 }
 
@@ -707,7 +748,8 @@ hipError_t launch_v_transpose(const bf16_t* qkv, bf16_t* vt, const int32_t* blk,
 
 hipError_t launch_attention(const bf16_t* qkv, const bf16_t* vt, bf16_t* out, const int32_t* blk, uint32_t nblk,
                             const int32_t* seq_start, const int32_t* seq_len, const int32_t* vt_start, uint32_t vt_ld,
-                            uint32_t heads, uint32_t kv_heads, uint32_t window, hipStream_t st) {
+                            uint32_t heads, uint32_t kv_heads, uint32_t window, const float* q_norm_w,
+                            const float* cos_sin, float eps, float q_scale, hipStream_t st) {
     if (nblk == 0) return hipSuccess;
     if (kv_heads == 0 || heads % kv_heads) return hipErrorInvalidValue;
 #ifndef CQS_ATT_TQ
@@ -720,7 +762,7 @@ hipError_t launch_attention(const bf16_t* qkv, const bf16_t* vt, bf16_t* out, co
 #define CQS_ATT(GV, TQV)                                                                                           \
     hipLaunchKernelGGL((attention_kernel<TQV * GV, GV>), dim3(nblk * (128 / (16 * TQV)), heads / GV),             \
                        dim3(64 * TQV * GV), 0, st, qkv, vt, out, blk, seq_start, seq_len, vt_start, vt_ld, heads,   \
-                       kv_heads, window)
+                       kv_heads, window, q_norm_w, cos_sin, eps, q_scale)
     // Small batches (fewer head-sharing workgroups than CUs: e.g. 32 short chunks) keep one q-head per
     // workgroup - more, thinner workgroups fill the chip better (measured +6 % on log-normal lengths).
     static int n_cu = 0;

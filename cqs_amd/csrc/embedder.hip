@@ -290,12 +290,14 @@ int32_t run_layers(cqs_hip_embedder* e, Slot& sl) {
         const LayerW& w = e->L[l];
         const bool full = ((l + 1u) % g.sliding_pattern) == 0u;
         E_TRY(e, cqs::launch_gemm_bf16(e->xn, w.wqkv, e->qkv, M, nqkv(g), H, nqkv(g), cqs::GEMM_OUT_BF16, st));
-        E_TRY(e, cqs::launch_qk_norm_rope(e->qkv, e->d_pos, w.n_q, w.n_k, full ? e->rope_global : e->rope_local,
-                                          g.rms_eps, g.q_scale, M, g.heads, g.kv_heads, st));
+        // k heads here; the attention kernel normalises / rotates its own Q fragments (q is 3/4 of this kernel's bytes)
+        const float* rope = full ? e->rope_global : e->rope_local;
+        E_TRY(e, cqs::launch_qk_norm_rope(e->qkv, e->d_pos, w.n_q, w.n_k, rope, g.rms_eps, g.q_scale, M, g.heads, g.kv_heads, 1, st));
         E_TRY(e, cqs::launch_v_transpose(e->qkv, e->vt, e->d_blk, nblk, e->d_seq_start, e->d_seq_len, e->d_vt_start,
                                          g.heads, g.kv_heads, e->vt_ld, st));
         E_TRY(e, cqs::launch_attention(e->qkv, e->vt, e->attn, e->d_blk, nblk, e->d_seq_start, e->d_seq_len,
-                                       e->d_vt_start, e->vt_ld, g.heads, g.kv_heads, full ? 0u : g.window, st));
+                                       e->d_vt_start, e->vt_ld, g.heads, g.kv_heads, full ? 0u : g.window, w.n_q, rope,
+                                       g.rms_eps, g.q_scale, st));
         E_TRY(e, cqs::launch_gemm_bf16(e->attn, w.wo, e->y, M, H, g.heads * g.head_dim, H, cqs::GEMM_OUT_BF16, st));
         E_TRY(e, cqs::launch_add_norm(e->x, e->y, w.n_post_attn, w.n_pre_ffw, g.rms_eps, e->xn, nullptr, 0, M, H, st));
         E_TRY(e, cqs::launch_gemm_bf16(e->xn, w.wgu, e->h, M, 2u * g.inter, H, g.inter, cqs::GEMM_OUT_GEGLU, st));

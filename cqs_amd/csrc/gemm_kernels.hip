@@ -236,52 +236,69 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16_t* __restric
     }
     // bf16 / GeGLU: through LDS, so that the workgroup writes WHOLE rows of its tile (a lane's 8 bytes of a 16 x 16
     // accumulator tile are a quarter of a 32-byte segment: stored directly, every 128-byte line is written in four
-    // pieces by four instructions - measured: the store phase was 25-35 % of these K = 768 GEMMs).  Two passes of 128
-    // rows (m-tiles 4p .. 4p+3 of both wave rows); LDS row = OC output columns + 8 bytes (bank shift 2 dwords / row).
-    {
-        constexpr int OC = OUT == GEMM_OUT_GEGLU ? BN / 2 : BN;     // output columns of the workgroup tile
-        constexpr int kStride = OC + 4;                             // elements
-        constexpr int kCPR = OC / 4;                                // 8-byte chunks per row
-        bf16_t* const stage = p8smem;                               // 128 x kStride elements <= 80 KiB + pad
-        const uint32_t oc0 = OUT == GEMM_OUT_GEGLU ? n0 / 2u : n0;
+    // pieces by four instructions - measured: the store phase was 25-35 % of these K = 768 GEMMs).
+    if (OUT == GEMM_OUT_BF16) {
+        // two passes of 128 rows (m-tiles 4p .. 4p+3 of both wave rows); LDS row = BN bf16 + 8 bytes (bank shift of
+        // 2 dwords per row: conflict-free 8-byte writes)
+        constexpr int kStride = BN + 4;                             // elements
+        constexpr int kCPR = BN / 4;                                // 8-byte chunks per row
+        bf16_t* const stage = p8smem;                               // 128 x kStride elements <= 81 KiB
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                const int i = 4 * p + t;
                 bf16_t* rowp = stage + (size_t)(wm * 64 + t * 16 + l15) * kStride;
-                if (OUT == GEMM_OUT_GEGLU) {
-                    static_assert(OUT != GEMM_OUT_GEGLU || TN == 4, "GeGLU epilogue needs 64 columns per wave");
-                    // W rows interleaved per 64: 32 gate rows then the same channels' 32 up rows (embedder.hip)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        bf4 o;
+                for (int j = 0; j < TN; ++j) {
+                    bf4 o;
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) o[r] = (bf16_t)(p8_gelu_tanh(acc[i][j][r]) * acc[i][(j + 2) % TN][r]);
-                        *(bf4*)(rowp + wn * 32 + j * 16 + 4 * lg) = o;
-                    }
-                } else {
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) {
-                        bf4 o;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) o[r] = (bf16_t)acc[i][j][r];
-                        *(bf4*)(rowp + wn * 16 * TN + j * 16 + 4 * lg) = o;
-                    }
+                    for (int r = 0; r < 4; ++r) o[r] = (bf16_t)acc[4 * p + t][j][r];
+                    *(bf4*)(rowp + wn * 16 * TN + j * 16 + 4 * lg) = o;
                 }
             }
             __syncthreads();
             for (uint32_t c = (uint32_t)tid; c < 128u * (uint32_t)kCPR; c += 512u) {
                 const uint32_t r = c / (uint32_t)kCPR, cc = c % (uint32_t)kCPR;
                 const uint32_t row = m0 + (r >> 6) * 128u + (uint32_t)(4 * p) * 16u + (r & 63u);
-                if (row < M) {
 #ifdef P8_ABLATE_NOSTORE
-                    if (acc[0][0][0] != 12345.678f) continue;
+                if (acc[0][0][0] != 12345.678f) continue;
 #endif
-                    *(bf4*)((bf16_t*)Cv + (size_t)row * ldc + oc0 + cc * 4u) = *(const bf4*)(stage + (size_t)r * kStride + cc * 4u);
-                }
+                if (row < M) *(bf4*)((bf16_t*)Cv + (size_t)row * ldc + n0 + cc * 4u) = *(const bf4*)(stage + (size_t)r * kStride + cc * 4u);
             }
             if (p == 0) __syncthreads();
+        }
+    } else {
+        // GeGLU: W rows are interleaved per 64 (32 gate rows, then the same channels' 32 up rows; embedder.hip), so a
+        // tile of 64 TN columns holds TN whole groups but a wave's 16 TN columns need not: the f32 accumulators go to LDS
+        // and the pairing happens on the way out.  Four passes of 64 rows (m-tiles 2p, 2p+1 of both wave rows); LDS row
+        // = BN f32 + 16 bytes (bank shift of 4 dwords per row: conflict-free 16-byte writes).
+        constexpr int kStride = BN + 4;                             // floats
+        constexpr int kGPR = BN / 8;                                // groups of 4 output channels per row
+        float* const stage = (float*)p8smem;                        // 64 x kStride floats <= 66 KiB
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                float* rowp = stage + (size_t)(wm * 32 + t * 16 + l15) * kStride;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) *(f4*)(rowp + wn * 16 * TN + j * 16 + 4 * lg) = acc[2 * p + t][j];
+            }
+            __syncthreads();
+            for (uint32_t c = (uint32_t)tid; c < 64u * (uint32_t)kGPR; c += 512u) {
+                const uint32_t r = c / (uint32_t)kGPR, g = c % (uint32_t)kGPR;
+                const uint32_t row = m0 + (r >> 5) * 128u + (uint32_t)(2 * p) * 16u + (r & 31u);
+                const uint32_t ch = g * 4u;                          // output channel inside the tile (0 .. BN/2)
+                const float* src = stage + (size_t)r * kStride + (ch >> 5) * 64u + (ch & 31u);
+                const f4 gate = *(const f4*)src, up = *(const f4*)(src + 32);
+                bf4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (bf16_t)(p8_gelu_tanh(gate[e]) * up[e]);
+#ifdef P8_ABLATE_NOSTORE
+                if (acc[0][0][0] != 12345.678f) continue;
+#endif
+                if (row < M) *(bf4*)((bf16_t*)Cv + (size_t)row * ldc + n0 / 2u + ch) = o;
+            }
+            if (p < 3) __syncthreads();
         }
     }
 }
@@ -305,8 +322,7 @@ hipError_t launch_p8(const bf16_t* A, const bf16_t* W, void* C, uint32_t M, uint
 
 }  // namespace
 
-// tn: n-tiles per wave (tile width 64 tn: 192 / 256 / 320); N % (64 tn) == 0, K % 64 == 0, M * K < 2^31 elements;
-// GeGLU: tn = 4 only.
+// tn: n-tiles per wave (tile width 64 tn: 192 / 256 / 320); N % (64 tn) == 0, K % 64 == 0, M * K < 2^31 elements.
 hipError_t launch_gemm_p8(const bf16_t* A, const bf16_t* W, void* C, uint32_t M, uint32_t N, uint32_t K, uint32_t ldc,
                           GemmOut out, int tn, hipStream_t st) {
     if (M == 0) return hipSuccess;
@@ -317,14 +333,11 @@ hipError_t launch_gemm_p8(const bf16_t* A, const bf16_t* W, void* C, uint32_t M,
     case TNV:                                                                                             \
         if (out == GEMM_OUT_BF16) return launch_p8<TNV, GEMM_OUT_BF16>(A, W, C, M, N, K, ldc, st);        \
         if (out == GEMM_OUT_F32) return launch_p8<TNV, GEMM_OUT_F32>(A, W, C, M, N, K, ldc, st);          \
-        break;
+        return launch_p8<TNV, GEMM_OUT_GEGLU>(A, W, C, M, N, K, ldc, st);
     switch (tn) {
         P8_CASE(3)
+        P8_CASE(4)
         P8_CASE(5)
-        case 4:
-            if (out == GEMM_OUT_BF16) return launch_p8<4, GEMM_OUT_BF16>(A, W, C, M, N, K, ldc, st);
-            if (out == GEMM_OUT_F32) return launch_p8<4, GEMM_OUT_F32>(A, W, C, M, N, K, ldc, st);
-            return launch_p8<4, GEMM_OUT_GEGLU>(A, W, C, M, N, K, ldc, st);
         default: break;
     }
 #undef P8_CASE
