@@ -69,6 +69,17 @@ extern "C" {
         seq_len: u32,
         out: *mut f32,
     ) -> i32;
+    // asynchronous form (up to 3 tickets in flight): the index pipeline keeps the device busy while the host
+    // tokenises / pads the next `embed_batch_size()` chunk
+    fn cqs_hip_embed_submit(
+        e: *mut CqsHipEmbedder,
+        input_ids: *const i64,
+        attention_mask: *const i64,
+        batch: u32,
+        seq_len: u32,
+        ticket: *mut u64,
+    ) -> i32;
+    fn cqs_hip_embed_collect(e: *mut CqsHipEmbedder, ticket: u64, out: *mut f32) -> i32;
 }
 
 /// The "session" of the Hip execution provider: owns the device weights of one model.
@@ -83,8 +94,9 @@ unsafe impl Send for HipEmbedSession {}
 
 impl HipEmbedSession {
     /// Replaces `create_session(model_path, provider)` (src/embedder/provider.rs:349-447).
-    /// `model_dir` holds the Hugging Face layout (`model.safetensors`, `2_Dense/`, `3_Dense/`) - the
-    /// local-directory hook the reference already has is `CQS_ONNX_DIR` (src/embedder/download.rs:12-41).
+    /// `model_dir` is what `ensure_model` resolves (src/embedder/download.rs:9-136): the directory that holds
+    /// `onnx/model.onnx` + `onnx/model.onnx_data` (or the flat `model.onnx`) - the library parses the ONNX
+    /// initialisers itself; a Hugging Face checkpoint directory (`model.safetensors`, `2_Dense/`, `3_Dense/`) works too.
     pub fn open(model_dir: &Path, device_id: i32) -> Result<Self, EmbedderError> {
         let dir = CString::new(model_dir.to_string_lossy().as_bytes())
             .map_err(|e| EmbedderError::InferenceFailed(format!("model dir: {e}")))?;
@@ -156,6 +168,34 @@ impl HipEmbedSession {
                 "cqs_hip_embed failed: status {rc}: {}",
                 self.last_error()
             )));
+        }
+        Ok(out)
+    }
+}
+
+impl HipEmbedSession {
+    /// `embed_documents` (src/embedder/core.rs:718-751) hands `embed_batch` one `embed_batch_size()` chunk after the
+    /// other and waits for each.  With the Hip provider the chunks can overlap: `submit` returns as soon as the batch
+    /// is packed into pinned staging and enqueued, `collect` waits for one ticket.  Keep at most 3 in flight.
+    pub fn submit(&mut self, input_ids: &[i64], attention_mask: &[i64], batch: usize, max_len: usize) -> Result<(u64, usize), EmbedderError> {
+        if input_ids.len() != batch * max_len || attention_mask.len() != batch * max_len {
+            return Err(EmbedderError::InferenceFailed("hip embed: shape mismatch".into()));
+        }
+        let mut ticket = 0u64;
+        let rc = unsafe {
+            cqs_hip_embed_submit(self.handle, input_ids.as_ptr(), attention_mask.as_ptr(), batch as u32, max_len as u32, &mut ticket)
+        };
+        if rc != CQS_HIP_OK {
+            return Err(EmbedderError::InferenceFailed(format!("cqs_hip_embed_submit failed: status {rc}: {}", self.last_error())));
+        }
+        Ok((ticket, batch))
+    }
+
+    pub fn collect(&mut self, ticket: (u64, usize)) -> Result<Vec<f32>, EmbedderError> {
+        let mut out = vec![0f32; ticket.1 * self.dim];
+        let rc = unsafe { cqs_hip_embed_collect(self.handle, ticket.0, out.as_mut_ptr()) };
+        if rc != CQS_HIP_OK {
+            return Err(EmbedderError::InferenceFailed(format!("cqs_hip_embed_collect failed: status {rc}: {}", self.last_error())));
         }
         Ok(out)
     }
