@@ -685,6 +685,19 @@ hipError_t launch_add_norm(float* x, const bf16_t* y, const float* w_post, const
                  : launch_add_norm_t<0>(x, y, w_post, w_next, eps, xn, out, M, H, st);
 }
 
+// One kernel for the whole [M, N] problem; tn = 0: the 128 x 128 kernel, 3..5: the 256 x (64 tn) ping-pong kernel.
+static hipError_t launch_gemm_one(const bf16_t* A, const bf16_t* W, void* C, uint32_t M, uint32_t N, uint32_t K,
+                                  uint32_t ldc, GemmOut out, int tn, hipStream_t st) {
+    if (tn) return launch_gemm_p8(A, W, C, M, N, K, ldc, out, tn, st);
+    const dim3 grid((N / 128u) * ((M + 127u) / 128u)), block(256);
+    switch (out) {
+        case GEMM_OUT_BF16: hipLaunchKernelGGL(gemm_bf16_kernel<GEMM_OUT_BF16>, grid, block, 0, st, A, W, C, M, N, K, ldc); break;
+        case GEMM_OUT_F32: hipLaunchKernelGGL(gemm_bf16_kernel<GEMM_OUT_F32>, grid, block, 0, st, A, W, C, M, N, K, ldc); break;
+        case GEMM_OUT_GEGLU: hipLaunchKernelGGL(gemm_bf16_kernel<GEMM_OUT_GEGLU>, grid, block, 0, st, A, W, C, M, N, K, ldc); break;
+    }
+    return hipGetLastError();
+}
+
 hipError_t launch_gemm_bf16(const bf16_t* A, const bf16_t* W, void* C, uint32_t M, uint32_t N, uint32_t K,
                             uint32_t ldc, GemmOut out, hipStream_t st) {
     if (M == 0) return hipSuccess;
@@ -696,35 +709,57 @@ hipError_t launch_gemm_bf16(const bf16_t* A, const bf16_t* W, void* C, uint32_t 
             hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
             n_cu = 256;
     }
-    // Kernel choice by rounds x measured cost of one round of tiles (microseconds at K = 768 on an MI355X, launch to
-    // launch; a round of the 256-row kernels costs ~8 us of prologue + epilogue on top of its K-steps, so they only
-    // pay when their rounds are well filled):  128 x 128: 9 | 256 x 192: 24 | 256 x 256: 25.5 | 256 x 320: 32.5.
+    // Kernel choice: rounds x measured cost of one round of tiles (microseconds at K = 768 on an MI355X, launch to
+    // launch).  A round of the 256-row kernel costs ~8 us of prologue + epilogue on top of its K-steps and rounds of one
+    // launch do not overlap (one workgroup per CU), so big tiles only pay when their rounds are FULL:
+    //   128 x 128: 9 (GeGLU 8.2) | 256 x 192: 24 | 256 x 256: 25.5 | 256 x 320: 32.5   (GeGLU epilogue: + 1.5)
+    // and a problem whose tile count is not a multiple of the CU count is cut in two launches along N: the part that
+    // makes whole rounds of big tiles + the rest (N = 2304 at 16 384 rows: 2048 columns = 2 rounds of 256 x 256, then
+    // 256 columns = one round of 128 x 128: 62 us instead of 73).
     const float kscale = (float)K / 768.f;
-    auto rounds = [&](uint32_t bm, uint32_t bn) { return (float)(((N / bn) * ((M + bm - 1u) / bm) + (uint32_t)n_cu - 1u) / (uint32_t)n_cu); };
-    int tn = 0;                                              // 0 = the 128 x 128 kernel
-    float best = rounds(128u, 128u) * (3.f + 6.f * kscale);
+    const float geglu = out == GEMM_OUT_GEGLU ? 1.f : 0.f;
+    const uint32_t cu = (uint32_t)n_cu;
     const bool fits = (uint64_t)M * K < (1ull << 31) && (uint64_t)N * K < (1ull << 31);
     const float cost[6] = {0.f, 0.f, 0.f, 24.f, 25.5f, 32.5f};
+    auto one = [&](uint32_t n, int t) -> float {              // cost of n columns with one kernel; < 0: not applicable
+        if (t == 0) return (float)(((n / 128u) * ((M + 127u) / 128u) + cu - 1u) / cu) * (3.f + (6.f - 0.8f * geglu) * kscale);
+        if (!fits || n % (64u * (uint32_t)t)) return -1.f;
+        return (float)(((n / (64u * (uint32_t)t)) * ((M + 255u) / 256u) + cu - 1u) / cu) * (8.f + 1.5f * geglu + (cost[t] - 8.f) * kscale);
+    };
+    auto best_one = [&](uint32_t n, int& t_out) -> float {
+        float best = one(n, 0);
+        t_out = 0;
+        for (int t = 3; t <= 5; ++t) { const float c = one(n, t); if (c >= 0.f && c < best) { best = c; t_out = t; } }
+        return best;
+    };
+    int tn1 = 0, tn2 = 0;
+    uint32_t n1 = N;
+    float best = best_one(N, tn1);
+    const uint32_t mt = (M + 255u) / 256u;
+    uint32_t g = mt, h = cu;
+    while (h) { const uint32_t r = g % h; g = h; h = r; }      // g = gcd(mt, cu)
     for (int t = 3; t <= 5 && fits; ++t) {
-        if (N % (64u * (uint32_t)t)) continue;
-        const float c = rounds(256u, 64u * (uint32_t)t) * (8.f + (cost[t] - 8.f) * kscale);
-        if (c < best) { best = c; tn = t; }
-    }
-    if (const char* f = getenv("CQS_HIP_GEMM_TILE")) {  // test hook: "small" / "pp:<tn>" force one kernel
-        if (f[0] == 's') tn = 0;
-        else if (f[0] == 'p') {
-            const int t = f[2] == ':' ? atoi(f + 3) : 4;
-            tn = (t >= 3 && t <= 5 && fits && N % (64u * (uint32_t)t) == 0) ? t : 0;
+        const uint32_t step = (cu / g) * 64u * (uint32_t)t;     // columns that make whole rounds of 256 x 64 t tiles
+        for (uint32_t c1 = step; c1 < N; c1 += step) {
+            if ((N - c1) % 128u) continue;
+            int t2 = 0;
+            const float c = one(c1, t) + best_one(N - c1, t2) + 2.f;   // + one kernel boundary
+            if (c < best) { best = c; n1 = c1; tn1 = t; tn2 = t2; }
         }
     }
-    if (tn) return launch_gemm_p8(A, W, C, M, N, K, ldc, out, tn, st);
-    const dim3 grid((N / 128u) * ((M + 127u) / 128u)), block(256);
-    switch (out) {
-        case GEMM_OUT_BF16: hipLaunchKernelGGL(gemm_bf16_kernel<GEMM_OUT_BF16>, grid, block, 0, st, A, W, C, M, N, K, ldc); break;
-        case GEMM_OUT_F32: hipLaunchKernelGGL(gemm_bf16_kernel<GEMM_OUT_F32>, grid, block, 0, st, A, W, C, M, N, K, ldc); break;
-        case GEMM_OUT_GEGLU: hipLaunchKernelGGL(gemm_bf16_kernel<GEMM_OUT_GEGLU>, grid, block, 0, st, A, W, C, M, N, K, ldc); break;
+    if (const char* f = getenv("CQS_HIP_GEMM_TILE")) {  // test hook: "small" / "pp:<tn>" force one kernel
+        n1 = N;
+        if (f[0] == 's') tn1 = 0;
+        else if (f[0] == 'p') {
+            const int t = f[2] == ':' ? atoi(f + 3) : 4;
+            tn1 = (t >= 3 && t <= 5 && fits && N % (64u * (uint32_t)t) == 0) ? t : 0;
+        }
     }
-    return hipGetLastError();
+    hipError_t e = launch_gemm_one(A, W, C, M, n1, K, ldc, out, tn1, st);
+    if (e != hipSuccess || n1 == N) return e;
+    const size_t coff = out == GEMM_OUT_GEGLU ? n1 / 2u : n1;    // output columns already written
+    void* c2 = out == GEMM_OUT_F32 ? (void*)((float*)C + coff) : (void*)((bf16_t*)C + coff);
+    return launch_gemm_one(A, W + (size_t)n1 * K, c2, M, N - n1, K, ldc, out, tn2, st);
 }
 
 hipError_t launch_qk_norm_rope(bf16_t* qkv, const int32_t* pos, const float* wq, const float* wk,
