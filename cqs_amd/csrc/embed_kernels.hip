@@ -9,6 +9,7 @@
 #include "embed_kernels.h"
 
 #include <cstdlib>
+#include <type_traits>
 
 namespace cqs {
 
@@ -234,6 +235,46 @@ constexpr int kVSub = kHD * 8;              // elements per lane-group sub-tile 
 constexpr float kRescaleThr = 8.0f;  // defer the O rescale while the running max grows by < e^8 (P stays < 2981)
 typedef float f4v __attribute__((ext_vector_type(4)));
 
+// Q^T fragments (B operand of S^T = K Q^T): lane feeds Q[q = lane & 15][dims 32s + 8 lg + 0..7], s = 0..7.
+// With q_norm_w: q-head RMSNorm * (1 + w), RoPE and the 1/sqrt(query_pre_attn_scalar) scale on the wave's own
+// fragments (what qk_norm_rope_kernel does for the k heads): the query's 256 dims live in this lane (64 of them) and
+// in lanes ^16, ^32, ^48; rotate_half pairs dim d with d +/- 128 = fragments s and s + 4 of the SAME lane.
+__device__ __forceinline__ void load_q_fragments(bf8 (&qf)[8], const bf16_t* __restrict__ qrow /*token row + head*/, int lg,
+                                                 const float* __restrict__ q_norm_w, const float* __restrict__ cs /*[128][2] of the position*/,
+                                                 float eps, float q_scale) {
+#pragma unroll
+    for (int s = 0; s < 8; ++s) qf[s] = *(const bf8*)(qrow + 32 * s + 8 * lg);
+    if (!q_norm_w) return;
+    float ss = 0.f;
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float v = (float)qf[s][j]; ss += v * v; }
+    ss += __shfl_xor(ss, 16, 64);
+    ss += __shfl_xor(ss, 32, 64);
+    const float inv = rsqrtf(ss / (float)kHD + eps);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const uint32_t d0 = (uint32_t)(32 * s + 8 * lg);    // dims d0 .. d0+7 (< 128) and their partners d0 + 128
+        f4 c[4], wlo[2], whi[2];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) c[u] = *(const f4*)(cs + 2u * d0 + 4u * (uint32_t)u);   // (cos,sin) x 2 dims each
+#pragma unroll
+        for (int u = 0; u < 2; ++u) { wlo[u] = *(const f4*)(q_norm_w + d0 + 4 * u); whi[u] = *(const f4*)(q_norm_w + 128u + d0 + 4 * u); }
+        bf8 lo, hi;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float co = c[j >> 1][2 * (j & 1)], si = c[j >> 1][2 * (j & 1) + 1];
+            const float nlo = (float)qf[s][j] * inv * (1.0f + wlo[j >> 2][j & 3]);
+            const float nhi = (float)qf[s + 4][j] * inv * (1.0f + whi[j >> 2][j & 3]);
+            lo[j] = (bf16_t)((nlo * co - nhi * si) * q_scale);      // d < 128: n cos - x[d+128] sin
+            hi[j] = (bf16_t)((nhi * co + nlo * si) * q_scale);      // d >= 128: n cos + x[d-128] sin
+        }
+        qf[s] = lo;
+        qf[s + 4] = hi;
+    }
+}
+
 template <int WAVES, int G>
 __global__ __launch_bounds__(64 * WAVES) void attention_kernel(const bf16_t* __restrict__ qkv,
                                                         const bf16_t* __restrict__ vt,
@@ -269,46 +310,9 @@ __global__ __launch_bounds__(64 * WAVES) void attention_kernel(const bf16_t* __r
     const bool wave_live = q0 < L;                          // waves past the sequence only help staging
     const uint32_t qi = q0 + (uint32_t)l15;                 // this lane's query
 
-    // Q^T fragments (B operand): lane feeds Q[q = l15][dims 32s + 8*lg + 0..7], s = 0..7
-    const uint32_t qtok = s0 + (qi < L ? qi : L - 1u);
+    const uint32_t qclamp = qi < L ? qi : L - 1u;           // position in the sequence (rows past the end: any real row)
     bf8 qf[8];
-#pragma unroll
-    for (int s = 0; s < 8; ++s) qf[s] = *(const bf8*)(qkv + (size_t)qtok * ld + head * kHD + 32 * s + 8 * lg);
-    if (q_norm_w) {
-        // q-head RMSNorm * (1 + w), RoPE and the 1/sqrt(query_pre_attn_scalar) scale on the wave's own fragments (what
-        // qk_norm_rope_kernel does for the k heads): the query's 256 dims live in this lane (64 of them) and in lanes
-        // ^16, ^32, ^48; rotate_half pairs dim d with d +/- 128 = fragments s and s + 4 of the SAME lane.
-        float ss = 0.f;
-#pragma unroll
-        for (int s = 0; s < 8; ++s)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { const float v = (float)qf[s][j]; ss += v * v; }
-        ss += __shfl_xor(ss, 16, 64);
-        ss += __shfl_xor(ss, 32, 64);
-        const float inv = rsqrtf(ss / (float)kHD + eps);
-        const uint32_t qpos = qi < L ? qi : L - 1u;           // position in the sequence
-        const float* cs = cos_sin + (size_t)qpos * 256u;       // [128][2] (cos, sin)
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const uint32_t d0 = (uint32_t)(32 * s + 8 * lg);    // dims d0 .. d0+7 (< 128) and their partners d0 + 128
-            f4 c[4], wlo[2], whi[2];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) c[u] = *(const f4*)(cs + 2u * d0 + 4u * (uint32_t)u);   // (cos,sin) x 2 dims each
-#pragma unroll
-            for (int u = 0; u < 2; ++u) { wlo[u] = *(const f4*)(q_norm_w + d0 + 4 * u); whi[u] = *(const f4*)(q_norm_w + 128u + d0 + 4 * u); }
-            bf8 lo, hi;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float co = c[j >> 1][2 * (j & 1)], si = c[j >> 1][2 * (j & 1) + 1];
-                const float nlo = (float)qf[s][j] * inv * (1.0f + wlo[j >> 2][j & 3]);
-                const float nhi = (float)qf[s + 4][j] * inv * (1.0f + whi[j >> 2][j & 3]);
-                lo[j] = (bf16_t)((nlo * co - nhi * si) * q_scale);      // d < 128: n cos - x[d+128] sin
-                hi[j] = (bf16_t)((nhi * co + nlo * si) * q_scale);      // d >= 128: n cos + x[d-128] sin
-            }
-            qf[s] = lo;
-            qf[s + 4] = hi;
-        }
-    }
+    load_q_fragments(qf, qkv + (size_t)(s0 + qclamp) * ld + head * kHD, lg, q_norm_w, cos_sin + (size_t)qclamp * 256u, eps, q_scale);
 
     f4v o[16];
 #pragma unroll
@@ -473,6 +477,341 @@ __global__ __launch_bounds__(64 * WAVES) void attention_kernel(const bf16_t* __r
 #pragma unroll
             for (int e = 0; e < 4; ++e) w[e] = (bf16_t)(o[d][e] * invl);
             *(bf4*)(op + 16 * d + 4 * lg) = w;
+        }
+    }
+}
+
+// ---- attention, second generation: 64-key blocks, LDS-DMA double buffer ---------------------------------
+// Same math and wave layout as attention_kernel (wave = 16 queries of one q-head; S^T = K Q^T, O^T += V^T P^T), but
+// the K / V^T tiles never pass through registers: each 64-key block (K 64 x 256, V^T 256 x 64: 32 KiB each) is
+// fetched by `global_load_lds_dwordx4` into the buffer the previous block is not using, ONE barrier per 64 keys
+// (attention_kernel: two per 32, plus 6 ds_write per thread), and the softmax's cross-lane steps use
+// v_permlane{16,32}_swap instead of ds_bpermute (which queues behind the fragment reads).
+// LDS images are unpadded; the bank swizzle is applied to the DMA's SOURCE address (the destination is lane-linear):
+//   K  [key row 0..63][32 chunks of 8 dims]   chunk c of row r lives at c ^ f(r), f(r) = 4 ((r >> 3) & 3) + (r & 3)
+//   V^T[dim 0..255][8 chunks of 8 keys]       chunk c of dim d lives at c ^ ((d >> 1) & 7)
+// The S^T tile (t, kt) takes its 16 key rows in the order row(i) = 32 t + 8 (i >> 2) + 4 kt + (i & 3), so that lane
+// group lg's C registers of tiles kt = 0, 1 hold the 8 CONSECUTIVE keys 32 t + 8 lg + 0..7 = one 16-byte V^T chunk
+// (the PV product's A fragment is a plain row read; attention_kernel needs two 8-byte pieces), and f(row(i)) = i.
+__device__ __forceinline__ float xor16_max(float v) {
+    typedef unsigned pu2 __attribute__((ext_vector_type(2)));
+    const pu2 a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+}
+__device__ __forceinline__ float xor32_max(float v) {
+    typedef unsigned pu2 __attribute__((ext_vector_type(2)));
+    const pu2 a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+}
+__device__ __forceinline__ float xor16_sum(float v) {
+    typedef unsigned pu2 __attribute__((ext_vector_type(2)));
+    const pu2 a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(a[0]) + __uint_as_float(a[1]);
+}
+__device__ __forceinline__ float xor32_sum(float v) {
+    typedef unsigned pu2 __attribute__((ext_vector_type(2)));
+    const pu2 a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(a[0]) + __uint_as_float(a[1]);
+}
+
+constexpr int kABlk = 64;                    // keys per block
+constexpr int kABuf = kABlk * kHD;           // elements of one K (or V^T) buffer: 32 KiB
+constexpr size_t kAttDmaLds = (size_t)4 * kABuf * sizeof(bf16_t);   // [2] K + [2] V^T = 128 KiB
+
+template <int WAVES, int G, int KRA_F>   // KRA_F: fragment reads in flight ahead of their MFMAs
+__global__ __launch_bounds__(64 * WAVES) void attention_dma_kernel(const bf16_t* __restrict__ qkv,
+                                                        const bf16_t* __restrict__ vt,
+                                                        bf16_t* __restrict__ out,
+                                                        const int32_t* __restrict__ blk,
+                                                        const int32_t* __restrict__ seq_start,
+                                                        const int32_t* __restrict__ seq_len,
+                                                        const int32_t* __restrict__ vt_start, uint32_t vt_ld,
+                                                        uint32_t heads, uint32_t kv_heads, uint32_t window,
+                                                        const float* __restrict__ q_norm_w,
+                                                        const float* __restrict__ cos_sin, float eps, float q_scale) {
+    extern __shared__ __attribute__((aligned(16))) bf16_t asmem[];   // K[2][64 x 256] | V^T[2][256 x 64]
+    constexpr int TQ = WAVES / G;                   // query tiles
+    constexpr uint32_t kParts = 128 / (16 * TQ);    // workgroups per 128-query super-block of the blk list
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, lg = lane >> 4;
+    // Workgroups go to the 8 XCDs round-robin by blockIdx.x; give each XCD one CONTIGUOUS run of the (sequence, query
+    // block) list, so the workgroups that share a sequence's K / V^T share an L2 (blockIdx.x-order put them on 8
+    // different XCDs: PMC showed 143 MB fetched per launch for 42 MB of q/k/v, every L2 streaming every sequence).
+    const uint32_t nwg = gridDim.x, xcd = blockIdx.x % 8u, q8 = nwg / 8u, r8 = nwg % 8u;
+    const uint32_t wg = (xcd < r8 ? xcd * (q8 + 1u) : r8 * (q8 + 1u) + (xcd - r8) * q8) + blockIdx.x / 8u;
+    const uint32_t sblk = wg / kParts, part = wg % kParts;
+    const uint32_t b = (uint32_t)blk[2 * sblk], sb = (uint32_t)blk[2 * sblk + 1];
+    const uint32_t head = blockIdx.y * (uint32_t)G + (uint32_t)(wid % G);
+    const uint32_t g = head / (heads / kv_heads);
+    const uint32_t s0 = (uint32_t)seq_start[b], L = (uint32_t)seq_len[b], v0 = (uint32_t)vt_start[b];
+    const uint32_t ld = (heads + 2u * kv_heads) * kHD;
+    const uint32_t koff = (heads + g) * kHD;
+    const uint32_t qbase = sb * 128u + part * (16u * TQ);      // the workgroup's first query
+    if (qbase >= L) return;                                    // (uniform: before any barrier)
+    const uint32_t q0 = qbase + (uint32_t)(wid / G) * 16u;     // this wave's first query
+    const bool wave_live = q0 < L;                          // waves past the sequence only help staging
+    const uint32_t qi = q0 + (uint32_t)l15;                 // this lane's query
+
+    // 64-key blocks that can hold an attendable key: workgroup range (staging) and this wave's own range
+    const uint32_t nkb = (L + (uint32_t)kABlk - 1u) / (uint32_t)kABlk;
+    uint32_t kb_lo = 0, kb_hi = nkb, wkb_lo = 0, wkb_hi = nkb;
+    if (window) {
+        const uint32_t glo = qbase, ghi = glo + 16u * TQ - 1u;     // workgroup's queries
+        kb_lo = (glo + 1u > window) ? (glo + 1u - window) / (uint32_t)kABlk : 0u;
+        kb_hi = (ghi + window - 1u) / (uint32_t)kABlk + 1u;
+        if (kb_hi > nkb) kb_hi = nkb;
+        const uint32_t qhi = q0 + 15u;                              // this wave's queries
+        wkb_lo = (q0 + 1u > window) ? (q0 + 1u - window) / (uint32_t)kABlk : 0u;
+        wkb_hi = (qhi + window - 1u) / (uint32_t)kABlk + 1u;
+    }
+
+    // LDS-DMA of one block: 32 K instructions (2 key rows of 512 B each) + 32 V^T instructions (8 dim rows of 128 B),
+    // instruction i by wave i % WAVES.  M0 = LDS byte address of the instruction's 1 KiB; lane l lands at byte 16 l.
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) bf16_t*)asmem;
+    const char* const gK = (const char*)(qkv + (size_t)s0 * ld + koff);
+    const char* const gV = (const char*)(vt + (size_t)g * kHD * vt_ld + v0);
+    auto dma = [&](const char* sbase, uint32_t voff, uint32_t lds_byte) {
+        asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                     :: "s"(lds_byte), "v"(voff), "s"(sbase) : "memory");
+    };
+    constexpr int NI = (32 + WAVES - 1) / WAVES;
+    auto stage = [&](uint32_t kb, uint32_t p) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const uint32_t i = (uint32_t)wid + (uint32_t)(WAVES * j);
+            if (32 % WAVES != 0 && i >= 32u) break;                 // wave-uniform
+            // K rows 2i, 2i + 1 of the block; rows past the sequence read its last key (finite; masked later)
+            const uint32_t r = 2u * i + (uint32_t)(lane >> 5);
+            uint32_t key = kb * (uint32_t)kABlk + r;
+            key = key < L ? key : L - 1u;
+            const uint32_t kc = (uint32_t)(lane & 31) ^ (4u * ((r >> 3) & 3u) + (r & 3u));
+            dma(gK, (key * ld + kc * 8u) * 2u, lds0 + p * (uint32_t)(kABuf * 2) + i * 1024u);
+            // V^T dims 8i .. 8i + 7, keys 64 kb .. + 63 (columns past the sequence's padded end belong to the next
+            // sequence or to the zeroed slack: finite, multiplied by P = 0)
+            const uint32_t d = 8u * i + (uint32_t)(lane >> 3);
+            const uint32_t vc = (uint32_t)(lane & 7) ^ ((d >> 1) & 7u);
+            dma(gV + (size_t)kb * (size_t)(kABlk * 2), (d * vt_ld + vc * 8u) * 2u,
+                lds0 + (uint32_t)(2 * kABuf * 2) + p * (uint32_t)(kABuf * 2) + i * 1024u);
+        }
+    };
+    if (kb_lo < kb_hi) stage(kb_lo, 0u);      // in flight under the Q prologue
+#ifdef CQS_ATT2_NO_QNORM
+    q_norm_w = nullptr;
+#endif
+
+    const uint32_t qclamp = qi < L ? qi : L - 1u;
+    bf8 qf[8];
+    load_q_fragments(qf, qkv + (size_t)(s0 + qclamp) * ld + head * kHD, lg, q_norm_w, cos_sin + (size_t)qclamp * 256u, eps, q_scale);
+    // Pin the fragments here: with their loads still "pending" at the loop head (the q_norm_w == NULL path), hipcc
+    // places its s_waitcnt vmcnt(n..0) inside the loop body, where it would drain the next block's DMA every iteration.
+#pragma unroll
+    for (int s = 0; s < 8; ++s) asm volatile("" : "+v"(qf[s]));
+
+    // fragment addresses (elements, buffer 0).  K: row(i = l15) of tile (t, kt) = 32 t + 4 kt + 8 (l15 >> 2) + (l15 & 3),
+    // chunk (4 st + lg) ^ l15 = 16 (st >> 2) + 4 ((st & 3) ^ (l15 >> 2)) + (lg ^ (l15 & 3)): four lane-dependent bases.
+    const bf16_t* kp[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+        kp[s] = asmem + (uint32_t)(8 * (l15 >> 2) + (l15 & 3)) * (uint32_t)kHD +
+                (uint32_t)(4 * (s ^ (l15 >> 2)) + (lg ^ (l15 & 3))) * 8u;
+    // V^T: dim 16 dt + l15, chunk (4 t + lg) ^ ((l15 >> 1) & 7)
+    const bf16_t* vp[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+        vp[t] = asmem + 2 * kABuf + (uint32_t)l15 * (uint32_t)kABlk + (uint32_t)((4 * t + lg) ^ ((l15 >> 1) & 7)) * 8u;
+
+    f4v o[16];
+#pragma unroll
+    for (int d = 0; d < 16; ++d) o[d] = (f4v)(0.f);
+    float m_run = -INFINITY, l_run = 0.f;
+
+#ifdef CQS_ATT2_NO_LOOP
+    kb_hi = kb_lo + 1u;
+#endif
+    for (uint32_t kb = kb_lo; kb < kb_hi; ++kb) {
+        const uint32_t p = (kb - kb_lo) & 1u;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's share of block kb has landed
+        __syncthreads();                                       // everyone's has; block kb - 1 is fully consumed
+#ifndef CQS_ATT2_NO_DMA
+        if (kb + 1u < kb_hi) stage(kb + 1u, p ^ 1u);
+#endif
+        if (!wave_live || kb < wkb_lo || kb >= wkb_hi) continue;   // wave-uniform
+#ifdef CQS_ATT2_NO_COMPUTE
+        if (kb != kb_lo) continue;
+#endif
+        const uint32_t pofs = p * (uint32_t)kABuf;
+        const uint32_t kb_first = kb * (uint32_t)kABlk;
+        using FencedRA = std::integral_constant<int, KRA_F>;
+        // S^T tiles kt = 0, 1 of half t: 16 MFMAs, fragment reads KRA ahead.  `fenced`: keep each read group ahead of its
+        // MFMA group (left alone, hipcc emits read -> wait -> MFMA pairs and every MFMA eats a full LDS round trip);
+        // unfenced, the caller lays the schedule down with sched_group_barrier.
+        auto s_phase = [&](int t, f4v (&sc)[2], auto ra_c) {
+            constexpr int RA = decltype(ra_c)::value;      // > 0: fenced groups of RA reads; < 0: unfenced, -RA
+            constexpr bool fenced = RA > 0;
+            constexpr int KRA = RA > 0 ? RA : -RA;
+            sc[0] = (f4v)(0.f);
+            sc[1] = (f4v)(0.f);
+#pragma unroll
+            for (int grp = 0; grp < 16 / KRA; ++grp) {
+                bf8 kf[KRA];
+#pragma unroll
+                for (int u = 0; u < KRA; ++u) {
+                    const int i = grp * KRA + u, st = i >> 1, kt = i & 1;
+#if defined(CQS_ATT2_NO_LDSREAD)
+                    kf[u] = qf[(st + kt) & 7];
+#else
+                    kf[u] = *(const bf8*)(kp[st & 3] + pofs + (uint32_t)((32 * t + 4 * kt) * kHD + (st >> 2) * 128));
+#endif
+                }
+                if (fenced) __builtin_amdgcn_sched_barrier(0);
+#ifndef CQS_ATT2_NO_S
+#pragma unroll
+                for (int u = 0; u < KRA; ++u) {
+                    const int i = grp * KRA + u, st = i >> 1, kt = i & 1;
+                    sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[u], qf[st], sc[kt], 0, 0, 0);
+                }
+#else
+#pragma unroll
+                for (int u = 0; u < KRA; ++u) sc[u & 1][0] += (float)kf[u][0];
+#endif
+            }
+        };
+        // O^T += V^T P^T over half t: 16 dim tiles, one 16-byte fragment each
+        auto pv_phase = [&](int t, const bf8& pf, auto ra_c) {
+            constexpr int RA = decltype(ra_c)::value;
+            constexpr bool fenced = RA > 0;
+            constexpr int KRA = RA > 0 ? RA : -RA;
+#pragma unroll
+            for (int grp = 0; grp < 16 / KRA; ++grp) {
+                bf8 vf[KRA];
+#pragma unroll
+#if defined(CQS_ATT2_NO_LDSREAD)
+                for (int u = 0; u < KRA; ++u) vf[u] = qf[(grp + u) & 7];
+#else
+                for (int u = 0; u < KRA; ++u) vf[u] = *(const bf8*)(vp[t] + pofs + (uint32_t)((grp * KRA + u) * 16 * kABlk));
+#endif
+                if (fenced) __builtin_amdgcn_sched_barrier(0);
+#ifndef CQS_ATT2_NO_PV
+#pragma unroll
+                for (int u = 0; u < KRA; ++u)
+                    o[grp * KRA + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[u], pf, o[grp * KRA + u], 0, 0, 0);
+#else
+#pragma unroll
+                for (int u = 0; u < KRA; ++u) o[grp * KRA + u][0] += (float)vf[u][0] * (float)pf[0];
+#endif
+            }
+        };
+        // Online softmax of one half (this lane: 8 keys of query qi; the other 24 live in lanes ^16, ^32, ^48), branch-free
+        // up to the (rare) rescale: sc[kt][r] = score of key k_first + 8 lg + 4 kt + r; returns P as the PV product's B
+        // fragment (k-index 8 lg + 4 kt + r).  Deferred rescale: the running max only moves when the half's max exceeds it
+        // by more than kRescaleThr; until then P = exp(s - m_run) <= e^8, exact in f32 and fine in bf16.
+        constexpr float kLog2e = 1.4426950408889634f;
+        auto softmax = [&](const f4v (&sc)[2], float mloc, bf8& pf, float& m_old, float& lsum) -> bool {
+            // (branch-free on purpose: one basic block with the MFMAs it is interleaved with; the caller applies the
+            // rescale of the lanes that return true - `need` - in a separate, rarely taken block)
+            mloc = xor32_max(xor16_max(mloc));
+            const bool need = (mloc > m_run + kRescaleThr) | ((m_run == -INFINITY) & (mloc != -INFINITY));   // (no short-circuit: no branch)
+            m_old = m_run;
+            m_run = need ? mloc : m_run;
+            const float mb = (m_run == -INFINITY) ? 0.f : m_run * kLog2e;   // no attendable key yet: every p = 0
+            lsum = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+#ifdef CQS_ATT2_NO_EXP
+                    const float pv = sc[kt][r] - mb;
+#else
+                    const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[kt][r], kLog2e, -mb));   // exp(-inf) = 0 for masked keys
+#endif
+                    lsum += pv;
+                    pf[kt * 4 + r] = (bf16_t)pv;
+                }
+            return need;
+        };
+        // lanes with `need` moved their running max from m_old to m_run: O and the row sum shrink by exp(m_old - m_run)
+        // (0 when there was no max yet: exp2(-inf))
+        auto rescale = [&](bool need, float m_old) {
+            const float a = need ? __builtin_amdgcn_exp2f((m_old - m_run) * kLog2e) : 1.f;
+            l_run *= a;
+#pragma unroll
+            for (int d = 0; d < 16; ++d) o[d] *= a;
+        };
+        auto max8 = [&](const f4v (&sc)[2]) {
+            float m = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) m = fmaxf(m, sc[kt][r]);
+            return m;
+        };
+
+        // Edge blocks (sequence end or a window edge inside them) mask key by key; a half without any attendable key
+        // just yields P = 0.  (Measured and dropped: half 1's S^T MFMAs issued between half 0's softmax VALU, half 0's
+        // PV MFMAs between half 1's softmax - sched_group_barrier interleave, 2 reads ahead to stay in 168 VGPRs:
+        // 44.9 us vs 42.5.  The loop is co-bound: per 32 keys the CU's 12 waves need 1536 clk of MFMA per SIMD, 1536 clk
+        // of LDS fragment reads and ~1000 clk of VALU, and removing any ONE of them leaves the time unchanged.)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const uint32_t k_first = kb_first + 32u * (uint32_t)t, k_last = k_first + 31u;
+            if (k_first >= L) break;                               // wave-uniform: the half lies past the sequence
+            if (window && (k_last + window <= q0 || k_first >= q0 + 15u + window)) continue;   // no query of the wave sees it
+            f4v sc[2];
+            s_phase(t, sc, FencedRA{});
+            // sc[kt][r] = score of key k_first + 8 lg + 4 kt + r for query qi
+            const bool interior = k_last < L && (!window || ((q0 + 15u < k_first + window) && (k_last < q0 + window)));
+            if (!interior) {
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const uint32_t key = k_first + (uint32_t)(8 * lg + 4 * kt + r);
+                        bool ok = key < L;
+                        if (window) {
+                            const uint32_t dist = key > qi ? key - qi : qi - key;
+                            ok = ok && dist < window;
+                        }
+                        sc[kt][r] = ok ? sc[kt][r] : -INFINITY;
+                    }
+            }
+            bf8 pf;
+            float m_old, lsum;
+            const bool need = softmax(sc, max8(sc), pf, m_old, lsum);
+            if (__any(need)) rescale(need, m_old);
+            l_run += lsum;              // per-lane partial of the row sum; reduced over the lane groups at the end
+            pv_phase(t, pf, FencedRA{});
+        }
+    }
+
+    // O^T[d][q]: lane <-> query l15, register r of tile d <-> dim 16d + 4lg + r.  Through the wave's own 8 KiB of LDS
+    // (the K buffers are dead after the barrier) so that the global stores are whole 512-byte head rows, 16 B per lane:
+    // direct 8-byte stores (16 rows x 32 B per instruction) cost 7.5 us of this kernel's 48.
+    l_run = xor32_sum(xor16_sum(l_run));
+    __syncthreads();
+    {
+        const float invl = l_run > 0.f ? 1.0f / l_run : 0.f;
+        // row q (512 B = 32 chunks of 8 dims): dims 16d + 4lg + 0..3 = half (lg & 1) of chunk 2d + (lg >> 1), stored at
+        // chunk position c ^ (q & 7) ... 8-byte writes: lanes l15 = 0..15 hit distinct rows (stride 512 B = same bank
+        // group) -> the XOR spreads them over 8 of the 16 slots; 2-way on a write costs nothing extra.
+        bf16_t* const so = asmem + (uint32_t)wid * (16u * kHD);
+#pragma unroll
+        for (int d = 0; d < 16; ++d) {
+            bf4 w;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w[e] = (bf16_t)(o[d][e] * invl);
+            const uint32_t c = (uint32_t)(2 * d + (lg >> 1)) ^ (uint32_t)(l15 & 7) ^ (uint32_t)((l15 >> 3) << 3);
+            *(bf4*)(so + (uint32_t)l15 * kHD + c * 8u + (uint32_t)(lg & 1) * 4u) = w;
+        }
+        // (same wave wrote and reads: no barrier, the compiler's lgkmcnt wait orders the LDS accesses)
+        const uint32_t rr = (uint32_t)(lane >> 5), cc = (uint32_t)(lane & 31);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const uint32_t q = 2u * (uint32_t)i + rr;                      // query row of the wave's tile
+            const uint32_t c = cc ^ (q & 7u) ^ ((q >> 3) << 3);
+            const u4 v = *(const u4*)(so + q * kHD + c * 8u);
+            if (wave_live && q0 + q < L)
+                *(u4*)(out + (size_t)(s0 + q0 + q) * (heads * kHD) + head * kHD + cc * 8u) = v;
         }
     }
 }
@@ -814,6 +1153,34 @@ hipError_t launch_attention(const bf16_t* qkv, const bf16_t* vt, bf16_t* out, co
         else if (f[0] == 'p') share = false;
     }
     if (!share) { CQS_ATT(1, 8); return hipGetLastError(); }
+    // Head-sharing workgroups (full batches): the 64-key LDS-DMA kernel; CQS_HIP_ATT_KERNEL=reg keeps the
+    // register-staged one (test hook: both are checked against the oracle).
+    bool use_dma = true;
+    if (const char* f = getenv("CQS_HIP_ATT_KERNEL")) use_dma = f[0] != 'r';
+#define CQS_ATT_DMA(GV, TQV, KRAV)                                                                                  \
+    do {                                                                                                            \
+        auto kern = attention_dma_kernel<TQV * GV, GV, KRAV>;                                                       \
+        static bool attr_set = false;                                                                               \
+        if (!attr_set) {                                                                                            \
+            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,       \
+                                               (int)kAttDmaLds);                                                    \
+            if (e != hipSuccess) return e;                                                                          \
+            attr_set = true;                                                                                        \
+        }                                                                                                           \
+        hipLaunchKernelGGL(kern, dim3(nblk * (128 / (16 * TQV)), heads / GV), dim3(64 * TQV * GV), kAttDmaLds, st,  \
+                           qkv, vt, out, blk, seq_start, seq_len, vt_start, vt_ld, heads, kv_heads, window,         \
+                           q_norm_w, cos_sin, eps, q_scale);                                                        \
+    } while (0)
+    if (use_dma) {
+        switch (ratio) {
+            case 2: CQS_ATT_DMA(2, 4, 8); break;
+            case 3: CQS_ATT_DMA(3, CQS_ATT_TQ, 4); break;
+            case 4: CQS_ATT_DMA(4, 2, 8); break;
+            default: return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    }
+#undef CQS_ATT_DMA
     switch (ratio) {
         case 2: CQS_ATT(2, 4); break;
         case 3: CQS_ATT(3, CQS_ATT_TQ); break;

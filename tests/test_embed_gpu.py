@@ -296,21 +296,43 @@ def test_gqa_two_kv_heads(hip):
     eng.close()
 
 
+@pytest.mark.parametrize("kernel", ["dma", "reg"])
 @pytest.mark.parametrize("layout,heads,kv", [("shared", 3, 1), ("per-head", 3, 1), ("shared", 4, 2), ("shared", 4, 1)])
-def test_attention_workgroup_layouts(hip, layout, heads, kv, monkeypatch):
+def test_attention_workgroup_layouts(hip, layout, heads, kv, kernel, monkeypatch):
     """The attention kernel has two workgroup layouts (all q-heads of a kv head share one staged K / V^T tile
     when the batch is large enough to fill the chip; one q-head per workgroup otherwise).  Both against the
     fp32 oracle on the real head geometry (3 q-heads, 1 kv head) and the 2:1 / 4:1 sharing variants,
     sliding + full layers, ragged lengths."""
     monkeypatch.setenv("CQS_HIP_ATT_LAYOUT", layout)
+    # head-sharing workgroups have two kernels: "dma" (64-key blocks fetched by LDS-DMA into a double buffer; the
+    # default) and "reg" (32-key blocks staged through registers); per-head workgroups always run the latter
+    monkeypatch.setenv("CQS_HIP_ATT_KERNEL", kernel)
+    if layout == "per-head" and kernel == "dma":
+        pytest.skip("per-head workgroups have one kernel")
     cfg = G.GemmaConfig(vocab_size=512, hidden=256, layers=3, heads=heads, kv_heads=kv, head_dim=256, intermediate=256,
                         dense_hidden=256, sliding_window=64, sliding_pattern=3, max_seq=512)
     eng, w = make(cfg, seed=41)
-    ids, mask = batch(cfg, [300, 65, 64, 1, 129, 200], seed=42)
+    ids, mask = batch(cfg, [300, 65, 64, 1, 129, 200, 33, 96, 511, 512, 63, 31], seed=42)
     got = eng.run(ids, mask)
     ref = G.forward(cfg, w, ids, mask)
     for i in range(len(ids)):
         assert cos(got[i], ref[i]) > 0.999, (layout, heads, kv, i, cos(got[i], ref[i]))
+    eng.close()
+
+
+@pytest.mark.parametrize("kernel", ["dma", "reg"])
+def test_attention_real_window_shared_layout(hip, kernel, monkeypatch):
+    """The production window (|q - k| < 257) on sequences around it, head-sharing workgroups, both kernels."""
+    monkeypatch.setenv("CQS_HIP_ATT_LAYOUT", "shared")
+    monkeypatch.setenv("CQS_HIP_ATT_KERNEL", kernel)
+    cfg = G.GemmaConfig(vocab_size=512, hidden=256, layers=2, heads=3, kv_heads=1, head_dim=256, intermediate=256,
+                        dense_hidden=256, sliding_window=512, sliding_pattern=2, max_seq=1024)
+    eng, w = make(cfg, seed=43)
+    ids, mask = batch(cfg, [1024, 700, 512, 258, 257, 256, 321, 40], seed=44)
+    got = eng.run(ids, mask)
+    ref = G.forward(cfg, w, ids, mask)
+    for i in range(len(ids)):
+        assert cos(got[i], ref[i]) > 0.999, (kernel, i, cos(got[i], ref[i]))
     eng.close()
 
 
