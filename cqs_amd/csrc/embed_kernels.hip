@@ -123,15 +123,15 @@ __global__ __launch_bounds__(256) void add_norm_kernel(float* __restrict__ x, co
 // (the token's cos/sin row - twice the bytes of one head - is fetched once for all heads, and the heads'
 // loads are in flight together)
 constexpr int kMaxQkHeads = 8;
-__global__ __launch_bounds__(256) void qk_norm_rope_kernel(bf16_t* __restrict__ qkv, const int32_t* __restrict__ pos,
-                                                           const float* __restrict__ wq, const float* __restrict__ wk,
-                                                           const float* __restrict__ cos_sin, float eps, float q_scale,
-                                                           uint32_t M, uint32_t heads, uint32_t kv_heads, uint32_t h_first) {
+__device__ __forceinline__ void qk_norm_rope_block(uint32_t bid, bf16_t* __restrict__ qkv, const int32_t* __restrict__ pos,
+                                                   const float* __restrict__ wq, const float* __restrict__ wk,
+                                                   const float* __restrict__ cos_sin, float eps, float q_scale,
+                                                   uint32_t M, uint32_t heads, uint32_t kv_heads, uint32_t h_first) {
     // heads [h_first, heads + kv_heads) of the fused q | k | v row: h_first = 0 -> q and k heads, h_first = heads -> the
     // k heads only (the attention kernel then normalises / rotates its own Q fragments)
     const int lane = threadIdx.x & 63;
     const uint32_t nh = heads + kv_heads - h_first;
-    const uint32_t m = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const uint32_t m = bid * 4u + (threadIdx.x >> 6);
     if (m >= M) return;
     const uint32_t ld = (heads + 2u * kv_heads) * kHD;
     bf16_t* row = qkv + (size_t)m * ld + (size_t)h_first * kHD + lane * 4;
@@ -170,6 +170,12 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(bf16_t* __restrict__ 
         *(bf4*)(row + (size_t)h * kHD) = o;
     }
 }
+__global__ __launch_bounds__(256) void qk_norm_rope_kernel(bf16_t* __restrict__ qkv, const int32_t* __restrict__ pos,
+                                                           const float* __restrict__ wq, const float* __restrict__ wk,
+                                                           const float* __restrict__ cos_sin, float eps, float q_scale,
+                                                           uint32_t M, uint32_t heads, uint32_t kv_heads, uint32_t h_first) {
+    qk_norm_rope_block(blockIdx.x, qkv, pos, wq, wk, cos_sin, eps, q_scale, M, heads, kv_heads, h_first);
+}
 
 // ---- V transpose: vt[g][d][vt_start[seq] + pos] = v[token][g][d] -------------------------------------
 // One workgroup = 64 positions (half a 128-position super-block of the attention's blk list) x 64 head
@@ -177,15 +183,15 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(bf16_t* __restrict__ 
 // positions of one head dim (V^T columns of a sequence start at a multiple of 32, so they are aligned);
 // 8 lanes cover one dim's 64 positions = one full 128-B line.  Positions past the sequence end are
 // written as zeros (the attention multiplies them by P = 0; they must stay finite).
-__global__ __launch_bounds__(256) void v_transpose_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ vt,
-                                                          const int32_t* __restrict__ blk,
-                                                          const int32_t* __restrict__ seq_start,
-                                                          const int32_t* __restrict__ seq_len,
-                                                          const int32_t* __restrict__ vt_start, uint32_t heads,
-                                                          uint32_t kv_heads, uint32_t vt_ld) {
+__device__ __forceinline__ void v_transpose_block(uint32_t bx, uint32_t by, const bf16_t* __restrict__ qkv,
+                                                  bf16_t* __restrict__ vt, const int32_t* __restrict__ blk,
+                                                  const int32_t* __restrict__ seq_start,
+                                                  const int32_t* __restrict__ seq_len,
+                                                  const int32_t* __restrict__ vt_start, uint32_t heads,
+                                                  uint32_t kv_heads, uint32_t vt_ld) {
     __shared__ __attribute__((aligned(16))) bf16_t tile[64][64 + 8];
-    const uint32_t g = blockIdx.y >> 2, d0 = (blockIdx.y & 3u) * 64u;
-    const uint32_t sblk = blockIdx.x >> 1, half = blockIdx.x & 1u;
+    const uint32_t g = by >> 2, d0 = (by & 3u) * 64u;
+    const uint32_t sblk = bx >> 1, half = bx & 1u;
     const uint32_t seq = (uint32_t)blk[2 * sblk], sb = (uint32_t)blk[2 * sblk + 1];
     const uint32_t len = (uint32_t)seq_len[seq], m_seq = (uint32_t)seq_start[seq], c_seq = (uint32_t)vt_start[seq];
     const uint32_t cols = (len + 31u) & ~31u;  // the sequence's padded V^T columns
@@ -210,6 +216,32 @@ __global__ __launch_bounds__(256) void v_transpose_kernel(const bf16_t* __restri
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = tile[t0 + e][d];
         *(bf8*)(vt + ((size_t)g * kHD + d0 + d) * vt_ld + c_seq + p0 + t0) = o;
+    }
+}
+__global__ __launch_bounds__(256) void v_transpose_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ vt,
+                                                          const int32_t* __restrict__ blk,
+                                                          const int32_t* __restrict__ seq_start,
+                                                          const int32_t* __restrict__ seq_len,
+                                                          const int32_t* __restrict__ vt_start, uint32_t heads,
+                                                          uint32_t kv_heads, uint32_t vt_ld) {
+    v_transpose_block(blockIdx.x, blockIdx.y, qkv, vt, blk, seq_start, seq_len, vt_start, heads, kv_heads, vt_ld);
+}
+
+// ---- k-head norm + RoPE and the V transpose in ONE launch (two 6-7 us latency-bound kernels with nothing in common
+// but their input row: workgroups [0, n_rope) take 4 tokens each, the rest one V^T tile each) -------------------------
+__global__ __launch_bounds__(256) void kv_prep_kernel(bf16_t* __restrict__ qkv, bf16_t* __restrict__ vt,
+                                                      const int32_t* __restrict__ pos, const float* __restrict__ wq,
+                                                      const float* __restrict__ wk, const float* __restrict__ cos_sin,
+                                                      float eps, float q_scale, uint32_t M, uint32_t heads,
+                                                      uint32_t kv_heads, uint32_t n_rope, const int32_t* __restrict__ blk,
+                                                      uint32_t nblk, const int32_t* __restrict__ seq_start,
+                                                      const int32_t* __restrict__ seq_len,
+                                                      const int32_t* __restrict__ vt_start, uint32_t vt_ld) {
+    if (blockIdx.x < n_rope) {
+        qk_norm_rope_block(blockIdx.x, qkv, pos, wq, wk, cos_sin, eps, q_scale, M, heads, kv_heads, heads);
+    } else {
+        const uint32_t b2 = blockIdx.x - n_rope;
+        v_transpose_block(b2 % (nblk * 2u), b2 / (nblk * 2u), qkv, vt, blk, seq_start, seq_len, vt_start, heads, kv_heads, vt_ld);
     }
 }
 
@@ -1108,6 +1140,18 @@ hipError_t launch_qk_norm_rope(bf16_t* qkv, const int32_t* pos, const float* wq,
     if (heads + kv_heads > (uint32_t)kMaxQkHeads) return hipErrorInvalidValue;
     hipLaunchKernelGGL(qk_norm_rope_kernel, dim3((M + 3u) / 4u), dim3(256), 0, st, qkv, pos, wq, wk, cos_sin, eps,
                        q_scale, M, heads, kv_heads, k_only ? heads : 0u);
+    return hipGetLastError();
+}
+
+hipError_t launch_kv_prep(bf16_t* qkv, bf16_t* vt, const int32_t* pos, const float* wq, const float* wk,
+                          const float* cos_sin, float eps, float q_scale, uint32_t M, uint32_t heads, uint32_t kv_heads,
+                          const int32_t* blk, uint32_t nblk, const int32_t* seq_start, const int32_t* seq_len,
+                          const int32_t* vt_start, uint32_t vt_ld, hipStream_t st) {
+    if (M == 0 || nblk == 0) return hipSuccess;
+    if (kv_heads > (uint32_t)kMaxQkHeads) return hipErrorInvalidValue;
+    const uint32_t n_rope = (M + 3u) / 4u, n_vt = nblk * 2u * kv_heads * 4u;
+    hipLaunchKernelGGL(kv_prep_kernel, dim3(n_rope + n_vt), dim3(256), 0, st, qkv, vt, pos, wq, wk, cos_sin, eps, q_scale, M,
+                       heads, kv_heads, n_rope, blk, nblk, seq_start, seq_len, vt_start, vt_ld);
     return hipGetLastError();
 }
 

@@ -8,5 +8,5 @@ for k in ${@:-dma reg}; do
   export CQS_HIP_ATT_KERNEL=$k
   timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/att_$k -o kt --output-format csv -- python3 $REPO/tools/embed_bench.py --iters 4 > $OUT/att_$k.txt 2> $OUT/att_$k.err
   echo "== $k: $(cat $OUT/att_$k.txt)"
-  python3 $REPO/tools/summarize_prof.py $OUT/att_$k | grep -E "attention|gemm_pp_kernel<3|add_norm_kernel<3,0>" 
+  python3 $REPO/tools/summarize_prof.py $OUT/att_$k | head -16 
 done
