@@ -282,10 +282,12 @@ int32_t cqs_hip_embed(cqs_hip_embedder* e, const int64_t* input_ids, const int64
                       uint32_t batch, uint32_t seq_len, float* out);
 /* Asynchronous form of the same call, for the index pipeline (the embed stage is its bottleneck when the cache is
  * cold, src/cli/pipeline/embedding.rs:226-421): submit validates and packs the batch into pinned staging, enqueues
- * tables H2D + forward + D2H on the engine's stream and returns a ticket without waiting; collect waits for that
- * ticket and copies its [batch, hidden] rows out.  Up to 3 tickets may be in flight: while the device runs batch i
- * the host packs batch i+1 and the caller tokenises batch i+2.  A 4th submit without a collect ->
- * CQS_HIP_ERR_INVALID.  Tickets may be collected in any order; results do not depend on what else is in flight.
+ * tables H2D + forward + D2H on one of the engine's two execution contexts (a HIP stream + activation scratch each;
+ * consecutive tickets alternate, so two batches' kernel chains interleave on the device) and returns a ticket
+ * without waiting; collect waits for that ticket and copies its [batch, hidden] rows out.  Up to 3 tickets may be in
+ * flight: while the device runs batches i and i+1 the host packs batch i+2.  A 4th submit without a collect ->
+ * CQS_HIP_ERR_INVALID.  Tickets may be collected in any order (and may finish out of order); results do not depend
+ * on what else is in flight.
  * submit_ragged takes the batch without padding: `tokens` = the sequences' ids back to back (i32), lens[b] = length
  * of sequence b (0 allowed -> zero vector) - what a length-sorted scheduler holds anyway. */
 int32_t cqs_hip_embed_submit(cqs_hip_embedder* e, const int64_t* input_ids, const int64_t* attention_mask,
@@ -299,7 +301,8 @@ void cqs_hip_normalize_l2_rows(float* rows, uint64_t n, uint32_t dim);
 /* Diagnostic twin: final-norm hidden states f32 [batch, seq_len, hidden] (zeros at padded positions). */
 int32_t cqs_hip_embed_hidden(cqs_hip_embedder* e, const int64_t* input_ids, const int64_t* attention_mask,
                              uint32_t batch, uint32_t seq_len, float* out_hidden);
-/* Milliseconds of device time of the most recent cqs_hip_embed* call (HIP events on its stream). */
+/* Milliseconds between the start and the end of the forward of the most recently COLLECTED batch (HIP events on its
+ * stream; with other tickets in flight that interval includes the time it shared the device with them). */
 float cqs_hip_embedder_last_ms(const cqs_hip_embedder* e);
 
 #ifdef __cplusplus
