@@ -58,12 +58,14 @@ hipError_t launch_v_transpose(const bf16_t* qkv, bf16_t* vt, const int32_t* blk,
                               const int32_t* seq_start, const int32_t* seq_len, const int32_t* vt_start, uint32_t heads,
                               uint32_t kv_heads, uint32_t vt_ld, hipStream_t st);
 
-// launch_qk_norm_rope(k_only = 1) + launch_v_transpose in one launch (what the forward runs between the QKV GEMM and
-// the attention).
+// launch_qk_norm_rope(k_only = 1) + (with_vt != 0) launch_v_transpose in one launch: what the forward runs between
+// the QKV GEMM and the attention.  with_vt = attention_reads_vt(...): the full-batch attention kernel reads V rows as
+// they lie in qkv (transposed LDS reads), only the small-batch kernel wants V^T.
 hipError_t launch_kv_prep(bf16_t* qkv, bf16_t* vt, const int32_t* pos, const float* wq, const float* wk,
                           const float* cos_sin, float eps, float q_scale, uint32_t M, uint32_t heads, uint32_t kv_heads,
                           const int32_t* blk, uint32_t nblk, const int32_t* seq_start, const int32_t* seq_len,
-                          const int32_t* vt_start, uint32_t vt_ld, hipStream_t st);
+                          const int32_t* vt_start, uint32_t vt_ld, int with_vt, hipStream_t st);
+bool attention_reads_vt(uint32_t nblk, uint32_t heads, uint32_t kv_heads);
 
 // Bidirectional (optionally windowed) attention over packed sequences.
 // blk[i] = {sequence, 128-row query super-block}; seq_start/seq_len in packed tokens; vt_start = first

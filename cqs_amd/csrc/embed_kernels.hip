@@ -515,16 +515,20 @@ __global__ __launch_bounds__(64 * WAVES) void attention_kernel(const bf16_t* __r
 
 // ---- attention, second generation: 64-key blocks, LDS-DMA double buffer ---------------------------------
 // Same math and wave layout as attention_kernel (wave = 16 queries of one q-head; S^T = K Q^T, O^T += V^T P^T), but
-// the K / V^T tiles never pass through registers: each 64-key block (K 64 x 256, V^T 256 x 64: 32 KiB each) is
-// fetched by `global_load_lds_dwordx4` into the buffer the previous block is not using, ONE barrier per 64 keys
-// (attention_kernel: two per 32, plus 6 ds_write per thread), and the softmax's cross-lane steps use
-// v_permlane{16,32}_swap instead of ds_bpermute (which queues behind the fragment reads).
+// the K / V tiles never pass through registers: each 64-key block (K and V rows as they lie in the qkv buffer, 64 x 256
+// each = 32 KiB) is fetched by `global_load_lds_dwordx4` into the buffer the previous block is not using, ONE barrier
+// per 64 keys (attention_kernel: two per 32, plus 6 ds_write per thread), the softmax's cross-lane steps use
+// v_permlane{16,32}_swap instead of ds_bpermute (which queues behind the fragment reads), and the PV product's V^T
+// fragments come from the ROW-major V image through `ds_read_b64_tr_b16` (hardware transpose: no V^T buffer, no
+// v_transpose launch on this path).
 // LDS images are unpadded; the bank swizzle is applied to the DMA's SOURCE address (the destination is lane-linear):
-//   K  [key row 0..63][32 chunks of 8 dims]   chunk c of row r lives at c ^ f(r), f(r) = 4 ((r >> 3) & 3) + (r & 3)
-//   V^T[dim 0..255][8 chunks of 8 keys]       chunk c of dim d lives at c ^ ((d >> 1) & 7)
+//   K [key row 0..63][32 chunks of 8 dims]   chunk c of row r lives at c ^ fK(r), fK(r) = 4 ((r >> 3) & 3) + (r & 3)
+//   V [key row 0..63][32 chunks of 8 dims]   chunk c of row r lives at c ^ fV(r), fV(r) = 2 (r & 3) + 8 ((r >> 3) & 1)
 // The S^T tile (t, kt) takes its 16 key rows in the order row(i) = 32 t + 8 (i >> 2) + 4 kt + (i & 3), so that lane
-// group lg's C registers of tiles kt = 0, 1 hold the 8 CONSECUTIVE keys 32 t + 8 lg + 0..7 = one 16-byte V^T chunk
-// (the PV product's A fragment is a plain row read; attention_kernel needs two 8-byte pieces), and f(row(i)) = i.
+// group lg's C registers of tiles kt = 0, 1 hold the 8 CONSECUTIVE keys 32 t + 8 lg + 0..7 = k-indices 8 lg + 0..7 of
+// the PV product, and fK(row(i)) = i.  A transposed read serves, per 16-lane group, 4 key rows x 16 dims: lane 4q + p
+// supplies the address of (key 8 lg + 4 h + q, dims 16 dt + 4 p ..+3) and lane i receives dim 16 dt + i of the 4 keys;
+// h = 0, 1 give the 8 k-indices.  fV makes the 8 rows a 32-lane half touches land in 8 distinct 32-byte bank slots.
 __device__ __forceinline__ float xor16_max(float v) {
     typedef unsigned pu2 __attribute__((ext_vector_type(2)));
     const pu2 a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
@@ -576,7 +580,7 @@ __global__ __launch_bounds__(64 * WAVES) void attention_dma_kernel(const bf16_t*
     const uint32_t b = (uint32_t)blk[2 * sblk], sb = (uint32_t)blk[2 * sblk + 1];
     const uint32_t head = blockIdx.y * (uint32_t)G + (uint32_t)(wid % G);
     const uint32_t g = head / (heads / kv_heads);
-    const uint32_t s0 = (uint32_t)seq_start[b], L = (uint32_t)seq_len[b], v0 = (uint32_t)vt_start[b];
+    const uint32_t s0 = (uint32_t)seq_start[b], L = (uint32_t)seq_len[b];   // (vt / vt_start / vt_ld: unused here)
     const uint32_t ld = (heads + 2u * kv_heads) * kHD;
     const uint32_t koff = (heads + g) * kHD;
     const uint32_t qbase = sb * 128u + part * (16u * TQ);      // the workgroup's first query
@@ -598,11 +602,12 @@ __global__ __launch_bounds__(64 * WAVES) void attention_dma_kernel(const bf16_t*
         wkb_hi = (qhi + window - 1u) / (uint32_t)kABlk + 1u;
     }
 
-    // LDS-DMA of one block: 32 K instructions (2 key rows of 512 B each) + 32 V^T instructions (8 dim rows of 128 B),
-    // instruction i by wave i % WAVES.  M0 = LDS byte address of the instruction's 1 KiB; lane l lands at byte 16 l.
+    // LDS-DMA of one block: 32 K instructions + 32 V instructions of 2 key rows (512 B each), instruction i by wave
+    // i % WAVES.  M0 = LDS byte address of the instruction's 1 KiB; lane l lands at byte 16 l.  Rows past the sequence
+    // read its last key (finite; masked / multiplied by P = 0 later).
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) bf16_t*)asmem;
     const char* const gK = (const char*)(qkv + (size_t)s0 * ld + koff);
-    const char* const gV = (const char*)(vt + (size_t)g * kHD * vt_ld + v0);
+    const uint32_t vrel = kv_heads * (uint32_t)kHD * 2u;          // byte distance from a token's k head to its v head
     auto dma = [&](const char* sbase, uint32_t voff, uint32_t lds_byte) {
         asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
                      :: "s"(lds_byte), "v"(voff), "s"(sbase) : "memory");
@@ -613,18 +618,13 @@ __global__ __launch_bounds__(64 * WAVES) void attention_dma_kernel(const bf16_t*
         for (int j = 0; j < NI; ++j) {
             const uint32_t i = (uint32_t)wid + (uint32_t)(WAVES * j);
             if (32 % WAVES != 0 && i >= 32u) break;                 // wave-uniform
-            // K rows 2i, 2i + 1 of the block; rows past the sequence read its last key (finite; masked later)
             const uint32_t r = 2u * i + (uint32_t)(lane >> 5);
             uint32_t key = kb * (uint32_t)kABlk + r;
             key = key < L ? key : L - 1u;
             const uint32_t kc = (uint32_t)(lane & 31) ^ (4u * ((r >> 3) & 3u) + (r & 3u));
+            const uint32_t vc = (uint32_t)(lane & 31) ^ (2u * (r & 3u) + 8u * ((r >> 3) & 1u));
             dma(gK, (key * ld + kc * 8u) * 2u, lds0 + p * (uint32_t)(kABuf * 2) + i * 1024u);
-            // V^T dims 8i .. 8i + 7, keys 64 kb .. + 63 (columns past the sequence's padded end belong to the next
-            // sequence or to the zeroed slack: finite, multiplied by P = 0)
-            const uint32_t d = 8u * i + (uint32_t)(lane >> 3);
-            const uint32_t vc = (uint32_t)(lane & 7) ^ ((d >> 1) & 7u);
-            dma(gV + (size_t)kb * (size_t)(kABlk * 2), (d * vt_ld + vc * 8u) * 2u,
-                lds0 + (uint32_t)(2 * kABuf * 2) + p * (uint32_t)(kABuf * 2) + i * 1024u);
+            dma(gK, (key * ld + vc * 8u) * 2u + vrel, lds0 + (uint32_t)(2 * kABuf * 2) + p * (uint32_t)(kABuf * 2) + i * 1024u);
         }
     };
     if (kb_lo < kb_hi) stage(kb_lo, 0u);      // in flight under the Q prologue
@@ -647,11 +647,16 @@ __global__ __launch_bounds__(64 * WAVES) void attention_dma_kernel(const bf16_t*
     for (int s = 0; s < 4; ++s)
         kp[s] = asmem + (uint32_t)(8 * (l15 >> 2) + (l15 & 3)) * (uint32_t)kHD +
                 (uint32_t)(4 * (s ^ (l15 >> 2)) + (lg ^ (l15 & 3))) * 8u;
-    // V^T: dim 16 dt + l15, chunk (4 t + lg) ^ ((l15 >> 1) & 7)
-    const bf16_t* vp[2];
+    // V (transposed reads): lane 16 lg + 4 q + p addresses key row 8 lg + q (+ 4 h + 32 t), chunk 2 dt + (p >> 1), half
+    // (p & 1); the chunk's position is 2 (dt ^ xq) + (p >> 1) with xq = q + 4 (lg & 1): eight lane-dependent bases by dt & 7.
+    typedef short tr4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) tr4* lds_tr4;
+    const int tq = (lane >> 2) & 3, tp = lane & 3, xq = tq + 4 * (lg & 1);
+    uint32_t vb[8];
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
-        vp[t] = asmem + 2 * kABuf + (uint32_t)l15 * (uint32_t)kABlk + (uint32_t)((4 * t + lg) ^ ((l15 >> 1) & 7)) * 8u;
+    for (int j = 0; j < 8; ++j)
+        vb[j] = lds0 + (uint32_t)(2 * kABuf * 2) + (uint32_t)(8 * lg + tq) * (uint32_t)(kHD * 2) +
+                (uint32_t)(2 * (j ^ xq) + (tp >> 1)) * 16u + (uint32_t)(tp & 1) * 8u;
 
     f4v o[16];
 #pragma unroll
@@ -661,18 +666,20 @@ __global__ __launch_bounds__(64 * WAVES) void attention_dma_kernel(const bf16_t*
 #ifdef CQS_ATT2_NO_LOOP
     kb_hi = kb_lo + 1u;
 #endif
-    for (uint32_t kb = kb_lo; kb < kb_hi; ++kb) {
-        const uint32_t p = (kb - kb_lo) & 1u;
+    // One 64-key block out of buffer P (compile-time: the buffer offset rides in the ds_read immediates, no per-block
+    // pointer arithmetic and no second set of address registers)
+    auto block = [&](uint32_t kb, auto par_c) {
+        constexpr uint32_t p = (uint32_t)decltype(par_c)::value;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's share of block kb has landed
         __syncthreads();                                       // everyone's has; block kb - 1 is fully consumed
 #ifndef CQS_ATT2_NO_DMA
         if (kb + 1u < kb_hi) stage(kb + 1u, p ^ 1u);
 #endif
-        if (!wave_live || kb < wkb_lo || kb >= wkb_hi) continue;   // wave-uniform
+        if (!wave_live || kb < wkb_lo || kb >= wkb_hi) return;     // wave-uniform
 #ifdef CQS_ATT2_NO_COMPUTE
-        if (kb != kb_lo) continue;
+        if (kb != kb_lo) return;
 #endif
-        const uint32_t pofs = p * (uint32_t)kABuf;
+        constexpr uint32_t pofs = p * (uint32_t)kABuf;
         const uint32_t kb_first = kb * (uint32_t)kABlk;
         using FencedRA = std::integral_constant<int, KRA_F>;
         // S^T tiles kt = 0, 1 of half t: 16 MFMAs, fragment reads KRA ahead.  `fenced`: keep each read group ahead of its
@@ -721,7 +728,13 @@ __global__ __launch_bounds__(64 * WAVES) void attention_dma_kernel(const bf16_t*
 #if defined(CQS_ATT2_NO_LDSREAD)
                 for (int u = 0; u < KRA; ++u) vf[u] = qf[(grp + u) & 7];
 #else
-                for (int u = 0; u < KRA; ++u) vf[u] = *(const bf8*)(vp[t] + pofs + (uint32_t)((grp * KRA + u) * 16 * kABlk));
+                for (int u = 0; u < KRA; ++u) {
+                    const int dt = grp * KRA + u;
+                    const uint32_t ad = vb[dt & 7] + pofs * 2u + (uint32_t)(t * 32 * kHD * 2 + (dt >> 3) * 256);
+                    const tr4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr4)(uintptr_t)ad);
+                    const tr4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr4)(uintptr_t)(ad + (uint32_t)(4 * kHD * 2)));
+                    vf[u] = __builtin_bit_cast(bf8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                }
 #endif
                 if (fenced) __builtin_amdgcn_sched_barrier(0);
 #ifndef CQS_ATT2_NO_PV
@@ -814,6 +827,10 @@ __global__ __launch_bounds__(64 * WAVES) void attention_dma_kernel(const bf16_t*
             l_run += lsum;              // per-lane partial of the row sum; reduced over the lane groups at the end
             pv_phase(t, pf, FencedRA{});
         }
+    };
+    for (uint32_t kb = kb_lo; kb < kb_hi; kb += 2u) {
+        block(kb, std::integral_constant<int, 0>{});
+        if (kb + 1u < kb_hi) block(kb + 1u, std::integral_constant<int, 1>{});
     }
 
     // O^T[d][q]: lane <-> query l15, register r of tile d <-> dim 16d + 4lg + r.  Through the wave's own 8 KiB of LDS
@@ -1089,7 +1106,8 @@ hipError_t launch_gemm_bf16(const bf16_t* A, const bf16_t* W, void* C, uint32_t 
     // 256 columns = one round of 128 x 128: 62 us instead of 73).
     const float kscale = (float)K / 768.f;
     const float geglu = out == GEMM_OUT_GEGLU ? 1.f : 0.f;
-    const uint32_t cu = (uint32_t)n_cu;
+    uint32_t cu = (uint32_t)n_cu;
+    if (const char* f = getenv("CQS_HIP_GEMM_CUS")) { const int v = atoi(f); if (v > 0) cu = (uint32_t)v; }   // experiment hook: plan for part of the chip
     const bool fits = (uint64_t)M * K < (1ull << 31) && (uint64_t)N * K < (1ull << 31);
     const float cost[6] = {0.f, 0.f, 0.f, 24.f, 25.5f, 32.5f};
     auto one = [&](uint32_t n, int t) -> float {              // cost of n columns with one kernel; < 0: not applicable
@@ -1146,10 +1164,10 @@ hipError_t launch_qk_norm_rope(bf16_t* qkv, const int32_t* pos, const float* wq,
 hipError_t launch_kv_prep(bf16_t* qkv, bf16_t* vt, const int32_t* pos, const float* wq, const float* wk,
                           const float* cos_sin, float eps, float q_scale, uint32_t M, uint32_t heads, uint32_t kv_heads,
                           const int32_t* blk, uint32_t nblk, const int32_t* seq_start, const int32_t* seq_len,
-                          const int32_t* vt_start, uint32_t vt_ld, hipStream_t st) {
+                          const int32_t* vt_start, uint32_t vt_ld, int with_vt, hipStream_t st) {
     if (M == 0 || nblk == 0) return hipSuccess;
     if (kv_heads > (uint32_t)kMaxQkHeads) return hipErrorInvalidValue;
-    const uint32_t n_rope = (M + 3u) / 4u, n_vt = nblk * 2u * kv_heads * 4u;
+    const uint32_t n_rope = (M + 3u) / 4u, n_vt = with_vt ? nblk * 2u * kv_heads * 4u : 0u;
     hipLaunchKernelGGL(kv_prep_kernel, dim3(n_rope + n_vt), dim3(256), 0, st, qkv, vt, pos, wq, wk, cos_sin, eps, q_scale, M,
                        heads, kv_heads, n_rope, blk, nblk, seq_start, seq_len, vt_start, vt_ld);
     return hipGetLastError();
@@ -1163,6 +1181,32 @@ hipError_t launch_v_transpose(const bf16_t* qkv, bf16_t* vt, const int32_t* blk,
                        vt_start, heads, kv_heads, vt_ld);
     return hipGetLastError();
 }
+
+// Which attention kernel a batch gets.  Small batches (fewer head-sharing workgroups than CUs: e.g. 32 short chunks)
+// keep one q-head per workgroup - more, thinner workgroups fill the chip better (measured +6 % on log-normal lengths) -
+// on the register-staged kernel, which reads V^T.  Full batches: head-sharing workgroups on the 64-key LDS-DMA kernel
+// (row-major V, no V^T); CQS_HIP_ATT_KERNEL=reg keeps the register-staged one there too, CQS_HIP_ATT_LAYOUT=shared /
+// per-head forces a layout (test hooks: every combination is checked against the oracle).
+struct AttPlan { bool share, dma; };
+static AttPlan att_plan(uint32_t nblk, uint32_t heads, uint32_t kv_heads) {
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
+            n_cu = 256;
+    }
+    const uint32_t ratio = kv_heads ? heads / kv_heads : 0u;
+    bool share = ratio > 1u && nblk * 2u * kv_heads >= (uint32_t)n_cu;
+    if (const char* f = getenv("CQS_HIP_ATT_LAYOUT")) {
+        if (f[0] == 's') share = ratio > 1u;
+        else if (f[0] == 'p') share = false;
+    }
+    bool dma = share && ratio >= 2u && ratio <= 4u;
+    if (const char* f = getenv("CQS_HIP_ATT_KERNEL")) dma = dma && f[0] != 'r';
+    return {share, dma};
+}
+bool attention_reads_vt(uint32_t nblk, uint32_t heads, uint32_t kv_heads) { return !att_plan(nblk, heads, kv_heads).dma; }
 
 hipError_t launch_attention(const bf16_t* qkv, const bf16_t* vt, bf16_t* out, const int32_t* blk, uint32_t nblk,
                             const int32_t* seq_start, const int32_t* seq_len, const int32_t* vt_start, uint32_t vt_ld,
@@ -1181,26 +1225,10 @@ hipError_t launch_attention(const bf16_t* qkv, const bf16_t* vt, bf16_t* out, co
     hipLaunchKernelGGL((attention_kernel<TQV * GV, GV>), dim3(nblk * (128 / (16 * TQV)), heads / GV),             \
                        dim3(64 * TQV * GV), 0, st, qkv, vt, out, blk, seq_start, seq_len, vt_start, vt_ld, heads,   \
                        kv_heads, window, q_norm_w, cos_sin, eps, q_scale)
-    // Small batches (fewer head-sharing workgroups than CUs: e.g. 32 short chunks) keep one q-head per
-    // workgroup - more, thinner workgroups fill the chip better (measured +6 % on log-normal lengths).
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess ||
-            hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
-            n_cu = 256;
-    }
     const uint32_t ratio = heads / kv_heads;
-    bool share = ratio > 1u && nblk * 2u * kv_heads >= (uint32_t)n_cu;
-    if (const char* f = getenv("CQS_HIP_ATT_LAYOUT")) {  // test hook: "shared" / "per-head" force one layout
-        if (f[0] == 's') share = ratio > 1u;
-        else if (f[0] == 'p') share = false;
-    }
+    const AttPlan plan = att_plan(nblk, heads, kv_heads);
+    const bool share = plan.share, use_dma = plan.dma;
     if (!share) { CQS_ATT(1, 8); return hipGetLastError(); }
-    // Head-sharing workgroups (full batches): the 64-key LDS-DMA kernel; CQS_HIP_ATT_KERNEL=reg keeps the
-    // register-staged one (test hook: both are checked against the oracle).
-    bool use_dma = true;
-    if (const char* f = getenv("CQS_HIP_ATT_KERNEL")) use_dma = f[0] != 'r';
 #define CQS_ATT_DMA(GV, TQV, KRAV)                                                                                  \
     do {                                                                                                            \
         auto kern = attention_dma_kernel<TQV * GV, GV, KRAV>;                                                       \

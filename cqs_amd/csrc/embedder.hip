@@ -295,6 +295,7 @@ int32_t run_layers(cqs_hip_embedder* e, Ctx& c, Slot& sl) {
     E_TRY(e, hipMemcpyAsync(c.d_meta, sl.meta, words * sizeof(int32_t), hipMemcpyHostToDevice, st));
     E_TRY(e, hipEventRecord(sl.ev0, st));
     const uint32_t nblk = sl.nblk;
+    const bool need_vt = cqs::attention_reads_vt(nblk, g.heads, g.kv_heads);
     E_TRY(e, cqs::launch_embed_norm(c.d_tok, e->emb, sqrtf((float)H), e->L[0].n_in, g.rms_eps, c.x, c.xn, M, H, st));
     for (uint32_t l = 0; l < g.layers; ++l) {
         const LayerW& w = e->L[l];
@@ -303,7 +304,7 @@ int32_t run_layers(cqs_hip_embedder* e, Ctx& c, Slot& sl) {
         // k heads + V^T here; the attention kernel normalises / rotates its own Q fragments (q is 3/4 of the rope's bytes)
         const float* rope = full ? e->rope_global : e->rope_local;
         E_TRY(e, cqs::launch_kv_prep(c.qkv, c.vt, c.d_pos, w.n_q, w.n_k, rope, g.rms_eps, g.q_scale, M, g.heads, g.kv_heads,
-                                     c.d_blk, nblk, c.d_seq_start, c.d_seq_len, c.d_vt_start, c.vt_ld, st));
+                                     c.d_blk, nblk, c.d_seq_start, c.d_seq_len, c.d_vt_start, c.vt_ld, need_vt ? 1 : 0, st));
         E_TRY(e, cqs::launch_attention(c.qkv, c.vt, c.attn, c.d_blk, nblk, c.d_seq_start, c.d_seq_len,
                                        c.d_vt_start, c.vt_ld, g.heads, g.kv_heads, full ? 0u : g.window, w.n_q, rope,
                                        g.rms_eps, g.q_scale, st));
