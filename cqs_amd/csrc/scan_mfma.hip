@@ -81,6 +81,8 @@ __global__ __launch_bounds__(256, 1) void scan_mfma_kernel(const MfmaParams p) {
     for (;; ) {
         if (task >= p.n_tasks) break;
         const uint32_t row0 = task * (uint32_t)RT;
+        uint32_t next_task = 0;
+        if (tid == 0) next_task = gridDim.x + atomicAdd(p.work, 1u);
 
         // global source pointers of this thread's staging slots (rows clamped inside the corpus)
         const float* src[PER_T];
@@ -120,32 +122,38 @@ __global__ __launch_bounds__(256, 1) void scan_mfma_kernel(const MfmaParams p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
+        // One barrier per stage, placed between k-groups 2 and 3: the next stage's operands (global loads issued in
+        // k-group 0, ds_writes in k-group 2, to the OTHER buffer) are visible after it, so k-group 3's MFMAs run while
+        // the next stage's first fragments are read - the matrix pipe (one wave per SIMD: nobody else feeds it) no
+        // longer drains at the stage boundary.  Within a k-group the loads / LDS operations are spread between the
+        // MFMAs (sched_group_barrier) instead of in front of them.
         f4 reg[PER_T];
         stage_load(0, reg);
         stage_write(0, reg);
         __syncthreads();
-        for (uint32_t s = 0; s < stages; ++s) {
-            const int buf = (int)(s & 1u);
-            if (s + 1u < stages) stage_load(s + 1u, reg);  // in flight under the MFMA phase
+        f4 af[2][QW], bf[2][RW];
+        auto read_frags = [&](int buf, int kg, int set) {
             const float* aQ = sQ + ((size_t)buf * QT + (size_t)(wq * QW) * 32 + l31) * kLDK + 4 * lh;
             const float* aR = sR + ((size_t)buf * RT + (size_t)(wr * RW) * 32 + l31) * kLDK + 4 * lh;
-            // fragments of k-group kg+1 are read while the 4*QW*RW MFMAs of k-group kg run
-            f4 af[2][QW], bf[2][RW];
-            auto read_frags = [&](int kg, int set) {
 #pragma unroll
-                for (int a = 0; a < QW; ++a) af[set][a] = *(const f4*)(aQ + (size_t)a * 32 * kLDK + kg * 8);
+            for (int a = 0; a < QW; ++a) af[set][a] = *(const f4*)(aQ + (size_t)a * 32 * kLDK + kg * 8);
 #pragma unroll
-                for (int b = 0; b < RW; ++b) bf[set][b] = *(const f4*)(aR + (size_t)b * 32 * kLDK + kg * 8);
-            };
-            read_frags(0, 0);
+            for (int b = 0; b < RW; ++b) bf[set][b] = *(const f4*)(aR + (size_t)b * 32 * kLDK + kg * 8);
+        };
+        read_frags(0, 0, 0);
+        for (uint32_t s = 0; s < stages; ++s) {
+            const int buf = (int)(s & 1u);
+            const bool more = s + 1u < stages;
 #pragma unroll
             for (int kg = 0; kg < kBK / 8; ++kg) {
                 const int cur = kg & 1;
-                if (kg + 1 < kBK / 8) read_frags(kg + 1, cur ^ 1);
-                // the next stage's operands (loaded at the top of this stage) go to the OTHER buffer half-way
-                // through the MFMA phase, so the ds_writes issue between MFMAs instead of after them
-                if (kg == kBK / 16 && s + 1u < stages) stage_write(buf ^ 1, reg);
-                __builtin_amdgcn_sched_barrier(0);
+                if (kg == 0 && more) stage_load(s + 1u, reg);          // in flight under k-groups 0 and 1
+                if (kg + 1 < kBK / 8) read_frags(buf, kg + 1, cur ^ 1);
+                if (kg == kBK / 8 - 2 && more) stage_write(buf ^ 1, reg);
+                if (kg == kBK / 8 - 1) {
+                    __syncthreads();                                    // next stage's tile is in place
+                    if (more) read_frags(buf ^ 1, 0, cur ^ 1);
+                }
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
 #pragma unroll
@@ -153,9 +161,19 @@ __global__ __launch_bounds__(256, 1) void scan_mfma_kernel(const MfmaParams p) {
 #pragma unroll
                         for (int b = 0; b < RW; ++b)
                             acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][a][c], bf[cur][b][c], acc[a][b], 0, 0, 0);
+#ifndef CQS_MFMA_NO_SGB
+                // one memory / LDS instruction after each MFMA while there are any (there are at most PER_T + QW + RW
+                // + PER_T of them in a k-group and 4 QW RW MFMAs)
+#pragma unroll
+                for (int i = 0; i < 4 * QW * RW; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x0b0, 1, 0);   // VMEM read | DS (read or write)
+                }
+#endif
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __syncthreads();
         }
+        __syncthreads();   // (the last stage's barrier came before its final k-group: everyone is done reading LDS)
 
         // ---- epilogue: lane&31 <-> corpus row, register <-> query ----
         const uint32_t nwords = (n + 31u) / 32u;
@@ -202,10 +220,11 @@ __global__ __launch_bounds__(256, 1) void scan_mfma_kernel(const MfmaParams p) {
                     if (l31 == 0 && qi < p.b)
                         p.gmax[(size_t)qi * (p.n_pad / 64u) + task * gpt + (uint32_t)(wr * (RW / 2) + g)] = m;
                 }
-        __syncthreads();   // everyone is done with s_task / the tile before the next dequeue
-        if (tid == 0) s_task = gridDim.x + atomicAdd(p.work, 1u);
+        // the next tile was claimed at the top of this one (the atomic's round trip hides under the tile)
+        if (tid == 0) s_task = next_task;
         __syncthreads();
         task = s_task;
+        __syncthreads();   // s_task is free for the next hand-over
     }
 }
 

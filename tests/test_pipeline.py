@@ -134,3 +134,30 @@ def test_submit_collect_matches_sync_and_oracle(hip):
         pipe.embed_token_lists(bad)                        # token id out of range -> InferenceFailed
     assert cos(pipe.embed_token_lists(chunks[:1])[0], ref[0]) > 0.999      # the engine is still usable
     eng.close()
+
+
+@pytest.mark.gpu
+def test_tickets_in_flight_are_bit_identical_to_blocking_calls(hip):
+    """Consecutive tickets run on the engine's two execution contexts (own stream + scratch, shared weights) and
+    their kernels interleave on the device: every in-flight result must equal, bit for bit, the blocking call on the
+    same batch (a scratch or table shared by mistake between the contexts shows up here)."""
+    from test_embed_gpu import SMALL, batch, make
+    eng, _ = make(SMALL, seed=19)
+    rng = np.random.default_rng(20)
+    batches = []
+    for j in range(6):
+        lens = list(rng.integers(1, SMALL.max_seq, size=12))
+        batches.append(batch(SMALL, lens, seed=21 + j))
+    want = [eng.run(ids, mask).copy() for ids, mask in batches]
+    for rep in range(3):
+        pend, got = [], {}
+        for j, (ids, mask) in enumerate(batches):
+            pend.append((j, eng.submit(ids, mask)))
+            if len(pend) == 3:
+                jj, t = pend.pop(0)
+                got[jj] = eng.collect(t, len(batches[jj][0]))
+        for jj, t in reversed(pend):                       # the tail out of order
+            got[jj] = eng.collect(t, len(batches[jj][0]))
+        for j in range(len(batches)):
+            assert np.array_equal(got[j], want[j]), (rep, j, float(np.max(np.abs(got[j] - want[j]))))
+    eng.close()

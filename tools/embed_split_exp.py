@@ -20,8 +20,9 @@ def run(engines, B, L, iters):
     [t.start() for t in th]; [t.join() for t in th]
     return len(engines) * iters * B / (time.perf_counter() - t0)
 
-e1, cfg = make_engine(0)
-print("cus=%s one engine 32x512: %.0f" % (os.environ.get("CQS_HIP_GEMM_CUS"), run([e1], 32, 512, 24)), flush=True)
-print("cus=%s one engine 16x512: %.0f" % (os.environ.get("CQS_HIP_GEMM_CUS"), run([e1], 16, 512, 48)), flush=True)
-e2, _ = make_engine(1)
-print("cus=%s two engines 16x512: %.0f" % (os.environ.get("CQS_HIP_GEMM_CUS"), run([e1, e2], 16, 512, 48)), flush=True)
+if __name__ == '__main__':
+    e1, cfg = make_engine(0)
+    print("cus=%s one engine 32x512: %.0f" % (os.environ.get("CQS_HIP_GEMM_CUS"), run([e1], 32, 512, 24)), flush=True)
+    print("cus=%s one engine 16x512: %.0f" % (os.environ.get("CQS_HIP_GEMM_CUS"), run([e1], 16, 512, 48)), flush=True)
+    e2, _ = make_engine(1)
+    print("cus=%s two engines 16x512: %.0f" % (os.environ.get("CQS_HIP_GEMM_CUS"), run([e1, e2], 16, 512, 48)), flush=True)
