@@ -511,8 +511,8 @@ int32_t cqs_hip_embedder_create(const cqs_hip_embed_config* c, int32_t device, c
     g.sliding_pattern = c->sliding_pattern; g.max_seq = c->max_seq; g.rms_eps = c->rms_eps;
     g.theta_global = c->rope_theta_global; g.theta_local = c->rope_theta_local;
     g.q_scale = 1.0f / sqrtf(c->query_pre_attn_scalar);
-    bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreateWithFlags(&e->ctx[0].stream, hipStreamNonBlocking) == hipSuccess &&
-              hipStreamCreateWithFlags(&e->ctx[1].stream, hipStreamNonBlocking) == hipSuccess;
+    bool ok = hipSetDevice(device) == hipSuccess;
+    for (cqs_hip_embedder::Ctx& c : e->ctx) ok = ok && hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking) == hipSuccess;
     const size_t H = g.hidden, D = g.head_dim;
     e->L.resize(g.layers);
     ok = ok && dmalloc(&e->emb, (size_t)g.vocab * H) == hipSuccess && dmalloc(&e->n_final, H) == hipSuccess &&
