@@ -44,6 +44,12 @@ hipError_t launch_gemm_bf16(const bf16_t* A, const bf16_t* W, void* C, uint32_t 
 hipError_t launch_gemm_p8(const bf16_t* A, const bf16_t* W, void* C, uint32_t M, uint32_t N, uint32_t K,
                           uint32_t ldc, GemmOut out, int tn, hipStream_t st);
 
+// Two column ranges of one GEMM (same A, M, K, ldc; different tile widths) in one launch.  hipErrorNotSupported when
+// the pair of widths is not built: launch the parts one after the other instead.
+hipError_t launch_gemm_p8_dual(const bf16_t* A, const bf16_t* Wa, void* Ca, uint32_t Na, int tn_a, const bf16_t* Wb,
+                               void* Cb, uint32_t Nb, int tn_b, uint32_t M, uint32_t K, uint32_t ldc, GemmOut out,
+                               hipStream_t st);
+
 // In place on qkv [M, (heads + 2 kv) * 256] bf16: per-head RMSNorm * (1 + w), RoPE from the
 // cos/sin table of the layer type, q additionally scaled by q_scale.  pos[m] = position in sequence.
 // k_only != 0: the k heads only (launch_attention then does the same for its own Q fragments, q_norm_w != NULL).

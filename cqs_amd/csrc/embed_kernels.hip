@@ -1144,10 +1144,15 @@ hipError_t launch_gemm_bf16(const bf16_t* A, const bf16_t* W, void* C, uint32_t 
             tn1 = (t >= 3 && t <= 5 && fits && N % (64u * (uint32_t)t) == 0) ? t : 0;
         }
     }
-    hipError_t e = launch_gemm_one(A, W, C, M, n1, K, ldc, out, tn1, st);
-    if (e != hipSuccess || n1 == N) return e;
-    const size_t coff = out == GEMM_OUT_GEGLU ? n1 / 2u : n1;    // output columns already written
+    if (n1 == N) return launch_gemm_one(A, W, C, M, N, K, ldc, out, tn1, st);
+    const size_t coff = out == GEMM_OUT_GEGLU ? n1 / 2u : n1;    // output columns of the first part
     void* c2 = out == GEMM_OUT_F32 ? (void*)((float*)C + coff) : (void*)((bf16_t*)C + coff);
+    if (tn1 >= 3 && tn2 >= 3 && tn1 != tn2 && !getenv("CQS_HIP_GEMM_NO_DUAL")) {   // both parts in one launch
+        const hipError_t d = launch_gemm_p8_dual(A, W, C, n1, tn1, W + (size_t)n1 * K, c2, N - n1, tn2, M, K, ldc, out, st);
+        if (d != hipErrorNotSupported) return d;
+    }
+    hipError_t e = launch_gemm_one(A, W, C, M, n1, K, ldc, out, tn1, st);
+    if (e != hipSuccess) return e;
     return launch_gemm_one(A, W + (size_t)n1 * K, c2, M, N - n1, K, ldc, out, tn2, st);
 }
 

@@ -19,6 +19,8 @@
 // ping-pong 1290-1360 TF.
 #include "embed_kernels.h"
 
+#include <utility>
+
 #include <cstdlib>
 #include <type_traits>
 
@@ -65,9 +67,9 @@ __device__ __forceinline__ float p8_gelu_tanh(float x) {
 // A piece read by both wave rows is dead one interval after the later row's LOAD; the refill sits one phase later, so
 // the same program is hazard-free for both rows.  DMA flight time: two phases (four intervals).
 template <int TN, int OUT>
-__global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
-                                                         void* __restrict__ Cv, uint32_t M, uint32_t N, uint32_t K,
-                                                         uint32_t ldc) {
+__device__ __forceinline__ void gemm_pp_body(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
+                                             void* __restrict__ Cv, uint32_t M, uint32_t N, uint32_t K, uint32_t ldc,
+                                             const uint32_t bid /*workgroup index among this problem's*/) {
     constexpr int BN = 64 * TN;
     constexpr int kBuf = (kP8M + BN) * 64;                      // elements per LDS buffer
     constexpr int PA = 2, PB = TN;                              // DMA instructions per wave: an A half / the B tile
@@ -79,7 +81,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16_t* __restric
     const int l15 = lane & 15, lg = lane >> 4;
 
     const uint32_t nt = N / BN, mt = (M + kP8M - 1) / kP8M, total = nt * mt;
-    const uint32_t bid = blockIdx.x, xcd = bid % 8u, q8 = total / 8u, r8 = total % 8u;
+    const uint32_t xcd = bid % 8u, q8 = total / 8u, r8 = total % 8u;   // (bid % 8 = the XCD: parts of a dual launch start at multiples of 8)
     const uint32_t tile = (xcd < r8 ? xcd * (q8 + 1u) : r8 * (q8 + 1u) + (xcd - r8) * q8) + bid / 8u;
     const uint32_t m0 = (tile / nt) * kP8M, n0 = (tile % nt) * BN;
 
@@ -304,6 +306,44 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16_t* __restric
 }
 
 template <int TN, int OUT>
+__global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
+                                                         void* __restrict__ Cv, uint32_t M, uint32_t N, uint32_t K,
+                                                         uint32_t ldc) {
+    gemm_pp_body<TN, OUT>(A, W, Cv, M, N, K, ldc, blockIdx.x);
+}
+
+// Two problems that share A, M and K (the two column ranges launch_gemm_bf16 cuts a GEMM into: whole rounds of one
+// tile width + the rest with another) in ONE launch: workgroups [0, n_first) run the first, the rest the second, so
+// the second part's workgroups start as CUs come free instead of after a kernel boundary.
+template <int TNA, int TNB, int OUT>
+__global__ __launch_bounds__(512, 2) void gemm_pp_dual_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Wa,
+                                                              void* __restrict__ Ca, uint32_t Na,
+                                                              const bf16_t* __restrict__ Wb, void* __restrict__ Cb,
+                                                              uint32_t Nb, uint32_t M, uint32_t K, uint32_t ldc,
+                                                              uint32_t n_first) {
+    if (blockIdx.x < n_first) gemm_pp_body<TNA, OUT>(A, Wa, Ca, M, Na, K, ldc, blockIdx.x);
+    else gemm_pp_body<TNB, OUT>(A, Wb, Cb, M, Nb, K, ldc, blockIdx.x - n_first);
+}
+
+template <int TNA, int TNB, int OUT>
+hipError_t launch_p8_dual(const bf16_t* A, const bf16_t* Wa, void* Ca, uint32_t Na, const bf16_t* Wb, void* Cb, uint32_t Nb,
+                          uint32_t M, uint32_t K, uint32_t ldc, hipStream_t st) {
+    constexpr int BNA = 64 * TNA, BNB = 64 * TNB, BNX = BNA > BNB ? BNA : BNB;
+    const uint32_t mt = (M + kP8M - 1) / kP8M;
+    const uint32_t n_first = (Na / BNA) * mt, n_second = (Nb / BNB) * mt;
+    const size_t lds = (size_t)2 * (kP8M + BNX) * 64 * sizeof(bf16_t);
+    auto kern = gemm_pp_dual_kernel<TNA, TNB, OUT>;
+    static bool attr_set = false;   // per instantiation
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(n_first + n_second), dim3(512), lds, st, A, Wa, Ca, Na, Wb, Cb, Nb, M, K, ldc, n_first);
+    return hipGetLastError();
+}
+
+template <int TN, int OUT>
 hipError_t launch_p8(const bf16_t* A, const bf16_t* W, void* C, uint32_t M, uint32_t N, uint32_t K, uint32_t ldc,
                      hipStream_t st) {
     constexpr int BN = 64 * TN;
@@ -342,6 +382,29 @@ hipError_t launch_gemm_p8(const bf16_t* A, const bf16_t* W, void* C, uint32_t M,
     }
 #undef P8_CASE
     return hipErrorInvalidValue;
+}
+
+// Two column ranges of one GEMM (same A, M, K, ldc) with different tile widths in one launch; tn_a != tn_b, both in
+// {3, 4, 5}; out = BF16 or GEGLU.  hipErrorNotSupported: the caller launches the two parts separately.
+hipError_t launch_gemm_p8_dual(const bf16_t* A, const bf16_t* Wa, void* Ca, uint32_t Na, int tn_a, const bf16_t* Wb,
+                               void* Cb, uint32_t Nb, int tn_b, uint32_t M, uint32_t K, uint32_t ldc, GemmOut out,
+                               hipStream_t st) {
+    if (M == 0) return hipSuccess;
+    if (tn_a < tn_b) { std::swap(Wa, Wb); std::swap(Ca, Cb); std::swap(Na, Nb); std::swap(tn_a, tn_b); }
+    if (out == GEMM_OUT_F32 || tn_a == tn_b || tn_b < 3 || tn_a > 5) return hipErrorNotSupported;
+    if (K % 64u || K < 64u || Na % (64u * (uint32_t)tn_a) || Nb % (64u * (uint32_t)tn_b) || (uint64_t)M * K >= (1ull << 31) ||
+        (uint64_t)Na * K >= (1ull << 31) || (uint64_t)Nb * K >= (1ull << 31))
+        return hipErrorInvalidValue;
+    if ((Na / (64u * (uint32_t)tn_a)) * ((M + kP8M - 1) / kP8M) % 8u) return hipErrorNotSupported;   // second part must start on XCD 0
+#define P8_DUAL(TA, TB)                                                                                              \
+    if (tn_a == TA && tn_b == TB)                                                                                    \
+        return out == GEMM_OUT_BF16 ? launch_p8_dual<TA, TB, GEMM_OUT_BF16>(A, Wa, Ca, Na, Wb, Cb, Nb, M, K, ldc, st) \
+                                    : launch_p8_dual<TA, TB, GEMM_OUT_GEGLU>(A, Wa, Ca, Na, Wb, Cb, Nb, M, K, ldc, st);
+    P8_DUAL(5, 4)
+    P8_DUAL(5, 3)
+    P8_DUAL(4, 3)
+#undef P8_DUAL
+    return hipErrorNotSupported;
 }
 
 }  // namespace cqs

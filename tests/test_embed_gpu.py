@@ -409,3 +409,34 @@ def test_gemm_kernels_exact_integer_data(hip, tile, monkeypatch):
                 want = (torch.nn.functional.gelu(r[:, :, 0], approximate="tanh") * r[:, :, 1]).reshape(M, N // 2)
                 err = (out.float() - want).abs().max().item()
                 assert err <= 0.02 * want.abs().max().item() + 1e-3, (tile, M, N, K, err)
+
+
+@pytest.mark.parametrize("dual", ["dual", "two-launches"])
+def test_gemm_planner_choices_at_full_batch_shapes(hip, dual, monkeypatch):
+    """The planner's own picks (nothing forced) at the shapes of a 16 384-token batch - whole rounds of one tile width +
+    the rest with another, both parts in ONE launch (`gemm_pp_dual_kernel`) or, with CQS_HIP_GEMM_NO_DUAL, in two -
+    bit-exact against torch on small-integer operands; ragged M too (the planner then mixes in the 128 x 128 kernel)."""
+    import ctypes as C
+    import torch
+    if dual != "dual":
+        monkeypatch.setenv("CQS_HIP_GEMM_NO_DUAL", "1")
+    f = _lib.load().cqs_hip_debug_gemm_run
+    f.restype = C.c_int32
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_uint32] * 4 + [C.c_int32, C.c_void_p]
+    g = torch.Generator(device="cuda"); g.manual_seed(11)
+    for M, N, K, kind in [(16384, 2304, 768, 2), (16384, 1280, 768, 0), (16384, 768, 1152, 0), (16384, 2304, 768, 0),
+                          (16000, 2304, 768, 2), (8192, 2304, 768, 2), (24576, 1280, 768, 0)]:
+        A = torch.randint(-4, 5, (M, K), generator=g, device="cuda").to(torch.bfloat16)
+        W = torch.randint(-3, 4, (N, K), generator=g, device="cuda").to(torch.bfloat16)
+        ref = A.float() @ W.float().T
+        ldc = N // 2 if kind == 2 else N
+        out = torch.full((M, ldc), 7.0, device="cuda", dtype=torch.bfloat16)
+        assert f(A.data_ptr(), W.data_ptr(), out.data_ptr(), M, N, K, ldc, kind, None) == 0
+        torch.cuda.synchronize()
+        if kind == 0:
+            assert torch.equal(out, ref.to(torch.bfloat16)), (dual, M, N, K)
+        else:
+            r = ref.view(M, N // 64, 2, 32)
+            want = (torch.nn.functional.gelu(r[:, :, 0], approximate="tanh") * r[:, :, 1]).reshape(M, N // 2)
+            err = (out.float() - want).abs().max().item()
+            assert err <= 0.02 * want.abs().max().item() + 1e-3, (dual, M, N, K, err)
