@@ -38,6 +38,11 @@ enum GemmOut { GEMM_OUT_BF16 = 0, GEMM_OUT_F32 = 1, GEMM_OUT_GEGLU = 2 };
 hipError_t launch_gemm_bf16(const bf16_t* A, const bf16_t* W, void* C, uint32_t M, uint32_t N, uint32_t K,
                             uint32_t ldc, GemmOut out, hipStream_t st);
 
+// A few rows against a big matrix (the Dense head: M = sequences of the batch): one workgroup per 16 x 16 output tile,
+// K split over its 4 waves.  GEMM_OUT_BF16 / GEMM_OUT_F32; N % 16 == 0, K % 32 == 0; M > 256 goes to launch_gemm_bf16.
+hipError_t launch_gemm_skinny(const bf16_t* A, const bf16_t* W, void* C, uint32_t M, uint32_t N, uint32_t K,
+                              uint32_t ldc, GemmOut out, hipStream_t st);
+
 // Second-generation kernel (gemm_kernels.hip): 256 x (64 tn) x 64 tiles, 8 waves in two rows that alternate load and
 // multiply intervals, counted-vmcnt LDS-DMA.  tn in {3, 4, 5}; N % (64 tn) == 0, K % 64 == 0.
 // launch_gemm_bf16 picks between it and the 128 x 128 kernel by shape.

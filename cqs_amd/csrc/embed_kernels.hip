@@ -1086,6 +1086,57 @@ static hipError_t launch_gemm_one(const bf16_t* A, const bf16_t* W, void* C, uin
     return hipGetLastError();
 }
 
+// ---- skinny GEMM: a handful of rows (the pooled sentence vectors through the two Dense layers: M = sequences of
+// the batch) against a big weight matrix.  The tiled kernels put 24 (or 6) workgroups on the chip for M = 32 and take
+// 43 + 14 us; this one is a batch of GEMVs: one workgroup = one 16 x 16 output tile, its 4 waves split K (each streams
+// its quarter of the 16 weight rows once, 16 B per lane, loads 8 k-steps deep), partial tiles summed through LDS.
+template <int OUT>
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
+                                                         void* __restrict__ Cv, uint32_t M, uint32_t N, uint32_t K,
+                                                         uint32_t ldc) {
+    __shared__ __attribute__((aligned(16))) float red[4][256];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const uint32_t n0 = blockIdx.x * 16u, m0 = blockIdx.y * 16u;
+    const uint32_t ksteps = K / 32u, per = (ksteps + 3u) / 4u;
+    const uint32_t s_lo = (uint32_t)wid * per, s_hi = s_lo + per < ksteps ? s_lo + per : ksteps;
+    const uint32_t mr = m0 + (uint32_t)l15 < M ? m0 + (uint32_t)l15 : M - 1u;    // rows past M: any real row, never stored
+    const bf16_t* ap = A + (size_t)mr * K + 8 * lg;
+    const bf16_t* wp = W + (size_t)(n0 + (uint32_t)l15) * K + 8 * lg;
+    f4 acc = (f4)(0.f);
+    constexpr int U = 8;
+    for (uint32_t s = s_lo; s < s_hi; s += U) {
+        bf8 af[U], wf[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t ss = s + (uint32_t)u < s_hi ? s + (uint32_t)u : s_hi - 1u;   // (tail: re-read, not accumulated)
+            af[u] = *(const bf8*)(ap + (size_t)ss * 32u);
+            wf[u] = *(const bf8*)(wp + (size_t)ss * 32u);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (s + (uint32_t)u < s_hi) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u], af[u], acc, 0, 0, 0);
+    }
+    // acc[r] = C[m = m0 + l15][n = n0 + 4 lg + r] (weights as the A operand: a lane holds 4 consecutive columns)
+    *(f4*)&red[wid][(l15 * 4 + lg) * 4] = acc;
+    __syncthreads();
+    if (wid == 0) {
+        f4 v = *(const f4*)&red[0][(l15 * 4 + lg) * 4];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) v += *(const f4*)&red[w][(l15 * 4 + lg) * 4];
+        const uint32_t m = m0 + (uint32_t)l15;
+        if (m < M) {
+            if (OUT == GEMM_OUT_F32) *(f4*)((float*)Cv + (size_t)m * ldc + n0 + 4 * lg) = v;
+            else {
+                bf4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = (bf16_t)v[r];
+                *(bf4*)((bf16_t*)Cv + (size_t)m * ldc + n0 + 4 * lg) = o;
+            }
+        }
+    }
+}
+
 hipError_t launch_gemm_bf16(const bf16_t* A, const bf16_t* W, void* C, uint32_t M, uint32_t N, uint32_t K,
                             uint32_t ldc, GemmOut out, hipStream_t st) {
     if (M == 0) return hipSuccess;
@@ -1155,6 +1206,22 @@ hipError_t launch_gemm_bf16(const bf16_t* A, const bf16_t* W, void* C, uint32_t 
     if (e != hipSuccess) return e;
     return launch_gemm_one(A, W + (size_t)n1 * K, c2, M, N - n1, K, ldc, out, tn2, st);
 }
+
+// The Dense head's GEMMs (M = sequences of the batch).  Not chosen by launch_gemm_bf16 itself: its K split sums in a
+// different order than the tiled kernels, and a token's activations must not depend on how many tokens share its
+// batch (tests/test_embed_gpu.py::test_padding_and_batch_invariance) - the head, applied once per sequence, always
+// takes this path up to 256 sequences, the tiled kernels beyond.
+hipError_t launch_gemm_skinny(const bf16_t* A, const bf16_t* W, void* C, uint32_t M, uint32_t N, uint32_t K,
+                              uint32_t ldc, GemmOut out, hipStream_t st) {
+    if (M == 0) return hipSuccess;
+    if (N % 16u || K % 32u || out == GEMM_OUT_GEGLU) return hipErrorInvalidValue;
+    if (M > 256u) return launch_gemm_bf16(A, W, C, M, N, K, ldc, out, st);
+    const dim3 grid(N / 16u, (M + 15u) / 16u);
+    if (out == GEMM_OUT_F32) hipLaunchKernelGGL(gemm_skinny_kernel<GEMM_OUT_F32>, grid, dim3(256), 0, st, A, W, C, M, N, K, ldc);
+    else hipLaunchKernelGGL(gemm_skinny_kernel<GEMM_OUT_BF16>, grid, dim3(256), 0, st, A, W, C, M, N, K, ldc);
+    return hipGetLastError();
+}
+
 
 hipError_t launch_qk_norm_rope(bf16_t* qkv, const int32_t* pos, const float* wq, const float* wk,
                                const float* cos_sin, float eps, float q_scale, uint32_t M, uint32_t heads,

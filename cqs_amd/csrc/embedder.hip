@@ -725,8 +725,8 @@ int32_t submit_locked(cqs_hip_embedder* e, uint32_t B, const std::function<int32
         if (rc != CQS_HIP_OK) return rc;
         const cqs::EmbedGeom& g = e->g;
         E_TRY(e, cqs::launch_mean_pool(c.hidden, c.d_seq_start, c.d_seq_len, c.pooled, B, H, st));
-        E_TRY(e, cqs::launch_gemm_bf16(c.pooled, e->dense1, c.d1, B, g.dense_hidden, H, g.dense_hidden, cqs::GEMM_OUT_BF16, st));
-        E_TRY(e, cqs::launch_gemm_bf16(c.d1, e->dense2, c.out, B, H, g.dense_hidden, H, cqs::GEMM_OUT_F32, st));
+        E_TRY(e, cqs::launch_gemm_skinny(c.pooled, e->dense1, c.d1, B, g.dense_hidden, H, g.dense_hidden, cqs::GEMM_OUT_BF16, st));
+        E_TRY(e, cqs::launch_gemm_skinny(c.d1, e->dense2, c.out, B, H, g.dense_hidden, H, cqs::GEMM_OUT_F32, st));
         E_TRY(e, hipEventRecord(sl->ev1, st));
         E_TRY(e, hipMemcpyAsync(sl->out, c.out, (size_t)B * H * sizeof(float), hipMemcpyDeviceToHost, st));
         E_TRY(e, hipEventRecord(sl->done, st));
@@ -847,8 +847,11 @@ void cqs_hip_normalize_l2_rows(float* rows, uint64_t n, uint32_t dim) {
 // (CQS_HIP_GEMM_TILE forces one).
 int32_t cqs_hip_debug_gemm_run(const void* A, const void* W, void* C, uint32_t M, uint32_t N, uint32_t K, uint32_t ldc,
                                int32_t out_kind, void* stream) {
-    const hipError_t e = cqs::launch_gemm_bf16((const bf16_t*)A, (const bf16_t*)W, C, M, N, K, ldc, (cqs::GemmOut)out_kind,
-                                               (hipStream_t)stream);
+    const hipError_t e = (out_kind & 0x100)   // + 0x100: the Dense head's skinny kernel
+                             ? cqs::launch_gemm_skinny((const bf16_t*)A, (const bf16_t*)W, C, M, N, K, ldc,
+                                                       (cqs::GemmOut)(out_kind & 0xff), (hipStream_t)stream)
+                             : cqs::launch_gemm_bf16((const bf16_t*)A, (const bf16_t*)W, C, M, N, K, ldc, (cqs::GemmOut)out_kind,
+                                                     (hipStream_t)stream);
     return e == hipSuccess ? CQS_HIP_OK : CQS_HIP_ERR_DEVICE;
 }
 

@@ -425,15 +425,21 @@ def test_gemm_planner_choices_at_full_batch_shapes(hip, dual, monkeypatch):
     f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_uint32] * 4 + [C.c_int32, C.c_void_p]
     g = torch.Generator(device="cuda"); g.manual_seed(11)
     for M, N, K, kind in [(16384, 2304, 768, 2), (16384, 1280, 768, 0), (16384, 768, 1152, 0), (16384, 2304, 768, 0),
-                          (16000, 2304, 768, 2), (8192, 2304, 768, 2), (24576, 1280, 768, 0)]:
+                          (16000, 2304, 768, 2), (8192, 2304, 768, 2), (24576, 1280, 768, 0),
+                          # a few rows x a big matrix (the Dense head: M = sequences of the batch): the skinny kernel
+                          # (kind + 0x100; beyond 256 rows it hands over to the tiled kernels)
+                          (32, 3072, 768, 0x100), (1, 768, 3072, 0x101), (100, 3072, 768, 0x100), (256, 768, 3072, 0x101),
+                          (17, 768, 64, 0x100), (300, 768, 3072, 0x101)]:
         A = torch.randint(-4, 5, (M, K), generator=g, device="cuda").to(torch.bfloat16)
         W = torch.randint(-3, 4, (N, K), generator=g, device="cuda").to(torch.bfloat16)
         ref = A.float() @ W.float().T
         ldc = N // 2 if kind == 2 else N
-        out = torch.full((M, ldc), 7.0, device="cuda", dtype=torch.bfloat16)
+        out = torch.full((M, ldc), 7.0, device="cuda", dtype=torch.float32 if (kind & 0xff) == 1 else torch.bfloat16)
         assert f(A.data_ptr(), W.data_ptr(), out.data_ptr(), M, N, K, ldc, kind, None) == 0
         torch.cuda.synchronize()
-        if kind == 0:
+        if (kind & 0xff) == 1:
+            assert torch.equal(out, ref), (dual, M, N, K)
+        elif (kind & 0xff) == 0:
             assert torch.equal(out, ref.to(torch.bfloat16)), (dual, M, N, K)
         else:
             r = ref.view(M, N // 64, 2, 32)
