@@ -87,7 +87,29 @@ SIGNATURES = [
     ("cqs_hip_embedder_last_ms", C.c_float, [_c_idx]),
     ("cqs_hip_index_set_timing", None, [_c_idx, C.c_int32]),
     ("cqs_hip_index_scan_time", C.c_int32, [_c_idx, _pp(C.c_uint32), _pp(C.c_double)]),
+    # BERT-family auxiliary models (SPLADE encoder / cross-encoder reranker)
+    ("cqs_hip_bert_config_default", C.c_int32, [C.c_uint32, C.c_void_p]),
+    ("cqs_hip_bert_create", C.c_int32, [C.c_void_p, C.c_int32, _pp(_c_idx)]),
+    ("cqs_hip_bert_set_tensor", C.c_int32, [_c_idx, C.c_char_p, C.c_void_p, C.c_uint64]),
+    ("cqs_hip_bert_finalize", C.c_int32, [_c_idx]),
+    ("cqs_hip_bert_destroy", None, [_c_idx]),
+    ("cqs_hip_splade_encode", C.c_int32, [_c_idx, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
+    ("cqs_hip_rerank_logits", C.c_int32, [_c_idx, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
+    ("cqs_hip_bert_hidden", C.c_int32, [_c_idx, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
+    ("cqs_hip_bert_vocab", C.c_uint32, [_c_idx]),
+    ("cqs_hip_bert_poisoned", C.c_int32, [_c_idx]),
+    ("cqs_hip_bert_last_error", C.c_size_t, [_c_idx, C.c_char_p, C.c_size_t]),
 ]
+
+BERT_HEAD_MLM = 0
+BERT_HEAD_CLASSIFIER = 1
+
+
+class BertConfig(C.Structure):
+    """`cqs_hip_bert_config` (include/cqs_hip.h)."""
+    _fields_ = [("vocab_size", C.c_uint32), ("hidden", C.c_uint32), ("layers", C.c_uint32), ("heads", C.c_uint32),
+                ("intermediate", C.c_uint32), ("max_pos", C.c_uint32), ("type_vocab", C.c_uint32),
+                ("num_labels", C.c_uint32), ("head", C.c_uint32), ("ln_eps", C.c_float)]
 
 
 

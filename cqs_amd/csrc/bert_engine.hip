@@ -1,0 +1,450 @@
+// bert_engine.hip — the BERT-family engine of libcqs_hip.so (include/cqs_hip.h, "BERT-family auxiliary models"):
+// the device side of cqs's SPLADE sparse encoder (`SpladeEncoder::encode_batch`, src/splade/mod.rs:774-1075: ORT runs a
+// BERT masked-LM, Rust pools its logits) and of its cross-encoder reranker (`compute_scores_opt`, src/reranker.rs:343-
+// 533: ORT runs BertForSequenceClassification, Rust applies a sigmoid).  SURVEY.md §8(f)4.  Operator semantics:
+// oracle/bert_ref.py.  No CPU fallback: without a GPU `cqs_hip_bert_create` fails.
+#include "../../include/cqs_hip.h"
+#include "bert_kernels.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+using cqs::bf16_t;
+
+namespace {
+
+uint16_t f32_to_bf16(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (uint16_t)((u >> 16) | 0x40u);   // NaN stays NaN
+    return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+
+struct BertLayer {
+    bf16_t *wqkv = nullptr, *wo = nullptr, *w1 = nullptr, *w2 = nullptr;
+    float *bqkv = nullptr, *bo = nullptr, *b1 = nullptr, *b2 = nullptr;
+    float *ln1_g = nullptr, *ln1_b = nullptr, *ln2_g = nullptr, *ln2_b = nullptr;
+};
+
+}  // namespace
+
+struct cqs_hip_bert {
+    int device = 0;
+    cqs_hip_bert_config cfg{};
+    uint32_t vpad = 0;                       // vocab rounded up to a multiple of 192 (decoder N tile)
+    hipStream_t stream = nullptr;
+    std::map<std::string, std::vector<float>> pending;    // host copies until finalize
+    bool finalized = false;
+
+    bf16_t *word = nullptr, *posw = nullptr, *typew = nullptr;     // word: [vpad, H] (rows >= vocab are zero)
+    float *emb_g = nullptr, *emb_b = nullptr;
+    std::vector<BertLayer> L;
+    // masked-LM head
+    bf16_t* wt = nullptr;
+    float *bt = nullptr, *lnt_g = nullptr, *lnt_b = nullptr, *bdec = nullptr;   // bdec [vpad]
+    // classifier head
+    bf16_t *wp = nullptr, *wc = nullptr;     // wc [16-padded labels, H]
+    float *bp = nullptr, *bc = nullptr;
+    std::vector<void*> owned;                // every device allocation of the weights
+
+    // scratch (one batch at a time; the engine is serialised by `mu`)
+    uint32_t tok_cap = 0, seq_cap = 0, blk_cap = 0;
+    bf16_t *x = nullptr, *y = nullptr, *qkv = nullptr, *att = nullptr, *h = nullptr, *logits = nullptr, *pooled = nullptr;
+    float *dense = nullptr, *cls = nullptr;
+    int32_t* d_meta = nullptr;
+    std::vector<int32_t> h_meta;
+
+    std::mutex mu;
+    std::atomic<bool> poisoned{false};
+    std::string last_error;
+};
+
+namespace {
+
+int32_t bfail(cqs_hip_bert* e, int32_t code, const std::string& what, hipError_t he = hipSuccess) {
+    std::string msg = what;
+    if (he != hipSuccess) msg += std::string(": ") + hipGetErrorString(he);
+    if (e) {
+        e->last_error = msg;
+        if (code == CQS_HIP_ERR_DEVICE) e->poisoned.store(true, std::memory_order_release);
+    }
+    return code;
+}
+#define B_TRY(e, expr)                                                                                                   \
+    do {                                                                                                                 \
+        hipError_t _h = (expr);                                                                                          \
+        if (_h != hipSuccess) return bfail((e), _h == hipErrorOutOfMemory ? CQS_HIP_ERR_NOMEM : CQS_HIP_ERR_DEVICE, #expr, _h); \
+    } while (0)
+
+const std::vector<float>* find(cqs_hip_bert* e, const std::string& name, size_t count) {
+    auto it = e->pending.find(name);
+    if (it == e->pending.end() || it->second.size() != count) return nullptr;
+    return &it->second;
+}
+
+int32_t up_bf16(cqs_hip_bert* e, bf16_t** dst, const float* src, size_t count, size_t alloc_count = 0) {
+    if (alloc_count < count) alloc_count = count;
+    std::vector<uint16_t> tmp(alloc_count, 0);
+    for (size_t i = 0; i < count; ++i) tmp[i] = f32_to_bf16(src[i]);
+    B_TRY(e, hipMalloc((void**)dst, alloc_count * 2));
+    e->owned.push_back(*dst);
+    B_TRY(e, hipMemcpy(*dst, tmp.data(), alloc_count * 2, hipMemcpyHostToDevice));
+    return CQS_HIP_OK;
+}
+int32_t up_f32(cqs_hip_bert* e, float** dst, const float* src, size_t count, size_t alloc_count = 0) {
+    if (alloc_count < count) alloc_count = count;
+    std::vector<float> tmp(alloc_count, 0.f);
+    memcpy(tmp.data(), src, count * 4);
+    B_TRY(e, hipMalloc((void**)dst, alloc_count * 4));
+    e->owned.push_back(*dst);
+    B_TRY(e, hipMemcpy(*dst, tmp.data(), alloc_count * 4, hipMemcpyHostToDevice));
+    return CQS_HIP_OK;
+}
+
+void free_scratch(cqs_hip_bert* e) {
+    void** all[] = {(void**)&e->x, (void**)&e->y, (void**)&e->qkv, (void**)&e->att, (void**)&e->h, (void**)&e->logits,
+                    (void**)&e->pooled, (void**)&e->dense, (void**)&e->cls, (void**)&e->d_meta};
+    for (void** p : all) { (void)hipFree(*p); *p = nullptr; }
+    e->tok_cap = e->seq_cap = e->blk_cap = 0;
+}
+
+int32_t ensure_scratch(cqs_hip_bert* e, uint32_t M, uint32_t B, uint32_t nblk) {
+    if (M <= e->tok_cap && B <= e->seq_cap && nblk <= e->blk_cap) return CQS_HIP_OK;
+    B_TRY(e, hipStreamSynchronize(e->stream));
+    const uint32_t Mc = std::max(M, e->tok_cap), Bc = std::max(B, e->seq_cap), bc = std::max(nblk, e->blk_cap);
+    free_scratch(e);
+    const cqs_hip_bert_config& c = e->cfg;
+    const size_t H = c.hidden;
+    B_TRY(e, hipMalloc((void**)&e->x, (size_t)Mc * H * 2));
+    B_TRY(e, hipMalloc((void**)&e->y, (size_t)Mc * H * 2));
+    B_TRY(e, hipMalloc((void**)&e->qkv, (size_t)Mc * 3 * H * 2));
+    B_TRY(e, hipMalloc((void**)&e->att, (size_t)Mc * H * 2));
+    B_TRY(e, hipMalloc((void**)&e->h, (size_t)Mc * c.intermediate * 2));
+    if (c.head == CQS_HIP_BERT_HEAD_MLM) {
+        B_TRY(e, hipMalloc((void**)&e->logits, (size_t)Mc * e->vpad * 2));
+        B_TRY(e, hipMalloc((void**)&e->dense, (size_t)Bc * c.vocab_size * 4));
+    } else {
+        B_TRY(e, hipMalloc((void**)&e->pooled, (size_t)Bc * H * 2));
+        B_TRY(e, hipMalloc((void**)&e->cls, (size_t)Bc * 16 * 4));
+    }
+    B_TRY(e, hipMalloc((void**)&e->d_meta, ((size_t)3 * Mc + (size_t)2 * Bc + (size_t)2 * bc) * 4));
+    e->tok_cap = Mc; e->seq_cap = Bc; e->blk_cap = bc;
+    return CQS_HIP_OK;
+}
+
+// Validate + pack a ragged batch, upload its tables, run the encoder; leaves the final hidden states in e->x.
+int32_t run_encoder(cqs_hip_bert* e, const int32_t* tokens, const int32_t* type_ids, const uint32_t* lens, uint32_t B,
+                    uint32_t* M_out) {
+    const cqs_hip_bert_config& c = e->cfg;
+    uint64_t M64 = 0, nblk64 = 0;
+    for (uint32_t b = 0; b < B; ++b) {
+        if (lens[b] > c.max_pos) return bfail(e, CQS_HIP_ERR_INVALID, "bert: sequence longer than max_position_embeddings");
+        M64 += lens[b];
+        nblk64 += (lens[b] + 63u) / 64u;
+    }
+    if (M64 > 0x7FFFFFFFull) return bfail(e, CQS_HIP_ERR_INVALID, "bert: batch holds too many tokens");
+    const uint32_t M = (uint32_t)M64, nblk = (uint32_t)nblk64;
+    *M_out = M;
+    if (M == 0) return CQS_HIP_OK;
+    // tables: [tok M][pos M][tt M][seq_start B][seq_len B][blk 2 nblk]
+    std::vector<int32_t>& t = e->h_meta;
+    t.assign((size_t)3 * M + (size_t)2 * B + (size_t)2 * nblk, 0);
+    int32_t *tok = t.data(), *pos = tok + M, *tt = pos + M, *seq_start = tt + M, *seq_len = seq_start + B, *blk = seq_len + B;
+    uint32_t m = 0, nb = 0;
+    for (uint32_t b = 0; b < B; ++b) {
+        seq_start[b] = (int32_t)m;
+        seq_len[b] = (int32_t)lens[b];
+        for (uint32_t j = 0; j < lens[b]; ++j) {
+            const int32_t id = tokens[m + j];
+            if (id < 0 || (uint32_t)id >= c.vocab_size) return bfail(e, CQS_HIP_ERR_INVALID, "bert: token id out of range");
+            const int32_t ty = type_ids ? type_ids[m + j] : 0;
+            if (ty < 0 || (uint32_t)ty >= c.type_vocab) return bfail(e, CQS_HIP_ERR_INVALID, "bert: token type id out of range");
+            tok[m + j] = id; pos[m + j] = (int32_t)j; tt[m + j] = ty;
+        }
+        for (uint32_t q = 0; q * 64u < lens[b]; ++q) { blk[2 * nb] = (int32_t)b; blk[2 * nb + 1] = (int32_t)q; ++nb; }
+        m += lens[b];
+    }
+    int32_t rc = ensure_scratch(e, M, B, nblk);
+    if (rc != CQS_HIP_OK) return rc;
+    hipStream_t st = e->stream;
+    B_TRY(e, hipMemcpyAsync(e->d_meta, t.data(), t.size() * 4, hipMemcpyHostToDevice, st));
+    const int32_t *d_tok = e->d_meta, *d_pos = d_tok + M, *d_tt = d_pos + M, *d_start = d_tt + M, *d_len = d_start + B,
+                  *d_blk = d_len + B;
+    const uint32_t H = c.hidden, I = c.intermediate;
+    B_TRY(e, cqs::launch_bert_embed_ln(d_tok, d_pos, d_tt, e->word, e->posw, e->typew, e->emb_g, e->emb_b, c.ln_eps, e->x, M, H, st));
+    for (uint32_t l = 0; l < c.layers; ++l) {
+        const BertLayer& w = e->L[l];
+        B_TRY(e, cqs::launch_gemm_bias(e->x, w.wqkv, w.bqkv, e->qkv, M, 3u * H, H, 3u * H, cqs::GEMM_OUT_BF16, st));
+        B_TRY(e, cqs::launch_bert_attention(e->qkv, e->att, d_blk, nblk, d_start, d_len, c.heads, H / c.heads, st));
+        B_TRY(e, cqs::launch_gemm_bias(e->att, w.wo, w.bo, e->y, M, H, H, H, cqs::GEMM_OUT_BF16, st));
+        B_TRY(e, cqs::launch_bert_add_ln(e->x, e->y, w.ln1_g, w.ln1_b, c.ln_eps, e->x, M, H, st));
+        B_TRY(e, cqs::launch_gemm_bias(e->x, w.w1, w.b1, e->h, M, I, H, I, cqs::GEMM_OUT_BF16_GELU, st));
+        B_TRY(e, cqs::launch_gemm_bias(e->h, w.w2, w.b2, e->y, M, H, I, H, cqs::GEMM_OUT_BF16, st));
+        B_TRY(e, cqs::launch_bert_add_ln(e->x, e->y, w.ln2_g, w.ln2_b, c.ln_eps, e->x, M, H, st));
+    }
+    return CQS_HIP_OK;
+}
+
+int32_t check_ready(cqs_hip_bert* e, uint32_t head) {
+    if (e->poisoned.load(std::memory_order_acquire)) return CQS_HIP_ERR_POISONED;
+    if (!e->finalized) return bfail(e, CQS_HIP_ERR_INVALID, "bert: weights not finalized");
+    if (head != 0xFFFFFFFFu && e->cfg.head != head) return bfail(e, CQS_HIP_ERR_INVALID, "bert: this engine was built with the other head");
+    return CQS_HIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t cqs_hip_bert_config_default(uint32_t head, cqs_hip_bert_config* c) {
+    if (!c) return CQS_HIP_ERR_INVALID;
+    memset(c, 0, sizeof(*c));
+    c->vocab_size = 30522; c->max_pos = 512; c->type_vocab = 2; c->ln_eps = 1e-12f; c->num_labels = 1; c->head = head;
+    if (head == CQS_HIP_BERT_HEAD_MLM) {            // naver/splade-cocondenser-ensembledistil = bert-base-uncased geometry
+        c->hidden = 768; c->layers = 12; c->heads = 12; c->intermediate = 3072;
+    } else if (head == CQS_HIP_BERT_HEAD_CLASSIFIER) {   // cross-encoder/ms-marco-MiniLM-L-6-v2 (src/reranker.rs:7,35)
+        c->hidden = 384; c->layers = 6; c->heads = 12; c->intermediate = 1536;
+    } else {
+        return CQS_HIP_ERR_INVALID;
+    }
+    return CQS_HIP_OK;
+}
+
+int32_t cqs_hip_bert_create(const cqs_hip_bert_config* cfg, int32_t device, cqs_hip_bert** out) {
+    if (!cfg || !out) return CQS_HIP_ERR_INVALID;
+    *out = nullptr;
+    const cqs_hip_bert_config& c = *cfg;
+    const bool ok_cfg = c.hidden && c.hidden % 192u == 0 && c.hidden % 128u == 0 && c.hidden <= 1024u && c.layers && c.heads &&
+                        c.hidden % c.heads == 0 && (c.hidden / c.heads == 32u || c.hidden / c.heads == 64u) &&
+                        c.intermediate % 192u == 0 && c.vocab_size && c.max_pos && c.type_vocab &&
+                        (c.head == CQS_HIP_BERT_HEAD_MLM || c.head == CQS_HIP_BERT_HEAD_CLASSIFIER) &&
+                        (c.head != CQS_HIP_BERT_HEAD_CLASSIFIER || (c.num_labels >= 1 && c.num_labels <= 16)) && c.ln_eps > 0.f;
+    if (!ok_cfg) return CQS_HIP_ERR_INVALID;    // (hidden / intermediate multiples of 192: the GEMM's narrowest tile)
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return CQS_HIP_ERR_NO_DEVICE;
+    cqs_hip_bert* e = new cqs_hip_bert();
+    e->device = device;
+    e->cfg = c;
+    e->vpad = (c.vocab_size + 191u) / 192u * 192u;
+    e->L.resize(c.layers);
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete e;
+        return CQS_HIP_ERR_DEVICE;
+    }
+    *out = e;
+    return CQS_HIP_OK;
+}
+
+// HF names, with or without the leading `bert.`; data f32, row-major; copied.
+int32_t cqs_hip_bert_set_tensor(cqs_hip_bert* e, const char* name, const float* data, uint64_t count) {
+    if (!e || !name || !data) return CQS_HIP_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (e->finalized) return bfail(e, CQS_HIP_ERR_INVALID, "bert: weights already finalized");
+    std::string n(name);
+    if (n.rfind("bert.", 0) == 0) n = n.substr(5);
+    e->pending[n].assign(data, data + count);
+    return CQS_HIP_OK;
+}
+
+int32_t cqs_hip_bert_finalize(cqs_hip_bert* e) {
+    if (!e) return CQS_HIP_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (e->finalized) return CQS_HIP_OK;
+    B_TRY(e, hipSetDevice(e->device));
+    const cqs_hip_bert_config& c = e->cfg;
+    const size_t H = c.hidden, I = c.intermediate, V = c.vocab_size;
+    auto need = [&](const std::string& name, size_t count) -> const float* {
+        const std::vector<float>* v = find(e, name, count);
+        if (!v) bfail(e, CQS_HIP_ERR_INVALID, "bert: missing or mis-sized tensor " + name);
+        return v ? v->data() : nullptr;
+    };
+    int32_t rc;
+#define NEED(var, name, count) const float* var = need(name, count); if (!var) return CQS_HIP_ERR_INVALID
+#define UP(call) if ((rc = (call)) != CQS_HIP_OK) return rc
+    NEED(word, "embeddings.word_embeddings.weight", V * H);
+    NEED(posw, "embeddings.position_embeddings.weight", (size_t)c.max_pos * H);
+    NEED(typew, "embeddings.token_type_embeddings.weight", (size_t)c.type_vocab * H);
+    NEED(eg, "embeddings.LayerNorm.weight", H);
+    NEED(eb, "embeddings.LayerNorm.bias", H);
+    UP(up_bf16(e, &e->word, word, V * H, (size_t)e->vpad * H));      // zero rows up to vpad: the tied decoder's padded N
+    UP(up_bf16(e, &e->posw, posw, (size_t)c.max_pos * H));
+    UP(up_bf16(e, &e->typew, typew, (size_t)c.type_vocab * H));
+    UP(up_f32(e, &e->emb_g, eg, H));
+    UP(up_f32(e, &e->emb_b, eb, H));
+    for (uint32_t l = 0; l < c.layers; ++l) {
+        const std::string p = "encoder.layer." + std::to_string(l) + ".";
+        BertLayer& w = e->L[l];
+        NEED(wq, p + "attention.self.query.weight", H * H);
+        NEED(wk, p + "attention.self.key.weight", H * H);
+        NEED(wv, p + "attention.self.value.weight", H * H);
+        NEED(bq, p + "attention.self.query.bias", H);
+        NEED(bk, p + "attention.self.key.bias", H);
+        NEED(bv, p + "attention.self.value.bias", H);
+        std::vector<float> fw(3 * H * H), fb(3 * H);
+        memcpy(fw.data(), wq, H * H * 4); memcpy(fw.data() + H * H, wk, H * H * 4); memcpy(fw.data() + 2 * H * H, wv, H * H * 4);
+        memcpy(fb.data(), bq, H * 4); memcpy(fb.data() + H, bk, H * 4); memcpy(fb.data() + 2 * H, bv, H * 4);
+        UP(up_bf16(e, &w.wqkv, fw.data(), fw.size()));
+        UP(up_f32(e, &w.bqkv, fb.data(), fb.size()));
+        NEED(wo, p + "attention.output.dense.weight", H * H);
+        NEED(bo, p + "attention.output.dense.bias", H);
+        NEED(g1, p + "attention.output.LayerNorm.weight", H);
+        NEED(b1n, p + "attention.output.LayerNorm.bias", H);
+        NEED(w1, p + "intermediate.dense.weight", I * H);
+        NEED(b1, p + "intermediate.dense.bias", I);
+        NEED(w2, p + "output.dense.weight", H * I);
+        NEED(b2, p + "output.dense.bias", H);
+        NEED(g2, p + "output.LayerNorm.weight", H);
+        NEED(b2n, p + "output.LayerNorm.bias", H);
+        UP(up_bf16(e, &w.wo, wo, H * H)); UP(up_f32(e, &w.bo, bo, H));
+        UP(up_f32(e, &w.ln1_g, g1, H)); UP(up_f32(e, &w.ln1_b, b1n, H));
+        UP(up_bf16(e, &w.w1, w1, I * H)); UP(up_f32(e, &w.b1, b1, I));
+        UP(up_bf16(e, &w.w2, w2, H * I)); UP(up_f32(e, &w.b2, b2, H));
+        UP(up_f32(e, &w.ln2_g, g2, H)); UP(up_f32(e, &w.ln2_b, b2n, H));
+    }
+    if (c.head == CQS_HIP_BERT_HEAD_MLM) {
+        NEED(wt, "cls.predictions.transform.dense.weight", H * H);
+        NEED(bt, "cls.predictions.transform.dense.bias", H);
+        NEED(lg, "cls.predictions.transform.LayerNorm.weight", H);
+        NEED(lb, "cls.predictions.transform.LayerNorm.bias", H);
+        NEED(bd, "cls.predictions.bias", V);
+        UP(up_bf16(e, &e->wt, wt, H * H)); UP(up_f32(e, &e->bt, bt, H));
+        UP(up_f32(e, &e->lnt_g, lg, H)); UP(up_f32(e, &e->lnt_b, lb, H));
+        UP(up_f32(e, &e->bdec, bd, V, e->vpad));
+    } else {
+        NEED(wp, "pooler.dense.weight", H * H);
+        NEED(bp, "pooler.dense.bias", H);
+        NEED(wc, "classifier.weight", (size_t)c.num_labels * H);
+        NEED(bc, "classifier.bias", c.num_labels);
+        UP(up_bf16(e, &e->wp, wp, H * H)); UP(up_f32(e, &e->bp, bp, H));
+        UP(up_bf16(e, &e->wc, wc, (size_t)c.num_labels * H, (size_t)16 * H));    // zero rows up to 16 labels
+        UP(up_f32(e, &e->bc, bc, c.num_labels, 16));
+    }
+#undef NEED
+#undef UP
+    e->pending.clear();
+    e->finalized = true;
+    return CQS_HIP_OK;
+}
+
+// `SpladeEncoder::encode_batch` below the tokenizer: sequences back to back (i32 ids) + their lengths; out_dense
+// [batch, vocab] f32 = ln(1 + max(0, max over the sequence's tokens of the MLM logits)) - the model's pre-pooled
+// `sparse_vector` output form (src/splade/mod.rs:960-978); the caller keeps entries > threshold.
+int32_t cqs_hip_splade_encode(cqs_hip_bert* e, const int32_t* tokens, const uint32_t* lens, uint32_t batch, float* out_dense) {
+    if (!e) return CQS_HIP_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(e->mu);
+    int32_t rc = check_ready(e, CQS_HIP_BERT_HEAD_MLM);
+    if (rc != CQS_HIP_OK) return rc;
+    if (batch == 0) return CQS_HIP_OK;
+    if (!lens || !out_dense) return bfail(e, CQS_HIP_ERR_INVALID, "splade: null buffer");
+    B_TRY(e, hipSetDevice(e->device));
+    uint32_t M = 0;
+    {
+        uint64_t tot = 0;
+        for (uint32_t b = 0; b < batch; ++b) tot += lens[b];
+        if (tot && !tokens) return bfail(e, CQS_HIP_ERR_INVALID, "splade: null tokens");
+    }
+    rc = run_encoder(e, tokens, nullptr, lens, batch, &M);
+    if (rc != CQS_HIP_OK) return rc;
+    const cqs_hip_bert_config& c = e->cfg;
+    const size_t V = c.vocab_size;
+    if (M == 0) { memset(out_dense, 0, (size_t)batch * V * 4); return CQS_HIP_OK; }   // all empty: ln(1 + 0) = 0 everywhere
+    hipStream_t st = e->stream;
+    const uint32_t H = c.hidden;
+    const int32_t *d_start = e->d_meta + (size_t)3 * M, *d_len = d_start + batch;
+    // BertLMPredictionHead: LayerNorm(gelu(x Wt^T + bt)) E^T + b, decoder tied to the (zero-padded) word embeddings
+    B_TRY(e, cqs::launch_gemm_bias(e->x, e->wt, e->bt, e->y, M, H, H, H, cqs::GEMM_OUT_BF16_GELU, st));
+    B_TRY(e, cqs::launch_bert_add_ln(e->y, nullptr, e->lnt_g, e->lnt_b, c.ln_eps, e->y, M, H, st));
+    B_TRY(e, cqs::launch_gemm_bias(e->y, e->word, e->bdec, e->logits, M, e->vpad, H, e->vpad, cqs::GEMM_OUT_BF16, st));
+    B_TRY(e, cqs::launch_splade_pool(e->logits, e->vpad, d_start, d_len, e->dense, batch, (uint32_t)V, st));
+    B_TRY(e, hipMemcpyAsync(out_dense, e->dense, (size_t)batch * V * 4, hipMemcpyDeviceToHost, st));
+    B_TRY(e, hipStreamSynchronize(st));
+    return CQS_HIP_OK;
+}
+
+// `compute_scores_opt` below the tokenizer (src/reranker.rs:343-533): (query, passage) pairs already encoded as ids +
+// token type ids; out_logits [batch, num_labels] f32 (the caller applies sigmoid to column 0).
+int32_t cqs_hip_rerank_logits(cqs_hip_bert* e, const int32_t* tokens, const int32_t* type_ids, const uint32_t* lens,
+                              uint32_t batch, float* out_logits) {
+    if (!e) return CQS_HIP_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(e->mu);
+    int32_t rc = check_ready(e, CQS_HIP_BERT_HEAD_CLASSIFIER);
+    if (rc != CQS_HIP_OK) return rc;
+    if (batch == 0) return CQS_HIP_OK;
+    if (!lens || !out_logits || !tokens) return bfail(e, CQS_HIP_ERR_INVALID, "rerank: null buffer");
+    for (uint32_t b = 0; b < batch; ++b)
+        if (lens[b] == 0) return bfail(e, CQS_HIP_ERR_INVALID, "rerank: empty sequence (no [CLS] row to pool)");
+    B_TRY(e, hipSetDevice(e->device));
+    uint32_t M = 0;
+    rc = run_encoder(e, tokens, type_ids, lens, batch, &M);
+    if (rc != CQS_HIP_OK) return rc;
+    const cqs_hip_bert_config& c = e->cfg;
+    hipStream_t st = e->stream;
+    const uint32_t H = c.hidden;
+    // BertPooler on every sequence's first token.  Rows are not equally spaced in the packed hidden states: gather
+    // them with one small copy per sequence (B is tens), then dense + tanh, then the classifier (labels padded to 16).
+    const int32_t* seq_start = e->h_meta.data() + (size_t)3 * M;
+    for (uint32_t b = 0; b < batch; ++b)
+        B_TRY(e, hipMemcpyAsync(e->pooled + (size_t)b * H, e->x + (size_t)seq_start[b] * H, (size_t)H * 2, hipMemcpyDeviceToDevice, st));
+    B_TRY(e, cqs::launch_gemm_rows(e->pooled, H, e->wp, e->bp, 1, e->att, batch, H, H, H, cqs::GEMM_OUT_BF16, st));
+    B_TRY(e, cqs::launch_gemm_rows(e->att, H, e->wc, e->bc, 0, e->cls, batch, 16, H, 16, cqs::GEMM_OUT_F32, st));
+    std::vector<float> tmp((size_t)batch * 16);
+    B_TRY(e, hipMemcpyAsync(tmp.data(), e->cls, tmp.size() * 4, hipMemcpyDeviceToHost, st));
+    B_TRY(e, hipStreamSynchronize(st));
+    for (uint32_t b = 0; b < batch; ++b)
+        for (uint32_t j = 0; j < c.num_labels; ++j) out_logits[(size_t)b * c.num_labels + j] = tmp[(size_t)b * 16 + j];
+    return CQS_HIP_OK;
+}
+
+// Diagnostic: final hidden states of the packed tokens, f32 [sum(lens), hidden].
+int32_t cqs_hip_bert_hidden(cqs_hip_bert* e, const int32_t* tokens, const int32_t* type_ids, const uint32_t* lens,
+                            uint32_t batch, float* out_hidden) {
+    if (!e) return CQS_HIP_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(e->mu);
+    int32_t rc = check_ready(e, 0xFFFFFFFFu);
+    if (rc != CQS_HIP_OK) return rc;
+    if (batch == 0) return CQS_HIP_OK;
+    if (!lens || !out_hidden || !tokens) return bfail(e, CQS_HIP_ERR_INVALID, "bert: null buffer");
+    B_TRY(e, hipSetDevice(e->device));
+    uint32_t M = 0;
+    rc = run_encoder(e, tokens, type_ids, lens, batch, &M);
+    if (rc != CQS_HIP_OK || M == 0) return rc;
+    std::vector<uint16_t> tmp((size_t)M * e->cfg.hidden);
+    B_TRY(e, hipMemcpyAsync(tmp.data(), e->x, tmp.size() * 2, hipMemcpyDeviceToHost, e->stream));
+    B_TRY(e, hipStreamSynchronize(e->stream));
+    for (size_t i = 0; i < tmp.size(); ++i) {
+        const uint32_t u = (uint32_t)tmp[i] << 16;
+        memcpy(&out_hidden[i], &u, 4);
+    }
+    return CQS_HIP_OK;
+}
+
+void cqs_hip_bert_destroy(cqs_hip_bert* e) {
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    for (void* p : e->owned) (void)hipFree(p);
+    free_scratch(e);
+    if (e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+}
+
+uint32_t cqs_hip_bert_vocab(const cqs_hip_bert* e) { return e ? e->cfg.vocab_size : 0; }
+int32_t cqs_hip_bert_poisoned(const cqs_hip_bert* e) { return e && e->poisoned.load(std::memory_order_acquire) ? 1 : 0; }
+size_t cqs_hip_bert_last_error(cqs_hip_bert* e, char* buf, size_t cap) {
+    if (!e || !buf || cap == 0) return 0;
+    std::lock_guard<std::mutex> lk(e->mu);
+    const size_t m = e->last_error.size() < cap - 1 ? e->last_error.size() : cap - 1;
+    memcpy(buf, e->last_error.data(), m);
+    buf[m] = 0;
+    return m;
+}
+
+}  // extern "C"

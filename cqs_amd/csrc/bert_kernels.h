@@ -1,0 +1,27 @@
+// bert_kernels.h — launch interface of the BERT-family kernels (SPLADE encoder / cross-encoder reranker).
+// Internal to libcqs_hip.so (public boundary: include/cqs_hip.h, BERT section).
+#pragma once
+#include "embed_kernels.h"
+
+namespace cqs {
+
+// out[m] = bf16(LayerNorm(word[tok[m]] + position[pos[m]] + token_type[tt[m]]) * gamma + beta); H % 128 == 0, H <= 1024
+hipError_t launch_bert_embed_ln(const int32_t* tok, const int32_t* pos, const int32_t* tt, const bf16_t* word,
+                                const bf16_t* posw, const bf16_t* typew, const float* gamma, const float* beta, float eps,
+                                bf16_t* out, uint32_t M, uint32_t H, hipStream_t st);
+
+// out[m] = bf16(LayerNorm(a[m] + r[m]) * gamma + beta); r == NULL: LayerNorm(a[m]); out may alias a
+hipError_t launch_bert_add_ln(const bf16_t* a, const bf16_t* r, const float* gamma, const float* beta, float eps,
+                              bf16_t* out, uint32_t M, uint32_t H, hipStream_t st);
+
+// Multi-head bidirectional attention over packed sequences.  qkv [M, 3 H] bf16 (q | k | v, heads contiguous, biases
+// already added), out [M, H]; blk[i] = {sequence, 64-query block}; head_dim 32 or 64; softmax(q k^T / sqrt(head_dim)) v.
+hipError_t launch_bert_attention(const bf16_t* qkv, bf16_t* out, const int32_t* blk /*[nblk][2]*/, uint32_t nblk,
+                                 const int32_t* seq_start, const int32_t* seq_len, uint32_t heads, uint32_t head_dim,
+                                 hipStream_t st);
+
+// out[b][v] = ln(1 + max(0, max over the tokens of sequence b of logits[token][v])), v < V (src/splade/mod.rs:1026-1062)
+hipError_t launch_splade_pool(const bf16_t* logits, uint32_t ldv, const int32_t* seq_start, const int32_t* seq_len,
+                              float* out, uint32_t B, uint32_t V, hipStream_t st);
+
+}  // namespace cqs

@@ -1,0 +1,311 @@
+// bert_kernels.hip — gfx950 kernels of the BERT-family forwards behind cqs's two auxiliary models:
+// the SPLADE sparse encoder (BERT-base masked-LM, src/splade/mod.rs) and the cross-encoder reranker (MiniLM-L6,
+// src/reranker.rs).  They replace the ORT `session.run` of those modules; semantics follow oracle/bert_ref.py (pinned
+// to transformers' BertForMaskedLM / BertForSequenceClassification).  The GEMMs are the ping-pong kernel of
+// gemm_kernels.hip with a bias (+ erf-GELU) epilogue; this file holds what is BERT-specific: the three-table
+// embedding + LayerNorm, residual + LayerNorm, multi-head attention for head dims 32 / 64 and the SPLADE pooling.
+// Tokens are packed (no padding reaches a kernel); bf16 operands, f32 accumulation and statistics.
+#include "bert_kernels.h"
+
+namespace cqs {
+
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+__device__ __forceinline__ float wave_sum64(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+constexpr int kMaxPairs = 8;   // hidden <= 1024: a lane holds hidden / 128 pairs
+
+// LayerNorm of one row held as pairs[i] = elements (128 i + 2 lane, + 1): mean and biased variance in f32 (two passes
+// over the registers), y = (x - mean) * rsqrt(var + eps) * gamma + beta (torch.nn.functional.layer_norm).
+__device__ __forceinline__ void ln_row_store(float (&v)[kMaxPairs][2], int np, uint32_t H, const float* __restrict__ gamma,
+                                             const float* __restrict__ beta, float eps, bf16_t* __restrict__ out, int lane) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < kMaxPairs; ++i)
+        if (i < np) s += v[i][0] + v[i][1];
+    const float mean = wave_sum64(s) / (float)H;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < kMaxPairs; ++i)
+        if (i < np) {
+            const float a = v[i][0] - mean, b = v[i][1] - mean;
+            q += a * a + b * b;
+        }
+    const float inv = rsqrtf(wave_sum64(q) / (float)H + eps);
+#pragma unroll
+    for (int i = 0; i < kMaxPairs; ++i)
+        if (i < np) {
+            const uint32_t c = (uint32_t)(128 * i + 2 * lane);
+            bf2 o;
+            o[0] = (bf16_t)((v[i][0] - mean) * inv * gamma[c] + beta[c]);
+            o[1] = (bf16_t)((v[i][1] - mean) * inv * gamma[c + 1] + beta[c + 1]);
+            *(bf2*)(out + c) = o;
+        }
+}
+
+// one wave per token: x = word[tok] + position[pos] + token_type[tt]; out = LN(x)
+__global__ __launch_bounds__(256) void bert_embed_ln_kernel(const int32_t* __restrict__ tok, const int32_t* __restrict__ pos,
+                                                            const int32_t* __restrict__ tt, const bf16_t* __restrict__ word,
+                                                            const bf16_t* __restrict__ posw, const bf16_t* __restrict__ typew,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            float eps, bf16_t* __restrict__ out, uint32_t M, uint32_t H) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t m = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const int np = (int)(H / 128u);
+    const bf16_t* a = word + (size_t)tok[m] * H;
+    const bf16_t* b = posw + (size_t)pos[m] * H;
+    const bf16_t* c = typew + (size_t)tt[m] * H;
+    float v[kMaxPairs][2];
+#pragma unroll
+    for (int i = 0; i < kMaxPairs; ++i)
+        if (i < np) {
+            const uint32_t col = (uint32_t)(128 * i + 2 * lane);
+            const bf2 x = *(const bf2*)(a + col), y = *(const bf2*)(b + col), z = *(const bf2*)(c + col);
+            v[i][0] = (float)x[0] + (float)y[0] + (float)z[0];
+            v[i][1] = (float)x[1] + (float)y[1] + (float)z[1];
+        }
+    ln_row_store(v, np, H, gamma, beta, eps, out + (size_t)m * H, lane);
+}
+
+// one wave per token: out = LN(a + r) (r == NULL: LN(a)); out may alias a
+__global__ __launch_bounds__(256) void bert_add_ln_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ r,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float eps, bf16_t* __restrict__ out, uint32_t M, uint32_t H) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t m = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const int np = (int)(H / 128u);
+    float v[kMaxPairs][2];
+#pragma unroll
+    for (int i = 0; i < kMaxPairs; ++i)
+        if (i < np) {
+            const uint32_t col = (uint32_t)(128 * i + 2 * lane);
+            const bf2 x = *(const bf2*)(a + (size_t)m * H + col);
+            v[i][0] = (float)x[0];
+            v[i][1] = (float)x[1];
+            if (r) {
+                const bf2 y = *(const bf2*)(r + (size_t)m * H + col);
+                v[i][0] += (float)y[0];
+                v[i][1] += (float)y[1];
+            }
+        }
+    ln_row_store(v, np, H, gamma, beta, eps, out + (size_t)m * H, lane);
+}
+
+// ---- multi-head attention, head dim HD = 32 or 64, bidirectional over one packed sequence -----------------------
+// One workgroup = 4 waves = 64 consecutive queries of ONE head of one sequence, 16 queries per wave.  Same product
+// layout as attention_dma_kernel (embed_kernels.hip): S^T = K Q^T with keys on MFMA rows (softmax is lane-local), the
+// S^T tile (t, kt) takes its key rows in the order 32 t + 8 (i >> 2) + 4 kt + (i & 3) so that a lane group's P values
+// are the 8 consecutive keys 8 lg .. 8 lg + 7 = the PV product's k-indices, and the V^T fragments come from the
+// ROW-major V tile by ds_read_b64_tr_b16 (lane 4 q + p of a 16-lane group addresses key 8 lg + 4 h + q, dims
+// 16 dt + 4 p ..+3).  K / V tiles of 64 keys go through registers into LDS (rows padded by 16 B).
+template <int HD>
+__global__ __launch_bounds__(256) void bert_attention_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+                                                             const int32_t* __restrict__ blk, const int32_t* __restrict__ seq_start,
+                                                             const int32_t* __restrict__ seq_len, uint32_t heads, float scale) {
+    constexpr int kRow = HD + 8;                       // LDS row stride (elements)
+    constexpr int kCh = HD / 8;                        // 16-byte chunks per row
+    constexpr int kU = 64 * kCh / 256;                 // chunks per thread per tile (1 or 2)
+    constexpr int kST = HD / 32, kDT = HD / 16;
+    __shared__ __attribute__((aligned(16))) bf16_t sK[64 * kRow];
+    __shared__ __attribute__((aligned(16))) bf16_t sV[64 * kRow];
+    typedef short tr4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) tr4* lds_tr4;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const uint32_t b = (uint32_t)blk[2 * blockIdx.x], qb = (uint32_t)blk[2 * blockIdx.x + 1];
+    const uint32_t head = blockIdx.y;
+    const uint32_t s0 = (uint32_t)seq_start[b], L = (uint32_t)seq_len[b];
+    const uint32_t H = heads * (uint32_t)HD, ld = 3u * H;
+    const uint32_t q0 = qb * 64u + (uint32_t)wid * 16u;    // this wave's first query (the block exists: qb * 64 < L)
+    const bool wave_live = q0 < L;
+    const uint32_t qi = q0 + (uint32_t)l15;
+    const uint32_t qrow = s0 + (qi < L ? qi : L - 1u);
+
+    bf8 qf[kST];
+#pragma unroll
+    for (int s = 0; s < kST; ++s) qf[s] = *(const bf8*)(qkv + (size_t)qrow * ld + head * HD + 32 * s + 8 * lg);
+
+    f4 o[kDT];
+#pragma unroll
+    for (int d = 0; d < kDT; ++d) o[d] = (f4)(0.f);
+    float m_run = -INFINITY, l_run = 0.f;
+    const float c = scale * 1.4426950408889634f;       // scores enter exp2 as s * c
+
+    const uint32_t nkb = (L + 63u) / 64u;
+    u4 rk[kU], rv[kU];
+    auto stage_load = [&](uint32_t kb) {
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const uint32_t i = (uint32_t)(u * 256 + tid), r = i / (uint32_t)kCh, ch = i % (uint32_t)kCh;
+            uint32_t key = kb * 64u + r;
+            key = key < L ? key : L - 1u;              // rows past the sequence: any real row (masked / P = 0)
+            const bf16_t* p = qkv + (size_t)(s0 + key) * ld + head * HD + ch * 8u;
+            rk[u] = *(const u4*)(p + H);
+            rv[u] = *(const u4*)(p + 2u * H);
+        }
+    };
+    auto stage_write = [&]() {
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const uint32_t i = (uint32_t)(u * 256 + tid), r = i / (uint32_t)kCh, ch = i % (uint32_t)kCh;
+            *(u4*)(sK + r * kRow + ch * 8u) = rk[u];
+            *(u4*)(sV + r * kRow + ch * 8u) = rv[u];
+        }
+    };
+    const uint32_t lds_v = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) bf16_t*)sV;
+    const int tq = (lane >> 2) & 3, tp = lane & 3;
+
+    stage_load(0);
+    for (uint32_t kb = 0; kb < nkb; ++kb) {
+        __syncthreads();                               // previous tile fully consumed
+        stage_write();
+        __syncthreads();
+        if (kb + 1u < nkb) stage_load(kb + 1u);
+        if (!wave_live) continue;                      // wave-uniform
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const uint32_t k_first = kb * 64u + 32u * (uint32_t)t;
+            if (k_first >= L) break;                   // wave-uniform
+            f4 sc[2];
+            sc[0] = (f4)(0.f);
+            sc[1] = (f4)(0.f);
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int s = 0; s < kST; ++s) {
+                    const int row = 32 * t + 8 * (l15 >> 2) + 4 * kt + (l15 & 3);
+                    const bf8 kf = *(const bf8*)(sK + row * kRow + 32 * s + 8 * lg);
+                    sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[s], sc[kt], 0, 0, 0);
+                }
+            // sc[kt][r] = q . k for key k_first + 8 lg + 4 kt + r
+            float mloc = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const uint32_t key = k_first + (uint32_t)(8 * lg + 4 * kt + r);
+                    sc[kt][r] = key < L ? sc[kt][r] : -INFINITY;
+                    mloc = fmaxf(mloc, sc[kt][r]);
+                }
+            mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
+            mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+            const float m_new = fmaxf(m_run, mloc);    // finite: key k_first < L is attendable for every query
+            const float a = __builtin_amdgcn_exp2f((m_run - m_new) * c);     // exp2(-inf) = 0 on the first half
+            l_run *= a;
+#pragma unroll
+            for (int d = 0; d < kDT; ++d) o[d] *= a;
+            m_run = m_new;
+            bf8 pf;
+            float lsum = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[kt][r], c, -m_new * c));
+                    lsum += pv;
+                    pf[kt * 4 + r] = (bf16_t)pv;
+                }
+            l_run += lsum;                             // per-lane partial; reduced over the lane groups at the end
+#pragma unroll
+            for (int dt = 0; dt < kDT; ++dt) {
+                const uint32_t ad = lds_v + (uint32_t)(((32 * t + 8 * lg + tq) * kRow + 16 * dt + 4 * tp) * 2);
+                const tr4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr4)(uintptr_t)ad);
+                const tr4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr4)(uintptr_t)(ad + (uint32_t)(4 * kRow * 2)));
+                const bf8 vf = __builtin_bit_cast(bf8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[dt], 0, 0, 0);
+            }
+        }
+    }
+    l_run += __shfl_xor(l_run, 16, 64);
+    l_run += __shfl_xor(l_run, 32, 64);
+    if (wave_live && qi < L) {
+        const float invl = l_run > 0.f ? 1.0f / l_run : 0.f;
+        bf16_t* op = out + (size_t)(s0 + qi) * H + head * HD;
+#pragma unroll
+        for (int d = 0; d < kDT; ++d) {
+            bf4 w;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w[e] = (bf16_t)(o[d][e] * invl);
+            *(bf4*)(op + 16 * d + 4 * lg) = w;          // O^T[dim 16 d + 4 lg + r][query l15]
+        }
+    }
+}
+
+// SPLADE pooling (src/splade/mod.rs:1026-1062): out[b][v] = ln(1 + max(0, max over the sequence's tokens of logits[s][v])),
+// the maximum folded with a strict `>` from -inf (a NaN logit never wins; an empty sequence gives ln(1 + 0) = 0).
+__global__ __launch_bounds__(256) void splade_pool_kernel(const bf16_t* __restrict__ logits, uint32_t ldv,
+                                                          const int32_t* __restrict__ seq_start,
+                                                          const int32_t* __restrict__ seq_len, float* __restrict__ out,
+                                                          uint32_t V) {
+    const uint32_t b = blockIdx.y, v0 = (blockIdx.x * 256u + threadIdx.x) * 2u;
+    if (v0 >= V) return;
+    const uint32_t s0 = (uint32_t)seq_start[b], L = (uint32_t)seq_len[b];
+    float m0 = -INFINITY, m1 = -INFINITY;
+    const bf16_t* p = logits + (size_t)s0 * ldv + v0;
+    for (uint32_t s = 0; s < L; ++s) {
+        const bf2 x = *(const bf2*)(p + (size_t)s * ldv);
+        const float a = (float)x[0], c = (float)x[1];
+        if (a > m0) m0 = a;
+        if (c > m1) m1 = c;
+    }
+    // Rust's f32::max(0.0): a NaN operand yields the other one (here m is never NaN: NaN never passed `>`)
+    out[(size_t)b * V + v0] = logf(1.0f + (m0 > 0.f ? m0 : 0.f));
+    if (v0 + 1u < V) out[(size_t)b * V + v0 + 1u] = logf(1.0f + (m1 > 0.f ? m1 : 0.f));
+}
+
+}  // namespace
+
+hipError_t launch_bert_embed_ln(const int32_t* tok, const int32_t* pos, const int32_t* tt, const bf16_t* word,
+                                const bf16_t* posw, const bf16_t* typew, const float* gamma, const float* beta, float eps,
+                                bf16_t* out, uint32_t M, uint32_t H, hipStream_t st) {
+    if (M == 0) return hipSuccess;
+    if (H % 128u || H > 128u * kMaxPairs) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(bert_embed_ln_kernel, dim3((M + 3u) / 4u), dim3(256), 0, st, tok, pos, tt, word, posw, typew, gamma,
+                       beta, eps, out, M, H);
+    return hipGetLastError();
+}
+
+hipError_t launch_bert_add_ln(const bf16_t* a, const bf16_t* r, const float* gamma, const float* beta, float eps,
+                              bf16_t* out, uint32_t M, uint32_t H, hipStream_t st) {
+    if (M == 0) return hipSuccess;
+    if (H % 128u || H > 128u * kMaxPairs) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(bert_add_ln_kernel, dim3((M + 3u) / 4u), dim3(256), 0, st, a, r, gamma, beta, eps, out, M, H);
+    return hipGetLastError();
+}
+
+hipError_t launch_bert_attention(const bf16_t* qkv, bf16_t* out, const int32_t* blk, uint32_t nblk,
+                                 const int32_t* seq_start, const int32_t* seq_len, uint32_t heads, uint32_t head_dim,
+                                 hipStream_t st) {
+    if (nblk == 0) return hipSuccess;
+    const float scale = 1.0f / sqrtf((float)head_dim);
+    if (head_dim == 64u)
+        hipLaunchKernelGGL(bert_attention_kernel<64>, dim3(nblk, heads), dim3(256), 0, st, qkv, out, blk, seq_start, seq_len, heads, scale);
+    else if (head_dim == 32u)
+        hipLaunchKernelGGL(bert_attention_kernel<32>, dim3(nblk, heads), dim3(256), 0, st, qkv, out, blk, seq_start, seq_len, heads, scale);
+    else
+        return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+hipError_t launch_splade_pool(const bf16_t* logits, uint32_t ldv, const int32_t* seq_start, const int32_t* seq_len,
+                              float* out, uint32_t B, uint32_t V, hipStream_t st) {
+    if (B == 0 || V == 0) return hipSuccess;
+    if (ldv % 2u) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(splade_pool_kernel, dim3((V + 511u) / 512u, B), dim3(256), 0, st, logits, ldv, seq_start, seq_len, out, V);
+    return hipGetLastError();
+}
+
+}  // namespace cqs

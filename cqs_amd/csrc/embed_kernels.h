@@ -34,7 +34,7 @@ hipError_t launch_add_norm(float* x, const bf16_t* y, const float* w_post, const
 //   GEMM_OUT_GEGLU: W rows are interleaved per 64: 32 gate rows then the 32 up rows of the same
 //                   channels; C bf16 [M, ldc] gets N/2 columns = gelu_tanh(gate) * up
 // Requires N % 128 == 0, K % 64 == 0.
-enum GemmOut { GEMM_OUT_BF16 = 0, GEMM_OUT_F32 = 1, GEMM_OUT_GEGLU = 2 };
+enum GemmOut { GEMM_OUT_BF16 = 0, GEMM_OUT_F32 = 1, GEMM_OUT_GEGLU = 2, GEMM_OUT_BF16_GELU = 3 /* bf16(gelu_erf(x + bias)): launch_gemm_p8 / _bias only */ };
 hipError_t launch_gemm_bf16(const bf16_t* A, const bf16_t* W, void* C, uint32_t M, uint32_t N, uint32_t K,
                             uint32_t ldc, GemmOut out, hipStream_t st);
 
@@ -43,11 +43,19 @@ hipError_t launch_gemm_bf16(const bf16_t* A, const bf16_t* W, void* C, uint32_t 
 hipError_t launch_gemm_skinny(const bf16_t* A, const bf16_t* W, void* C, uint32_t M, uint32_t N, uint32_t K,
                               uint32_t ldc, GemmOut out, hipStream_t st);
 
+// The skinny kernel on rows `lda` elements apart, + bias (nullable) and optional tanh; any M (the BERT heads).
+hipError_t launch_gemm_rows(const bf16_t* A, uint32_t lda, const bf16_t* W, const float* bias, int act_tanh, void* C,
+                            uint32_t M, uint32_t N, uint32_t K, uint32_t ldc, GemmOut out, hipStream_t st);
+
 // Second-generation kernel (gemm_kernels.hip): 256 x (64 tn) x 64 tiles, 8 waves in two rows that alternate load and
 // multiply intervals, counted-vmcnt LDS-DMA.  tn in {3, 4, 5}; N % (64 tn) == 0, K % 64 == 0.
 // launch_gemm_bf16 picks between it and the 128 x 128 kernel by shape.
 hipError_t launch_gemm_p8(const bf16_t* A, const bf16_t* W, void* C, uint32_t M, uint32_t N, uint32_t K,
-                          uint32_t ldc, GemmOut out, int tn, hipStream_t st);
+                          uint32_t ldc, GemmOut out, int tn, hipStream_t st, const float* bias = nullptr /*[N], f32*/);
+// C = act(A W^T + bias) for the BERT-family engines (bias may be NULL): picks the tile width among those that divide N
+// (N % 192 == 0 at least), 256-row ping-pong kernel only.  out: GEMM_OUT_BF16, GEMM_OUT_BF16_GELU or GEMM_OUT_F32.
+hipError_t launch_gemm_bias(const bf16_t* A, const bf16_t* W, const float* bias, void* C, uint32_t M, uint32_t N,
+                            uint32_t K, uint32_t ldc, GemmOut out, hipStream_t st);
 
 // Two column ranges of one GEMM (same A, M, K, ldc; different tile widths) in one launch.  hipErrorNotSupported when
 // the pair of widths is not built: launch the parts one after the other instead.

@@ -1082,6 +1082,7 @@ static hipError_t launch_gemm_one(const bf16_t* A, const bf16_t* W, void* C, uin
         case GEMM_OUT_BF16: hipLaunchKernelGGL(gemm_bf16_kernel<GEMM_OUT_BF16>, grid, block, 0, st, A, W, C, M, N, K, ldc); break;
         case GEMM_OUT_F32: hipLaunchKernelGGL(gemm_bf16_kernel<GEMM_OUT_F32>, grid, block, 0, st, A, W, C, M, N, K, ldc); break;
         case GEMM_OUT_GEGLU: hipLaunchKernelGGL(gemm_bf16_kernel<GEMM_OUT_GEGLU>, grid, block, 0, st, A, W, C, M, N, K, ldc); break;
+        default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
 }
@@ -1093,7 +1094,8 @@ static hipError_t launch_gemm_one(const bf16_t* A, const bf16_t* W, void* C, uin
 template <int OUT>
 __global__ __launch_bounds__(256) void gemm_skinny_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
                                                          void* __restrict__ Cv, uint32_t M, uint32_t N, uint32_t K,
-                                                         uint32_t ldc) {
+                                                         uint32_t ldc, uint32_t lda /*row stride of A, elements*/,
+                                                         const float* __restrict__ bias /*nullable*/, int act /*1: tanh*/) {
     __shared__ __attribute__((aligned(16))) float red[4][256];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int l15 = lane & 15, lg = lane >> 4;
@@ -1101,7 +1103,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const bf16_t* __restri
     const uint32_t ksteps = K / 32u, per = (ksteps + 3u) / 4u;
     const uint32_t s_lo = (uint32_t)wid * per, s_hi = s_lo + per < ksteps ? s_lo + per : ksteps;
     const uint32_t mr = m0 + (uint32_t)l15 < M ? m0 + (uint32_t)l15 : M - 1u;    // rows past M: any real row, never stored
-    const bf16_t* ap = A + (size_t)mr * K + 8 * lg;
+    const bf16_t* ap = A + (size_t)mr * lda + 8 * lg;
     const bf16_t* wp = W + (size_t)(n0 + (uint32_t)l15) * K + 8 * lg;
     f4 acc = (f4)(0.f);
     constexpr int U = 8;
@@ -1125,6 +1127,11 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const bf16_t* __restri
 #pragma unroll
         for (int w = 1; w < 4; ++w) v += *(const f4*)&red[w][(l15 * 4 + lg) * 4];
         const uint32_t m = m0 + (uint32_t)l15;
+        if (bias) v += *(const f4*)(bias + n0 + 4 * lg);
+        if (act == 1) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = tanhf(v[r]);
+        }
         if (m < M) {
             if (OUT == GEMM_OUT_F32) *(f4*)((float*)Cv + (size_t)m * ldc + n0 + 4 * lg) = v;
             else {
@@ -1207,6 +1214,31 @@ hipError_t launch_gemm_bf16(const bf16_t* A, const bf16_t* W, void* C, uint32_t 
     return launch_gemm_one(A, W + (size_t)n1 * K, c2, M, N - n1, K, ldc, out, tn2, st);
 }
 
+hipError_t launch_gemm_bias(const bf16_t* A, const bf16_t* W, const float* bias, void* C, uint32_t M, uint32_t N,
+                            uint32_t K, uint32_t ldc, GemmOut out, hipStream_t st) {
+    if (M == 0) return hipSuccess;
+    if (out == GEMM_OUT_GEGLU || K % 64u) return hipErrorInvalidValue;
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
+            n_cu = 256;
+    }
+    // rounds x cost of a round (launch_gemm_bf16's table), over the tile widths that divide N
+    const float cost[6] = {0.f, 0.f, 0.f, 24.f, 25.5f, 32.5f};
+    int best_t = 0;
+    float best = 0.f;
+    for (int t = 3; t <= 5; ++t) {
+        if (N % (64u * (uint32_t)t)) continue;
+        const uint32_t tiles = (N / (64u * (uint32_t)t)) * ((M + 255u) / 256u);
+        const float c = (float)((tiles + (uint32_t)n_cu - 1u) / (uint32_t)n_cu) * (8.f + (cost[t] - 8.f) * (float)K / 768.f);
+        if (!best_t || c < best) { best = c; best_t = t; }
+    }
+    if (!best_t) return hipErrorInvalidValue;
+    return launch_gemm_p8(A, W, C, M, N, K, ldc, out, best_t, st, bias);
+}
+
 // The Dense head's GEMMs (M = sequences of the batch).  Not chosen by launch_gemm_bf16 itself: its K split sums in a
 // different order than the tiled kernels, and a token's activations must not depend on how many tokens share its
 // batch (tests/test_embed_gpu.py::test_padding_and_batch_invariance) - the head, applied once per sequence, always
@@ -1214,11 +1246,22 @@ hipError_t launch_gemm_bf16(const bf16_t* A, const bf16_t* W, void* C, uint32_t 
 hipError_t launch_gemm_skinny(const bf16_t* A, const bf16_t* W, void* C, uint32_t M, uint32_t N, uint32_t K,
                               uint32_t ldc, GemmOut out, hipStream_t st) {
     if (M == 0) return hipSuccess;
-    if (N % 16u || K % 32u || out == GEMM_OUT_GEGLU) return hipErrorInvalidValue;
+    if (N % 16u || K % 32u || (out != GEMM_OUT_BF16 && out != GEMM_OUT_F32)) return hipErrorInvalidValue;
     if (M > 256u) return launch_gemm_bf16(A, W, C, M, N, K, ldc, out, st);
+    return launch_gemm_rows(A, K, W, nullptr, 0, C, M, N, K, ldc, out, st);
+}
+
+// The same kernel on strided rows with a bias and an optional tanh (the BERT pooler reads every sequence's first
+// token out of the packed hidden states: lda = its stride; any M).
+hipError_t launch_gemm_rows(const bf16_t* A, uint32_t lda, const bf16_t* W, const float* bias, int act_tanh, void* C,
+                            uint32_t M, uint32_t N, uint32_t K, uint32_t ldc, GemmOut out, hipStream_t st) {
+    if (M == 0) return hipSuccess;
+    if (N % 16u || K % 32u || (out != GEMM_OUT_BF16 && out != GEMM_OUT_F32)) return hipErrorInvalidValue;
     const dim3 grid(N / 16u, (M + 15u) / 16u);
-    if (out == GEMM_OUT_F32) hipLaunchKernelGGL(gemm_skinny_kernel<GEMM_OUT_F32>, grid, dim3(256), 0, st, A, W, C, M, N, K, ldc);
-    else hipLaunchKernelGGL(gemm_skinny_kernel<GEMM_OUT_BF16>, grid, dim3(256), 0, st, A, W, C, M, N, K, ldc);
+    if (out == GEMM_OUT_F32)
+        hipLaunchKernelGGL(gemm_skinny_kernel<GEMM_OUT_F32>, grid, dim3(256), 0, st, A, W, C, M, N, K, ldc, lda, bias, act_tanh);
+    else
+        hipLaunchKernelGGL(gemm_skinny_kernel<GEMM_OUT_BF16>, grid, dim3(256), 0, st, A, W, C, M, N, K, ldc, lda, bias, act_tanh);
     return hipGetLastError();
 }
 

@@ -69,7 +69,8 @@ __device__ __forceinline__ float p8_gelu_tanh(float x) {
 template <int TN, int OUT>
 __device__ __forceinline__ void gemm_pp_body(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
                                              void* __restrict__ Cv, uint32_t M, uint32_t N, uint32_t K, uint32_t ldc,
-                                             const uint32_t bid /*workgroup index among this problem's*/) {
+                                             const uint32_t bid /*workgroup index among this problem's*/,
+                                             const float* __restrict__ bias = nullptr /*[N] added before the activation*/) {
     constexpr int BN = 64 * TN;
     constexpr int kBuf = (kP8M + BN) * 64;                      // elements per LDS buffer
     constexpr int PA = 2, PB = TN;                              // DMA instructions per wave: an A half / the B tile
@@ -231,15 +232,23 @@ __device__ __forceinline__ void gemm_pp_body(const bf16_t* __restrict__ A, const
             const uint32_t row = m0 + (uint32_t)(wm * 128 + i * 16 + l15);
             if (row >= M) continue;
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
-                *(f4*)((float*)Cv + (size_t)row * ldc + n0 + (uint32_t)(wn * 16 * TN + j * 16 + 4 * lg)) = acc[i][j];
+            for (int j = 0; j < TN; ++j) {
+                const uint32_t col = n0 + (uint32_t)(wn * 16 * TN + j * 16 + 4 * lg);
+                f4 v = acc[i][j];
+                if (bias) v += *(const f4*)(bias + col);
+                *(f4*)((float*)Cv + (size_t)row * ldc + col) = v;
+            }
         }
         return;
     }
     // bf16 / GeGLU: through LDS, so that the workgroup writes WHOLE rows of its tile (a lane's 8 bytes of a 16 x 16
     // accumulator tile are a quarter of a 32-byte segment: stored directly, every 128-byte line is written in four
     // pieces by four instructions - measured: the store phase was 25-35 % of these K = 768 GEMMs).
-    if (OUT == GEMM_OUT_BF16) {
+    if (OUT == GEMM_OUT_BF16 || OUT == GEMM_OUT_BF16_GELU) {
+        f4 bv[TN];                                                  // this lane's 4 columns of each n-tile
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+            bv[j] = bias ? *(const f4*)(bias + n0 + (uint32_t)(wn * 16 * TN + j * 16 + 4 * lg)) : (f4)(0.f);
         // two passes of 128 rows (m-tiles 4p .. 4p+3 of both wave rows); LDS row = BN bf16 + 8 bytes (bank shift of
         // 2 dwords per row: conflict-free 8-byte writes)
         constexpr int kStride = BN + 4;                             // elements
@@ -254,7 +263,11 @@ __device__ __forceinline__ void gemm_pp_body(const bf16_t* __restrict__ A, const
                 for (int j = 0; j < TN; ++j) {
                     bf4 o;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) o[r] = (bf16_t)acc[4 * p + t][j][r];
+                    for (int r = 0; r < 4; ++r) {
+                        float v = acc[4 * p + t][j][r] + bv[j][r];
+                        if (OUT == GEMM_OUT_BF16_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));   // erf GELU (BERT)
+                        o[r] = (bf16_t)v;
+                    }
                     *(bf4*)(rowp + wn * 16 * TN + j * 16 + 4 * lg) = o;
                 }
             }
@@ -308,8 +321,8 @@ __device__ __forceinline__ void gemm_pp_body(const bf16_t* __restrict__ A, const
 template <int TN, int OUT>
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
                                                          void* __restrict__ Cv, uint32_t M, uint32_t N, uint32_t K,
-                                                         uint32_t ldc) {
-    gemm_pp_body<TN, OUT>(A, W, Cv, M, N, K, ldc, blockIdx.x);
+                                                         uint32_t ldc, const float* __restrict__ bias) {
+    gemm_pp_body<TN, OUT>(A, W, Cv, M, N, K, ldc, blockIdx.x, bias);
 }
 
 // Two problems that share A, M and K (the two column ranges launch_gemm_bf16 cuts a GEMM into: whole rounds of one
@@ -345,7 +358,7 @@ hipError_t launch_p8_dual(const bf16_t* A, const bf16_t* Wa, void* Ca, uint32_t 
 
 template <int TN, int OUT>
 hipError_t launch_p8(const bf16_t* A, const bf16_t* W, void* C, uint32_t M, uint32_t N, uint32_t K, uint32_t ldc,
-                     hipStream_t st) {
+                     const float* bias, hipStream_t st) {
     constexpr int BN = 64 * TN;
     const dim3 grid((N / BN) * ((M + kP8M - 1) / kP8M));
     const size_t lds = (size_t)2 * (kP8M + BN) * 64 * sizeof(bf16_t);
@@ -356,7 +369,7 @@ hipError_t launch_p8(const bf16_t* A, const bf16_t* W, void* C, uint32_t M, uint
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, A, W, C, M, N, K, ldc);
+    hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, A, W, C, M, N, K, ldc, bias);
     return hipGetLastError();
 }
 
@@ -364,16 +377,18 @@ hipError_t launch_p8(const bf16_t* A, const bf16_t* W, void* C, uint32_t M, uint
 
 // tn: n-tiles per wave (tile width 64 tn: 192 / 256 / 320); N % (64 tn) == 0, K % 64 == 0, M * K < 2^31 elements.
 hipError_t launch_gemm_p8(const bf16_t* A, const bf16_t* W, void* C, uint32_t M, uint32_t N, uint32_t K, uint32_t ldc,
-                          GemmOut out, int tn, hipStream_t st) {
+                          GemmOut out, int tn, hipStream_t st, const float* bias) {
     if (M == 0) return hipSuccess;
     if (K % 64u || K < 64u || tn < 3 || tn > 5 || N % (64u * (uint32_t)tn) || (uint64_t)M * K >= (1ull << 31) ||
         (uint64_t)N * K >= (1ull << 31))
         return hipErrorInvalidValue;
 #define P8_CASE(TNV)                                                                                      \
     case TNV:                                                                                             \
-        if (out == GEMM_OUT_BF16) return launch_p8<TNV, GEMM_OUT_BF16>(A, W, C, M, N, K, ldc, st);        \
-        if (out == GEMM_OUT_F32) return launch_p8<TNV, GEMM_OUT_F32>(A, W, C, M, N, K, ldc, st);          \
-        return launch_p8<TNV, GEMM_OUT_GEGLU>(A, W, C, M, N, K, ldc, st);
+        if (out == GEMM_OUT_BF16) return launch_p8<TNV, GEMM_OUT_BF16>(A, W, C, M, N, K, ldc, bias, st);  \
+        if (out == GEMM_OUT_F32) return launch_p8<TNV, GEMM_OUT_F32>(A, W, C, M, N, K, ldc, bias, st);    \
+        if (out == GEMM_OUT_BF16_GELU) return launch_p8<TNV, GEMM_OUT_BF16_GELU>(A, W, C, M, N, K, ldc, bias, st); \
+        if (bias) return hipErrorInvalidValue;                                                            \
+        return launch_p8<TNV, GEMM_OUT_GEGLU>(A, W, C, M, N, K, ldc, nullptr, st);
     switch (tn) {
         P8_CASE(3)
         P8_CASE(4)

@@ -1,0 +1,149 @@
+"""Host mirror of cqs's two BERT-family auxiliary models over the C ABI (include/cqs_hip.h, BERT section):
+
+  * `SpladeEncoder` — `SpladeEncoder::{encode, encode_batch}` (src/splade/mod.rs:595-760, :774-1075) below the
+    tokenizer: token-id sequences in, `SparseVector`s (`Vec<(u32, f32)>`, ascending id, weight > threshold) out;
+  * `Reranker` — `Reranker::compute_scores_opt` (src/reranker.rs:343-533) below the tokenizer: encoded (query, passage)
+    pairs in, `sigmoid(logit)` scores out.
+
+The tokenizer stays on the host in the reference too (tokenizers crate); tests and the bench feed token ids.
+There is no CPU fallback here: without libcqs_hip.so / a GPU the constructors raise."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+
+SparseVector = List[Tuple[int, float]]
+DEFAULT_SPLADE_THRESHOLD = 0.01        # src/splade/mod.rs:400-410 (CQS_SPLADE_THRESHOLD overrides it in the reference)
+
+
+class BertError(RuntimeError):
+    pass
+
+
+def bert_config(head: int, **overrides) -> _lib.BertConfig:
+    cfg = _lib.BertConfig()
+    rc = _lib.load().cqs_hip_bert_config_default(head, C.byref(cfg))
+    if rc != _lib.OK:
+        raise BertError(f"cqs_hip_bert_config_default failed ({rc})")
+    for k, v in overrides.items():
+        setattr(cfg, k, v)
+    return cfg
+
+
+class HipBertEngine:
+    """One `cqs_hip_bert` handle (an encoder + one head)."""
+
+    def __init__(self, cfg: _lib.BertConfig, device: int = 0):
+        self._lib = _lib.load()
+        self.cfg = cfg
+        h = C.c_void_p()
+        rc = self._lib.cqs_hip_bert_create(C.byref(cfg), device, C.byref(h))
+        if rc != _lib.OK:
+            raise BertError(f"cqs_hip_bert_create failed ({rc})")
+        self._h = h
+
+    def close(self):
+        if self._h:
+            self._lib.cqs_hip_bert_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def last_error(self) -> str:
+        buf = C.create_string_buffer(512)
+        self._lib.cqs_hip_bert_last_error(self._h, buf, 512)
+        return buf.value.decode("utf-8", "replace")
+
+    def _check(self, rc: int, what: str):
+        if rc != _lib.OK:
+            raise BertError(f"{what}: {self.last_error()} ({rc})")
+
+    def set_weights(self, weights: Dict[str, np.ndarray]):
+        for name, t in weights.items():
+            a = np.ascontiguousarray(t, dtype=np.float32)
+            self._check(self._lib.cqs_hip_bert_set_tensor(self._h, name.encode(), a.ctypes.data_as(C.c_void_p), a.size),
+                        "set_tensor " + name)
+        self._check(self._lib.cqs_hip_bert_finalize(self._h), "finalize")
+
+    @staticmethod
+    def _pack(seqs: Sequence[np.ndarray]):
+        lens = np.array([len(s) for s in seqs], np.uint32)
+        toks = np.concatenate([np.asarray(s, np.int32) for s in seqs]) if len(seqs) and lens.sum() else np.zeros(0, np.int32)
+        return np.ascontiguousarray(toks, np.int32), lens
+
+    def splade_dense(self, seqs: Sequence[np.ndarray]) -> np.ndarray:
+        """[B, vocab] f32 activations ln(1 + max(0, max_s logits))."""
+        toks, lens = self._pack(seqs)
+        out = np.empty((len(seqs), int(self.cfg.vocab_size)), np.float32)
+        self._check(self._lib.cqs_hip_splade_encode(self._h, toks.ctypes.data_as(C.c_void_p), lens.ctypes.data_as(C.c_void_p),
+                                                    len(seqs), out.ctypes.data_as(C.c_void_p)), "splade_encode")
+        return out
+
+    def rerank_logits(self, seqs: Sequence[np.ndarray], type_ids: Optional[Sequence[np.ndarray]]) -> np.ndarray:
+        toks, lens = self._pack(seqs)
+        tt = None
+        if type_ids is not None:
+            tt, tl = self._pack(type_ids)
+            if not np.array_equal(tl, lens):
+                raise BertError("token_type_ids do not line up with input_ids")
+        out = np.empty((len(seqs), int(self.cfg.num_labels)), np.float32)
+        self._check(self._lib.cqs_hip_rerank_logits(self._h, toks.ctypes.data_as(C.c_void_p),
+                                                    tt.ctypes.data_as(C.c_void_p) if tt is not None else None,
+                                                    lens.ctypes.data_as(C.c_void_p), len(seqs), out.ctypes.data_as(C.c_void_p)),
+                    "rerank_logits")
+        return out
+
+    def hidden(self, seqs: Sequence[np.ndarray], type_ids: Optional[Sequence[np.ndarray]] = None) -> np.ndarray:
+        toks, lens = self._pack(seqs)
+        tt = self._pack(type_ids)[0] if type_ids is not None else None
+        out = np.empty((int(lens.sum()), int(self.cfg.hidden)), np.float32)
+        self._check(self._lib.cqs_hip_bert_hidden(self._h, toks.ctypes.data_as(C.c_void_p),
+                                                  tt.ctypes.data_as(C.c_void_p) if tt is not None else None,
+                                                  lens.ctypes.data_as(C.c_void_p), len(seqs), out.ctypes.data_as(C.c_void_p)),
+                    "bert_hidden")
+        return out
+
+
+class SpladeEncoder:
+    """`SpladeEncoder` (src/splade/mod.rs:95-118) over a HIP engine: `encode_batch` on token-id sequences."""
+
+    def __init__(self, engine: HipBertEngine, threshold: float = DEFAULT_SPLADE_THRESHOLD, max_seq_len: int = 512):
+        self.engine, self.threshold, self.max_seq_len = engine, float(threshold), int(max_seq_len)
+
+    def encode_batch(self, seqs: Sequence[Sequence[int]]) -> List[SparseVector]:
+        if not len(seqs):
+            return []
+        cut = [np.asarray(s, np.int32)[: self.max_seq_len] for s in seqs]     # truncation (src/splade/mod.rs:860-880)
+        dense = self.engine.splade_dense(cut)
+        out = []
+        thr = np.float32(self.threshold)
+        for row in dense:
+            keep = np.nonzero(row > thr)[0]                                    # ascending id; NaN > t is False
+            out.append([(int(i), float(row[i])) for i in keep])
+        return out
+
+    def encode(self, seq: Sequence[int]) -> SparseVector:
+        return self.encode_batch([seq])[0]
+
+
+class Reranker:
+    """`Reranker::compute_scores_opt` (src/reranker.rs:343-533) on encoded pairs: sigmoid of the first logit."""
+
+    def __init__(self, engine: HipBertEngine, max_length: int = 512):
+        self.engine, self.max_length = engine, int(max_length)
+
+    def scores(self, ids: Sequence[Sequence[int]], type_ids: Optional[Sequence[Sequence[int]]] = None) -> np.ndarray:
+        if not len(ids):
+            return np.zeros(0, np.float32)
+        a = [np.asarray(s, np.int32)[: self.max_length] for s in ids]
+        t = [np.asarray(s, np.int32)[: self.max_length] for s in type_ids] if type_ids is not None else None
+        logits = self.engine.rerank_logits(a, t)
+        return (1.0 / (1.0 + np.exp(-logits[:, 0].astype(np.float64)))).astype(np.float32)

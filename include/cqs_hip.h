@@ -305,6 +305,53 @@ int32_t cqs_hip_embed_hidden(cqs_hip_embedder* e, const int64_t* input_ids, cons
  * stream; with other tickets in flight that interval includes the time it shared the device with them). */
 float cqs_hip_embedder_last_ms(const cqs_hip_embedder* e);
 
+/* ---- BERT-family auxiliary models ---------------------------------------------------------
+ * The two other ONNX models of the reference reuse `create_session` (src/embedder/provider.rs) and are BERT
+ * encoders with a small head.  One engine type, two heads:
+ *   CQS_HIP_BERT_HEAD_MLM         SPLADE sparse encoder (naver/splade-cocondenser-ensembledistil: BERT-base masked-LM);
+ *                                 replaces the `session.run` of `SpladeEncoder::encode` / `encode_batch`
+ *                                 (src/splade/mod.rs:595-760, :774-1075)
+ *   CQS_HIP_BERT_HEAD_CLASSIFIER  cross-encoder reranker (cross-encoder/ms-marco-MiniLM-L-6-v2); replaces the
+ *                                 `session.run` of `Reranker::compute_scores_opt` (src/reranker.rs:343-533)
+ * The tokenizer stays on the host as in the reference; token ids come in packed (sequences back to back + lengths).
+ * Weights are handed over by HF tensor name (set_tensor, f32, copied) and frozen by finalize.  Calls on one engine
+ * are serialised by an internal mutex.  Geometry limits: hidden a multiple of 384 (<= 1024), head dim 32 or 64,
+ * intermediate a multiple of 192. */
+typedef struct cqs_hip_bert cqs_hip_bert;
+enum { CQS_HIP_BERT_HEAD_MLM = 0, CQS_HIP_BERT_HEAD_CLASSIFIER = 1 };
+typedef struct cqs_hip_bert_config {
+    uint32_t vocab_size, hidden, layers, heads, intermediate, max_pos, type_vocab;
+    uint32_t num_labels;   /* classifier head: outputs per sequence (1..16) */
+    uint32_t head;         /* CQS_HIP_BERT_HEAD_* */
+    float ln_eps;
+} cqs_hip_bert_config;
+/* The two presets the reference ships with: head = MLM -> BERT-base / vocab 30522 (src/splade/mod.rs:120-150);
+ * head = CLASSIFIER -> MiniLM-L6-H384, one label (src/reranker.rs:7,35). */
+int32_t cqs_hip_bert_config_default(uint32_t head, cqs_hip_bert_config* out);
+int32_t cqs_hip_bert_create(const cqs_hip_bert_config* cfg, int32_t device, cqs_hip_bert** out);
+/* name: the Hugging Face tensor name, with or without the leading `bert.` (e.g.
+ * `encoder.layer.3.attention.self.query.weight`, `cls.predictions.transform.dense.bias`, `cls.predictions.bias`,
+ * `pooler.dense.weight`, `classifier.weight`); the MLM decoder is tied to `embeddings.word_embeddings.weight`. */
+int32_t cqs_hip_bert_set_tensor(cqs_hip_bert* e, const char* name, const float* data, uint64_t count);
+int32_t cqs_hip_bert_finalize(cqs_hip_bert* e);
+void    cqs_hip_bert_destroy(cqs_hip_bert* e);
+/* SPLADE: tokens = the sequences' ids back to back, lens[b] = tokens of sequence b (0 allowed: an all-zero row).
+ * out_dense [batch, vocab] f32 = ln(1 + max(0, max over the sequence's tokens of the masked-LM logits)): the
+ * pre-pooled `sparse_vector` output form (src/splade/mod.rs:960-978); the caller keeps (id, weight) with
+ * weight > threshold, ascending id (src/splade/mod.rs:1049-1062).  The maximum is folded with a strict `>` from -inf
+ * (src/splade/mod.rs:1033-1043). */
+int32_t cqs_hip_splade_encode(cqs_hip_bert* e, const int32_t* tokens, const uint32_t* lens, uint32_t batch, float* out_dense);
+/* Reranker: (query, passage) pairs as ids + token type ids (NULL = all zero), packed like the above; every sequence
+ * non-empty.  out_logits [batch, num_labels] f32; score = sigmoid(out_logits[b * num_labels]) (src/reranker.rs:516-518). */
+int32_t cqs_hip_rerank_logits(cqs_hip_bert* e, const int32_t* tokens, const int32_t* type_ids, const uint32_t* lens,
+                              uint32_t batch, float* out_logits);
+/* Diagnostic: final encoder hidden states of the packed tokens, f32 [sum(lens), hidden]. */
+int32_t cqs_hip_bert_hidden(cqs_hip_bert* e, const int32_t* tokens, const int32_t* type_ids, const uint32_t* lens,
+                            uint32_t batch, float* out_hidden);
+uint32_t cqs_hip_bert_vocab(const cqs_hip_bert* e);
+int32_t  cqs_hip_bert_poisoned(const cqs_hip_bert* e);
+size_t   cqs_hip_bert_last_error(cqs_hip_bert* e, char* buf, size_t cap);
+
 #ifdef __cplusplus
 }
 #endif
