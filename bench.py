@@ -439,6 +439,103 @@ def other_configs(torch, np, HipIndex, idx, rows, queries, dim, dev, st):
     return out
 
 
+def aux_models_leg(a, np):
+    """the two BERT-family auxiliary models at their real geometry (seeded weights, synthetic token
+    ids): SPLADE encode (BERT-base masked-LM + pooling -> sparse vectors) and reranker scoring (MiniLM-L6
+    cross-encoder).  Each is checked against the fp32 CPU oracle on a small batch outside the timed region; the CPU
+    baseline is that oracle (torch CPU) on a bounded sample."""
+    from oracle import bert_ref as R
+    from cqs_amd import _lib
+    from cqs_amd.splade import HipBertEngine, Reranker, SpladeEncoder, bert_config
+    rng = np.random.default_rng(0xC950009)
+    out = {}
+
+    def padded(seqs, types=None):
+        L = max(len(s) for s in seqs)
+        ids = np.zeros((len(seqs), L), np.int64); mask = np.zeros((len(seqs), L), np.int64); tt = np.zeros((len(seqs), L), np.int64)
+        for i, s in enumerate(seqs):
+            ids[i, :len(s)] = s; mask[i, :len(s)] = 1
+            if types is not None:
+                tt[i, :len(s)] = types[i]
+        return ids, mask, tt
+
+    # SPLADE
+    cfg = R.splade_base()
+    w = R.seeded_weights(cfg, "mlm", seed=1)
+    eng = HipBertEngine(bert_config(_lib.BERT_HEAD_MLM))
+    eng.set_weights(w)
+    small = [rng.integers(1, cfg.vocab_size, size=n).astype(np.int32) for n in (48, 200, 7)]
+    got = eng.splade_dense(small)
+    t0 = time.perf_counter()
+    _, want = R.splade_encode_batch(cfg, w, *padded(small)[:2], 0.01)
+    cpu_s = time.perf_counter() - t0
+    err = float(np.max(np.abs(got - want)))
+    assert err < 0.08, "splade activations differ from the fp32 oracle: %g" % err
+    B, L = 64, 256
+    seqs = [rng.integers(1, cfg.vocab_size, size=L).astype(np.int32) for _ in range(B)]
+    # seeded weights make half the vocabulary "active"; a trained SPLADE keeps 100-300 entries per document
+    # (src/splade/mod.rs:44): put the threshold where ~200 survive so the host-side filter does realistic work
+    warm = eng.splade_dense(seqs)
+    thr = float(np.sort(warm[0])[-200])
+    enc = SpladeEncoder(eng, threshold=thr)
+    t_end = time.perf_counter() + 0.5                                  # (let the oracle's CPU threads stop spinning)
+    while time.perf_counter() < t_end:
+        enc.encode_batch(seqs)
+    steps = max(4, a.embed_steps)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        sv = enc.encode_batch(seqs)
+    dt = (time.perf_counter() - t0) / steps
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        eng.splade_dense(seqs)
+    dt_dense = (time.perf_counter() - t0) / steps
+    flops = 2.0 * B * L * (cfg.layers * (4 * cfg.hidden * cfg.hidden + 2 * cfg.hidden * cfg.intermediate) + cfg.hidden * cfg.hidden
+                           + cfg.hidden * cfg.vocab_size) + 4.0 * B * cfg.layers * L * L * cfg.hidden
+    out["splade"] = {"model": "BERT-base masked-LM geometry (12 x [768 | 12 x 64 | 3072], vocab 30522), seeded weights",
+                     "batch": B, "tokens_per_doc": L, "docs_per_sec": round(B / dt, 1), "tokens_per_sec": round(B * L / dt, 1),
+                     "ms_per_batch": round(dt * 1e3, 3), "ms_per_batch_device_side": round(dt_dense * 1e3, 3),
+                     "tflops": round(flops / dt_dense / 1e12, 1), "nnz_per_doc": round(float(np.mean([len(v) for v in sv])), 1),
+                     "checked": {"max_abs_err_vs_fp32_oracle": round(err, 4)},
+                     "cpu_baseline": {"docs_per_sec": round(3 / cpu_s, 2), "kind": "port", "sample": "oracle/bert_ref (torch CPU fp32), 3 docs / 255 tokens"},
+                     "threshold": round(thr, 4),
+                     "note": "host API: token ids in, sparse vectors out (threshold filter on the host as in src/splade/mod.rs:1049-1062); "
+                             "threshold set where ~200 entries per document survive (seeded weights are not sparse)"}
+    eng.close()
+
+    # reranker
+    cfg = R.minilm_l6()
+    w = R.seeded_weights(cfg, "classifier", seed=2)
+    eng = HipBertEngine(bert_config(_lib.BERT_HEAD_CLASSIFIER))
+    eng.set_weights(w)
+    rr = Reranker(eng)
+    small = [rng.integers(1, cfg.vocab_size, size=n).astype(np.int32) for n in (64, 300, 20, 128)]
+    st = [np.r_[np.zeros(12, np.int32), np.ones(len(s) - 12, np.int32)] for s in small]
+    got = rr.scores(small, st)
+    t0 = time.perf_counter()
+    want = R.rerank_scores(cfg, w, *padded(small, st))
+    cpu_s = time.perf_counter() - t0
+    err = float(np.max(np.abs(got - want)))
+    assert err < 0.02, "reranker scores differ from the fp32 oracle: %g" % err
+    B, L = 32, 512                                                     # the reference's batch (src/reranker.rs:83)
+    seqs = [rng.integers(1, cfg.vocab_size, size=L).astype(np.int32) for _ in range(B)]
+    tts = [np.r_[np.zeros(16, np.int32), np.ones(L - 16, np.int32)] for _ in range(B)]
+    t_end = time.perf_counter() + 0.5                                  # (let the oracle's CPU threads stop spinning)
+    while time.perf_counter() < t_end:
+        rr.scores(seqs, tts)
+    steps = max(20, 4 * a.embed_steps)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        rr.scores(seqs, tts)
+    dt = (time.perf_counter() - t0) / steps
+    out["reranker"] = {"model": "MiniLM-L6-H384 cross-encoder geometry (6 x [384 | 12 x 32 | 1536]), seeded weights",
+                       "batch": B, "tokens_per_pair": L, "pairs_per_sec": round(B / dt, 1), "ms_per_batch": round(dt * 1e3, 3),
+                       "checked": {"max_abs_err_vs_fp32_oracle": round(err, 4)},
+                       "cpu_baseline": {"pairs_per_sec": round(4 / cpu_s, 2), "kind": "port", "sample": "oracle/bert_ref (torch CPU fp32), 4 pairs / 512 tokens"}}
+    eng.close()
+    return out
+
+
 def abi_sharded_leg(a, torch, np, rows, queries, k, dim):
     """Single-process multi-GPU path behind the C ABI (cqs_hip_index_create_sharded): synchronous host-API queries
     on the same corpus, checked against the single-device answer."""
@@ -746,6 +843,10 @@ def main():
             e2e = e2e_leg(a, torch, np, dev, eng, ecfg, eweights)
         eng.close()
 
+    aux = None
+    if rank == 0 and world == 1 and mode == "single" and a.extras and a.embed_steps > 0:
+        aux = aux_models_leg(a, np)
+
     if rank == 0:
         if mode == "weak":
             total_q = K * bq * world
@@ -784,6 +885,7 @@ def main():
             "abi_sharded": abi,
             "embed": embed,
             "e2e": e2e,
+            "aux_models": aux,
         }
         print(json.dumps(line), flush=True)
     if a.embed_steps <= 0:

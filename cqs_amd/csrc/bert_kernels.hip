@@ -250,20 +250,26 @@ __global__ __launch_bounds__(256) void splade_pool_kernel(const bf16_t* __restri
                                                           const int32_t* __restrict__ seq_start,
                                                           const int32_t* __restrict__ seq_len, float* __restrict__ out,
                                                           uint32_t V) {
-    const uint32_t b = blockIdx.y, v0 = (blockIdx.x * 256u + threadIdx.x) * 2u;
-    if (v0 >= V) return;
+    // a thread owns 8 consecutive vocabulary columns (16-byte loads: a wave reads 1 KiB of every token row)
+    const uint32_t b = blockIdx.y, v0 = (blockIdx.x * 256u + threadIdx.x) * 8u;
+    if (v0 >= V) return;                       // (ldv = V rounded up to a multiple of 192: columns v0 .. v0 + 7 exist)
     const uint32_t s0 = (uint32_t)seq_start[b], L = (uint32_t)seq_len[b];
-    float m0 = -INFINITY, m1 = -INFINITY;
+    float m[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) m[j] = -INFINITY;
     const bf16_t* p = logits + (size_t)s0 * ldv + v0;
     for (uint32_t s = 0; s < L; ++s) {
-        const bf2 x = *(const bf2*)(p + (size_t)s * ldv);
-        const float a = (float)x[0], c = (float)x[1];
-        if (a > m0) m0 = a;
-        if (c > m1) m1 = c;
+        const bf8 x = *(const bf8*)(p + (size_t)s * ldv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float a = (float)x[j];
+            if (a > m[j]) m[j] = a;            // strict `>`: a NaN logit never wins
+        }
     }
-    // Rust's f32::max(0.0): a NaN operand yields the other one (here m is never NaN: NaN never passed `>`)
-    out[(size_t)b * V + v0] = logf(1.0f + (m0 > 0.f ? m0 : 0.f));
-    if (v0 + 1u < V) out[(size_t)b * V + v0 + 1u] = logf(1.0f + (m1 > 0.f ? m1 : 0.f));
+    // Rust's f32::max(0.0): a NaN operand yields the other one (m is never NaN here)
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        if (v0 + (uint32_t)j < V) out[(size_t)b * V + v0 + (uint32_t)j] = logf(1.0f + (m[j] > 0.f ? m[j] : 0.f));
 }
 
 }  // namespace
@@ -303,8 +309,8 @@ hipError_t launch_bert_attention(const bf16_t* qkv, bf16_t* out, const int32_t* 
 hipError_t launch_splade_pool(const bf16_t* logits, uint32_t ldv, const int32_t* seq_start, const int32_t* seq_len,
                               float* out, uint32_t B, uint32_t V, hipStream_t st) {
     if (B == 0 || V == 0) return hipSuccess;
-    if (ldv % 2u) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(splade_pool_kernel, dim3((V + 511u) / 512u, B), dim3(256), 0, st, logits, ldv, seq_start, seq_len, out, V);
+    if (ldv % 8u || ldv < ((V + 7u) & ~7u)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(splade_pool_kernel, dim3((V + 2047u) / 2048u, B), dim3(256), 0, st, logits, ldv, seq_start, seq_len, out, V);
     return hipGetLastError();
 }
 

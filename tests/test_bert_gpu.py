@@ -158,3 +158,32 @@ def test_bert_io_contract(hip):
     with pytest.raises(BertError):
         e2.set_weights({"embeddings.word_embeddings.weight": np.zeros((500, 384), np.float32)})   # incomplete
     e2.close()
+
+
+def test_full_geometry_presets(hip):
+    """The two presets at their real dims (BERT-base masked-LM with the 30 522-word tied decoder, padded to the GEMM's
+    tile; MiniLM-L6 classifier) on a small batch against the oracle."""
+    from cqs_amd.splade import Reranker, SpladeEncoder
+    cfg = R.splade_base()
+    eng, w = _engine(cfg, "mlm", seed=11)
+    seqs = _seqs(cfg, [90, 300, 12], seed=12)
+    dense = eng.splade_dense(seqs)
+    ids, mask, _ = _padded(seqs)
+    _, want = R.splade_encode_batch(cfg, w, ids, mask, 0.01)
+    assert dense.shape == (3, 30522)
+    for i in range(3):
+        assert np.max(np.abs(dense[i] - want[i])) < 0.08 and cos(dense[i], want[i]) > 0.999, (i, np.max(np.abs(dense[i] - want[i])))
+    top_g, top_w = np.argsort(-dense[1])[:50], np.argsort(-want[1])[:50]
+    assert len(set(top_g) & set(top_w)) >= 45                              # the heavy vocabulary entries agree
+    sv = SpladeEncoder(eng, threshold=1.0).encode_batch(seqs)
+    assert all(len(v) > 0 and all(wt > 1.0 for _, wt in v) for v in sv)
+    eng.close()
+    cfg = R.minilm_l6()
+    eng, w = _engine(cfg, "classifier", seed=13)
+    seqs = _seqs(cfg, [128, 512, 40, 77], seed=14)
+    types = [np.r_[np.zeros(16, np.int32), np.ones(len(s) - 16, np.int32)] for s in seqs]
+    got = Reranker(eng).scores(seqs, types)
+    ids, mask, tt = _padded(seqs, types)
+    want = R.rerank_scores(cfg, w, ids, mask, tt)
+    assert np.max(np.abs(got - want)) < 0.02, (got, want)
+    eng.close()
