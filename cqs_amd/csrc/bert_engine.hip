@@ -5,12 +5,16 @@
 // oracle/bert_ref.py.  No CPU fallback: without a GPU `cqs_hip_bert_create` fails.
 #include "../../include/cqs_hip.h"
 #include "bert_kernels.h"
+#include "onnx_reader.h"
+#include "safetensors_reader.h"
 
 #include <hip/hip_runtime.h>
+#include <sys/stat.h>
 
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -423,6 +427,65 @@ int32_t cqs_hip_bert_hidden(cqs_hip_bert* e, const int32_t* tokens, const int32_
         const uint32_t u = (uint32_t)tmp[i] << 16;
         memcpy(&out_hidden[i], &u, 4);
     }
+    return CQS_HIP_OK;
+}
+
+// `create_session` for these two models (src/embedder/provider.rs:254-447 via src/splade/mod.rs:433-560 and
+// src/reranker.rs:266-330): the local bundle is `{dir}/onnx/model.onnx` (+ external data) or `{dir}/model.onnx`
+// (src/reranker.rs:548-556); a Hugging Face checkpoint directory (`model.safetensors`) is accepted as well.
+// ONNX initialisers are found as in the embedding engine (onnx_reader.cpp): named tensors by name, anonymous
+// transposed MatMul operands through the consuming node's module path.
+int32_t cqs_hip_bert_load_dir(const char* model_dir, const cqs_hip_bert_config* cfg, int32_t device, cqs_hip_bert** out) {
+    if (!model_dir || !cfg || !out) return CQS_HIP_ERR_INVALID;
+    *out = nullptr;
+    cqs_hip_bert* e = nullptr;
+    int32_t rc = cqs_hip_bert_create(cfg, device, &e);
+    if (rc != CQS_HIP_OK) return rc;
+    const std::string d(model_dir);
+    auto exists = [](const std::string& p) { struct stat st; return stat(p.c_str(), &st) == 0; };
+    // names both readers may hand over -> the engine's; unknown tensors (graph constants, position_ids) are skipped
+    auto canon = [&](std::string n) -> std::string {
+        if (n.rfind("bert.", 0) == 0) n = n.substr(5);
+        if (n.rfind("layer.", 0) == 0) n = "encoder." + n;                 // (onnx_reader strips a leading `encoder.`)
+        if (n == "cls.predictions.decoder.bias") n = "cls.predictions.bias";
+        if (n == "cls.predictions.decoder.weight") return std::string();    // tied to the word embeddings
+        const bool known = n.rfind("embeddings.", 0) == 0 || n.rfind("encoder.layer.", 0) == 0 ||
+                           (e->cfg.head == CQS_HIP_BERT_HEAD_MLM && n.rfind("cls.predictions.", 0) == 0) ||
+                           (e->cfg.head == CQS_HIP_BERT_HEAD_CLASSIFIER && (n.rfind("pooler.", 0) == 0 || n.rfind("classifier.", 0) == 0));
+        return known ? n : std::string();
+    };
+    std::string err;
+    int fed = -1;
+    std::string onnx = d + "/onnx/model.onnx";
+    if (!exists(onnx)) onnx = d + "/model.onnx";
+    if (exists(onnx)) {
+        fed = cqs_onnx::load(onnx, e->cfg.hidden, 0,
+            [&](const std::string& name, const float* data, uint64_t count, const std::vector<uint64_t>&) -> int {
+                const std::string n = canon(name);
+                if (n.empty()) return 0;
+                return cqs_hip_bert_set_tensor(e, n.c_str(), data, count) == CQS_HIP_OK ? 1 : -1;
+            }, err);
+    } else if (exists(d + "/model.safetensors")) {
+        fed = cqs_st::load(d + "/model.safetensors", [&](const std::string& name, const float* data, uint64_t count) -> int {
+            const std::string n = canon(name);
+            if (n.empty()) return 0;
+            return cqs_hip_bert_set_tensor(e, n.c_str(), data, count) == CQS_HIP_OK ? 1 : -1;
+        }, err);
+    } else {
+        err = "no onnx/model.onnx, model.onnx or model.safetensors under " + d;
+    }
+    if (fed < 0) {
+        fprintf(stderr, "[cqs_hip] bert load_dir failed: %s\n", err.c_str());
+        cqs_hip_bert_destroy(e);
+        return CQS_HIP_ERR_INVALID;
+    }
+    rc = cqs_hip_bert_finalize(e);
+    if (rc != CQS_HIP_OK) {
+        fprintf(stderr, "[cqs_hip] bert load_dir failed: %s\n", e->last_error.c_str());
+        cqs_hip_bert_destroy(e);
+        return rc;
+    }
+    *out = e;
     return CQS_HIP_OK;
 }
 

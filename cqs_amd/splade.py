@@ -46,6 +46,19 @@ class HipBertEngine:
             raise BertError(f"cqs_hip_bert_create failed ({rc})")
         self._h = h
 
+    @classmethod
+    def load_dir(cls, model_dir: str, cfg: _lib.BertConfig, device: int = 0) -> "HipBertEngine":
+        """`cqs_hip_bert_load_dir`: onnx/model.onnx, model.onnx or model.safetensors under `model_dir`."""
+        self = cls.__new__(cls)
+        self._lib = _lib.load()
+        self.cfg = cfg
+        h = C.c_void_p()
+        rc = self._lib.cqs_hip_bert_load_dir(str(model_dir).encode(), C.byref(cfg), device, C.byref(h))
+        self._h = h if rc == _lib.OK else None
+        if rc != _lib.OK:
+            raise BertError(f"cqs_hip_bert_load_dir failed ({rc})")
+        return self
+
     def close(self):
         if self._h:
             self._lib.cqs_hip_bert_destroy(self._h)

@@ -334,6 +334,11 @@ int32_t cqs_hip_bert_create(const cqs_hip_bert_config* cfg, int32_t device, cqs_
  * `pooler.dense.weight`, `classifier.weight`); the MLM decoder is tied to `embeddings.word_embeddings.weight`. */
 int32_t cqs_hip_bert_set_tensor(cqs_hip_bert* e, const char* name, const float* data, uint64_t count);
 int32_t cqs_hip_bert_finalize(cqs_hip_bert* e);
+/* create + weights from a model directory + finalize: `{dir}/onnx/model.onnx` or `{dir}/model.onnx` (+ external data;
+ * the bundle layout of src/reranker.rs:548-556 and src/splade/mod.rs:433-460), else a Hugging Face checkpoint
+ * (`{dir}/model.safetensors`).  cfg gives the geometry (config.json stays the host's business,
+ * src/splade/mod.rs:125-150). */
+int32_t cqs_hip_bert_load_dir(const char* model_dir, const cqs_hip_bert_config* cfg, int32_t device, cqs_hip_bert** out);
 void    cqs_hip_bert_destroy(cqs_hip_bert* e);
 /* SPLADE: tokens = the sequences' ids back to back, lens[b] = tokens of sequence b (0 allowed: an all-zero row).
  * out_dense [batch, vocab] f32 = ln(1 + max(0, max over the sequence's tokens of the masked-LM logits)): the

@@ -187,3 +187,83 @@ def test_full_geometry_presets(hip):
     want = R.rerank_scores(cfg, w, ids, mask, tt)
     assert np.max(np.abs(got - want)) < 0.02, (got, want)
     eng.close()
+
+
+def _bert_cfg(cfg, head):
+    from cqs_amd import _lib
+    from cqs_amd.splade import bert_config
+    kind = _lib.BERT_HEAD_MLM if head == "mlm" else _lib.BERT_HEAD_CLASSIFIER
+    return bert_config(kind, vocab_size=cfg.vocab_size, hidden=cfg.hidden, layers=cfg.layers, heads=cfg.heads,
+                       intermediate=cfg.intermediate, max_pos=cfg.max_pos, type_vocab=cfg.type_vocab,
+                       num_labels=cfg.num_labels, ln_eps=cfg.ln_eps)
+
+
+def test_load_dir_safetensors_checkpoint(hip, tmp_path):
+    """`cqs_hip_bert_load_dir` on a Hugging Face checkpoint: `bert.`-prefixed names, the tied decoder present twice,
+    an int64 buffer that is not a weight, one tensor stored as f16."""
+    import torch
+    from safetensors.torch import save_file
+    from cqs_amd.splade import HipBertEngine
+    cfg = R.BertConfig(vocab_size=700, hidden=384, layers=2, heads=6, intermediate=768, max_pos=96)
+    eng, w = _engine(cfg, "mlm", seed=21)
+    body = {k: v for k, v in R.hf_state_dict(cfg, w, "mlm").items()}
+    body = {k: v.clone() for k, v in body.items()}
+    body["bert.embeddings.position_ids"] = torch.arange(cfg.max_pos, dtype=torch.int64)[None]
+    body["bert.encoder.layer.1.output.dense.weight"] = body["bert.encoder.layer.1.output.dense.weight"].to(torch.float16)
+    save_file(body, str(tmp_path / "model.safetensors"), metadata={"format": "pt"})
+    eng2 = HipBertEngine.load_dir(str(tmp_path), _bert_cfg(cfg, "mlm"))
+    seqs = _seqs(cfg, [50, 9, 96], seed=22)
+    a, b = eng.splade_dense(seqs), eng2.splade_dense(seqs)
+    assert np.max(np.abs(a - b)) < 0.03 and all(cos(a[i], b[i]) > 0.9999 for i in range(3))   # one weight went through f16
+    eng.close(); eng2.close()
+
+
+@pytest.mark.parametrize("flat", [False, True])
+def test_load_dir_onnx_export(hip, tmp_path, flat):
+    """`cqs_hip_bert_load_dir` on the bundle layout the reference uses (`{dir}/onnx/model.onnx`, src/reranker.rs:548-556):
+    embeddings / LayerNorm / biases as named initialisers, `Linear` weights as anonymous TRANSPOSED MatMul operands found
+    through the consuming node's module path, the pooler / classifier as named Gemm weights, big tensors in the external
+    data sidecar.  Written by the byte-level encoder of tests/onnx_bytes.py (no `onnx` package in the image)."""
+    import onnx_bytes as ob
+    from cqs_amd.splade import HipBertEngine
+    cfg = R.BertConfig(vocab_size=600, hidden=384, layers=2, heads=12, intermediate=768, max_pos=80, num_labels=1)
+    eng, w = _engine(cfg, "classifier", seed=23)
+    d = tmp_path if flat else tmp_path / "onnx"
+    d.mkdir(parents=True, exist_ok=True)
+    side = bytearray(b"\0" * 8)
+    nodes, inits, n = [], [], [0]
+
+    def ext(arr):
+        raw = ob.encode_values(arr, ob.FLOAT)
+        off = len(side)
+        side.extend(raw)
+        side.extend(b"\0" * ((-len(side)) % 16))
+        return ("model.onnx_data", off, len(raw))
+
+    for k, v in w.items():
+        is_linear = k.endswith(".weight") and v.ndim == 2 and k.startswith("encoder.")
+        if is_linear:
+            n[0] += 1
+            iname = f"onnx::MatMul_{2000 + n[0]}"
+            path = "/bert/" + k[:-len(".weight")].replace(".", "/").replace("layer/", "layer.") + "/MatMul"
+            t = np.ascontiguousarray(v.T)
+            big = v.size > 200_000
+            nodes.append(ob.node("MatMul", path, [f"h{n[0]}", iname], [f"o{n[0]}"]))
+            inits.append(ob.tensor(iname, t, ob.FLOAT, "external" if big else "raw", external=ext(t) if big else None))
+        elif k.startswith(("pooler.", "classifier.")):
+            inits.append(ob.tensor(("bert." if k.startswith("pooler.") else "") + k, v))      # Gemm: [out, in], by name
+        else:
+            big = v.size > 200_000
+            inits.append(ob.tensor("bert." + k, v, ob.FLOAT, "external" if big else "raw", external=ext(v) if big else None))
+    inits.append(ob.tensor("onnx::Reshape_5", np.array([0, -1, 12, 32]), ob.INT64))
+    (d / "model.onnx").write_bytes(ob.model(nodes, inits))
+    (d / "model.onnx_data").write_bytes(bytes(side))
+    eng2 = HipBertEngine.load_dir(str(tmp_path), _bert_cfg(cfg, "classifier"))
+    seqs = _seqs(cfg, [40, 80, 5], seed=24)
+    types = [np.r_[np.zeros(2, np.int32), np.ones(len(s) - 2, np.int32)] for s in seqs]
+    assert np.array_equal(eng.rerank_logits(seqs, types), eng2.rerank_logits(seqs, types))
+    eng.close(); eng2.close()
+    (d / "model.onnx").write_bytes(b"\x00\x01garbage")
+    from cqs_amd.splade import BertError
+    with pytest.raises(BertError):
+        HipBertEngine.load_dir(str(tmp_path), _bert_cfg(cfg, "classifier"))
