@@ -1,0 +1,150 @@
+//! MI355X forwards of cqs's two BERT-family auxiliary models over libcqs_hip.so (C ABI: include/cqs_hip.h, "BERT-family
+//! auxiliary models"): the `session.run` of `SpladeEncoder::{encode, encode_batch}` (src/splade/mod.rs:595-760,
+//! :774-1075) and of `Reranker::compute_scores_opt` (src/reranker.rs:343-533).
+//!
+//! Drop-in: `src/splade/hip.rs` / `src/reranker_hip.rs` behind a `hip-aux` feature; in `SpladeEncoder::new` and
+//! `Reranker::session()` the `create_session(...)` call gets a sibling arm that opens `HipBert` on the same model
+//! directory, and the two `session.run` blocks call `splade_dense` / `rerank_logits` below.  Everything around the
+//! forward stays: tokenizer, truncation to `max_seq_len`, the vocab probe (`cqs_hip_bert_vocab`), the threshold
+//! filter, the sigmoid, batching (`reranker_batch_size`), caches.
+//!
+//! Not compiled here (no Rust toolchain in the build image); the same entry points are exercised by
+//! `cqs_amd/splade.py` and `tests/test_bert_gpu.py`.
+
+use std::ffi::CString;
+use std::os::raw::c_char;
+use std::path::Path;
+
+#[repr(C)]
+struct CqsHipBert {
+    _private: [u8; 0],
+}
+
+/// `cqs_hip_bert_config` - field order and types as in the header.
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct CqsHipBertConfig {
+    pub vocab_size: u32,
+    pub hidden: u32,
+    pub layers: u32,
+    pub heads: u32,
+    pub intermediate: u32,
+    pub max_pos: u32,
+    pub type_vocab: u32,
+    pub num_labels: u32,
+    pub head: u32,
+    pub ln_eps: f32,
+}
+
+pub const HEAD_MLM: u32 = 0;
+pub const HEAD_CLASSIFIER: u32 = 1;
+const CQS_HIP_OK: i32 = 0;
+
+#[link(name = "cqs_hip")]
+extern "C" {
+    fn cqs_hip_bert_config_default(head: u32, out: *mut CqsHipBertConfig) -> i32;
+    fn cqs_hip_bert_load_dir(dir: *const c_char, cfg: *const CqsHipBertConfig, device: i32, out: *mut *mut CqsHipBert) -> i32;
+    fn cqs_hip_bert_destroy(e: *mut CqsHipBert);
+    fn cqs_hip_splade_encode(e: *mut CqsHipBert, tokens: *const i32, lens: *const u32, batch: u32, out_dense: *mut f32) -> i32;
+    fn cqs_hip_rerank_logits(e: *mut CqsHipBert, tokens: *const i32, type_ids: *const i32, lens: *const u32, batch: u32,
+                             out_logits: *mut f32) -> i32;
+    fn cqs_hip_bert_vocab(e: *const CqsHipBert) -> u32;
+    fn cqs_hip_bert_last_error(e: *mut CqsHipBert, buf: *mut c_char, cap: usize) -> usize;
+}
+
+pub struct HipBert {
+    raw: *mut CqsHipBert,
+    cfg: CqsHipBertConfig,
+}
+
+// The library serialises calls on one engine with an internal mutex (header, BERT section).
+unsafe impl Send for HipBert {}
+unsafe impl Sync for HipBert {}
+
+impl HipBert {
+    /// `head`: HEAD_MLM (SPLADE) or HEAD_CLASSIFIER (reranker).  `hidden_size` etc. come from the directory's
+    /// `config.json` exactly as `probe_splade_hidden_size` reads them today (src/splade/mod.rs:125-150); pass `None`
+    /// to keep the preset.
+    pub fn open(model_dir: &Path, head: u32, device: i32, overrides: Option<&dyn Fn(&mut CqsHipBertConfig)>) -> Result<Self, String> {
+        let mut cfg = unsafe { std::mem::zeroed::<CqsHipBertConfig>() };
+        if unsafe { cqs_hip_bert_config_default(head, &mut cfg) } != CQS_HIP_OK {
+            return Err("cqs_hip_bert_config_default".into());
+        }
+        if let Some(f) = overrides {
+            f(&mut cfg);
+        }
+        let dir = CString::new(model_dir.to_string_lossy().as_bytes()).map_err(|e| e.to_string())?;
+        let mut raw: *mut CqsHipBert = std::ptr::null_mut();
+        let rc = unsafe { cqs_hip_bert_load_dir(dir.as_ptr(), &cfg, device, &mut raw) };
+        if rc != CQS_HIP_OK || raw.is_null() {
+            return Err(format!("cqs_hip_bert_load_dir({}) failed: {rc}", model_dir.display()));
+        }
+        Ok(Self { raw, cfg })
+    }
+
+    pub fn vocab(&self) -> usize {
+        unsafe { cqs_hip_bert_vocab(self.raw) as usize }
+    }
+
+    fn last_error(&self) -> String {
+        let mut buf = vec![0u8; 512];
+        let n = unsafe { cqs_hip_bert_last_error(self.raw, buf.as_mut_ptr() as *mut c_char, buf.len()) };
+        String::from_utf8_lossy(&buf[..n]).into_owned()
+    }
+
+    fn pack(encodings: &[&[u32]]) -> (Vec<i32>, Vec<u32>) {
+        let lens: Vec<u32> = encodings.iter().map(|e| e.len() as u32).collect();
+        let toks: Vec<i32> = encodings.iter().flat_map(|e| e.iter().map(|&t| t as i32)).collect();
+        (toks, lens)
+    }
+
+    /// The pre-pooled `sparse_vector` form of the model output (src/splade/mod.rs:960-978): `[batch, vocab]` f32 of
+    /// `ln(1 + max(0, max_s logits))`; the caller keeps `(id, w)` with `w > threshold` as it does today.
+    pub fn splade_dense(&self, encodings: &[&[u32]]) -> Result<Vec<f32>, String> {
+        let (toks, lens) = Self::pack(encodings);
+        let mut out = vec![0f32; encodings.len() * self.vocab()];
+        let rc = unsafe { cqs_hip_splade_encode(self.raw, toks.as_ptr(), lens.as_ptr(), lens.len() as u32, out.as_mut_ptr()) };
+        if rc != CQS_HIP_OK {
+            return Err(format!("cqs_hip_splade_encode: {} ({rc})", self.last_error()));
+        }
+        Ok(out)
+    }
+
+    /// `[batch, num_labels]` logits for encoded (query, passage) pairs; `score = sigmoid(logits[i * num_labels])`
+    /// (src/reranker.rs:516-518).  `type_ids`: `Encoding::get_type_ids` per pair, or empty when the model takes none.
+    pub fn rerank_logits(&self, encodings: &[&[u32]], type_ids: &[&[u32]]) -> Result<Vec<f32>, String> {
+        let (toks, lens) = Self::pack(encodings);
+        let tt: Vec<i32> = type_ids.iter().flat_map(|e| e.iter().map(|&t| t as i32)).collect();
+        let mut out = vec![0f32; encodings.len() * self.cfg.num_labels as usize];
+        let rc = unsafe {
+            cqs_hip_rerank_logits(self.raw, toks.as_ptr(), if tt.is_empty() { std::ptr::null() } else { tt.as_ptr() },
+                                  lens.as_ptr(), lens.len() as u32, out.as_mut_ptr())
+        };
+        if rc != CQS_HIP_OK {
+            return Err(format!("cqs_hip_rerank_logits: {} ({rc})", self.last_error()));
+        }
+        Ok(out)
+    }
+}
+
+impl Drop for HipBert {
+    fn drop(&mut self) {
+        unsafe { cqs_hip_bert_destroy(self.raw) }
+    }
+}
+
+// ---- call sites ------------------------------------------------------------------------------------------------
+// src/splade/mod.rs, encode_batch, in place of the `session.run` + output match (:900-1075):
+//
+//     let encs: Vec<&[u32]> = encodings.iter().map(|e| &e.get_ids()[..e.get_ids().len().min(max_seq_len)]).collect();
+//     let dense = hip.splade_dense(&encs).map_err(SpladeError::InferenceFailed)?;
+//     let vocab = hip.vocab();
+//     Ok((0..batch_size).map(|b| dense[b * vocab..(b + 1) * vocab].iter().enumerate()
+//             .filter_map(|(id, &v)| if v > threshold { Some((id as u32, v)) } else { None }).collect()).collect())
+//
+// src/reranker.rs, run_chunk, in place of the `session.run` + extraction (:455-520):
+//
+//     let ids: Vec<&[u32]> = chunk.iter().map(|e| &e.get_ids()[..e.get_ids().len().min(max_len)]).collect();
+//     let tys: Vec<&[u32]> = chunk.iter().map(|e| &e.get_type_ids()[..e.get_ids().len().min(max_len)]).collect();
+//     let logits = hip.rerank_logits(&ids, &tys).map_err(RerankerError::Inference)?;
+//     Ok(logits.chunks(stride).map(|row| Some(sigmoid(row[0]))).collect())
