@@ -480,11 +480,11 @@ def aux_models_leg(a, np):
     enc = SpladeEncoder(eng, threshold=thr)
     t_end = time.perf_counter() + 0.5                                  # (let the oracle's CPU threads stop spinning)
     while time.perf_counter() < t_end:
-        enc.encode_batch(seqs)
+        enc.encode_batch_arrays(seqs)
     steps = max(4, a.embed_steps)
     t0 = time.perf_counter()
     for _ in range(steps):
-        sv = enc.encode_batch(seqs)
+        sv = enc.encode_batch_arrays(seqs)
     dt = (time.perf_counter() - t0) / steps
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -495,7 +495,7 @@ def aux_models_leg(a, np):
     out["splade"] = {"model": "BERT-base masked-LM geometry (12 x [768 | 12 x 64 | 3072], vocab 30522), seeded weights",
                      "batch": B, "tokens_per_doc": L, "docs_per_sec": round(B / dt, 1), "tokens_per_sec": round(B * L / dt, 1),
                      "ms_per_batch": round(dt * 1e3, 3), "ms_per_batch_device_side": round(dt_dense * 1e3, 3),
-                     "tflops": round(flops / dt_dense / 1e12, 1), "nnz_per_doc": round(float(np.mean([len(v) for v in sv])), 1),
+                     "tflops": round(flops / dt_dense / 1e12, 1), "nnz_per_doc": round(float(np.mean([len(v[0]) for v in sv])), 1),
                      "checked": {"max_abs_err_vs_fp32_oracle": round(err, 4)},
                      "cpu_baseline": {"docs_per_sec": round(3 / cpu_s, 2), "kind": "port", "sample": "oracle/bert_ref (torch CPU fp32), 3 docs / 255 tokens"},
                      "threshold": round(thr, 4),

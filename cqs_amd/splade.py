@@ -131,17 +131,21 @@ class SpladeEncoder:
     def __init__(self, engine: HipBertEngine, threshold: float = DEFAULT_SPLADE_THRESHOLD, max_seq_len: int = 512):
         self.engine, self.threshold, self.max_seq_len = engine, float(threshold), int(max_seq_len)
 
-    def encode_batch(self, seqs: Sequence[Sequence[int]]) -> List[SparseVector]:
+    def encode_batch_arrays(self, seqs: Sequence[Sequence[int]]) -> List[Tuple[np.ndarray, np.ndarray]]:
+        """`encode_batch` with each sparse vector as (ids u32 ascending, weights f32) arrays - what a caller that
+        feeds an inverted index wants; one vectorised threshold pass over the [batch, vocab] activations."""
         if not len(seqs):
             return []
         cut = [np.asarray(s, np.int32)[: self.max_seq_len] for s in seqs]     # truncation (src/splade/mod.rs:860-880)
         dense = self.engine.splade_dense(cut)
-        out = []
-        thr = np.float32(self.threshold)
-        for row in dense:
-            keep = np.nonzero(row > thr)[0]                                    # ascending id; NaN > t is False
-            out.append([(int(i), float(row[i])) for i in keep])
-        return out
+        rows, cols = np.nonzero(dense > np.float32(self.threshold))           # row-major: ascending id per row; NaN > t is False
+        bounds = np.searchsorted(rows, np.arange(len(seqs) + 1))
+        vals = dense[rows, cols]
+        return [(cols[bounds[b]:bounds[b + 1]].astype(np.uint32), vals[bounds[b]:bounds[b + 1]]) for b in range(len(seqs))]
+
+    def encode_batch(self, seqs: Sequence[Sequence[int]]) -> List[SparseVector]:
+        """`SpladeEncoder::encode_batch`: `Vec<SparseVector>`, a sparse vector = [(token id, weight)] ascending id."""
+        return [list(zip(ids.tolist(), wts.tolist())) for ids, wts in self.encode_batch_arrays(seqs)]
 
     def encode(self, seq: Sequence[int]) -> SparseVector:
         return self.encode_batch([seq])[0]
