@@ -1073,10 +1073,79 @@ hipError_t launch_add_norm(float* x, const bf16_t* y, const float* w_post, const
                  : launch_add_norm_t<0>(x, y, w_post, w_next, eps, xn, out, M, H, st);
 }
 
+// ---- few-rows GEMM: small batches (a query, a handful of chunks) ---------------------------------------------
+// At M = 32 tokens the 128 x 128 kernel puts 6-18 workgroups on the chip and takes 12 us per projection (4 per layer:
+// 70 % of a query's 1.6 ms).  Here ONE WAVE owns a 32 x 32 output tile (GeGLU: 32 x 64 = the gate and up halves of 32
+// channels) and walks K by itself with operands straight from global memory / L2 (16 B per lane per 16-k step, 8
+// steps in flight), no LDS, no barrier: N / 32 waves per 32 rows.  Same MFMA (32x32x16), same operand roles and the
+// same K order as gemm_bf16_kernel, so the two kernels agree bit for bit and a chunk still embeds to the same bits
+// alone or in a batch (test_padding_and_batch_invariance).
+template <int OUT>
+__global__ __launch_bounds__(64) void gemm_fewrows_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
+                                                          void* __restrict__ Cv, uint32_t M, uint32_t N, uint32_t K,
+                                                          uint32_t ldc) {
+    constexpr int NT = OUT == GEMM_OUT_GEGLU ? 2 : 1;          // 32-column tiles per wave
+    const int lane = threadIdx.x, l31 = lane & 31, lh = lane >> 5;
+    const uint32_t n0 = blockIdx.x * (uint32_t)(32 * NT), m0 = blockIdx.y * 32u;
+    const uint32_t mr = m0 + (uint32_t)l31 < M ? m0 + (uint32_t)l31 : M - 1u;     // rows past M: any real row, never stored
+    const bf16_t* ap = A + (size_t)mr * K + 8 * lh;
+    const bf16_t* wp[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) wp[j] = W + (size_t)(n0 + (uint32_t)(32 * j + l31)) * K + 8 * lh;
+    f16v acc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+    const uint32_t steps = K / 16u;                             // K % 64 == 0
+    constexpr int U = 8;
+    for (uint32_t s = 0; s < steps; s += U) {
+        bf8 af[U], wf[NT][U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t ss = s + (uint32_t)u < steps ? s + (uint32_t)u : steps - 1u;     // (tail: re-read, not accumulated)
+            af[u] = *(const bf8*)(ap + (size_t)ss * 16u);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) wf[j][u] = *(const bf8*)(wp[j] + (size_t)ss * 16u);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (s + (uint32_t)u < steps) {
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[u], wf[j][u], acc[j], 0, 0, 0);
+            }
+    }
+    // C tile element (row = (e & 3) + 8 (e >> 2) + 4 lh, col = l31), as in gemm_bf16_kernel
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const uint32_t row = m0 + (uint32_t)((e & 3) + 8 * (e >> 2) + 4 * lh);
+        if (row >= M) continue;
+        if (OUT == GEMM_OUT_GEGLU) {
+            const float v = gelu_tanh(acc[0][e]) * acc[NT - 1][e];
+            ((bf16_t*)Cv)[(size_t)row * ldc + n0 / 2u + (uint32_t)l31] = (bf16_t)v;
+        } else if (OUT == GEMM_OUT_F32) {
+            ((float*)Cv)[(size_t)row * ldc + n0 + (uint32_t)l31] = acc[0][e];
+        } else {
+            ((bf16_t*)Cv)[(size_t)row * ldc + n0 + (uint32_t)l31] = (bf16_t)acc[0][e];
+        }
+    }
+}
+
 // One kernel for the whole [M, N] problem; tn = 0: the 128 x 128 kernel, 3..5: the 256 x (64 tn) ping-pong kernel.
 static hipError_t launch_gemm_one(const bf16_t* A, const bf16_t* W, void* C, uint32_t M, uint32_t N, uint32_t K,
                                   uint32_t ldc, GemmOut out, int tn, hipStream_t st) {
     if (tn) return launch_gemm_p8(A, W, C, M, N, K, ldc, out, tn, st);
+    static const uint32_t few_max = [] { const char* f = getenv("CQS_HIP_GEMM_FEWROWS"); return f ? (uint32_t)atoi(f) : 512u; }();
+    if (M <= few_max && !getenv("CQS_HIP_GEMM_TILE")) {         // small batch: one wave per 32 x 32 tile (bit-identical results)
+        const dim3 fg(N / (out == GEMM_OUT_GEGLU ? 64u : 32u), (M + 31u) / 32u);
+        switch (out) {
+            case GEMM_OUT_BF16: hipLaunchKernelGGL(gemm_fewrows_kernel<GEMM_OUT_BF16>, fg, dim3(64), 0, st, A, W, C, M, N, K, ldc); break;
+            case GEMM_OUT_F32: hipLaunchKernelGGL(gemm_fewrows_kernel<GEMM_OUT_F32>, fg, dim3(64), 0, st, A, W, C, M, N, K, ldc); break;
+            case GEMM_OUT_GEGLU: hipLaunchKernelGGL(gemm_fewrows_kernel<GEMM_OUT_GEGLU>, fg, dim3(64), 0, st, A, W, C, M, N, K, ldc); break;
+            default: return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    }
     const dim3 grid((N / 128u) * ((M + 127u) / 128u)), block(256);
     switch (out) {
         case GEMM_OUT_BF16: hipLaunchKernelGGL(gemm_bf16_kernel<GEMM_OUT_BF16>, grid, block, 0, st, A, W, C, M, N, K, ldc); break;

@@ -446,3 +446,32 @@ def test_gemm_planner_choices_at_full_batch_shapes(hip, dual, monkeypatch):
             want = (torch.nn.functional.gelu(r[:, :, 0], approximate="tanh") * r[:, :, 1]).reshape(M, N // 2)
             err = (out.float() - want).abs().max().item()
             assert err <= 0.02 * want.abs().max().item() + 1e-3, (dual, M, N, K, err)
+
+
+def test_fewrows_gemm_is_bit_identical_to_the_tiled_kernel(hip, monkeypatch):
+    """Small batches run `gemm_fewrows_kernel` (one wave per 32 x 32 tile, no LDS); it must agree BIT FOR BIT with the
+    128 x 128 kernel on arbitrary data (same MFMA, operand roles and K order), or a chunk's embedding would depend on
+    how many tokens share its batch."""
+    import ctypes as C
+    import torch
+    f = _lib.load().cqs_hip_debug_gemm_run
+    f.restype = C.c_int32
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_uint32] * 4 + [C.c_int32, C.c_void_p]
+    g = torch.Generator(device="cuda"); g.manual_seed(5)
+    for M, N, K in [(1, 1280, 768), (9, 768, 768), (33, 2304, 768), (64, 768, 1152), (100, 1280, 768), (512, 2304, 768), (300, 768, 64)]:
+        A = torch.randn(M, K, generator=g, device="cuda").to(torch.bfloat16)
+        W = (torch.randn(N, K, generator=g, device="cuda") / K ** 0.5).to(torch.bfloat16)
+        for kind in (0, 1, 2):
+            ldc = N // 2 if kind == 2 else N
+            dt = torch.float32 if kind == 1 else torch.bfloat16
+            a = torch.zeros(M, ldc, device="cuda", dtype=dt)
+            b = torch.zeros(M, ldc, device="cuda", dtype=dt)
+            monkeypatch.delenv("CQS_HIP_GEMM_TILE", raising=False)
+            assert f(A.data_ptr(), W.data_ptr(), a.data_ptr(), M, N, K, ldc, kind, None) == 0      # few-rows kernel
+            monkeypatch.setenv("CQS_HIP_GEMM_TILE", "small")
+            assert f(A.data_ptr(), W.data_ptr(), b.data_ptr(), M, N, K, ldc, kind, None) == 0      # 128 x 128 kernel
+            torch.cuda.synchronize()
+            assert torch.equal(a, b), (M, N, K, kind, float((a.float() - b.float()).abs().max()))
+            if kind == 1:
+                ref = A.float() @ W.float().T
+                assert float((a - ref).abs().max()) < 2e-2
