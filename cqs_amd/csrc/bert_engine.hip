@@ -61,7 +61,7 @@ struct cqs_hip_bert {
 
     // scratch (one batch at a time; the engine is serialised by `mu`)
     uint32_t tok_cap = 0, seq_cap = 0, blk_cap = 0;
-    bf16_t *x = nullptr, *y = nullptr, *qkv = nullptr, *att = nullptr, *h = nullptr, *logits = nullptr, *pooled = nullptr;
+    bf16_t *x = nullptr, *y = nullptr, *qkv = nullptr, *att = nullptr, *h = nullptr, *pooled = nullptr;
     float *dense = nullptr, *cls = nullptr;
     int32_t* d_meta = nullptr;
     std::vector<int32_t> h_meta;
@@ -114,7 +114,7 @@ int32_t up_f32(cqs_hip_bert* e, float** dst, const float* src, size_t count, siz
 }
 
 void free_scratch(cqs_hip_bert* e) {
-    void** all[] = {(void**)&e->x, (void**)&e->y, (void**)&e->qkv, (void**)&e->att, (void**)&e->h, (void**)&e->logits,
+    void** all[] = {(void**)&e->x, (void**)&e->y, (void**)&e->qkv, (void**)&e->att, (void**)&e->h,
                     (void**)&e->pooled, (void**)&e->dense, (void**)&e->cls, (void**)&e->d_meta};
     for (void** p : all) { (void)hipFree(*p); *p = nullptr; }
     e->tok_cap = e->seq_cap = e->blk_cap = 0;
@@ -133,13 +133,12 @@ int32_t ensure_scratch(cqs_hip_bert* e, uint32_t M, uint32_t B, uint32_t nblk) {
     B_TRY(e, hipMalloc((void**)&e->att, (size_t)Mc * H * 2));
     B_TRY(e, hipMalloc((void**)&e->h, (size_t)Mc * c.intermediate * 2));
     if (c.head == CQS_HIP_BERT_HEAD_MLM) {
-        B_TRY(e, hipMalloc((void**)&e->logits, (size_t)Mc * e->vpad * 2));
         B_TRY(e, hipMalloc((void**)&e->dense, (size_t)Bc * c.vocab_size * 4));
     } else {
         B_TRY(e, hipMalloc((void**)&e->pooled, (size_t)Bc * H * 2));
         B_TRY(e, hipMalloc((void**)&e->cls, (size_t)Bc * 16 * 4));
     }
-    B_TRY(e, hipMalloc((void**)&e->d_meta, ((size_t)3 * Mc + (size_t)2 * Bc + (size_t)2 * bc) * 4));
+    B_TRY(e, hipMalloc((void**)&e->d_meta, ((size_t)4 * Mc + (size_t)2 * Bc + (size_t)2 * bc) * 4));
     e->tok_cap = Mc; e->seq_cap = Bc; e->blk_cap = bc;
     return CQS_HIP_OK;
 }
@@ -158,10 +157,11 @@ int32_t run_encoder(cqs_hip_bert* e, const int32_t* tokens, const int32_t* type_
     const uint32_t M = (uint32_t)M64, nblk = (uint32_t)nblk64;
     *M_out = M;
     if (M == 0) return CQS_HIP_OK;
-    // tables: [tok M][pos M][tt M][seq_start B][seq_len B][blk 2 nblk]
+    // tables: [tok M][pos M][tt M][seq_start B][seq_len B][blk 2 nblk][row_seq M]
     std::vector<int32_t>& t = e->h_meta;
-    t.assign((size_t)3 * M + (size_t)2 * B + (size_t)2 * nblk, 0);
+    t.assign((size_t)4 * M + (size_t)2 * B + (size_t)2 * nblk, 0);
     int32_t *tok = t.data(), *pos = tok + M, *tt = pos + M, *seq_start = tt + M, *seq_len = seq_start + B, *blk = seq_len + B;
+    int32_t* row_seq = blk + (size_t)2 * nblk;
     uint32_t m = 0, nb = 0;
     for (uint32_t b = 0; b < B; ++b) {
         seq_start[b] = (int32_t)m;
@@ -171,7 +171,7 @@ int32_t run_encoder(cqs_hip_bert* e, const int32_t* tokens, const int32_t* type_
             if (id < 0 || (uint32_t)id >= c.vocab_size) return bfail(e, CQS_HIP_ERR_INVALID, "bert: token id out of range");
             const int32_t ty = type_ids ? type_ids[m + j] : 0;
             if (ty < 0 || (uint32_t)ty >= c.type_vocab) return bfail(e, CQS_HIP_ERR_INVALID, "bert: token type id out of range");
-            tok[m + j] = id; pos[m + j] = (int32_t)j; tt[m + j] = ty;
+            tok[m + j] = id; pos[m + j] = (int32_t)j; tt[m + j] = ty; row_seq[m + j] = (int32_t)b;
         }
         for (uint32_t q = 0; q * 64u < lens[b]; ++q) { blk[2 * nb] = (int32_t)b; blk[2 * nb + 1] = (int32_t)q; ++nb; }
         m += lens[b];
@@ -363,11 +363,17 @@ int32_t cqs_hip_splade_encode(cqs_hip_bert* e, const int32_t* tokens, const uint
     hipStream_t st = e->stream;
     const uint32_t H = c.hidden;
     const int32_t *d_start = e->d_meta + (size_t)3 * M, *d_len = d_start + batch;
-    // BertLMPredictionHead: LayerNorm(gelu(x Wt^T + bt)) E^T + b, decoder tied to the (zero-padded) word embeddings
+    // BertLMPredictionHead: LayerNorm(gelu(x Wt^T + bt)) E^T + b, decoder tied to the (zero-padded) word embeddings.
+    // The [tokens, vocab] logits are never stored: the decoder GEMM's epilogue keeps, per sequence and vocabulary
+    // entry, the maximum of max(0, logit) (atomic max on the float bits), then one small pass takes ln(1 + .).
+    const uint32_t nblk = (uint32_t)((e->h_meta.size() - (size_t)4 * M - (size_t)2 * batch) / 2);
+    const int32_t* d_rowseq = d_len + batch + (size_t)2 * nblk;
+    (void)d_start;
     B_TRY(e, cqs::launch_gemm_bias(e->x, e->wt, e->bt, e->y, M, H, H, H, cqs::GEMM_OUT_BF16_GELU, st));
     B_TRY(e, cqs::launch_bert_add_ln(e->y, nullptr, e->lnt_g, e->lnt_b, c.ln_eps, e->y, M, H, st));
-    B_TRY(e, cqs::launch_gemm_bias(e->y, e->word, e->bdec, e->logits, M, e->vpad, H, e->vpad, cqs::GEMM_OUT_BF16, st));
-    B_TRY(e, cqs::launch_splade_pool(e->logits, e->vpad, d_start, d_len, e->dense, batch, (uint32_t)V, st));
+    B_TRY(e, hipMemsetAsync(e->dense, 0, (size_t)batch * V * 4, st));
+    B_TRY(e, cqs::launch_gemm_rowmax(e->y, e->word, e->bdec, (uint32_t*)e->dense, M, e->vpad, H, (uint32_t)V, d_rowseq, (uint32_t)V, st));
+    B_TRY(e, cqs::launch_splade_activate(e->dense, (size_t)batch * V, st));
     B_TRY(e, hipMemcpyAsync(out_dense, e->dense, (size_t)batch * V * 4, hipMemcpyDeviceToHost, st));
     B_TRY(e, hipStreamSynchronize(st));
     return CQS_HIP_OK;

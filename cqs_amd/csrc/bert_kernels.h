@@ -20,8 +20,7 @@ hipError_t launch_bert_attention(const bf16_t* qkv, bf16_t* out, const int32_t* 
                                  const int32_t* seq_start, const int32_t* seq_len, uint32_t heads, uint32_t head_dim,
                                  hipStream_t st);
 
-// out[b][v] = ln(1 + max(0, max over the tokens of sequence b of logits[token][v])), v < V (src/splade/mod.rs:1026-1062)
-hipError_t launch_splade_pool(const bf16_t* logits, uint32_t ldv, const int32_t* seq_start, const int32_t* seq_len,
-                              float* out, uint32_t B, uint32_t V, hipStream_t st);
+// x[i] <- ln(1 + x[i]) in place (the activation of src/splade/mod.rs:1049-1053 over launch_gemm_rowmax's maxima)
+hipError_t launch_splade_activate(float* x, size_t n, hipStream_t st);
 
 }  // namespace cqs

@@ -3,7 +3,8 @@
 // src/reranker.rs).  They replace the ORT `session.run` of those modules; semantics follow oracle/bert_ref.py (pinned
 // to transformers' BertForMaskedLM / BertForSequenceClassification).  The GEMMs are the ping-pong kernel of
 // gemm_kernels.hip with a bias (+ erf-GELU) epilogue; this file holds what is BERT-specific: the three-table
-// embedding + LayerNorm, residual + LayerNorm, multi-head attention for head dims 32 / 64 and the SPLADE pooling.
+// embedding + LayerNorm, residual + LayerNorm, multi-head attention for head dims 32 / 64 and the SPLADE activation
+// (the pooling itself is the decoder GEMM's epilogue, launch_gemm_rowmax).
 // Tokens are packed (no padding reaches a kernel); bf16 operands, f32 accumulation and statistics.
 #include "bert_kernels.h"
 
@@ -244,32 +245,11 @@ __global__ __launch_bounds__(256) void bert_attention_kernel(const bf16_t* __res
     }
 }
 
-// SPLADE pooling (src/splade/mod.rs:1026-1062): out[b][v] = ln(1 + max(0, max over the sequence's tokens of logits[s][v])),
-// the maximum folded with a strict `>` from -inf (a NaN logit never wins; an empty sequence gives ln(1 + 0) = 0).
-__global__ __launch_bounds__(256) void splade_pool_kernel(const bf16_t* __restrict__ logits, uint32_t ldv,
-                                                          const int32_t* __restrict__ seq_start,
-                                                          const int32_t* __restrict__ seq_len, float* __restrict__ out,
-                                                          uint32_t V) {
-    // a thread owns 8 consecutive vocabulary columns (16-byte loads: a wave reads 1 KiB of every token row)
-    const uint32_t b = blockIdx.y, v0 = (blockIdx.x * 256u + threadIdx.x) * 8u;
-    if (v0 >= V) return;                       // (ldv = V rounded up to a multiple of 192: columns v0 .. v0 + 7 exist)
-    const uint32_t s0 = (uint32_t)seq_start[b], L = (uint32_t)seq_len[b];
-    float m[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) m[j] = -INFINITY;
-    const bf16_t* p = logits + (size_t)s0 * ldv + v0;
-    for (uint32_t s = 0; s < L; ++s) {
-        const bf8 x = *(const bf8*)(p + (size_t)s * ldv);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float a = (float)x[j];
-            if (a > m[j]) m[j] = a;            // strict `>`: a NaN logit never wins
-        }
-    }
-    // Rust's f32::max(0.0): a NaN operand yields the other one (m is never NaN here)
-#pragma unroll
-    for (int j = 0; j < 8; ++j)
-        if (v0 + (uint32_t)j < V) out[(size_t)b * V + v0 + (uint32_t)j] = logf(1.0f + (m[j] > 0.f ? m[j] : 0.f));
+// SPLADE activation (src/splade/mod.rs:1049-1053) over the pooled maxima the decoder GEMM left behind
+// (launch_gemm_rowmax: max(0, max_s logits), NaN never taken): x <- ln(1 + x), in place.
+__global__ __launch_bounds__(256) void splade_activate_kernel(float* __restrict__ x, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
+    if (i < n) x[i] = logf(1.0f + x[i]);
 }
 
 }  // namespace
@@ -306,11 +286,9 @@ hipError_t launch_bert_attention(const bf16_t* qkv, bf16_t* out, const int32_t* 
     return hipGetLastError();
 }
 
-hipError_t launch_splade_pool(const bf16_t* logits, uint32_t ldv, const int32_t* seq_start, const int32_t* seq_len,
-                              float* out, uint32_t B, uint32_t V, hipStream_t st) {
-    if (B == 0 || V == 0) return hipSuccess;
-    if (ldv % 8u || ldv < ((V + 7u) & ~7u)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(splade_pool_kernel, dim3((V + 2047u) / 2048u, B), dim3(256), 0, st, logits, ldv, seq_start, seq_len, out, V);
+hipError_t launch_splade_activate(float* x, size_t n, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(splade_activate_kernel, dim3((unsigned)((n + 255u) / 256u)), dim3(256), 0, st, x, n);
     return hipGetLastError();
 }
 

@@ -34,7 +34,8 @@ hipError_t launch_add_norm(float* x, const bf16_t* y, const float* w_post, const
 //   GEMM_OUT_GEGLU: W rows are interleaved per 64: 32 gate rows then the 32 up rows of the same
 //                   channels; C bf16 [M, ldc] gets N/2 columns = gelu_tanh(gate) * up
 // Requires N % 128 == 0, K % 64 == 0.
-enum GemmOut { GEMM_OUT_BF16 = 0, GEMM_OUT_F32 = 1, GEMM_OUT_GEGLU = 2, GEMM_OUT_BF16_GELU = 3 /* bf16(gelu_erf(x + bias)): launch_gemm_p8 / _bias only */ };
+enum GemmOut { GEMM_OUT_BF16 = 0, GEMM_OUT_F32 = 1, GEMM_OUT_GEGLU = 2, GEMM_OUT_BF16_GELU = 3 /* bf16(gelu_erf(x + bias)): launch_gemm_p8 / _bias only */,
+               GEMM_OUT_ROWMAX = 4 /* launch_gemm_rowmax only */ };
 hipError_t launch_gemm_bf16(const bf16_t* A, const bf16_t* W, void* C, uint32_t M, uint32_t N, uint32_t K,
                             uint32_t ldc, GemmOut out, hipStream_t st);
 
@@ -56,6 +57,11 @@ hipError_t launch_gemm_p8(const bf16_t* A, const bf16_t* W, void* C, uint32_t M,
 // (N % 192 == 0 at least), 256-row ping-pong kernel only.  out: GEMM_OUT_BF16, GEMM_OUT_BF16_GELU or GEMM_OUT_F32.
 hipError_t launch_gemm_bias(const bf16_t* A, const bf16_t* W, const float* bias, void* C, uint32_t M, uint32_t N,
                             uint32_t K, uint32_t ldc, GemmOut out, hipStream_t st);
+
+// Per-sequence column maxima of max(0, bf16(A W^T + bias)) without storing the product (SPLADE decoder + pooling):
+// out_bits[row_seq[m]][v] = max(.., float bits), v < n_valid; out_bits [sequences, ldc] u32 zeroed by the caller.
+hipError_t launch_gemm_rowmax(const bf16_t* A, const bf16_t* W, const float* bias, uint32_t* out_bits, uint32_t M, uint32_t N,
+                              uint32_t K, uint32_t ldc, const int32_t* row_seq, uint32_t n_valid, hipStream_t st);
 
 // Two column ranges of one GEMM (same A, M, K, ldc; different tile widths) in one launch.  hipErrorNotSupported when
 // the pair of widths is not built: launch the parts one after the other instead.

@@ -79,7 +79,9 @@ template <int TN, int OUT>
 __device__ __forceinline__ void gemm_pp_body(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
                                              void* __restrict__ Cv, uint32_t M, uint32_t N, uint32_t K, uint32_t ldc,
                                              const uint32_t bid /*workgroup index among this problem's*/,
-                                             const float* __restrict__ bias = nullptr /*[N] added before the activation*/) {
+                                             const float* __restrict__ bias = nullptr /*[N] added before the activation*/,
+                                             const int32_t* __restrict__ row_seq = nullptr /*ROWMAX: sequence of each row*/,
+                                             uint32_t n_valid = 0 /*ROWMAX: columns >= n_valid are padding*/) {
     constexpr int BN = 64 * TN;
     constexpr int kBuf = (kP8M + BN) * 64;                      // elements per LDS buffer
     constexpr int PA = 2, PB = TN;                              // DMA instructions per wave: an A half / the B tile
@@ -253,7 +255,7 @@ __device__ __forceinline__ void gemm_pp_body(const bf16_t* __restrict__ A, const
     // bf16 / GeGLU: through LDS, so that the workgroup writes WHOLE rows of its tile (a lane's 8 bytes of a 16 x 16
     // accumulator tile are a quarter of a 32-byte segment: stored directly, every 128-byte line is written in four
     // pieces by four instructions - measured: the store phase was 25-35 % of these K = 768 GEMMs).
-    if (OUT == GEMM_OUT_BF16 || OUT == GEMM_OUT_BF16_GELU) {
+    if (OUT == GEMM_OUT_BF16 || OUT == GEMM_OUT_BF16_GELU || OUT == GEMM_OUT_ROWMAX) {
         f4 bv[TN];                                                  // this lane's 4 columns of each n-tile
 #pragma unroll
         for (int j = 0; j < TN; ++j)
@@ -281,13 +283,51 @@ __device__ __forceinline__ void gemm_pp_body(const bf16_t* __restrict__ A, const
                 }
             }
             __syncthreads();
-            for (uint32_t c = (uint32_t)tid; c < 128u * (uint32_t)kCPR; c += 512u) {
-                const uint32_t r = c / (uint32_t)kCPR, cc = c % (uint32_t)kCPR;
-                const uint32_t row = m0 + (r >> 6) * 128u + (uint32_t)(4 * p) * 16u + (r & 63u);
+            if (OUT == GEMM_OUT_ROWMAX) {
+                // Column maxima per sequence instead of the tile (SPLADE pooling, src/splade/mod.rs:1026-1043, folded
+                // into the decoder GEMM: the [tokens, vocab] logits never reach HBM).  Thread = one column x one of the
+                // pass's two 64-row runs; the running maximum of max(0, x) is flushed with an atomic max on the bits
+                // (non-negative floats order like unsigned integers; x <= 0 and NaN never pass `> 0`, which is the
+                // reference's strict `>` from -inf followed by max(., 0)) whenever the row's sequence changes.
+                if (tid < 2 * BN) {
+                    const uint32_t col = (uint32_t)tid % (uint32_t)BN, run = (uint32_t)tid / (uint32_t)BN;
+                    const uint32_t v = n0 + col;
+                    const uint32_t row0 = m0 + run * 128u + (uint32_t)(4 * p) * 16u;
+                    if (v < n_valid && row0 < M) {
+                        uint32_t* const outp = (uint32_t*)Cv + v;
+                        const uint32_t cnt = M - row0 < 64u ? M - row0 : 64u;
+                        const bf16_t* const sp = stage + (size_t)(run * 64u) * kStride + col;
+                        int32_t cur = row_seq[row0];
+                        float best = 0.f;
+                        if (cur == row_seq[row0 + cnt - 1u]) {             // rows are in sequence order: the run is ONE sequence
+                            for (uint32_t i = 0; i < cnt; ++i) {
+                                const float x = (float)sp[(size_t)i * kStride];
+                                if (x > best) best = x;
+                            }
+                        } else {
+                            for (uint32_t i = 0; i < cnt; ++i) {
+                                const int32_t sq = row_seq[row0 + i];
+                                if (sq != cur) {
+                                    if (best > 0.f) atomicMax(outp + (size_t)cur * ldc, __float_as_uint(best));
+                                    cur = sq;
+                                    best = 0.f;
+                                }
+                                const float x = (float)sp[(size_t)i * kStride];
+                                if (x > best) best = x;
+                            }
+                        }
+                        if (best > 0.f) atomicMax(outp + (size_t)cur * ldc, __float_as_uint(best));
+                    }
+                }
+            } else {
+                for (uint32_t c = (uint32_t)tid; c < 128u * (uint32_t)kCPR; c += 512u) {
+                    const uint32_t r = c / (uint32_t)kCPR, cc = c % (uint32_t)kCPR;
+                    const uint32_t row = m0 + (r >> 6) * 128u + (uint32_t)(4 * p) * 16u + (r & 63u);
 #ifdef P8_ABLATE_NOSTORE
-                if (acc[0][0][0] != 12345.678f) continue;
+                    if (acc[0][0][0] != 12345.678f) continue;
 #endif
-                if (row < M) *(bf4*)((bf16_t*)Cv + (size_t)row * ldc + n0 + cc * 4u) = *(const bf4*)(stage + (size_t)r * kStride + cc * 4u);
+                    if (row < M) *(bf4*)((bf16_t*)Cv + (size_t)row * ldc + n0 + cc * 4u) = *(const bf4*)(stage + (size_t)r * kStride + cc * 4u);
+                }
             }
             if (p == 0) __syncthreads();
         }
@@ -330,8 +370,9 @@ __device__ __forceinline__ void gemm_pp_body(const bf16_t* __restrict__ A, const
 template <int TN, int OUT>
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
                                                          void* __restrict__ Cv, uint32_t M, uint32_t N, uint32_t K,
-                                                         uint32_t ldc, const float* __restrict__ bias) {
-    gemm_pp_body<TN, OUT>(A, W, Cv, M, N, K, ldc, blockIdx.x, bias);
+                                                         uint32_t ldc, const float* __restrict__ bias,
+                                                         const int32_t* __restrict__ row_seq, uint32_t n_valid) {
+    gemm_pp_body<TN, OUT>(A, W, Cv, M, N, K, ldc, blockIdx.x, bias, row_seq, n_valid);
 }
 
 // Two problems that share A, M and K (the two column ranges launch_gemm_bf16 cuts a GEMM into: whole rounds of one
@@ -367,7 +408,7 @@ hipError_t launch_p8_dual(const bf16_t* A, const bf16_t* Wa, void* Ca, uint32_t 
 
 template <int TN, int OUT>
 hipError_t launch_p8(const bf16_t* A, const bf16_t* W, void* C, uint32_t M, uint32_t N, uint32_t K, uint32_t ldc,
-                     const float* bias, hipStream_t st) {
+                     const float* bias, hipStream_t st, const int32_t* row_seq = nullptr, uint32_t n_valid = 0) {
     constexpr int BN = 64 * TN;
     const dim3 grid((N / BN) * ((M + kP8M - 1) / kP8M));
     const size_t lds = (size_t)2 * (kP8M + BN) * 64 * sizeof(bf16_t);
@@ -378,7 +419,7 @@ hipError_t launch_p8(const bf16_t* A, const bf16_t* W, void* C, uint32_t M, uint
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, A, W, C, M, N, K, ldc, bias);
+    hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, A, W, C, M, N, K, ldc, bias, row_seq, n_valid);
     return hipGetLastError();
 }
 
@@ -406,6 +447,17 @@ hipError_t launch_gemm_p8(const bf16_t* A, const bf16_t* W, void* C, uint32_t M,
     }
 #undef P8_CASE
     return hipErrorInvalidValue;
+}
+
+// out_bits[row_seq[m]][v] = max(out_bits, bits of max(0, bf16(A W^T + bias)[m][v])) for v < n_valid: per-sequence column
+// maxima of a GEMM whose result is never stored (the SPLADE decoder + pooling).  out_bits [sequences, ldc] u32, zeroed by
+// the caller; N % 192 == 0.
+hipError_t launch_gemm_rowmax(const bf16_t* A, const bf16_t* W, const float* bias, uint32_t* out_bits, uint32_t M, uint32_t N,
+                              uint32_t K, uint32_t ldc, const int32_t* row_seq, uint32_t n_valid, hipStream_t st) {
+    if (M == 0) return hipSuccess;
+    if (K % 64u || K < 64u || N % 192u || !row_seq || (uint64_t)M * K >= (1ull << 31) || (uint64_t)N * K >= (1ull << 31))
+        return hipErrorInvalidValue;
+    return launch_p8<3, GEMM_OUT_ROWMAX>(A, W, out_bits, M, N, K, ldc, bias, st, row_seq, n_valid);
 }
 
 // Two column ranges of one GEMM (same A, M, K, ldc) with different tile widths in one launch; tn_a != tn_b, both in
