@@ -24,84 +24,95 @@ __device__ __forceinline__ float wave_sum64(float v) {
     return v;
 }
 
-constexpr int kMaxPairs = 8;   // hidden <= 1024: a lane holds hidden / 128 pairs
+constexpr int kMaxChunks = 8;   // hidden <= 1024
 
-// LayerNorm of one row held as pairs[i] = elements (128 i + 2 lane, + 1): mean and biased variance in f32 (two passes
-// over the registers), y = (x - mean) * rsqrt(var + eps) * gamma + beta (torch.nn.functional.layer_norm).
-__device__ __forceinline__ void ln_row_store(float (&v)[kMaxPairs][2], int np, uint32_t H, const float* __restrict__ gamma,
+// A token row lives in one wave as chunks of VEC consecutive elements: chunk i of lane l = elements
+// (64 i + l) * VEC ..+VEC-1 (VEC = 4: 8-byte accesses, hidden % 256 == 0; VEC = 2 otherwise, hidden % 128 == 0).
+// LayerNorm: mean and biased variance in f32 (two passes over the registers), y = (x - mean) * rsqrt(var + eps) *
+// gamma + beta (torch.nn.functional.layer_norm).
+template <int VEC>
+__device__ __forceinline__ void ln_row_store(float (&v)[kMaxChunks][VEC], int nc, uint32_t H, const float* __restrict__ gamma,
                                              const float* __restrict__ beta, float eps, bf16_t* __restrict__ out, int lane) {
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < kMaxPairs; ++i)
-        if (i < np) s += v[i][0] + v[i][1];
+    for (int i = 0; i < kMaxChunks; ++i)
+        if (i < nc) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) s += v[i][e];
+        }
     const float mean = wave_sum64(s) / (float)H;
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < kMaxPairs; ++i)
-        if (i < np) {
-            const float a = v[i][0] - mean, b = v[i][1] - mean;
-            q += a * a + b * b;
+    for (int i = 0; i < kMaxChunks; ++i)
+        if (i < nc) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) { const float a = v[i][e] - mean; q += a * a; }
         }
     const float inv = rsqrtf(wave_sum64(q) / (float)H + eps);
+    typedef __bf16 bfv __attribute__((ext_vector_type(VEC)));
 #pragma unroll
-    for (int i = 0; i < kMaxPairs; ++i)
-        if (i < np) {
-            const uint32_t c = (uint32_t)(128 * i + 2 * lane);
-            bf2 o;
-            o[0] = (bf16_t)((v[i][0] - mean) * inv * gamma[c] + beta[c]);
-            o[1] = (bf16_t)((v[i][1] - mean) * inv * gamma[c + 1] + beta[c + 1]);
-            *(bf2*)(out + c) = o;
+    for (int i = 0; i < kMaxChunks; ++i)
+        if (i < nc) {
+            const uint32_t c = (uint32_t)((64 * i + lane) * VEC);
+            bfv o;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) o[e] = (bf16_t)((v[i][e] - mean) * inv * gamma[c + e] + beta[c + e]);
+            *(bfv*)(out + c) = o;
         }
 }
 
 // one wave per token: x = word[tok] + position[pos] + token_type[tt]; out = LN(x)
+template <int VEC>
 __global__ __launch_bounds__(256) void bert_embed_ln_kernel(const int32_t* __restrict__ tok, const int32_t* __restrict__ pos,
                                                             const int32_t* __restrict__ tt, const bf16_t* __restrict__ word,
                                                             const bf16_t* __restrict__ posw, const bf16_t* __restrict__ typew,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             float eps, bf16_t* __restrict__ out, uint32_t M, uint32_t H) {
+    typedef __bf16 bfv __attribute__((ext_vector_type(VEC)));
     const int lane = threadIdx.x & 63;
     const uint32_t m = blockIdx.x * 4u + (threadIdx.x >> 6);
     if (m >= M) return;
-    const int np = (int)(H / 128u);
+    const int nc = (int)(H / (64u * VEC));
     const bf16_t* a = word + (size_t)tok[m] * H;
     const bf16_t* b = posw + (size_t)pos[m] * H;
     const bf16_t* c = typew + (size_t)tt[m] * H;
-    float v[kMaxPairs][2];
+    float v[kMaxChunks][VEC];
 #pragma unroll
-    for (int i = 0; i < kMaxPairs; ++i)
-        if (i < np) {
-            const uint32_t col = (uint32_t)(128 * i + 2 * lane);
-            const bf2 x = *(const bf2*)(a + col), y = *(const bf2*)(b + col), z = *(const bf2*)(c + col);
-            v[i][0] = (float)x[0] + (float)y[0] + (float)z[0];
-            v[i][1] = (float)x[1] + (float)y[1] + (float)z[1];
+    for (int i = 0; i < kMaxChunks; ++i)
+        if (i < nc) {
+            const uint32_t col = (uint32_t)((64 * i + lane) * VEC);
+            const bfv x = *(const bfv*)(a + col), y = *(const bfv*)(b + col), z = *(const bfv*)(c + col);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) v[i][e] = (float)x[e] + (float)y[e] + (float)z[e];
         }
-    ln_row_store(v, np, H, gamma, beta, eps, out + (size_t)m * H, lane);
+    ln_row_store<VEC>(v, nc, H, gamma, beta, eps, out + (size_t)m * H, lane);
 }
 
 // one wave per token: out = LN(a + r) (r == NULL: LN(a)); out may alias a
+template <int VEC>
 __global__ __launch_bounds__(256) void bert_add_ln_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ r,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           float eps, bf16_t* __restrict__ out, uint32_t M, uint32_t H) {
+    typedef __bf16 bfv __attribute__((ext_vector_type(VEC)));
     const int lane = threadIdx.x & 63;
     const uint32_t m = blockIdx.x * 4u + (threadIdx.x >> 6);
     if (m >= M) return;
-    const int np = (int)(H / 128u);
-    float v[kMaxPairs][2];
+    const int nc = (int)(H / (64u * VEC));
+    float v[kMaxChunks][VEC];
 #pragma unroll
-    for (int i = 0; i < kMaxPairs; ++i)
-        if (i < np) {
-            const uint32_t col = (uint32_t)(128 * i + 2 * lane);
-            const bf2 x = *(const bf2*)(a + (size_t)m * H + col);
-            v[i][0] = (float)x[0];
-            v[i][1] = (float)x[1];
+    for (int i = 0; i < kMaxChunks; ++i)
+        if (i < nc) {
+            const uint32_t col = (uint32_t)((64 * i + lane) * VEC);
+            const bfv x = *(const bfv*)(a + (size_t)m * H + col);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) v[i][e] = (float)x[e];
             if (r) {
-                const bf2 y = *(const bf2*)(r + (size_t)m * H + col);
-                v[i][0] += (float)y[0];
-                v[i][1] += (float)y[1];
+                const bfv y = *(const bfv*)(r + (size_t)m * H + col);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) v[i][e] += (float)y[e];
             }
         }
-    ln_row_store(v, np, H, gamma, beta, eps, out + (size_t)m * H, lane);
+    ln_row_store<VEC>(v, nc, H, gamma, beta, eps, out + (size_t)m * H, lane);
 }
 
 // ---- multi-head attention, head dim HD = 32 or 64, bidirectional over one packed sequence -----------------------
@@ -258,17 +269,22 @@ hipError_t launch_bert_embed_ln(const int32_t* tok, const int32_t* pos, const in
                                 const bf16_t* posw, const bf16_t* typew, const float* gamma, const float* beta, float eps,
                                 bf16_t* out, uint32_t M, uint32_t H, hipStream_t st) {
     if (M == 0) return hipSuccess;
-    if (H % 128u || H > 128u * kMaxPairs) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(bert_embed_ln_kernel, dim3((M + 3u) / 4u), dim3(256), 0, st, tok, pos, tt, word, posw, typew, gamma,
-                       beta, eps, out, M, H);
+    if (H % 128u || H > 1024u) return hipErrorInvalidValue;
+    if (H % 256u == 0)
+        hipLaunchKernelGGL(bert_embed_ln_kernel<4>, dim3((M + 3u) / 4u), dim3(256), 0, st, tok, pos, tt, word, posw, typew, gamma,
+                           beta, eps, out, M, H);
+    else
+        hipLaunchKernelGGL(bert_embed_ln_kernel<2>, dim3((M + 3u) / 4u), dim3(256), 0, st, tok, pos, tt, word, posw, typew, gamma,
+                           beta, eps, out, M, H);
     return hipGetLastError();
 }
 
 hipError_t launch_bert_add_ln(const bf16_t* a, const bf16_t* r, const float* gamma, const float* beta, float eps,
                               bf16_t* out, uint32_t M, uint32_t H, hipStream_t st) {
     if (M == 0) return hipSuccess;
-    if (H % 128u || H > 128u * kMaxPairs) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(bert_add_ln_kernel, dim3((M + 3u) / 4u), dim3(256), 0, st, a, r, gamma, beta, eps, out, M, H);
+    if (H % 128u || H > 1024u) return hipErrorInvalidValue;
+    if (H % 256u == 0) hipLaunchKernelGGL(bert_add_ln_kernel<4>, dim3((M + 3u) / 4u), dim3(256), 0, st, a, r, gamma, beta, eps, out, M, H);
+    else hipLaunchKernelGGL(bert_add_ln_kernel<2>, dim3((M + 3u) / 4u), dim3(256), 0, st, a, r, gamma, beta, eps, out, M, H);
     return hipGetLastError();
 }
 
