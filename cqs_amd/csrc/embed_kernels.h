@@ -4,9 +4,24 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 namespace cqs {
 
 typedef __bf16 bf16_t;
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per DEVICE; a process may run engines on several GPUs.  One bit per
+// device ordinal in a per-call-site mask: the attribute is set the first time a kernel is launched on each device.
+inline hipError_t set_max_dynamic_lds(const void* kernel, size_t bytes, std::atomic<uint64_t>& done_mask) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const uint64_t bit = 1ull << (dev & 63);
+    if (dev < 64 && (done_mask.load(std::memory_order_acquire) & bit)) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess && dev < 64) done_mask.fetch_or(bit, std::memory_order_release);
+    return e;
+}
 
 // Model geometry (Gemma3 text encoder + sentence-transformers head); see
 // oracle/gemma3_ref.py for the semantics each field drives.

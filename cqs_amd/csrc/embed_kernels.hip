@@ -1416,12 +1416,10 @@ hipError_t launch_attention(const bf16_t* qkv, const bf16_t* vt, bf16_t* out, co
 #define CQS_ATT_DMA(GV, TQV, KRAV)                                                                                  \
     do {                                                                                                            \
         auto kern = attention_dma_kernel<TQV * GV, GV, KRAV>;                                                       \
-        static bool attr_set = false;                                                                               \
-        if (!attr_set) {                                                                                            \
-            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,       \
-                                               (int)kAttDmaLds);                                                    \
+        static std::atomic<uint64_t> attr_devices{0};                                                               \
+        {                                                                                                           \
+            const hipError_t e = set_max_dynamic_lds((const void*)kern, kAttDmaLds, attr_devices);                  \
             if (e != hipSuccess) return e;                                                                          \
-            attr_set = true;                                                                                        \
         }                                                                                                           \
         hipLaunchKernelGGL(kern, dim3(nblk * (128 / (16 * TQV)), heads / GV), dim3(64 * TQV * GV), kAttDmaLds, st,  \
                            qkv, vt, out, blk, seq_start, seq_len, vt_start, vt_ld, heads, kv_heads, window,         \

@@ -396,11 +396,10 @@ hipError_t launch_p8_dual(const bf16_t* A, const bf16_t* Wa, void* Ca, uint32_t 
     const uint32_t n_first = (Na / BNA) * mt, n_second = (Nb / BNB) * mt;
     const size_t lds = (size_t)2 * (kP8M + BNX) * 64 * sizeof(bf16_t);
     auto kern = gemm_pp_dual_kernel<TNA, TNB, OUT>;
-    static bool attr_set = false;   // per instantiation
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static std::atomic<uint64_t> attr_devices{0};   // per instantiation, per device
+    {
+        const hipError_t e = set_max_dynamic_lds((const void*)kern, lds, attr_devices);
         if (e != hipSuccess) return e;
-        attr_set = true;
     }
     hipLaunchKernelGGL(kern, dim3(n_first + n_second), dim3(512), lds, st, A, Wa, Ca, Na, Wb, Cb, Nb, M, K, ldc, n_first);
     return hipGetLastError();
@@ -413,11 +412,10 @@ hipError_t launch_p8(const bf16_t* A, const bf16_t* W, void* C, uint32_t M, uint
     const dim3 grid((N / BN) * ((M + kP8M - 1) / kP8M));
     const size_t lds = (size_t)2 * (kP8M + BN) * 64 * sizeof(bf16_t);
     auto kern = gemm_pp_kernel<TN, OUT>;
-    static bool attr_set = false;   // per instantiation
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static std::atomic<uint64_t> attr_devices{0};   // per instantiation, per device
+    {
+        const hipError_t e = set_max_dynamic_lds((const void*)kern, lds, attr_devices);
         if (e != hipSuccess) return e;
-        attr_set = true;
     }
     hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, A, W, C, M, N, K, ldc, bias, row_seq, n_valid);
     return hipGetLastError();
