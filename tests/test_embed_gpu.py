@@ -352,6 +352,22 @@ def test_full_depth_full_geometry(hip):
     eng.close()
 
 
+def test_default_config_real_vocabulary(hip):
+    """`cqs_hip_embed_config_default` as it ships - the 262 144-row token table (403 MB in bf16: the gather reaches rows
+    far apart), 24 layers, max_seq 2048 - on a small ragged batch that includes the highest token ids, against the fp32
+    oracle.  (bench.py's e2e leg checks the same configuration on hundreds of chunks; this is the unit-test twin.)"""
+    cfg = G.GemmaConfig()
+    assert cfg.vocab_size == 262144 and cfg.layers == 24
+    eng, w = make(cfg, seed=53)
+    ids, mask = batch(cfg, [70, 9, 257], seed=54)
+    ids[0, :4] = [262143, 262142, 1, 131072]
+    got = eng.run(ids, mask)
+    ref = G.forward(cfg, w, ids, mask)
+    cs = [cos(got[i], ref[i]) for i in range(len(ids))]
+    assert min(cs) > 0.999, cs
+    eng.close()
+
+
 @pytest.mark.parametrize("tile", ["small", "pp:3", "pp:4", "pp:5"])
 def test_gemm_tile_kernels(hip, tile, monkeypatch):
     """The forward has two GEMM kernels (128 x 128 tiles; the 256 x {192, 256, 320} ping-pong kernel where it fills whole
