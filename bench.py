@@ -499,7 +499,7 @@ def aux_models_leg(a, np):
                      "checked": {"max_abs_err_vs_fp32_oracle": round(err, 4)},
                      "cpu_baseline": {"docs_per_sec": round(3 / cpu_s, 2), "kind": "port", "sample": "oracle/bert_ref (torch CPU fp32), 3 docs / 255 tokens"},
                      "threshold": round(thr, 4),
-                     "note": "host API: token ids in, sparse vectors out (threshold filter on the host as in src/splade/mod.rs:1049-1062); "
+                     "note": "host API: token ids in, sparse vectors out (threshold filter of src/splade/mod.rs:1049-1062 on the device, cqs_hip_splade_encode_sparse); "
                              "threshold set where ~200 entries per document survive (seeded weights are not sparse)"}
     eng.close()
 

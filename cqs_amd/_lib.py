@@ -95,6 +95,8 @@ SIGNATURES = [
     ("cqs_hip_bert_load_dir", C.c_int32, [C.c_char_p, C.c_void_p, C.c_int32, _pp(_c_idx)]),
     ("cqs_hip_bert_destroy", None, [_c_idx]),
     ("cqs_hip_splade_encode", C.c_int32, [_c_idx, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
+    ("cqs_hip_splade_encode_sparse", C.c_int32,
+     [_c_idx, C.c_void_p, C.c_void_p, C.c_uint32, C.c_float, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("cqs_hip_rerank_logits", C.c_int32, [_c_idx, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
     ("cqs_hip_bert_hidden", C.c_int32, [_c_idx, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
     ("cqs_hip_bert_vocab", C.c_uint32, [_c_idx]),

@@ -63,6 +63,9 @@ struct cqs_hip_bert {
     uint32_t tok_cap = 0, seq_cap = 0, blk_cap = 0;
     bf16_t *x = nullptr, *y = nullptr, *qkv = nullptr, *att = nullptr, *h = nullptr, *pooled = nullptr;
     float *dense = nullptr, *cls = nullptr;
+    uint32_t *sp_ids = nullptr, *sp_cnt = nullptr;      // device-side threshold filter: [sp_rows * sp_cap] ids / weights, [sp_rows] counts
+    float* sp_w = nullptr;
+    size_t sp_rows = 0, sp_cap = 0;
     int32_t* d_meta = nullptr;
     std::vector<int32_t> h_meta;
 
@@ -117,6 +120,8 @@ void free_scratch(cqs_hip_bert* e) {
     void** all[] = {(void**)&e->x, (void**)&e->y, (void**)&e->qkv, (void**)&e->att, (void**)&e->h,
                     (void**)&e->pooled, (void**)&e->dense, (void**)&e->cls, (void**)&e->d_meta};
     for (void** p : all) { (void)hipFree(*p); *p = nullptr; }
+    (void)hipFree(e->sp_ids); (void)hipFree(e->sp_w); (void)hipFree(e->sp_cnt);
+    e->sp_ids = e->sp_cnt = nullptr; e->sp_w = nullptr; e->sp_rows = e->sp_cap = 0;
     e->tok_cap = e->seq_cap = e->blk_cap = 0;
 }
 
@@ -338,6 +343,38 @@ int32_t cqs_hip_bert_finalize(cqs_hip_bert* e) {
     return CQS_HIP_OK;
 }
 
+namespace {
+
+// Encoder + masked-LM head + pooling + activation: leaves the [batch, vocab] activations in e->dense (device).
+// *M_out == 0: every sequence empty (nothing was launched; the activations are all ln(1 + 0) = 0).
+int32_t splade_forward(cqs_hip_bert* e, const int32_t* tokens, const uint32_t* lens, uint32_t batch, uint32_t* M_out) {
+    uint64_t tot = 0;
+    for (uint32_t b = 0; b < batch; ++b) tot += lens[b];
+    if (tot && !tokens) return bfail(e, CQS_HIP_ERR_INVALID, "splade: null tokens");
+    int32_t rc = run_encoder(e, tokens, nullptr, lens, batch, M_out);
+    if (rc != CQS_HIP_OK) return rc;
+    const uint32_t M = *M_out;
+    if (M == 0) return CQS_HIP_OK;
+    const cqs_hip_bert_config& c = e->cfg;
+    const size_t V = c.vocab_size;
+    hipStream_t st = e->stream;
+    const uint32_t H = c.hidden;
+    const int32_t* d_len = e->d_meta + (size_t)3 * M + batch;
+    // BertLMPredictionHead: LayerNorm(gelu(x Wt^T + bt)) E^T + b, decoder tied to the (zero-padded) word embeddings.
+    // The [tokens, vocab] logits are never stored: the decoder GEMM's epilogue keeps, per sequence and vocabulary
+    // entry, the maximum of max(0, logit) (atomic max on the float bits), then one small pass takes ln(1 + .).
+    const uint32_t nblk = (uint32_t)((e->h_meta.size() - (size_t)4 * M - (size_t)2 * batch) / 2);
+    const int32_t* d_rowseq = d_len + batch + (size_t)2 * nblk;
+    B_TRY(e, cqs::launch_gemm_bias(e->x, e->wt, e->bt, e->y, M, H, H, H, cqs::GEMM_OUT_BF16_GELU, st));
+    B_TRY(e, cqs::launch_bert_add_ln(e->y, nullptr, e->lnt_g, e->lnt_b, c.ln_eps, e->y, M, H, st));
+    B_TRY(e, hipMemsetAsync(e->dense, 0, (size_t)batch * V * 4, st));
+    B_TRY(e, cqs::launch_gemm_rowmax(e->y, e->word, e->bdec, (uint32_t*)e->dense, M, e->vpad, H, (uint32_t)V, d_rowseq, (uint32_t)V, st));
+    B_TRY(e, cqs::launch_splade_activate(e->dense, (size_t)batch * V, st));
+    return CQS_HIP_OK;
+}
+
+}  // namespace
+
 // `SpladeEncoder::encode_batch` below the tokenizer: sequences back to back (i32 ids) + their lengths; out_dense
 // [batch, vocab] f32 = ln(1 + max(0, max over the sequence's tokens of the MLM logits)) - the model's pre-pooled
 // `sparse_vector` output form (src/splade/mod.rs:960-978); the caller keeps entries > threshold.
@@ -350,31 +387,48 @@ int32_t cqs_hip_splade_encode(cqs_hip_bert* e, const int32_t* tokens, const uint
     if (!lens || !out_dense) return bfail(e, CQS_HIP_ERR_INVALID, "splade: null buffer");
     B_TRY(e, hipSetDevice(e->device));
     uint32_t M = 0;
-    {
-        uint64_t tot = 0;
-        for (uint32_t b = 0; b < batch; ++b) tot += lens[b];
-        if (tot && !tokens) return bfail(e, CQS_HIP_ERR_INVALID, "splade: null tokens");
-    }
-    rc = run_encoder(e, tokens, nullptr, lens, batch, &M);
+    rc = splade_forward(e, tokens, lens, batch, &M);
     if (rc != CQS_HIP_OK) return rc;
-    const cqs_hip_bert_config& c = e->cfg;
-    const size_t V = c.vocab_size;
+    const size_t V = e->cfg.vocab_size;
     if (M == 0) { memset(out_dense, 0, (size_t)batch * V * 4); return CQS_HIP_OK; }   // all empty: ln(1 + 0) = 0 everywhere
+    B_TRY(e, hipMemcpyAsync(out_dense, e->dense, (size_t)batch * V * 4, hipMemcpyDeviceToHost, e->stream));
+    B_TRY(e, hipStreamSynchronize(e->stream));
+    return CQS_HIP_OK;
+}
+
+// The same with the threshold filter of src/splade/mod.rs:1049-1062 on the device: sequence b's entries > threshold
+// as (id, weight), ascending id, at out_ids / out_weights [b * cap ..]; out_counts[b] = how many passed.  A count above
+// `cap` means the row was cut off after its first `cap` entries: the caller re-encodes that sequence through
+// cqs_hip_splade_encode (trained models keep 100-300 entries, src/splade/mod.rs:44).
+int32_t cqs_hip_splade_encode_sparse(cqs_hip_bert* e, const int32_t* tokens, const uint32_t* lens, uint32_t batch,
+                                     float threshold, uint32_t cap, uint32_t* out_ids, float* out_weights, uint32_t* out_counts) {
+    if (!e) return CQS_HIP_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(e->mu);
+    int32_t rc = check_ready(e, CQS_HIP_BERT_HEAD_MLM);
+    if (rc != CQS_HIP_OK) return rc;
+    if (batch == 0) return CQS_HIP_OK;
+    if (!lens || !out_ids || !out_weights || !out_counts || cap == 0) return bfail(e, CQS_HIP_ERR_INVALID, "splade: null buffer / zero cap");
+    B_TRY(e, hipSetDevice(e->device));
+    uint32_t M = 0;
+    rc = splade_forward(e, tokens, lens, batch, &M);
+    if (rc != CQS_HIP_OK) return rc;
+    if (M == 0) { memset(out_counts, 0, (size_t)batch * 4); return CQS_HIP_OK; }      // activations all 0: nothing passes `>`
+    if ((size_t)batch > e->sp_rows || (size_t)cap > e->sp_cap) {
+        B_TRY(e, hipStreamSynchronize(e->stream));
+        (void)hipFree(e->sp_ids); (void)hipFree(e->sp_w); (void)hipFree(e->sp_cnt);
+        e->sp_ids = e->sp_cnt = nullptr; e->sp_w = nullptr;
+        const size_t rows = std::max<size_t>(batch, e->sp_rows), cp = std::max<size_t>(cap, e->sp_cap);
+        e->sp_rows = e->sp_cap = 0;
+        B_TRY(e, hipMalloc((void**)&e->sp_ids, rows * cp * 4));
+        B_TRY(e, hipMalloc((void**)&e->sp_w, rows * cp * 4));
+        B_TRY(e, hipMalloc((void**)&e->sp_cnt, rows * 4));
+        e->sp_rows = rows; e->sp_cap = cp;
+    }
     hipStream_t st = e->stream;
-    const uint32_t H = c.hidden;
-    const int32_t *d_start = e->d_meta + (size_t)3 * M, *d_len = d_start + batch;
-    // BertLMPredictionHead: LayerNorm(gelu(x Wt^T + bt)) E^T + b, decoder tied to the (zero-padded) word embeddings.
-    // The [tokens, vocab] logits are never stored: the decoder GEMM's epilogue keeps, per sequence and vocabulary
-    // entry, the maximum of max(0, logit) (atomic max on the float bits), then one small pass takes ln(1 + .).
-    const uint32_t nblk = (uint32_t)((e->h_meta.size() - (size_t)4 * M - (size_t)2 * batch) / 2);
-    const int32_t* d_rowseq = d_len + batch + (size_t)2 * nblk;
-    (void)d_start;
-    B_TRY(e, cqs::launch_gemm_bias(e->x, e->wt, e->bt, e->y, M, H, H, H, cqs::GEMM_OUT_BF16_GELU, st));
-    B_TRY(e, cqs::launch_bert_add_ln(e->y, nullptr, e->lnt_g, e->lnt_b, c.ln_eps, e->y, M, H, st));
-    B_TRY(e, hipMemsetAsync(e->dense, 0, (size_t)batch * V * 4, st));
-    B_TRY(e, cqs::launch_gemm_rowmax(e->y, e->word, e->bdec, (uint32_t*)e->dense, M, e->vpad, H, (uint32_t)V, d_rowseq, (uint32_t)V, st));
-    B_TRY(e, cqs::launch_splade_activate(e->dense, (size_t)batch * V, st));
-    B_TRY(e, hipMemcpyAsync(out_dense, e->dense, (size_t)batch * V * 4, hipMemcpyDeviceToHost, st));
+    B_TRY(e, cqs::launch_splade_sparsify(e->dense, batch, e->cfg.vocab_size, threshold, cap, e->sp_ids, e->sp_w, e->sp_cnt, st));
+    B_TRY(e, hipMemcpyAsync(out_ids, e->sp_ids, (size_t)batch * cap * 4, hipMemcpyDeviceToHost, st));
+    B_TRY(e, hipMemcpyAsync(out_weights, e->sp_w, (size_t)batch * cap * 4, hipMemcpyDeviceToHost, st));
+    B_TRY(e, hipMemcpyAsync(out_counts, e->sp_cnt, (size_t)batch * 4, hipMemcpyDeviceToHost, st));
     B_TRY(e, hipStreamSynchronize(st));
     return CQS_HIP_OK;
 }

@@ -23,4 +23,9 @@ hipError_t launch_bert_attention(const bf16_t* qkv, bf16_t* out, const int32_t* 
 // x[i] <- ln(1 + x[i]) in place (the activation of src/splade/mod.rs:1049-1053 over launch_gemm_rowmax's maxima)
 hipError_t launch_splade_activate(float* x, size_t n, hipStream_t st);
 
+// Row b of dense [B, V] -> its entries > threshold as (id, weight), ascending id, the first `cap` of them at
+// out_ids / out_w [b * cap ..]; out_count[b] = how many passed (may exceed cap).
+hipError_t launch_splade_sparsify(const float* dense, uint32_t B, uint32_t V, float threshold, uint32_t cap, uint32_t* out_ids,
+                                  float* out_w, uint32_t* out_count, hipStream_t st);
+
 }  // namespace cqs

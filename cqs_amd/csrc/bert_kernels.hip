@@ -263,7 +263,62 @@ __global__ __launch_bounds__(256) void splade_activate_kernel(float* __restrict_
     if (i < n) x[i] = logf(1.0f + x[i]);
 }
 
+// Threshold filter of src/splade/mod.rs:1049-1062 on the device: row b of the [B, V] activations -> its entries
+// > threshold as (id, weight), ascending id, at most `cap` of them (count[b] reports how many there ARE: a count above
+// cap tells the caller to take the dense row instead).  One workgroup per row; 1024 columns per step, ordered by a
+// block-wide exclusive scan of the per-thread hit counts.  NaN > t is false (dropped), +Inf passes, as in the reference.
+__global__ __launch_bounds__(256) void splade_sparsify_kernel(const float* __restrict__ dense, uint32_t V, float threshold,
+                                                              uint32_t cap, uint32_t* __restrict__ out_ids,
+                                                              float* __restrict__ out_w, uint32_t* __restrict__ out_count) {
+    __shared__ uint32_t wave_tot[4];
+    __shared__ uint32_t base_s;
+    const uint32_t b = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
+    const float* row = dense + (size_t)b * V;
+    if (tid == 0) base_s = 0;
+    __syncthreads();
+    for (uint32_t v0 = 0; v0 < V; v0 += 1024u) {
+        const uint32_t v = v0 + tid * 4u;
+        float x[4];
+        uint32_t hit = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            x[j] = v + (uint32_t)j < V ? row[v + (uint32_t)j] : 0.f;
+            hit |= (uint32_t)(v + (uint32_t)j < V && x[j] > threshold) << j;
+        }
+        const uint32_t n = (uint32_t)__builtin_popcount(hit);
+        // exclusive scan of n over the workgroup: inside the wave by shuffles, across the 4 waves through LDS
+        uint32_t inc = n;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t t = __shfl_up(inc, off, 64);
+            if (lane >= (uint32_t)off) inc += t;
+        }
+        if (lane == 63u) wave_tot[wid] = inc;
+        __syncthreads();
+        uint32_t before = base_s;
+        for (uint32_t w = 0; w < wid; ++w) before += wave_tot[w];
+        uint32_t pos = before + inc - n;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if ((hit >> j) & 1u) {
+                if (pos < cap) { out_ids[(size_t)b * cap + pos] = v + (uint32_t)j; out_w[(size_t)b * cap + pos] = x[j]; }
+                ++pos;
+            }
+        __syncthreads();
+        if (tid == 0) base_s += wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+        __syncthreads();
+    }
+    if (tid == 0) out_count[b] = base_s;
+}
+
 }  // namespace
+
+hipError_t launch_splade_sparsify(const float* dense, uint32_t B, uint32_t V, float threshold, uint32_t cap, uint32_t* out_ids,
+                                  float* out_w, uint32_t* out_count, hipStream_t st) {
+    if (B == 0) return hipSuccess;
+    hipLaunchKernelGGL(splade_sparsify_kernel, dim3(B), dim3(256), 0, st, dense, V, threshold, cap, out_ids, out_w, out_count);
+    return hipGetLastError();
+}
 
 hipError_t launch_bert_embed_ln(const int32_t* tok, const int32_t* pos, const int32_t* tt, const bf16_t* word,
                                 const bf16_t* posw, const bf16_t* typew, const float* gamma, const float* beta, float eps,

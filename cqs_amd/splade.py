@@ -100,6 +100,17 @@ class HipBertEngine:
                                                     len(seqs), out.ctypes.data_as(C.c_void_p)), "splade_encode")
         return out
 
+    def splade_sparse(self, seqs: Sequence[np.ndarray], threshold: float, cap: int = 2048):
+        """`cqs_hip_splade_encode_sparse`: (ids u32 [B, cap], weights f32 [B, cap], counts u32 [B]); counts may exceed cap."""
+        toks, lens = self._pack(seqs)
+        B = len(seqs)
+        ids = np.empty((B, cap), np.uint32); wts = np.empty((B, cap), np.float32); cnt = np.empty(B, np.uint32)
+        self._check(self._lib.cqs_hip_splade_encode_sparse(self._h, toks.ctypes.data_as(C.c_void_p), lens.ctypes.data_as(C.c_void_p),
+                                                           B, C.c_float(threshold), cap, ids.ctypes.data_as(C.c_void_p),
+                                                           wts.ctypes.data_as(C.c_void_p), cnt.ctypes.data_as(C.c_void_p)),
+                    "splade_encode_sparse")
+        return ids, wts, cnt
+
     def rerank_logits(self, seqs: Sequence[np.ndarray], type_ids: Optional[Sequence[np.ndarray]]) -> np.ndarray:
         toks, lens = self._pack(seqs)
         tt = None
@@ -128,8 +139,10 @@ class HipBertEngine:
 class SpladeEncoder:
     """`SpladeEncoder` (src/splade/mod.rs:95-118) over a HIP engine: `encode_batch` on token-id sequences."""
 
-    def __init__(self, engine: HipBertEngine, threshold: float = DEFAULT_SPLADE_THRESHOLD, max_seq_len: int = 512):
+    def __init__(self, engine: HipBertEngine, threshold: float = DEFAULT_SPLADE_THRESHOLD, max_seq_len: int = 512,
+                 sparse_cap: int = 2048):
         self.engine, self.threshold, self.max_seq_len = engine, float(threshold), int(max_seq_len)
+        self.sparse_cap = int(sparse_cap)
 
     def encode_batch_arrays(self, seqs: Sequence[Sequence[int]]) -> List[Tuple[np.ndarray, np.ndarray]]:
         """`encode_batch` with each sparse vector as (ids u32 ascending, weights f32) arrays - what a caller that
@@ -137,11 +150,23 @@ class SpladeEncoder:
         if not len(seqs):
             return []
         cut = [np.asarray(s, np.int32)[: self.max_seq_len] for s in seqs]     # truncation (src/splade/mod.rs:860-880)
+        if hasattr(self.engine, "splade_sparse"):
+            # threshold filter on the device; a row with more survivors than the cap goes through the dense form
+            ids, wts, cnt = self.engine.splade_sparse(cut, self.threshold, self.sparse_cap)
+            out = [(ids[b, :cnt[b]].copy(), wts[b, :cnt[b]].copy()) if cnt[b] <= self.sparse_cap else None for b in range(len(cut))]
+            over = [b for b, o in enumerate(out) if o is None]
+            if over:
+                for b, o in zip(over, self._from_dense([cut[b] for b in over])):
+                    out[b] = o
+            return out
+        return self._from_dense(cut)
+
+    def _from_dense(self, cut) -> List[Tuple[np.ndarray, np.ndarray]]:
         dense = self.engine.splade_dense(cut)
         rows, cols = np.nonzero(dense > np.float32(self.threshold))           # row-major: ascending id per row; NaN > t is False
-        bounds = np.searchsorted(rows, np.arange(len(seqs) + 1))
+        bounds = np.searchsorted(rows, np.arange(len(cut) + 1))
         vals = dense[rows, cols]
-        return [(cols[bounds[b]:bounds[b + 1]].astype(np.uint32), vals[bounds[b]:bounds[b + 1]]) for b in range(len(seqs))]
+        return [(cols[bounds[b]:bounds[b + 1]].astype(np.uint32), vals[bounds[b]:bounds[b + 1]]) for b in range(len(cut))]
 
     def encode_batch(self, seqs: Sequence[Sequence[int]]) -> List[SparseVector]:
         """`SpladeEncoder::encode_batch`: `Vec<SparseVector>`, a sparse vector = [(token id, weight)] ascending id."""

@@ -346,6 +346,12 @@ void    cqs_hip_bert_destroy(cqs_hip_bert* e);
  * weight > threshold, ascending id (src/splade/mod.rs:1049-1062).  The maximum is folded with a strict `>` from -inf
  * (src/splade/mod.rs:1033-1043). */
 int32_t cqs_hip_splade_encode(cqs_hip_bert* e, const int32_t* tokens, const uint32_t* lens, uint32_t batch, float* out_dense);
+/* The same with that threshold filter done on the device (no [batch, vocab] transfer, no host pass over it): sequence
+ * b's (id, weight) pairs with weight > threshold, ascending id, at out_ids / out_weights [b * cap ..]; out_counts[b] =
+ * how many passed - above `cap` the row was cut off after its first `cap` entries and the caller takes that sequence
+ * through cqs_hip_splade_encode instead (trained models keep 100-300 entries, src/splade/mod.rs:44). */
+int32_t cqs_hip_splade_encode_sparse(cqs_hip_bert* e, const int32_t* tokens, const uint32_t* lens, uint32_t batch,
+                                     float threshold, uint32_t cap, uint32_t* out_ids, float* out_weights, uint32_t* out_counts);
 /* Reranker: (query, passage) pairs as ids + token type ids (NULL = all zero), packed like the above; every sequence
  * non-empty.  out_logits [batch, num_labels] f32; score = sigmoid(out_logits[b * num_labels]) (src/reranker.rs:516-518). */
 int32_t cqs_hip_rerank_logits(cqs_hip_bert* e, const int32_t* tokens, const int32_t* type_ids, const uint32_t* lens,

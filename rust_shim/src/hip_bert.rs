@@ -46,6 +46,8 @@ extern "C" {
     fn cqs_hip_bert_load_dir(dir: *const c_char, cfg: *const CqsHipBertConfig, device: i32, out: *mut *mut CqsHipBert) -> i32;
     fn cqs_hip_bert_destroy(e: *mut CqsHipBert);
     fn cqs_hip_splade_encode(e: *mut CqsHipBert, tokens: *const i32, lens: *const u32, batch: u32, out_dense: *mut f32) -> i32;
+    fn cqs_hip_splade_encode_sparse(e: *mut CqsHipBert, tokens: *const i32, lens: *const u32, batch: u32, threshold: f32,
+                                    cap: u32, out_ids: *mut u32, out_weights: *mut f32, out_counts: *mut u32) -> i32;
     fn cqs_hip_rerank_logits(e: *mut CqsHipBert, tokens: *const i32, type_ids: *const i32, lens: *const u32, batch: u32,
                              out_logits: *mut f32) -> i32;
     fn cqs_hip_bert_vocab(e: *const CqsHipBert) -> u32;
@@ -110,6 +112,33 @@ impl HipBert {
         Ok(out)
     }
 
+    /// `encode_batch` with the threshold filter on the device: `Vec<SparseVector>` directly (ascending ids, weight >
+    /// threshold).  A sequence with more than `cap` survivors (never with a trained model: 100-300 entries,
+    /// src/splade/mod.rs:44) is re-encoded through `splade_dense`.
+    pub fn splade_sparse(&self, encodings: &[&[u32]], threshold: f32, cap: usize) -> Result<Vec<Vec<(u32, f32)>>, String> {
+        let (toks, lens) = Self::pack(encodings);
+        let b = encodings.len();
+        let (mut ids, mut wts, mut cnt) = (vec![0u32; b * cap], vec![0f32; b * cap], vec![0u32; b]);
+        let rc = unsafe {
+            cqs_hip_splade_encode_sparse(self.raw, toks.as_ptr(), lens.as_ptr(), b as u32, threshold, cap as u32,
+                                         ids.as_mut_ptr(), wts.as_mut_ptr(), cnt.as_mut_ptr())
+        };
+        if rc != CQS_HIP_OK {
+            return Err(format!("cqs_hip_splade_encode_sparse: {} ({rc})", self.last_error()));
+        }
+        let mut out = Vec::with_capacity(b);
+        for i in 0..b {
+            let n = cnt[i] as usize;
+            if n <= cap {
+                out.push((0..n).map(|j| (ids[i * cap + j], wts[i * cap + j])).collect());
+            } else {
+                let dense = self.splade_dense(&encodings[i..i + 1])?;
+                out.push(dense.iter().enumerate().filter_map(|(id, &v)| if v > threshold { Some((id as u32, v)) } else { None }).collect());
+            }
+        }
+        Ok(out)
+    }
+
     /// `[batch, num_labels]` logits for encoded (query, passage) pairs; `score = sigmoid(logits[i * num_labels])`
     /// (src/reranker.rs:516-518).  `type_ids`: `Encoding::get_type_ids` per pair, or empty when the model takes none.
     pub fn rerank_logits(&self, encodings: &[&[u32]], type_ids: &[&[u32]]) -> Result<Vec<f32>, String> {
@@ -137,10 +166,8 @@ impl Drop for HipBert {
 // src/splade/mod.rs, encode_batch, in place of the `session.run` + output match (:900-1075):
 //
 //     let encs: Vec<&[u32]> = encodings.iter().map(|e| &e.get_ids()[..e.get_ids().len().min(max_seq_len)]).collect();
-//     let dense = hip.splade_dense(&encs).map_err(SpladeError::InferenceFailed)?;
-//     let vocab = hip.vocab();
-//     Ok((0..batch_size).map(|b| dense[b * vocab..(b + 1) * vocab].iter().enumerate()
-//             .filter_map(|(id, &v)| if v > threshold { Some((id as u32, v)) } else { None }).collect()).collect())
+//     Ok(hip.splade_sparse(&encs, self.threshold, 2048).map_err(SpladeError::InferenceFailed)?)
+//     // (or the 2-D `sparse_vector` branch unchanged on `hip.splade_dense(&encs)`: [batch, vocab] activations)
 //
 // src/reranker.rs, run_chunk, in place of the `session.run` + extraction (:455-520):
 //

@@ -267,3 +267,28 @@ def test_load_dir_onnx_export(hip, tmp_path, flat):
     from cqs_amd.splade import BertError
     with pytest.raises(BertError):
         HipBertEngine.load_dir(str(tmp_path), _bert_cfg(cfg, "classifier"))
+
+
+def test_splade_device_side_threshold_filter(hip):
+    """`cqs_hip_splade_encode_sparse` = the dense activations + the host filter, entry for entry; a row with more
+    survivors than the cap reports its true count (and its first `cap` entries), an empty sequence reports 0."""
+    from cqs_amd.splade import SpladeEncoder
+    cfg = R.BertConfig(vocab_size=2500, hidden=384, layers=2, heads=6, intermediate=768, max_pos=128)
+    eng, _ = _engine(cfg, "mlm", seed=31)
+    seqs = _seqs(cfg, [40, 0, 128, 3, 77], seed=32)
+    dense = eng.splade_dense(seqs)
+    for thr in (0.05, 0.5, 1.2):
+        ids, wts, cnt = eng.splade_sparse(seqs, thr, cap=4096)
+        for b in range(len(seqs)):
+            keep = np.nonzero(dense[b] > np.float32(thr))[0]
+            assert cnt[b] == len(keep), (thr, b, cnt[b], len(keep))
+            assert np.array_equal(ids[b, :cnt[b]], keep.astype(np.uint32)) and np.array_equal(wts[b, :cnt[b]], dense[b][keep])
+    ids, wts, cnt = eng.splade_sparse(seqs, 0.05, cap=64)                   # cap smaller than the survivors
+    keep0 = np.nonzero(dense[0] > np.float32(0.05))[0]
+    assert cnt[0] == len(keep0) > 64 and np.array_equal(ids[0], keep0[:64].astype(np.uint32)) and cnt[1] == 0
+    enc = SpladeEncoder(eng, threshold=0.05, sparse_cap=64)                  # the mirror falls back to the dense form for such rows
+    got = enc.encode_batch_arrays(seqs)
+    for b in range(len(seqs)):
+        keep = np.nonzero(dense[b] > np.float32(0.05))[0]
+        assert np.array_equal(got[b][0], keep.astype(np.uint32)) and np.array_equal(got[b][1], dense[b][keep])
+    eng.close()
