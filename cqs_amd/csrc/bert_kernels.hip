@@ -18,6 +18,23 @@ typedef uint32_t u4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
+// cross-lane-group reductions of the attention's softmax by v_permlane{16,32}_swap (VALU) instead of ds_bpermute
+// (LDS queue): lanes l, l^16, l^32, l^48 hold the same query's other keys
+__device__ __forceinline__ float xg_max(float v) {
+    typedef unsigned pu2 __attribute__((ext_vector_type(2)));
+    const pu2 a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    const pu2 b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+__device__ __forceinline__ float xg_sum(float v) {
+    typedef unsigned pu2 __attribute__((ext_vector_type(2)));
+    const pu2 a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    const pu2 b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
 __device__ __forceinline__ float wave_sum64(float v) {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -204,16 +221,20 @@ __global__ __launch_bounds__(256) void bert_attention_kernel(const bf16_t* __res
                 }
             // sc[kt][r] = q . k for key k_first + 8 lg + 4 kt + r
             float mloc = -INFINITY;
+            if (k_first + 31u >= L) {                  // (wave-uniform) the half reaches past the sequence: mask key by key
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const uint32_t key = k_first + (uint32_t)(8 * lg + 4 * kt + r);
+                        sc[kt][r] = key < L ? sc[kt][r] : -INFINITY;
+                    }
+            }
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const uint32_t key = k_first + (uint32_t)(8 * lg + 4 * kt + r);
-                    sc[kt][r] = key < L ? sc[kt][r] : -INFINITY;
-                    mloc = fmaxf(mloc, sc[kt][r]);
-                }
-            mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
-            mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+                for (int r = 0; r < 4; ++r) mloc = fmaxf(mloc, sc[kt][r]);
+            mloc = xg_max(mloc);
             const float m_new = fmaxf(m_run, mloc);    // finite: key k_first < L is attendable for every query
             const float a = __builtin_amdgcn_exp2f((m_run - m_new) * c);     // exp2(-inf) = 0 on the first half
             l_run *= a;
@@ -241,8 +262,7 @@ __global__ __launch_bounds__(256) void bert_attention_kernel(const bf16_t* __res
             }
         }
     }
-    l_run += __shfl_xor(l_run, 16, 64);
-    l_run += __shfl_xor(l_run, 32, 64);
+    l_run = xg_sum(l_run);
     if (wave_live && qi < L) {
         const float invl = l_run > 0.f ? 1.0f / l_run : 0.f;
         bf16_t* op = out + (size_t)(s0 + qi) * H + head * HD;
