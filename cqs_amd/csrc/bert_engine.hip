@@ -452,12 +452,10 @@ int32_t cqs_hip_rerank_logits(cqs_hip_bert* e, const int32_t* tokens, const int3
     const cqs_hip_bert_config& c = e->cfg;
     hipStream_t st = e->stream;
     const uint32_t H = c.hidden;
-    // BertPooler on every sequence's first token.  Rows are not equally spaced in the packed hidden states: gather
-    // them with one small copy per sequence (B is tens), then dense + tanh, then the classifier (labels padded to 16).
-    const int32_t* seq_start = e->h_meta.data() + (size_t)3 * M;
-    for (uint32_t b = 0; b < batch; ++b)
-        B_TRY(e, hipMemcpyAsync(e->pooled + (size_t)b * H, e->x + (size_t)seq_start[b] * H, (size_t)H * 2, hipMemcpyDeviceToDevice, st));
-    B_TRY(e, cqs::launch_gemm_rows(e->pooled, H, e->wp, e->bp, 1, e->att, batch, H, H, H, cqs::GEMM_OUT_BF16, st));
+    // BertPooler on every sequence's first token (row seq_start[b] of the packed hidden states: the skinny GEMM reads its
+    // rows through that table), dense + tanh, then the classifier (labels padded to 16).
+    const int32_t* d_start = e->d_meta + (size_t)3 * M;
+    B_TRY(e, cqs::launch_gemm_rows(e->x, H, e->wp, e->bp, 1, e->att, batch, H, H, H, cqs::GEMM_OUT_BF16, st, d_start));
     B_TRY(e, cqs::launch_gemm_rows(e->att, H, e->wc, e->bc, 0, e->cls, batch, 16, H, 16, cqs::GEMM_OUT_F32, st));
     std::vector<float> tmp((size_t)batch * 16);
     B_TRY(e, hipMemcpyAsync(tmp.data(), e->cls, tmp.size() * 4, hipMemcpyDeviceToHost, st));

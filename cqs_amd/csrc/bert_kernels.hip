@@ -290,20 +290,21 @@ __global__ __launch_bounds__(256) void splade_activate_kernel(float* __restrict_
 __global__ __launch_bounds__(256) void splade_sparsify_kernel(const float* __restrict__ dense, uint32_t V, float threshold,
                                                               uint32_t cap, uint32_t* __restrict__ out_ids,
                                                               float* __restrict__ out_w, uint32_t* __restrict__ out_count) {
+    constexpr uint32_t PER = 16;                         // consecutive columns per thread per step (4096 per workgroup step)
     __shared__ uint32_t wave_tot[4];
     __shared__ uint32_t base_s;
     const uint32_t b = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
     const float* row = dense + (size_t)b * V;
     if (tid == 0) base_s = 0;
     __syncthreads();
-    for (uint32_t v0 = 0; v0 < V; v0 += 1024u) {
-        const uint32_t v = v0 + tid * 4u;
-        float x[4];
+    for (uint32_t v0 = 0; v0 < V; v0 += 256u * PER) {
+        const uint32_t v = v0 + tid * PER;
+        float x[PER];
         uint32_t hit = 0;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            x[j] = v + (uint32_t)j < V ? row[v + (uint32_t)j] : 0.f;
-            hit |= (uint32_t)(v + (uint32_t)j < V && x[j] > threshold) << j;
+        for (uint32_t j = 0; j < PER; ++j) {
+            x[j] = v + j < V ? row[v + j] : 0.f;
+            hit |= (uint32_t)(v + j < V && x[j] > threshold) << j;
         }
         const uint32_t n = (uint32_t)__builtin_popcount(hit);
         // exclusive scan of n over the workgroup: inside the wave by shuffles, across the 4 waves through LDS
@@ -319,9 +320,9 @@ __global__ __launch_bounds__(256) void splade_sparsify_kernel(const float* __res
         for (uint32_t w = 0; w < wid; ++w) before += wave_tot[w];
         uint32_t pos = before + inc - n;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (uint32_t j = 0; j < PER; ++j)
             if ((hit >> j) & 1u) {
-                if (pos < cap) { out_ids[(size_t)b * cap + pos] = v + (uint32_t)j; out_w[(size_t)b * cap + pos] = x[j]; }
+                if (pos < cap) { out_ids[(size_t)b * cap + pos] = v + j; out_w[(size_t)b * cap + pos] = x[j]; }
                 ++pos;
             }
         __syncthreads();

@@ -61,7 +61,8 @@ hipError_t launch_gemm_skinny(const bf16_t* A, const bf16_t* W, void* C, uint32_
 
 // The skinny kernel on rows `lda` elements apart, + bias (nullable) and optional tanh; any M (the BERT heads).
 hipError_t launch_gemm_rows(const bf16_t* A, uint32_t lda, const bf16_t* W, const float* bias, int act_tanh, void* C,
-                            uint32_t M, uint32_t N, uint32_t K, uint32_t ldc, GemmOut out, hipStream_t st);
+                            uint32_t M, uint32_t N, uint32_t K, uint32_t ldc, GemmOut out, hipStream_t st,
+                            const int32_t* row_index = nullptr /*device: output row m reads A row row_index[m]*/);
 
 // Second-generation kernel (gemm_kernels.hip): 256 x (64 tn) x 64 tiles, 8 waves in two rows that alternate load and
 // multiply intervals, counted-vmcnt LDS-DMA.  tn in {3, 4, 5}; N % (64 tn) == 0, K % 64 == 0.

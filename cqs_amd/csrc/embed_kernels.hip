@@ -1080,10 +1080,18 @@ hipError_t launch_add_norm(float* x, const bf16_t* y, const float* w_post, const
 // steps in flight), no LDS, no barrier: N / 32 waves per 32 rows.  Same MFMA (32x32x16), same operand roles and the
 // same K order as gemm_bf16_kernel, so the two kernels agree bit for bit and a chunk still embeds to the same bits
 // alone or in a batch (test_padding_and_batch_invariance).
+__device__ __forceinline__ float gelu_erf(float x) {      // as p8_gelu_erf (gemm_kernels.hip): Abramowitz-Stegun 7.1.26
+    const float z = __builtin_fabsf(x) * 0.70710678118654752f;
+    const float t = __frcp_rn(1.0f + 0.3275911f * z);
+    const float poly = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f) * t;
+    const float e = 1.0f - poly * __expf(-z * z);
+    return 0.5f * x * (1.0f + __builtin_copysignf(e, x));
+}
+
 template <int OUT>
 __global__ __launch_bounds__(64) void gemm_fewrows_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
                                                           void* __restrict__ Cv, uint32_t M, uint32_t N, uint32_t K,
-                                                          uint32_t ldc) {
+                                                          uint32_t ldc, const float* __restrict__ bias /*nullable; not GEGLU*/) {
     constexpr int NT = OUT == GEMM_OUT_GEGLU ? 2 : 1;          // 32-column tiles per wave
     const int lane = threadIdx.x, l31 = lane & 31, lh = lane >> 5;
     const uint32_t n0 = blockIdx.x * (uint32_t)(32 * NT), m0 = blockIdx.y * 32u;
@@ -1123,12 +1131,28 @@ __global__ __launch_bounds__(64) void gemm_fewrows_kernel(const bf16_t* __restri
         if (OUT == GEMM_OUT_GEGLU) {
             const float v = gelu_tanh(acc[0][e]) * acc[NT - 1][e];
             ((bf16_t*)Cv)[(size_t)row * ldc + n0 / 2u + (uint32_t)l31] = (bf16_t)v;
-        } else if (OUT == GEMM_OUT_F32) {
-            ((float*)Cv)[(size_t)row * ldc + n0 + (uint32_t)l31] = acc[0][e];
         } else {
-            ((bf16_t*)Cv)[(size_t)row * ldc + n0 + (uint32_t)l31] = (bf16_t)acc[0][e];
+            float v = acc[0][e];
+            if (bias) v += bias[n0 + (uint32_t)l31];
+            if (OUT == GEMM_OUT_BF16_GELU) v = gelu_erf(v);
+            if (OUT == GEMM_OUT_F32) ((float*)Cv)[(size_t)row * ldc + n0 + (uint32_t)l31] = v;
+            else ((bf16_t*)Cv)[(size_t)row * ldc + n0 + (uint32_t)l31] = (bf16_t)v;
         }
     }
+}
+
+static hipError_t launch_gemm_fewrows(const bf16_t* A, const bf16_t* W, const float* bias, void* C, uint32_t M, uint32_t N,
+                                      uint32_t K, uint32_t ldc, GemmOut out, hipStream_t st) {
+    if (N % 64u || K % 64u || (bias && out == GEMM_OUT_GEGLU)) return hipErrorInvalidValue;
+    const dim3 fg(N / (out == GEMM_OUT_GEGLU ? 64u : 32u), (M + 31u) / 32u);
+    switch (out) {
+        case GEMM_OUT_BF16: hipLaunchKernelGGL(gemm_fewrows_kernel<GEMM_OUT_BF16>, fg, dim3(64), 0, st, A, W, C, M, N, K, ldc, bias); break;
+        case GEMM_OUT_F32: hipLaunchKernelGGL(gemm_fewrows_kernel<GEMM_OUT_F32>, fg, dim3(64), 0, st, A, W, C, M, N, K, ldc, bias); break;
+        case GEMM_OUT_GEGLU: hipLaunchKernelGGL(gemm_fewrows_kernel<GEMM_OUT_GEGLU>, fg, dim3(64), 0, st, A, W, C, M, N, K, ldc, bias); break;
+        case GEMM_OUT_BF16_GELU: hipLaunchKernelGGL(gemm_fewrows_kernel<GEMM_OUT_BF16_GELU>, fg, dim3(64), 0, st, A, W, C, M, N, K, ldc, bias); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
 }
 
 // One kernel for the whole [M, N] problem; tn = 0: the 128 x 128 kernel, 3..5: the 256 x (64 tn) ping-pong kernel.
@@ -1136,16 +1160,8 @@ static hipError_t launch_gemm_one(const bf16_t* A, const bf16_t* W, void* C, uin
                                   uint32_t ldc, GemmOut out, int tn, hipStream_t st) {
     if (tn) return launch_gemm_p8(A, W, C, M, N, K, ldc, out, tn, st);
     static const uint32_t few_max = [] { const char* f = getenv("CQS_HIP_GEMM_FEWROWS"); return f ? (uint32_t)atoi(f) : 512u; }();
-    if (M <= few_max && !getenv("CQS_HIP_GEMM_TILE")) {         // small batch: one wave per 32 x 32 tile (bit-identical results)
-        const dim3 fg(N / (out == GEMM_OUT_GEGLU ? 64u : 32u), (M + 31u) / 32u);
-        switch (out) {
-            case GEMM_OUT_BF16: hipLaunchKernelGGL(gemm_fewrows_kernel<GEMM_OUT_BF16>, fg, dim3(64), 0, st, A, W, C, M, N, K, ldc); break;
-            case GEMM_OUT_F32: hipLaunchKernelGGL(gemm_fewrows_kernel<GEMM_OUT_F32>, fg, dim3(64), 0, st, A, W, C, M, N, K, ldc); break;
-            case GEMM_OUT_GEGLU: hipLaunchKernelGGL(gemm_fewrows_kernel<GEMM_OUT_GEGLU>, fg, dim3(64), 0, st, A, W, C, M, N, K, ldc); break;
-            default: return hipErrorInvalidValue;
-        }
-        return hipGetLastError();
-    }
+    if (M <= few_max && !getenv("CQS_HIP_GEMM_TILE"))           // small batch: one wave per 32 x 32 tile (bit-identical results)
+        return launch_gemm_fewrows(A, W, nullptr, C, M, N, K, ldc, out, st);
     const dim3 grid((N / 128u) * ((M + 127u) / 128u)), block(256);
     switch (out) {
         case GEMM_OUT_BF16: hipLaunchKernelGGL(gemm_bf16_kernel<GEMM_OUT_BF16>, grid, block, 0, st, A, W, C, M, N, K, ldc); break;
@@ -1164,7 +1180,8 @@ template <int OUT>
 __global__ __launch_bounds__(256) void gemm_skinny_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
                                                          void* __restrict__ Cv, uint32_t M, uint32_t N, uint32_t K,
                                                          uint32_t ldc, uint32_t lda /*row stride of A, elements*/,
-                                                         const float* __restrict__ bias /*nullable*/, int act /*1: tanh*/) {
+                                                         const float* __restrict__ bias /*nullable*/, int act /*1: tanh*/,
+                                                         const int32_t* __restrict__ row_index /*nullable: A row of output row m*/) {
     __shared__ __attribute__((aligned(16))) float red[4][256];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int l15 = lane & 15, lg = lane >> 4;
@@ -1172,7 +1189,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const bf16_t* __restri
     const uint32_t ksteps = K / 32u, per = (ksteps + 3u) / 4u;
     const uint32_t s_lo = (uint32_t)wid * per, s_hi = s_lo + per < ksteps ? s_lo + per : ksteps;
     const uint32_t mr = m0 + (uint32_t)l15 < M ? m0 + (uint32_t)l15 : M - 1u;    // rows past M: any real row, never stored
-    const bf16_t* ap = A + (size_t)mr * lda + 8 * lg;
+    const bf16_t* ap = A + (size_t)(row_index ? (uint32_t)row_index[mr] : mr) * lda + 8 * lg;
     const bf16_t* wp = W + (size_t)(n0 + (uint32_t)l15) * K + 8 * lg;
     f4 acc = (f4)(0.f);
     constexpr int U = 8;
@@ -1287,6 +1304,10 @@ hipError_t launch_gemm_bias(const bf16_t* A, const bf16_t* W, const float* bias,
                             uint32_t K, uint32_t ldc, GemmOut out, hipStream_t st) {
     if (M == 0) return hipSuccess;
     if (out == GEMM_OUT_GEGLU || K % 64u) return hipErrorInvalidValue;
+    // small batches (a query, a rerank of a few dozen passages): one wave per 32 x 32 tile, no fixed cost of the 256-row
+    // kernel's prologue / epilogue (13-50 us per projection at a few thousand tokens; measured crossover below)
+    static const uint32_t few_max = [] { const char* f = getenv("CQS_HIP_GEMM_BIAS_FEWROWS"); return f ? (uint32_t)atoi(f) : 2048u; }();
+    if (M <= few_max && N % 64u == 0) return launch_gemm_fewrows(A, W, bias, C, M, N, K, ldc, out, st);
     static int n_cu = 0;
     if (n_cu == 0) {
         int dev = 0;
@@ -1317,20 +1338,21 @@ hipError_t launch_gemm_skinny(const bf16_t* A, const bf16_t* W, void* C, uint32_
     if (M == 0) return hipSuccess;
     if (N % 16u || K % 32u || (out != GEMM_OUT_BF16 && out != GEMM_OUT_F32)) return hipErrorInvalidValue;
     if (M > 256u) return launch_gemm_bf16(A, W, C, M, N, K, ldc, out, st);
-    return launch_gemm_rows(A, K, W, nullptr, 0, C, M, N, K, ldc, out, st);
+    return launch_gemm_rows(A, K, W, nullptr, 0, C, M, N, K, ldc, out, st, nullptr);
 }
 
 // The same kernel on strided rows with a bias and an optional tanh (the BERT pooler reads every sequence's first
 // token out of the packed hidden states: lda = its stride; any M).
 hipError_t launch_gemm_rows(const bf16_t* A, uint32_t lda, const bf16_t* W, const float* bias, int act_tanh, void* C,
-                            uint32_t M, uint32_t N, uint32_t K, uint32_t ldc, GemmOut out, hipStream_t st) {
+                            uint32_t M, uint32_t N, uint32_t K, uint32_t ldc, GemmOut out, hipStream_t st,
+                            const int32_t* row_index) {
     if (M == 0) return hipSuccess;
     if (N % 16u || K % 32u || (out != GEMM_OUT_BF16 && out != GEMM_OUT_F32)) return hipErrorInvalidValue;
     const dim3 grid(N / 16u, (M + 15u) / 16u);
     if (out == GEMM_OUT_F32)
-        hipLaunchKernelGGL(gemm_skinny_kernel<GEMM_OUT_F32>, grid, dim3(256), 0, st, A, W, C, M, N, K, ldc, lda, bias, act_tanh);
+        hipLaunchKernelGGL(gemm_skinny_kernel<GEMM_OUT_F32>, grid, dim3(256), 0, st, A, W, C, M, N, K, ldc, lda, bias, act_tanh, row_index);
     else
-        hipLaunchKernelGGL(gemm_skinny_kernel<GEMM_OUT_BF16>, grid, dim3(256), 0, st, A, W, C, M, N, K, ldc, lda, bias, act_tanh);
+        hipLaunchKernelGGL(gemm_skinny_kernel<GEMM_OUT_BF16>, grid, dim3(256), 0, st, A, W, C, M, N, K, ldc, lda, bias, act_tanh, row_index);
     return hipGetLastError();
 }
 
