@@ -503,6 +503,38 @@ def aux_models_leg(a, np):
                              "threshold set where ~200 entries per document survive (seeded weights are not sparse)"}
     eng.close()
 
+    # BERT-family embedder presets of the `Embedder` seam (bge-large = the reference's strongest: src/embedder/models.rs:374-405)
+    for name, cfg, B, L in (("bge_large", R.bge_large(), 32, 512), ("e5_base", R.e5_base(), 32, 512)):
+        w = R.seeded_weights(cfg, "none", seed=3)
+        eng = HipBertEngine(bert_config(_lib.BERT_HEAD_NONE, hidden=cfg.hidden, layers=cfg.layers, heads=cfg.heads,
+                                        intermediate=cfg.intermediate))
+        eng.set_weights(w)
+        small = [rng.integers(1, cfg.vocab_size, size=n).astype(np.int32) for n in (40, 130)]
+        got = eng.embed(small, None, "mean")
+        t0 = time.perf_counter()
+        want = R.pooled_embedding(cfg, w, *padded(small)[:2])
+        cpu_s = time.perf_counter() - t0
+        cs = min(float(np.dot(got[i], want[i]) / (np.linalg.norm(got[i]) * np.linalg.norm(want[i]))) for i in range(2))
+        assert cs > 0.999, "%s embeddings differ from the fp32 oracle: cos %g" % (name, cs)
+        seqs = [rng.integers(1, cfg.vocab_size, size=L).astype(np.int32) for _ in range(B)]
+        t_end = time.perf_counter() + 0.3
+        while time.perf_counter() < t_end:
+            eng.embed(seqs, None, "mean")
+        steps = max(4, a.embed_steps)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            eng.embed(seqs, None, "mean")
+        dt = (time.perf_counter() - t0) / steps
+        flops = 2.0 * B * L * cfg.layers * (4 * cfg.hidden * cfg.hidden + 2 * cfg.hidden * cfg.intermediate) + 4.0 * B * cfg.layers * L * L * cfg.hidden
+        out["embedder_" + name] = {"model": "%s geometry (%d x [%d | %d x 64 | %d]), seeded weights, mean pooling" % (
+                                       name.replace("_", "-"), cfg.layers, cfg.hidden, cfg.heads, cfg.intermediate),
+                                   "batch": B, "tokens_per_chunk": L, "chunks_per_sec": round(B / dt, 1), "tokens_per_sec": round(B * L / dt, 1),
+                                   "ms_per_batch": round(dt * 1e3, 3), "tflops": round(flops / dt / 1e12, 1),
+                                   "checked": {"min_cosine_vs_fp32_oracle": round(cs, 6)},
+                                   "cpu_baseline": {"chunks_per_sec": round(2 / cpu_s, 2), "kind": "port", "sample": "oracle/bert_ref (torch CPU fp32), 2 chunks / 170 tokens"}}
+        eng.close()
+        del w
+
     # reranker
     cfg = R.minilm_l6()
     w = R.seeded_weights(cfg, "classifier", seed=2)

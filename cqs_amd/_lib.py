@@ -98,6 +98,7 @@ SIGNATURES = [
     ("cqs_hip_splade_encode_sparse", C.c_int32,
      [_c_idx, C.c_void_p, C.c_void_p, C.c_uint32, C.c_float, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("cqs_hip_rerank_logits", C.c_int32, [_c_idx, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
+    ("cqs_hip_bert_embed", C.c_int32, [_c_idx, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
     ("cqs_hip_bert_hidden", C.c_int32, [_c_idx, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
     ("cqs_hip_bert_vocab", C.c_uint32, [_c_idx]),
     ("cqs_hip_bert_poisoned", C.c_int32, [_c_idx]),
@@ -106,6 +107,7 @@ SIGNATURES = [
 
 BERT_HEAD_MLM = 0
 BERT_HEAD_CLASSIFIER = 1
+BERT_HEAD_NONE = 2
 
 
 class BertConfig(C.Structure):

@@ -139,6 +139,8 @@ int32_t ensure_scratch(cqs_hip_bert* e, uint32_t M, uint32_t B, uint32_t nblk) {
     B_TRY(e, hipMalloc((void**)&e->h, (size_t)Mc * c.intermediate * 2));
     if (c.head == CQS_HIP_BERT_HEAD_MLM) {
         B_TRY(e, hipMalloc((void**)&e->dense, (size_t)Bc * c.vocab_size * 4));
+    } else if (c.head == CQS_HIP_BERT_HEAD_NONE) {
+        B_TRY(e, hipMalloc((void**)&e->dense, (size_t)Bc * H * 4));            // pooled embeddings
     } else {
         B_TRY(e, hipMalloc((void**)&e->pooled, (size_t)Bc * H * 2));
         B_TRY(e, hipMalloc((void**)&e->cls, (size_t)Bc * 16 * 4));
@@ -221,6 +223,8 @@ int32_t cqs_hip_bert_config_default(uint32_t head, cqs_hip_bert_config* c) {
         c->hidden = 768; c->layers = 12; c->heads = 12; c->intermediate = 3072;
     } else if (head == CQS_HIP_BERT_HEAD_CLASSIFIER) {   // cross-encoder/ms-marco-MiniLM-L-6-v2 (src/reranker.rs:7,35)
         c->hidden = 384; c->layers = 6; c->heads = 12; c->intermediate = 1536;
+    } else if (head == CQS_HIP_BERT_HEAD_NONE) {         // intfloat/e5-base-v2 = BERT-base (src/embedder/models.rs:346-358)
+        c->hidden = 768; c->layers = 12; c->heads = 12; c->intermediate = 3072;
     } else {
         return CQS_HIP_ERR_INVALID;
     }
@@ -231,12 +235,13 @@ int32_t cqs_hip_bert_create(const cqs_hip_bert_config* cfg, int32_t device, cqs_
     if (!cfg || !out) return CQS_HIP_ERR_INVALID;
     *out = nullptr;
     const cqs_hip_bert_config& c = *cfg;
-    const bool ok_cfg = c.hidden && c.hidden % 192u == 0 && c.hidden % 128u == 0 && c.hidden <= 1024u && c.layers && c.heads &&
+    auto tiles = [](uint32_t n) { return n && (n % 192u == 0 || n % 256u == 0 || n % 320u == 0); };   // a GEMM tile width divides it
+    const bool ok_cfg = c.hidden && c.hidden % 128u == 0 && c.hidden <= 1024u && c.layers && c.heads &&
                         c.hidden % c.heads == 0 && (c.hidden / c.heads == 32u || c.hidden / c.heads == 64u) &&
-                        c.intermediate % 192u == 0 && c.vocab_size && c.max_pos && c.type_vocab &&
-                        (c.head == CQS_HIP_BERT_HEAD_MLM || c.head == CQS_HIP_BERT_HEAD_CLASSIFIER) &&
+                        tiles(c.hidden) && tiles(3u * c.hidden) && tiles(c.intermediate) && c.vocab_size && c.max_pos && c.type_vocab &&
+                        (c.head == CQS_HIP_BERT_HEAD_MLM || c.head == CQS_HIP_BERT_HEAD_CLASSIFIER || c.head == CQS_HIP_BERT_HEAD_NONE) &&
                         (c.head != CQS_HIP_BERT_HEAD_CLASSIFIER || (c.num_labels >= 1 && c.num_labels <= 16)) && c.ln_eps > 0.f;
-    if (!ok_cfg) return CQS_HIP_ERR_INVALID;    // (hidden / intermediate multiples of 192: the GEMM's narrowest tile)
+    if (!ok_cfg) return CQS_HIP_ERR_INVALID;
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return CQS_HIP_ERR_NO_DEVICE;
     cqs_hip_bert* e = new cqs_hip_bert();
@@ -327,7 +332,7 @@ int32_t cqs_hip_bert_finalize(cqs_hip_bert* e) {
         UP(up_bf16(e, &e->wt, wt, H * H)); UP(up_f32(e, &e->bt, bt, H));
         UP(up_f32(e, &e->lnt_g, lg, H)); UP(up_f32(e, &e->lnt_b, lb, H));
         UP(up_f32(e, &e->bdec, bd, V, e->vpad));
-    } else {
+    } else if (c.head == CQS_HIP_BERT_HEAD_CLASSIFIER) {
         NEED(wp, "pooler.dense.weight", H * H);
         NEED(bp, "pooler.dense.bias", H);
         NEED(wc, "classifier.weight", (size_t)c.num_labels * H);
@@ -462,6 +467,36 @@ int32_t cqs_hip_rerank_logits(cqs_hip_bert* e, const int32_t* tokens, const int3
     B_TRY(e, hipStreamSynchronize(st));
     for (uint32_t b = 0; b < batch; ++b)
         for (uint32_t j = 0; j < c.num_labels; ++j) out_logits[(size_t)b * c.num_labels + j] = tmp[(size_t)b * 16 + j];
+    return CQS_HIP_OK;
+}
+
+// The BERT-family EMBEDDER presets (e5-base, v9-200k, bge-large, bge-large-ft: src/embedder/models.rs:346-405) below the
+// tokenizer: `session.run` -> last_hidden_state -> `mean_pool` / `cls_pool` (src/embedder/pooling.rs:87-128), all on the
+// device.  out [batch, hidden] f32, NOT normalised (the caller's `normalize_l2`, core.rs:1196-1203).
+int32_t cqs_hip_bert_embed(cqs_hip_bert* e, const int32_t* tokens, const int32_t* type_ids, const uint32_t* lens, uint32_t batch,
+                           uint32_t pooling, float* out) {
+    if (!e) return CQS_HIP_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(e->mu);
+    int32_t rc = check_ready(e, CQS_HIP_BERT_HEAD_NONE);
+    if (rc != CQS_HIP_OK) return rc;
+    if (batch == 0) return CQS_HIP_OK;
+    if (!lens || !out || pooling > 1u) return bfail(e, CQS_HIP_ERR_INVALID, "bert_embed: null buffer / unknown pooling");
+    {
+        uint64_t tot = 0;
+        for (uint32_t b = 0; b < batch; ++b) tot += lens[b];
+        if (tot && !tokens) return bfail(e, CQS_HIP_ERR_INVALID, "bert_embed: null tokens");
+    }
+    B_TRY(e, hipSetDevice(e->device));
+    uint32_t M = 0;
+    rc = run_encoder(e, tokens, type_ids, lens, batch, &M);
+    if (rc != CQS_HIP_OK) return rc;
+    const uint32_t H = e->cfg.hidden;
+    if (M == 0) { memset(out, 0, (size_t)batch * H * 4); return CQS_HIP_OK; }      // every sequence empty: zero vectors
+    const int32_t *d_start = e->d_meta + (size_t)3 * M, *d_len = d_start + batch;
+    hipStream_t st = e->stream;
+    B_TRY(e, cqs::launch_bert_pool(e->x, d_start, d_len, e->dense, batch, H, (int)pooling, st));
+    B_TRY(e, hipMemcpyAsync(out, e->dense, (size_t)batch * H * 4, hipMemcpyDeviceToHost, st));
+    B_TRY(e, hipStreamSynchronize(st));
     return CQS_HIP_OK;
 }
 

@@ -20,6 +20,10 @@ hipError_t launch_bert_attention(const bf16_t* qkv, bf16_t* out, const int32_t* 
                                  const int32_t* seq_start, const int32_t* seq_len, uint32_t heads, uint32_t head_dim,
                                  hipStream_t st);
 
+// out[b] = mean over the sequence's tokens of x (mode 0; empty sequence: zeros) or its first token (mode 1), f32 [B, H]
+hipError_t launch_bert_pool(const bf16_t* x, const int32_t* seq_start, const int32_t* seq_len, float* out, uint32_t B,
+                            uint32_t H, int mode, hipStream_t st);
+
 // x[i] <- ln(1 + x[i]) in place (the activation of src/splade/mod.rs:1049-1053 over launch_gemm_rowmax's maxima)
 hipError_t launch_splade_activate(float* x, size_t n, hipStream_t st);
 

@@ -332,7 +332,40 @@ __global__ __launch_bounds__(256) void splade_sparsify_kernel(const float* __res
     if (tid == 0) out_count[b] = base_s;
 }
 
+// Pooling of the BERT-family EMBEDDERS (e5-base, v9-200k, bge-large presets: src/embedder/models.rs:346-405), over the
+// packed final hidden states: mode 0 = `mean_pool` (src/embedder/pooling.rs:87-121: sum over the sequence's tokens /
+// their count, an empty sequence gives zeros), mode 1 = `cls_pool` (:123-128: the first token).  One workgroup per
+// sequence, a thread per 4 columns; f32 accumulation in token order.
+__global__ __launch_bounds__(256) void bert_pool_kernel(const bf16_t* __restrict__ x, const int32_t* __restrict__ seq_start,
+                                                        const int32_t* __restrict__ seq_len, float* __restrict__ out,
+                                                        uint32_t H, int mode) {
+    const uint32_t b = blockIdx.x, c = threadIdx.x * 4u;
+    if (c >= H) return;
+    const uint32_t s0 = (uint32_t)seq_start[b], L = (uint32_t)seq_len[b];
+    f4 acc = (f4)(0.f);
+    const uint32_t n = mode == 1 ? (L ? 1u : 0u) : L;
+    for (uint32_t t = 0; t < n; ++t) {
+        const bf4 v = *(const bf4*)(x + (size_t)(s0 + t) * H + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] += (float)v[e];
+    }
+    if (mode == 0 && L) {
+        const float cnt = (float)L;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = acc[e] / cnt;
+    }
+    *(f4*)(out + (size_t)b * H + c) = acc;
+}
+
 }  // namespace
+
+hipError_t launch_bert_pool(const bf16_t* x, const int32_t* seq_start, const int32_t* seq_len, float* out, uint32_t B,
+                            uint32_t H, int mode, hipStream_t st) {
+    if (B == 0) return hipSuccess;
+    if (H % 4u || H > 1024u) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(bert_pool_kernel, dim3(B), dim3(256), 0, st, x, seq_start, seq_len, out, H, mode);
+    return hipGetLastError();
+}
 
 hipError_t launch_splade_sparsify(const float* dense, uint32_t B, uint32_t V, float threshold, uint32_t cap, uint32_t* out_ids,
                                   float* out_w, uint32_t* out_count, hipStream_t st) {

@@ -125,6 +125,17 @@ class HipBertEngine:
                     "rerank_logits")
         return out
 
+    def embed(self, seqs: Sequence[np.ndarray], type_ids: Optional[Sequence[np.ndarray]] = None, pooling: str = "mean") -> np.ndarray:
+        """`cqs_hip_bert_embed`: pooled sentence vectors f32 [B, hidden], not normalised (head = NONE engines)."""
+        toks, lens = self._pack(seqs)
+        tt = self._pack(type_ids)[0] if type_ids is not None else None
+        out = np.empty((len(seqs), int(self.cfg.hidden)), np.float32)
+        self._check(self._lib.cqs_hip_bert_embed(self._h, toks.ctypes.data_as(C.c_void_p),
+                                                 tt.ctypes.data_as(C.c_void_p) if tt is not None else None,
+                                                 lens.ctypes.data_as(C.c_void_p), len(seqs), {"mean": 0, "cls": 1}[pooling],
+                                                 out.ctypes.data_as(C.c_void_p)), "bert_embed")
+        return out
+
     def hidden(self, seqs: Sequence[np.ndarray], type_ids: Optional[Sequence[np.ndarray]] = None) -> np.ndarray:
         toks, lens = self._pack(seqs)
         tt = self._pack(type_ids)[0] if type_ids is not None else None

@@ -313,12 +313,15 @@ float cqs_hip_embedder_last_ms(const cqs_hip_embedder* e);
  *                                 (src/splade/mod.rs:595-760, :774-1075)
  *   CQS_HIP_BERT_HEAD_CLASSIFIER  cross-encoder reranker (cross-encoder/ms-marco-MiniLM-L-6-v2); replaces the
  *                                 `session.run` of `Reranker::compute_scores_opt` (src/reranker.rs:343-533)
+ *   CQS_HIP_BERT_HEAD_NONE        the BERT-family EMBEDDER presets of the `Embedder` seam (e5-base, v9-200k: BERT-base;
+ *                                 bge-large, bge-large-ft: BERT-large; src/embedder/models.rs:346-405): replaces
+ *                                 `session.run` + `mean_pool` / `cls_pool` (src/embedder/pooling.rs:87-128)
  * The tokenizer stays on the host as in the reference; token ids come in packed (sequences back to back + lengths).
  * Weights are handed over by HF tensor name (set_tensor, f32, copied) and frozen by finalize.  Calls on one engine
- * are serialised by an internal mutex.  Geometry limits: hidden a multiple of 384 (<= 1024), head dim 32 or 64,
- * intermediate a multiple of 192. */
+ * are serialised by an internal mutex.  Geometry limits: hidden a multiple of 128 (<= 1024), head dim 32 or 64, and
+ * hidden, 3 x hidden and intermediate each a multiple of 192, 256 or 320 (a GEMM tile width). */
 typedef struct cqs_hip_bert cqs_hip_bert;
-enum { CQS_HIP_BERT_HEAD_MLM = 0, CQS_HIP_BERT_HEAD_CLASSIFIER = 1 };
+enum { CQS_HIP_BERT_HEAD_MLM = 0, CQS_HIP_BERT_HEAD_CLASSIFIER = 1, CQS_HIP_BERT_HEAD_NONE = 2 /* encoder only: the BERT-family embedders */ };
 typedef struct cqs_hip_bert_config {
     uint32_t vocab_size, hidden, layers, heads, intermediate, max_pos, type_vocab;
     uint32_t num_labels;   /* classifier head: outputs per sequence (1..16) */
@@ -356,6 +359,11 @@ int32_t cqs_hip_splade_encode_sparse(cqs_hip_bert* e, const int32_t* tokens, con
  * non-empty.  out_logits [batch, num_labels] f32; score = sigmoid(out_logits[b * num_labels]) (src/reranker.rs:516-518). */
 int32_t cqs_hip_rerank_logits(cqs_hip_bert* e, const int32_t* tokens, const int32_t* type_ids, const uint32_t* lens,
                               uint32_t batch, float* out_logits);
+/* Embedder presets (head = NONE): pooled sentence vectors f32 [batch, hidden], NOT normalised (the caller applies
+ * `normalize_l2`, src/embedder/core.rs:1196-1203).  pooling: 0 = mean over the sequence's tokens (`PoolingStrategy::Mean`,
+ * an empty sequence gives zeros), 1 = first token (`PoolingStrategy::Cls`).  type_ids NULL = all zero. */
+int32_t cqs_hip_bert_embed(cqs_hip_bert* e, const int32_t* tokens, const int32_t* type_ids, const uint32_t* lens,
+                           uint32_t batch, uint32_t pooling, float* out);
 /* Diagnostic: final encoder hidden states of the packed tokens, f32 [sum(lens), hidden]. */
 int32_t cqs_hip_bert_hidden(cqs_hip_bert* e, const int32_t* tokens, const int32_t* type_ids, const uint32_t* lens,
                             uint32_t batch, float* out_hidden);

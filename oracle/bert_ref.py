@@ -62,8 +62,18 @@ def minilm_l6() -> BertConfig:
     return BertConfig(hidden=384, layers=6, heads=12, intermediate=1536, num_labels=1)
 
 
+def e5_base() -> BertConfig:
+    """intfloat/e5-base-v2 and the v9-200k fine-tune: BERT-base (src/embedder/models.rs:346-372)."""
+    return BertConfig()
+
+
+def bge_large() -> BertConfig:
+    """BAAI/bge-large-en-v1.5 and bge-large-ft: BERT-large (src/embedder/models.rs:374-405)."""
+    return BertConfig(hidden=1024, layers=24, heads=16, intermediate=4096)
+
+
 def tensor_specs(cfg: BertConfig, head: str) -> List[Tuple[str, tuple, str]]:
-    """(name, shape, kind): HF names without the leading `bert.`; head = "mlm" | "classifier"."""
+    """(name, shape, kind): HF names without the leading `bert.`; head = "mlm" | "classifier" | "none"."""
     H, I = cfg.hidden, cfg.intermediate
     s = [("embeddings.word_embeddings.weight", (cfg.vocab_size, H), "embed"),
          ("embeddings.position_embeddings.weight", (cfg.max_pos, H), "embed"),
@@ -85,7 +95,7 @@ def tensor_specs(cfg: BertConfig, head: str) -> List[Tuple[str, tuple, str]]:
     elif head == "classifier":
         s += [("pooler.dense.weight", (H, H), "linear"), ("pooler.dense.bias", (H,), "beta"),
               ("classifier.weight", (cfg.num_labels, H), "linear"), ("classifier.bias", (cfg.num_labels,), "beta")]
-    else:
+    elif head != "none":
         raise ValueError(head)
     return s
 
@@ -209,6 +219,19 @@ def splade_encode_batch(cfg: BertConfig, w, ids: np.ndarray, mask: np.ndarray, t
     lens = mask.sum(axis=1)
     dense = np.stack([activate(splade_pool(logits[b], int(lens[b]))) for b in range(len(ids))])
     return [sparse_vector(splade_pool(logits[b], int(lens[b])), threshold) for b in range(len(ids))], dense
+
+
+def pooled_embedding(cfg: BertConfig, w, ids: np.ndarray, mask: np.ndarray, type_ids: np.ndarray | None = None,
+                     pooling: str = "mean") -> np.ndarray:
+    """The BERT-family embedder presets: last_hidden_state -> `mean_pool` (src/embedder/pooling.rs:87-121: masked sum /
+    count, zero rows for an empty mask) or `cls_pool` (:123-128).  Not normalised."""
+    h = encode(cfg, w, ids, mask, type_ids).numpy()
+    if pooling == "cls":
+        return h[:, 0].astype(np.float32)
+    m = mask.astype(np.float32)[:, :, None]
+    cnt = m.sum(axis=1)
+    summed = (h * m).sum(axis=1)
+    return np.where(cnt > 0, summed / np.maximum(cnt, 1.0), 0.0).astype(np.float32)
 
 
 def sigmoid(x):

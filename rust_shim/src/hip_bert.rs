@@ -38,6 +38,8 @@ pub struct CqsHipBertConfig {
 
 pub const HEAD_MLM: u32 = 0;
 pub const HEAD_CLASSIFIER: u32 = 1;
+/// Encoder only: the BERT-family embedder presets (e5-base, v9-200k, bge-large, bge-large-ft).
+pub const HEAD_NONE: u32 = 2;
 const CQS_HIP_OK: i32 = 0;
 
 #[link(name = "cqs_hip")]
@@ -50,6 +52,8 @@ extern "C" {
                                     cap: u32, out_ids: *mut u32, out_weights: *mut f32, out_counts: *mut u32) -> i32;
     fn cqs_hip_rerank_logits(e: *mut CqsHipBert, tokens: *const i32, type_ids: *const i32, lens: *const u32, batch: u32,
                              out_logits: *mut f32) -> i32;
+    fn cqs_hip_bert_embed(e: *mut CqsHipBert, tokens: *const i32, type_ids: *const i32, lens: *const u32, batch: u32,
+                          pooling: u32, out: *mut f32) -> i32;
     fn cqs_hip_bert_vocab(e: *const CqsHipBert) -> u32;
     fn cqs_hip_bert_last_error(e: *mut CqsHipBert, buf: *mut c_char, cap: usize) -> usize;
 }
@@ -135,6 +139,23 @@ impl HipBert {
                 let dense = self.splade_dense(&encodings[i..i + 1])?;
                 out.push(dense.iter().enumerate().filter_map(|(id, &v)| if v > threshold { Some((id as u32, v)) } else { None }).collect());
             }
+        }
+        Ok(out)
+    }
+
+    /// The BERT-family embedder presets (src/embedder/models.rs:346-405): `session.run` + `mean_pool` / `cls_pool`
+    /// (src/embedder/pooling.rs:87-128) in one call; `[batch, hidden]`, not normalised - `Embedder::embed_batch` keeps its
+    /// `normalize_l2` (core.rs:1196-1203).  `cls`: `PoolingStrategy::Cls`.
+    pub fn embed(&self, encodings: &[&[u32]], type_ids: &[&[u32]], cls: bool) -> Result<Vec<f32>, String> {
+        let (toks, lens) = Self::pack(encodings);
+        let tt: Vec<i32> = type_ids.iter().flat_map(|e| e.iter().map(|&t| t as i32)).collect();
+        let mut out = vec![0f32; encodings.len() * self.cfg.hidden as usize];
+        let rc = unsafe {
+            cqs_hip_bert_embed(self.raw, toks.as_ptr(), if tt.is_empty() { std::ptr::null() } else { tt.as_ptr() },
+                               lens.as_ptr(), lens.len() as u32, cls as u32, out.as_mut_ptr())
+        };
+        if rc != CQS_HIP_OK {
+            return Err(format!("cqs_hip_bert_embed: {} ({rc})", self.last_error()));
         }
         Ok(out)
     }

@@ -22,7 +22,7 @@ def hip():
 def _engine(cfg, head, seed):
     from cqs_amd import _lib
     from cqs_amd.splade import HipBertEngine, bert_config
-    kind = _lib.BERT_HEAD_MLM if head == "mlm" else _lib.BERT_HEAD_CLASSIFIER
+    kind = {"mlm": _lib.BERT_HEAD_MLM, "classifier": _lib.BERT_HEAD_CLASSIFIER, "none": _lib.BERT_HEAD_NONE}[head]
     c = bert_config(kind, vocab_size=cfg.vocab_size, hidden=cfg.hidden, layers=cfg.layers, heads=cfg.heads,
                     intermediate=cfg.intermediate, max_pos=cfg.max_pos, type_vocab=cfg.type_vocab,
                     num_labels=cfg.num_labels, ln_eps=cfg.ln_eps)
@@ -192,7 +192,7 @@ def test_full_geometry_presets(hip):
 def _bert_cfg(cfg, head):
     from cqs_amd import _lib
     from cqs_amd.splade import bert_config
-    kind = _lib.BERT_HEAD_MLM if head == "mlm" else _lib.BERT_HEAD_CLASSIFIER
+    kind = {"mlm": _lib.BERT_HEAD_MLM, "classifier": _lib.BERT_HEAD_CLASSIFIER, "none": _lib.BERT_HEAD_NONE}[head]
     return bert_config(kind, vocab_size=cfg.vocab_size, hidden=cfg.hidden, layers=cfg.layers, heads=cfg.heads,
                        intermediate=cfg.intermediate, max_pos=cfg.max_pos, type_vocab=cfg.type_vocab,
                        num_labels=cfg.num_labels, ln_eps=cfg.ln_eps)
@@ -291,4 +291,41 @@ def test_splade_device_side_threshold_filter(hip):
     for b in range(len(seqs)):
         keep = np.nonzero(dense[b] > np.float32(0.05))[0]
         assert np.array_equal(got[b][0], keep.astype(np.uint32)) and np.array_equal(got[b][1], dense[b][keep])
+    eng.close()
+
+
+@pytest.mark.parametrize("hidden,heads,inter", [(384, 6, 768), (768, 12, 3072), (1024, 16, 1024)])
+def test_bert_embedder_presets_pooling(hip, hidden, heads, inter):
+    """The BERT-family EMBEDDER presets (e5-base / v9-200k: BERT-base; bge-large: BERT-large, hidden 1024): encoder +
+    `mean_pool` / `cls_pool` (src/embedder/pooling.rs:87-128) on the device against the oracle; an empty sequence pools
+    to zeros; results do not depend on the batch."""
+    cfg = R.BertConfig(vocab_size=900, hidden=hidden, layers=2, heads=heads, intermediate=inter, max_pos=160)
+    eng, w = _engine(cfg, "none", seed=41)
+    lens = [50, 0, 160, 1, 97]
+    seqs = _seqs(cfg, lens, seed=42)
+    types = [np.zeros(n, np.int32) for n in lens]
+    live = [i for i, n in enumerate(lens) if n]
+    ids, mask, tt = _padded([seqs[i] for i in live], [types[i] for i in live])
+    for pooling in ("mean", "cls"):
+        got = eng.embed(seqs, types, pooling=pooling)
+        want = R.pooled_embedding(cfg, w, ids, mask, tt, pooling)
+        assert got.shape == (len(lens), hidden) and np.all(got[1] == 0)
+        for j, i in enumerate(live):
+            assert cos(got[i], want[j]) > 0.999 and np.max(np.abs(got[i] - want[j])) < 0.05 * np.abs(want[j]).max() + 0.02, (pooling, i)
+        assert np.array_equal(eng.embed([seqs[2]], None, pooling=pooling)[0], got[2])       # alone == in the batch (type ids default 0)
+    with pytest.raises(Exception):
+        eng.splade_dense(seqs)                                                               # wrong head
+    eng.close()
+
+
+def test_bge_large_full_geometry(hip):
+    cfg = R.bge_large()
+    eng, w = _engine(cfg, "none", seed=43)
+    seqs = _seqs(cfg, [120, 512, 30], seed=44)
+    got = eng.embed(seqs, None, pooling="mean")
+    ids, mask, tt = _padded(seqs)
+    want = R.pooled_embedding(cfg, w, ids, mask, tt, "mean")
+    assert got.shape == (3, 1024)
+    for i in range(3):
+        assert cos(got[i], want[i]) > 0.999, (i, cos(got[i], want[i]))
     eng.close()
