@@ -328,8 +328,9 @@ typedef struct cqs_hip_bert_config {
     uint32_t head;         /* CQS_HIP_BERT_HEAD_* */
     float ln_eps;
 } cqs_hip_bert_config;
-/* The two presets the reference ships with: head = MLM -> BERT-base / vocab 30522 (src/splade/mod.rs:120-150);
- * head = CLASSIFIER -> MiniLM-L6-H384, one label (src/reranker.rs:7,35). */
+/* Presets: head = MLM -> BERT-base / vocab 30522 (src/splade/mod.rs:120-150); head = CLASSIFIER -> MiniLM-L6-H384, one
+ * label (src/reranker.rs:7,35); head = NONE -> BERT-base (e5-base / v9-200k; for bge-large set hidden 1024, layers 24,
+ * heads 16, intermediate 4096: src/embedder/models.rs:346-405). */
 int32_t cqs_hip_bert_config_default(uint32_t head, cqs_hip_bert_config* out);
 int32_t cqs_hip_bert_create(const cqs_hip_bert_config* cfg, int32_t device, cqs_hip_bert** out);
 /* name: the Hugging Face tensor name, with or without the leading `bert.` (e.g.
