@@ -216,6 +216,14 @@ def test_load_dir_safetensors_checkpoint(hip, tmp_path):
     a, b = eng.splade_dense(seqs), eng2.splade_dense(seqs)
     assert np.max(np.abs(a - b)) < 0.03 and all(cos(a[i], b[i]) > 0.9999 for i in range(3))   # one weight went through f16
     eng.close(); eng2.close()
+    # the same checkpoint opened as an EMBEDDER (encoder only): head tensors in the file are skipped
+    eng3 = HipBertEngine.load_dir(str(tmp_path), _bert_cfg(cfg, "none"))
+    ids, mask, tt = _padded(seqs)
+    w16 = dict(w)
+    want = R.pooled_embedding(cfg, w16, ids, mask, tt, "mean")
+    got = eng3.embed(seqs, None, "mean")
+    assert all(cos(got[i], want[i]) > 0.999 for i in range(3))
+    eng3.close()
 
 
 @pytest.mark.parametrize("flat", [False, True])
