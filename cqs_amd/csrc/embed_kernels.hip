@@ -1306,8 +1306,11 @@ hipError_t launch_gemm_bias(const bf16_t* A, const bf16_t* W, const float* bias,
     if (out == GEMM_OUT_GEGLU || K % 64u) return hipErrorInvalidValue;
     // small batches (a query, a rerank of a few dozen passages): one wave per 32 x 32 tile, no fixed cost of the 256-row
     // kernel's prologue / epilogue (13-50 us per projection at a few thousand tokens; measured crossover below)
-    static const uint32_t few_max = [] { const char* f = getenv("CQS_HIP_GEMM_BIAS_FEWROWS"); return f ? (uint32_t)atoi(f) : 2048u; }();
-    if (M <= few_max && N % 64u == 0) return launch_gemm_fewrows(A, W, bias, C, M, N, K, ldc, out, st);
+    // Crossover measured on whole forwards (tools/bert_fewrows_sweep.py): few-rows wins up to ~900 tokens for BERT-base
+    // (hidden 768), ~600 for BERT-large (1024), ~2000 for MiniLM (384) - for ALL of a layer's projections, the K = 4 x
+    // hidden one included - i.e. tokens x hidden <~ 640 Ki; min(N, K) is the hidden size of every BERT projection.
+    static const uint64_t few_mh = [] { const char* f = getenv("CQS_HIP_GEMM_BIAS_FEWROWS_MH"); return f ? (uint64_t)atoll(f) : 640ull * 1024ull; }();
+    if ((uint64_t)M * (N < K ? N : K) <= few_mh && N % 64u == 0) return launch_gemm_fewrows(A, W, bias, C, M, N, K, ldc, out, st);
     static int n_cu = 0;
     if (n_cu == 0) {
         int dev = 0;
