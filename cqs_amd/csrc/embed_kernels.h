@@ -52,7 +52,7 @@ hipError_t launch_add_norm(float* x, const bf16_t* y, const float* w_post, const
 enum GemmOut { GEMM_OUT_BF16 = 0, GEMM_OUT_F32 = 1, GEMM_OUT_GEGLU = 2, GEMM_OUT_BF16_GELU = 3 /* bf16(gelu_erf(x + bias)): launch_gemm_p8 / _bias only */,
                GEMM_OUT_ROWMAX = 4 /* launch_gemm_rowmax only */ };
 hipError_t launch_gemm_bf16(const bf16_t* A, const bf16_t* W, void* C, uint32_t M, uint32_t N, uint32_t K,
-                            uint32_t ldc, GemmOut out, hipStream_t st);
+                            uint32_t ldc, GemmOut out, hipStream_t st, const float* bias = nullptr /*[N] f32; not with GEGLU*/);
 
 // A few rows against a big matrix (the Dense head: M = sequences of the batch): one workgroup per 16 x 16 output tile,
 // K split over its 4 waves.  GEMM_OUT_BF16 / GEMM_OUT_F32; N % 16 == 0, K % 32 == 0; M > 256 goes to launch_gemm_bf16.
