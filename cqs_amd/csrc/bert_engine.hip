@@ -4,6 +4,7 @@
 // 533: ORT runs BertForSequenceClassification, Rust applies a sigmoid).  SURVEY.md §8(f)4.  Operator semantics:
 // oracle/bert_ref.py.  No CPU fallback: without a GPU `cqs_hip_bert_create` fails.
 #include "../../include/cqs_hip.h"
+#include "abi_guard.h"
 #include "bert_kernels.h"
 #include "onnx_reader.h"
 #include "safetensors_reader.h"
@@ -17,6 +18,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -215,7 +217,7 @@ int32_t check_ready(cqs_hip_bert* e, uint32_t head) {
 
 extern "C" {
 
-int32_t cqs_hip_bert_config_default(uint32_t head, cqs_hip_bert_config* c) {
+int32_t cqs_hip_bert_config_default(uint32_t head, cqs_hip_bert_config* c) CQS_ABI_TRY {
     if (!c) return CQS_HIP_ERR_INVALID;
     memset(c, 0, sizeof(*c));
     c->vocab_size = 30522; c->max_pos = 512; c->type_vocab = 2; c->ln_eps = 1e-12f; c->num_labels = 1; c->head = head;
@@ -229,9 +231,9 @@ int32_t cqs_hip_bert_config_default(uint32_t head, cqs_hip_bert_config* c) {
         return CQS_HIP_ERR_INVALID;
     }
     return CQS_HIP_OK;
-}
+} CQS_ABI_CATCH_NOHANDLE
 
-int32_t cqs_hip_bert_create(const cqs_hip_bert_config* cfg, int32_t device, cqs_hip_bert** out) {
+int32_t cqs_hip_bert_create(const cqs_hip_bert_config* cfg, int32_t device, cqs_hip_bert** out) CQS_ABI_TRY {
     if (!cfg || !out) return CQS_HIP_ERR_INVALID;
     *out = nullptr;
     const cqs_hip_bert_config& c = *cfg;
@@ -244,21 +246,21 @@ int32_t cqs_hip_bert_create(const cqs_hip_bert_config* cfg, int32_t device, cqs_
     if (!ok_cfg) return CQS_HIP_ERR_INVALID;
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return CQS_HIP_ERR_NO_DEVICE;
-    cqs_hip_bert* e = new cqs_hip_bert();
+    cqs_hip_bert* e = new (std::nothrow) cqs_hip_bert();
+    if (!e) return CQS_HIP_ERR_NOMEM;
+    std::unique_ptr<cqs_hip_bert> owner(e);     // a throwing resize below must not leak the handle
     e->device = device;
     e->cfg = c;
     e->vpad = (c.vocab_size + 191u) / 192u * 192u;
     e->L.resize(c.layers);
-    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) {
-        delete e;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess)
         return CQS_HIP_ERR_DEVICE;
-    }
-    *out = e;
+    *out = owner.release();
     return CQS_HIP_OK;
-}
+} CQS_ABI_CATCH_NOHANDLE
 
 // HF names, with or without the leading `bert.`; data f32, row-major; copied.
-int32_t cqs_hip_bert_set_tensor(cqs_hip_bert* e, const char* name, const float* data, uint64_t count) {
+int32_t cqs_hip_bert_set_tensor(cqs_hip_bert* e, const char* name, const float* data, uint64_t count) CQS_ABI_TRY {
     if (!e || !name || !data) return CQS_HIP_ERR_INVALID;
     std::lock_guard<std::mutex> lk(e->mu);
     if (e->finalized) return bfail(e, CQS_HIP_ERR_INVALID, "bert: weights already finalized");
@@ -266,9 +268,9 @@ int32_t cqs_hip_bert_set_tensor(cqs_hip_bert* e, const char* name, const float* 
     if (n.rfind("bert.", 0) == 0) n = n.substr(5);
     e->pending[n].assign(data, data + count);
     return CQS_HIP_OK;
-}
+} CQS_ABI_CATCH(e)
 
-int32_t cqs_hip_bert_finalize(cqs_hip_bert* e) {
+int32_t cqs_hip_bert_finalize(cqs_hip_bert* e) CQS_ABI_TRY {
     if (!e) return CQS_HIP_ERR_INVALID;
     std::lock_guard<std::mutex> lk(e->mu);
     if (e->finalized) return CQS_HIP_OK;
@@ -346,7 +348,7 @@ int32_t cqs_hip_bert_finalize(cqs_hip_bert* e) {
     e->pending.clear();
     e->finalized = true;
     return CQS_HIP_OK;
-}
+} CQS_ABI_CATCH(e)
 
 namespace {
 
@@ -383,7 +385,7 @@ int32_t splade_forward(cqs_hip_bert* e, const int32_t* tokens, const uint32_t* l
 // `SpladeEncoder::encode_batch` below the tokenizer: sequences back to back (i32 ids) + their lengths; out_dense
 // [batch, vocab] f32 = ln(1 + max(0, max over the sequence's tokens of the MLM logits)) - the model's pre-pooled
 // `sparse_vector` output form (src/splade/mod.rs:960-978); the caller keeps entries > threshold.
-int32_t cqs_hip_splade_encode(cqs_hip_bert* e, const int32_t* tokens, const uint32_t* lens, uint32_t batch, float* out_dense) {
+int32_t cqs_hip_splade_encode(cqs_hip_bert* e, const int32_t* tokens, const uint32_t* lens, uint32_t batch, float* out_dense) CQS_ABI_TRY {
     if (!e) return CQS_HIP_ERR_INVALID;
     std::lock_guard<std::mutex> lk(e->mu);
     int32_t rc = check_ready(e, CQS_HIP_BERT_HEAD_MLM);
@@ -399,14 +401,14 @@ int32_t cqs_hip_splade_encode(cqs_hip_bert* e, const int32_t* tokens, const uint
     B_TRY(e, hipMemcpyAsync(out_dense, e->dense, (size_t)batch * V * 4, hipMemcpyDeviceToHost, e->stream));
     B_TRY(e, hipStreamSynchronize(e->stream));
     return CQS_HIP_OK;
-}
+} CQS_ABI_CATCH(e)
 
 // The same with the threshold filter of src/splade/mod.rs:1049-1062 on the device: sequence b's entries > threshold
 // as (id, weight), ascending id, at out_ids / out_weights [b * cap ..]; out_counts[b] = how many passed.  A count above
 // `cap` means the row was cut off after its first `cap` entries: the caller re-encodes that sequence through
 // cqs_hip_splade_encode (trained models keep 100-300 entries, src/splade/mod.rs:44).
 int32_t cqs_hip_splade_encode_sparse(cqs_hip_bert* e, const int32_t* tokens, const uint32_t* lens, uint32_t batch,
-                                     float threshold, uint32_t cap, uint32_t* out_ids, float* out_weights, uint32_t* out_counts) {
+                                     float threshold, uint32_t cap, uint32_t* out_ids, float* out_weights, uint32_t* out_counts) CQS_ABI_TRY {
     if (!e) return CQS_HIP_ERR_INVALID;
     std::lock_guard<std::mutex> lk(e->mu);
     int32_t rc = check_ready(e, CQS_HIP_BERT_HEAD_MLM);
@@ -436,12 +438,12 @@ int32_t cqs_hip_splade_encode_sparse(cqs_hip_bert* e, const int32_t* tokens, con
     B_TRY(e, hipMemcpyAsync(out_counts, e->sp_cnt, (size_t)batch * 4, hipMemcpyDeviceToHost, st));
     B_TRY(e, hipStreamSynchronize(st));
     return CQS_HIP_OK;
-}
+} CQS_ABI_CATCH(e)
 
 // `compute_scores_opt` below the tokenizer (src/reranker.rs:343-533): (query, passage) pairs already encoded as ids +
 // token type ids; out_logits [batch, num_labels] f32 (the caller applies sigmoid to column 0).
 int32_t cqs_hip_rerank_logits(cqs_hip_bert* e, const int32_t* tokens, const int32_t* type_ids, const uint32_t* lens,
-                              uint32_t batch, float* out_logits) {
+                              uint32_t batch, float* out_logits) CQS_ABI_TRY {
     if (!e) return CQS_HIP_ERR_INVALID;
     std::lock_guard<std::mutex> lk(e->mu);
     int32_t rc = check_ready(e, CQS_HIP_BERT_HEAD_CLASSIFIER);
@@ -468,13 +470,13 @@ int32_t cqs_hip_rerank_logits(cqs_hip_bert* e, const int32_t* tokens, const int3
     for (uint32_t b = 0; b < batch; ++b)
         for (uint32_t j = 0; j < c.num_labels; ++j) out_logits[(size_t)b * c.num_labels + j] = tmp[(size_t)b * 16 + j];
     return CQS_HIP_OK;
-}
+} CQS_ABI_CATCH(e)
 
 // The BERT-family EMBEDDER presets (e5-base, v9-200k, bge-large, bge-large-ft: src/embedder/models.rs:346-405) below the
 // tokenizer: `session.run` -> last_hidden_state -> `mean_pool` / `cls_pool` (src/embedder/pooling.rs:87-128), all on the
 // device.  out [batch, hidden] f32, NOT normalised (the caller's `normalize_l2`, core.rs:1196-1203).
 int32_t cqs_hip_bert_embed(cqs_hip_bert* e, const int32_t* tokens, const int32_t* type_ids, const uint32_t* lens, uint32_t batch,
-                           uint32_t pooling, float* out) {
+                           uint32_t pooling, float* out) CQS_ABI_TRY {
     if (!e) return CQS_HIP_ERR_INVALID;
     std::lock_guard<std::mutex> lk(e->mu);
     int32_t rc = check_ready(e, CQS_HIP_BERT_HEAD_NONE);
@@ -498,11 +500,11 @@ int32_t cqs_hip_bert_embed(cqs_hip_bert* e, const int32_t* tokens, const int32_t
     B_TRY(e, hipMemcpyAsync(out, e->dense, (size_t)batch * H * 4, hipMemcpyDeviceToHost, st));
     B_TRY(e, hipStreamSynchronize(st));
     return CQS_HIP_OK;
-}
+} CQS_ABI_CATCH(e)
 
 // Diagnostic: final hidden states of the packed tokens, f32 [sum(lens), hidden].
 int32_t cqs_hip_bert_hidden(cqs_hip_bert* e, const int32_t* tokens, const int32_t* type_ids, const uint32_t* lens,
-                            uint32_t batch, float* out_hidden) {
+                            uint32_t batch, float* out_hidden) CQS_ABI_TRY {
     if (!e) return CQS_HIP_ERR_INVALID;
     std::lock_guard<std::mutex> lk(e->mu);
     int32_t rc = check_ready(e, 0xFFFFFFFFu);
@@ -521,19 +523,23 @@ int32_t cqs_hip_bert_hidden(cqs_hip_bert* e, const int32_t* tokens, const int32_
         memcpy(&out_hidden[i], &u, 4);
     }
     return CQS_HIP_OK;
-}
+} CQS_ABI_CATCH(e)
 
 // `create_session` for these two models (src/embedder/provider.rs:254-447 via src/splade/mod.rs:433-560 and
 // src/reranker.rs:266-330): the local bundle is `{dir}/onnx/model.onnx` (+ external data) or `{dir}/model.onnx`
 // (src/reranker.rs:548-556); a Hugging Face checkpoint directory (`model.safetensors`) is accepted as well.
 // ONNX initialisers are found as in the embedding engine (onnx_reader.cpp): named tensors by name, anonymous
 // transposed MatMul operands through the consuming node's module path.
-int32_t cqs_hip_bert_load_dir(const char* model_dir, const cqs_hip_bert_config* cfg, int32_t device, cqs_hip_bert** out) {
+int32_t cqs_hip_bert_load_dir(const char* model_dir, const cqs_hip_bert_config* cfg, int32_t device, cqs_hip_bert** out) CQS_ABI_TRY {
     if (!model_dir || !cfg || !out) return CQS_HIP_ERR_INVALID;
     *out = nullptr;
     cqs_hip_bert* e = nullptr;
     int32_t rc = cqs_hip_bert_create(cfg, device, &e);
     if (rc != CQS_HIP_OK) return rc;
+    struct Owner {   // every exit but the last, exceptions out of the readers included, gives the handle back
+        cqs_hip_bert* p;
+        ~Owner() { if (p) cqs_hip_bert_destroy(p); }
+    } owner{e};
     const std::string d(model_dir);
     auto exists = [](const std::string& p) { struct stat st; return stat(p.c_str(), &st) == 0; };
     // names both readers may hand over -> the engine's; unknown tensors (graph constants, position_ids) are skipped
@@ -569,20 +575,19 @@ int32_t cqs_hip_bert_load_dir(const char* model_dir, const cqs_hip_bert_config* 
     }
     if (fed < 0) {
         fprintf(stderr, "[cqs_hip] bert load_dir failed: %s\n", err.c_str());
-        cqs_hip_bert_destroy(e);
         return CQS_HIP_ERR_INVALID;
     }
     rc = cqs_hip_bert_finalize(e);
     if (rc != CQS_HIP_OK) {
         fprintf(stderr, "[cqs_hip] bert load_dir failed: %s\n", e->last_error.c_str());
-        cqs_hip_bert_destroy(e);
         return rc;
     }
+    owner.p = nullptr;
     *out = e;
     return CQS_HIP_OK;
-}
+} CQS_ABI_CATCH_NOHANDLE
 
-void cqs_hip_bert_destroy(cqs_hip_bert* e) {
+void cqs_hip_bert_destroy(cqs_hip_bert* e) CQS_ABI_TRY {
     if (!e) return;
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
@@ -590,17 +595,17 @@ void cqs_hip_bert_destroy(cqs_hip_bert* e) {
     free_scratch(e);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
-}
+} CQS_ABI_CATCH_VOID
 
-uint32_t cqs_hip_bert_vocab(const cqs_hip_bert* e) { return e ? e->cfg.vocab_size : 0; }
-int32_t cqs_hip_bert_poisoned(const cqs_hip_bert* e) { return e && e->poisoned.load(std::memory_order_acquire) ? 1 : 0; }
-size_t cqs_hip_bert_last_error(cqs_hip_bert* e, char* buf, size_t cap) {
+uint32_t cqs_hip_bert_vocab(const cqs_hip_bert* e) CQS_ABI_TRY { return e ? e->cfg.vocab_size : 0; } CQS_ABI_CATCH_VAL(0)
+int32_t cqs_hip_bert_poisoned(const cqs_hip_bert* e) CQS_ABI_TRY { return e && e->poisoned.load(std::memory_order_acquire) ? 1 : 0; } CQS_ABI_CATCH_NOHANDLE
+size_t cqs_hip_bert_last_error(cqs_hip_bert* e, char* buf, size_t cap) CQS_ABI_TRY {
     if (!e || !buf || cap == 0) return 0;
     std::lock_guard<std::mutex> lk(e->mu);
     const size_t m = e->last_error.size() < cap - 1 ? e->last_error.size() : cap - 1;
     memcpy(buf, e->last_error.data(), m);
     buf[m] = 0;
     return m;
-}
+} CQS_ABI_CATCH_VAL(0)
 
 }  // extern "C"

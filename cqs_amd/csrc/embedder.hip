@@ -21,6 +21,7 @@
 #include <sys/stat.h>
 
 #include "../../include/cqs_hip.h"
+#include "abi_guard.h"
 #include "embed_kernels.h"
 #include "onnx_reader.h"
 #include "safetensors_reader.h"
@@ -333,14 +334,14 @@ bool known_tensor(const cqs_hip_embedder* e, const std::string& name) {
 
 extern "C" {
 
-void cqs_hip_embed_config_default(cqs_hip_embed_config* c) {
+void cqs_hip_embed_config_default(cqs_hip_embed_config* c) CQS_ABI_TRY {
     if (!c) return;
     c->vocab_size = 262144; c->hidden = 768; c->layers = 24; c->heads = 3; c->kv_heads = 1; c->head_dim = 256;
     c->intermediate = 1152; c->dense_hidden = 3072; c->sliding_window = 512; c->sliding_pattern = 6; c->max_seq = 2048;
     c->rms_eps = 1e-6f; c->rope_theta_global = 1e6f; c->rope_theta_local = 1e4f; c->query_pre_attn_scalar = 256.f;
-}
+} CQS_ABI_CATCH_VOID
 
-int32_t cqs_hip_embedder_create(const cqs_hip_embed_config* c, int32_t device, cqs_hip_embedder** out) {
+int32_t cqs_hip_embedder_create(const cqs_hip_embed_config* c, int32_t device, cqs_hip_embedder** out) CQS_ABI_TRY {
     if (!c || !out) return CQS_HIP_ERR_INVALID;
     *out = nullptr;
     if (c->head_dim != 256 || c->hidden == 0 || c->hidden % 256 || c->hidden > 1024 || c->intermediate % 64 ||
@@ -352,6 +353,10 @@ int32_t cqs_hip_embedder_create(const cqs_hip_embed_config* c, int32_t device, c
     if (device < 0 || device >= cnt) return CQS_HIP_ERR_INVALID;
     cqs_hip_embedder* e = new (std::nothrow) cqs_hip_embedder();
     if (!e) return CQS_HIP_ERR_NOMEM;
+    struct Owner {   // an exception below (L.resize, the rope table) must not leak the handle or its device buffers
+        cqs_hip_embedder* p;
+        ~Owner() { if (p) cqs_hip_embedder_destroy(p); }
+    } owner{e};
     e->device = device;
     e->cfg = *c;
     cqs::EmbedGeom& g = e->g;
@@ -375,7 +380,7 @@ int32_t cqs_hip_embedder_create(const cqs_hip_embed_config* c, int32_t device, c
              dmalloc(&w.n_in, H) == hipSuccess && dmalloc(&w.n_post_attn, H) == hipSuccess && dmalloc(&w.n_pre_ffw, H) == hipSuccess &&
              dmalloc(&w.n_post_ffw, H) == hipSuccess && dmalloc(&w.n_q, D) == hipSuccess && dmalloc(&w.n_k, D) == hipSuccess;
     }
-    if (!ok) { cqs_hip_embedder_destroy(e); return CQS_HIP_ERR_NOMEM; }
+    if (!ok) return CQS_HIP_ERR_NOMEM;
     // RoPE tables, computed like transformers does (fp32 inv_freq, fp32 angle; modeling_gemma3.py:188-224)
     std::vector<float> tab((size_t)g.max_seq * 256);
     for (int t = 0; t < 2; ++t) {
@@ -387,16 +392,15 @@ int32_t cqs_hip_embedder_create(const cqs_hip_embed_config* c, int32_t device, c
                 tab[((size_t)pz * 128 + i) * 2] = cosf(a);
                 tab[((size_t)pz * 128 + i) * 2 + 1] = sinf(a);
             }
-        if (hipMemcpy(t == 0 ? e->rope_global : e->rope_local, tab.data(), tab.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
-            cqs_hip_embedder_destroy(e);
+        if (hipMemcpy(t == 0 ? e->rope_global : e->rope_local, tab.data(), tab.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
             return CQS_HIP_ERR_DEVICE;
-        }
     }
+    owner.p = nullptr;
     *out = e;
     return CQS_HIP_OK;
-}
+} CQS_ABI_CATCH_NOHANDLE
 
-int32_t cqs_hip_embedder_set_tensor(cqs_hip_embedder* e, const char* cname, const float* data, uint64_t count) {
+int32_t cqs_hip_embedder_set_tensor(cqs_hip_embedder* e, const char* cname, const float* data, uint64_t count) CQS_ABI_TRY {
     if (!e || !cname || !data) return CQS_HIP_ERR_INVALID;
     std::lock_guard<std::mutex> lk(e->mu);
     if (e->finalized) return efail(e, CQS_HIP_ERR_INVALID, "set_tensor after finalize");
@@ -443,9 +447,9 @@ int32_t cqs_hip_embedder_set_tensor(cqs_hip_embedder* e, const char* cname, cons
     if (rc == CQS_HIP_ERR_INVALID) return efail(e, rc, "set_tensor: wrong element count for " + name);
     if (rc == CQS_HIP_OK) e->seen[name] = true;
     return rc;
-}
+} CQS_ABI_CATCH(e)
 
-int32_t cqs_hip_embedder_finalize(cqs_hip_embedder* e) {
+int32_t cqs_hip_embedder_finalize(cqs_hip_embedder* e) CQS_ABI_TRY {
     if (!e) return CQS_HIP_ERR_INVALID;
     std::lock_guard<std::mutex> lk(e->mu);
     std::vector<std::string> need = {"embed_tokens.weight", "norm.weight", "dense1.weight", "dense2.weight"};
@@ -455,15 +459,19 @@ int32_t cqs_hip_embedder_finalize(cqs_hip_embedder* e) {
         if (!e->seen.count(n)) return efail(e, CQS_HIP_ERR_INVALID, "finalize: missing tensor " + n);
     e->finalized = true;
     return CQS_HIP_OK;
-}
+} CQS_ABI_CATCH(e)
 
-int32_t cqs_hip_embedder_load_dir(const char* dir, const cqs_hip_embed_config* cfg, int32_t device, cqs_hip_embedder** out) {
+int32_t cqs_hip_embedder_load_dir(const char* dir, const cqs_hip_embed_config* cfg, int32_t device, cqs_hip_embedder** out) CQS_ABI_TRY {
     if (!dir || !out) return CQS_HIP_ERR_INVALID;
     cqs_hip_embed_config c;
     if (cfg) c = *cfg; else cqs_hip_embed_config_default(&c);
     cqs_hip_embedder* e = nullptr;
     int32_t rc = cqs_hip_embedder_create(&c, device, &e);
     if (rc != CQS_HIP_OK) return rc;
+    struct Owner {   // every exit but the last, exceptions out of the readers included, gives the handle back
+        cqs_hip_embedder* p;
+        ~Owner() { if (p) cqs_hip_embedder_destroy(p); }
+    } owner{e};
     const std::string d(dir);
     auto strip = [](const std::string& n) -> std::string {  // HF checkpoints prefix text-model tensors with "model."
         if (n.rfind("model.", 0) == 0) return n.substr(6);
@@ -495,14 +503,14 @@ int32_t cqs_hip_embedder_load_dir(const char* dir, const cqs_hip_embed_config* c
     if (rc == CQS_HIP_OK) rc = cqs_hip_embedder_finalize(e);
     if (rc != CQS_HIP_OK) {
         fprintf(stderr, "[cqs_hip] embedder load_dir failed: %s\n", e->last_error.c_str());
-        cqs_hip_embedder_destroy(e);
         return rc;
     }
+    owner.p = nullptr;
     *out = e;
     return CQS_HIP_OK;
-}
+} CQS_ABI_CATCH_NOHANDLE
 
-void cqs_hip_embedder_destroy(cqs_hip_embedder* e) {
+void cqs_hip_embedder_destroy(cqs_hip_embedder* e) CQS_ABI_TRY {
     if (!e) return;
     (void)hipSetDevice(e->device);
     for (Ctx& c : e->ctx)
@@ -524,20 +532,20 @@ void cqs_hip_embedder_destroy(cqs_hip_embedder* e) {
     for (Ctx& c : e->ctx)
         if (c.stream) (void)hipStreamDestroy(c.stream);
     delete e;
-}
+} CQS_ABI_CATCH_VOID
 
-uint32_t cqs_hip_embedder_dim(const cqs_hip_embedder* e) { return e ? e->g.hidden : 0; }
-uint32_t cqs_hip_embedder_max_seq(const cqs_hip_embedder* e) { return e ? e->g.max_seq : 0; }
-int32_t cqs_hip_embedder_poisoned(const cqs_hip_embedder* e) { return e && e->poisoned.load(std::memory_order_acquire) ? 1 : 0; }
-float cqs_hip_embedder_last_ms(const cqs_hip_embedder* e) { return e ? e->last_ms : -1.f; }
-size_t cqs_hip_embedder_last_error(const cqs_hip_embedder* e, char* buf, size_t cap) {
+uint32_t cqs_hip_embedder_dim(const cqs_hip_embedder* e) CQS_ABI_TRY { return e ? e->g.hidden : 0; } CQS_ABI_CATCH_VAL(0)
+uint32_t cqs_hip_embedder_max_seq(const cqs_hip_embedder* e) CQS_ABI_TRY { return e ? e->g.max_seq : 0; } CQS_ABI_CATCH_VAL(0)
+int32_t cqs_hip_embedder_poisoned(const cqs_hip_embedder* e) CQS_ABI_TRY { return e && e->poisoned.load(std::memory_order_acquire) ? 1 : 0; } CQS_ABI_CATCH_NOHANDLE
+float cqs_hip_embedder_last_ms(const cqs_hip_embedder* e) CQS_ABI_TRY { return e ? e->last_ms : -1.f; } CQS_ABI_CATCH_VAL(-1.f)
+size_t cqs_hip_embedder_last_error(const cqs_hip_embedder* e, char* buf, size_t cap) CQS_ABI_TRY {
     if (!e || !buf || cap == 0) return 0;
     std::lock_guard<std::mutex> lk(e->mu);
     const size_t m = e->last_error.size() < cap - 1 ? e->last_error.size() : cap - 1;
     memcpy(buf, e->last_error.data(), m);
     buf[m] = 0;
     return m;
-}
+} CQS_ABI_CATCH_VAL(0)
 
 // ---- submit / collect ---------------------------------------------------------------------------------------
 // submit: validate + pack into a free slot's pinned tables (host work), enqueue H2D + forward + pool / dense +
@@ -589,22 +597,22 @@ int32_t submit_locked(cqs_hip_embedder* e, uint32_t B, const std::function<int32
 }  // namespace
 
 int32_t cqs_hip_embed_submit(cqs_hip_embedder* e, const int64_t* ids, const int64_t* mask, uint32_t B, uint32_t L,
-                             uint64_t* ticket) {
+                             uint64_t* ticket) CQS_ABI_TRY {
     if (!e) return CQS_HIP_ERR_INVALID;
     std::lock_guard<std::mutex> lk(e->mu);
     if (!ids || !mask || L == 0) return efail(e, CQS_HIP_ERR_INVALID, "embed: null buffer / empty sequence");
     return submit_locked(e, B, [&](cqs_hip_embedder::Slot& sl) { return pack_padded(e, sl, ids, mask, B, L); }, ticket);
-}
+} CQS_ABI_CATCH(e)
 
 int32_t cqs_hip_embed_submit_ragged(cqs_hip_embedder* e, const int32_t* tokens, const uint32_t* lens, uint32_t B,
-                                    uint64_t* ticket) {
+                                    uint64_t* ticket) CQS_ABI_TRY {
     if (!e) return CQS_HIP_ERR_INVALID;
     std::lock_guard<std::mutex> lk(e->mu);
     if (!lens || (!tokens && B)) return efail(e, CQS_HIP_ERR_INVALID, "embed: null buffer");
     return submit_locked(e, B, [&](cqs_hip_embedder::Slot& sl) { return pack_ragged(e, sl, tokens, lens, B); }, ticket);
-}
+} CQS_ABI_CATCH(e)
 
-int32_t cqs_hip_embed_collect(cqs_hip_embedder* e, uint64_t ticket, float* out) {
+int32_t cqs_hip_embed_collect(cqs_hip_embedder* e, uint64_t ticket, float* out) CQS_ABI_TRY {
     if (!e) return CQS_HIP_ERR_INVALID;
     cqs_hip_embedder::Slot* sl = nullptr;
     {
@@ -628,10 +636,10 @@ int32_t cqs_hip_embed_collect(cqs_hip_embedder* e, uint64_t ticket, float* out) 
     if (hipEventElapsedTime(&ms, sl->ev0, sl->ev1) == hipSuccess) e->last_ms = ms;
     sl->ticket = 0;
     return CQS_HIP_OK;
-}
+} CQS_ABI_CATCH(e)
 
 // `session.run` (src/embedder/core.rs:1097): submit + collect.
-int32_t cqs_hip_embed(cqs_hip_embedder* e, const int64_t* ids, const int64_t* mask, uint32_t B, uint32_t L, float* out) {
+int32_t cqs_hip_embed(cqs_hip_embedder* e, const int64_t* ids, const int64_t* mask, uint32_t B, uint32_t L, float* out) CQS_ABI_TRY {
     if (!e) return CQS_HIP_ERR_INVALID;
     if (B == 0) return CQS_HIP_OK;
     if (!out) { std::lock_guard<std::mutex> lk(e->mu); return efail(e, CQS_HIP_ERR_INVALID, "embed: null buffer / empty sequence"); }
@@ -639,10 +647,10 @@ int32_t cqs_hip_embed(cqs_hip_embedder* e, const int64_t* ids, const int64_t* ma
     const int32_t rc = cqs_hip_embed_submit(e, ids, mask, B, L, &t);
     if (rc != CQS_HIP_OK) return rc;
     return cqs_hip_embed_collect(e, t, out);
-}
+} CQS_ABI_CATCH(e)
 
 // Diagnostic twin (synchronous): final-norm hidden states [B, L, hidden], zeros at padded positions.
-int32_t cqs_hip_embed_hidden(cqs_hip_embedder* e, const int64_t* ids, const int64_t* mask, uint32_t B, uint32_t L, float* out) {
+int32_t cqs_hip_embed_hidden(cqs_hip_embedder* e, const int64_t* ids, const int64_t* mask, uint32_t B, uint32_t L, float* out) CQS_ABI_TRY {
     if (!e) return CQS_HIP_ERR_INVALID;
     std::lock_guard<std::mutex> lk(e->mu);
     if (e->poisoned.load(std::memory_order_acquire)) return CQS_HIP_ERR_POISONED;
@@ -674,11 +682,11 @@ int32_t cqs_hip_embed_hidden(cqs_hip_embedder* e, const int64_t* ids, const int6
     float ms = -1.f;
     if (hipEventElapsedTime(&ms, sl->ev0, sl->ev1) == hipSuccess) e->last_ms = ms;
     return CQS_HIP_OK;
-}
+} CQS_ABI_CATCH(e)
 
 // `normalize_l2` (src/embedder/pooling.rs:60-67) over the rows of a host matrix: norm_sq folded left to right in
 // f32, scaled by 1/sqrt when > 0, zero rows stay zero.  Host helper for callers that keep embeddings in one array.
-void cqs_hip_normalize_l2_rows(float* rows, uint64_t n, uint32_t dim) {
+void cqs_hip_normalize_l2_rows(float* rows, uint64_t n, uint32_t dim) CQS_ABI_TRY {
 #pragma clang fp contract(off)   // Rust does not fuse x * x + acc: keep the reference's roundings
     if (!rows) return;
     for (uint64_t r = 0; r < n; ++r) {
@@ -690,24 +698,24 @@ void cqs_hip_normalize_l2_rows(float* rows, uint64_t n, uint32_t dim) {
             for (uint32_t i = 0; i < dim; ++i) v[i] *= inv;
         }
     }
-}
+} CQS_ABI_CATCH_VOID
 
 // Test / tuning aid (not part of the public header): one GEMM launch on caller-provided device buffers
 // (bf16 A [M,K], bf16 W [N,K], C per out_kind) on `stream`; the kernel is chosen like in the forward
 // (CQS_HIP_GEMM_TILE forces one).
 int32_t cqs_hip_debug_gemm_run(const void* A, const void* W, void* C, uint32_t M, uint32_t N, uint32_t K, uint32_t ldc,
-                               int32_t out_kind, void* stream) {
+                               int32_t out_kind, void* stream) CQS_ABI_TRY {
     const hipError_t e = (out_kind & 0x100)   // + 0x100: the Dense head's skinny kernel
                              ? cqs::launch_gemm_skinny((const bf16_t*)A, (const bf16_t*)W, C, M, N, K, ldc,
                                                        (cqs::GemmOut)(out_kind & 0xff), (hipStream_t)stream)
                              : cqs::launch_gemm_bf16((const bf16_t*)A, (const bf16_t*)W, C, M, N, K, ldc, (cqs::GemmOut)out_kind,
                                                      (hipStream_t)stream);
     return e == hipSuccess ? CQS_HIP_OK : CQS_HIP_ERR_DEVICE;
-}
+} CQS_ABI_CATCH_NOHANDLE
 
 // Tuning aid (not part of the public header): average milliseconds of one C[M,N] = A[M,K] W[N,K]^T
 // launch over `iters` back-to-back launches on random bf16 operands.
-float cqs_hip_debug_gemm_ms(uint32_t M, uint32_t N, uint32_t K, uint32_t iters, int32_t out_kind) {
+float cqs_hip_debug_gemm_ms(uint32_t M, uint32_t N, uint32_t K, uint32_t iters, int32_t out_kind) CQS_ABI_TRY {
     bf16_t *A = nullptr, *W = nullptr;
     void* C = nullptr;
     if (dmalloc(&A, (size_t)M * K) != hipSuccess || dmalloc(&W, (size_t)N * K) != hipSuccess ||
@@ -731,6 +739,6 @@ float cqs_hip_debug_gemm_ms(uint32_t M, uint32_t N, uint32_t K, uint32_t iters, 
     (void)hipFree(A); (void)hipFree(W); (void)hipFree(C);
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     return ms / (float)iters;
-}
+} CQS_ABI_CATCH_VAL(-1.f)
 
 }  // extern "C"

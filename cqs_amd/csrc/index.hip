@@ -24,6 +24,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include "abi_guard.h"
 #include "index_internal.h"
 
 using cqs::kMaxK;
@@ -200,25 +201,25 @@ using namespace cqs_idx;
 
 extern "C" {
 
-const char* cqs_hip_version(void) { return "cqs-hip 0.1.0 (gfx950)"; }
+const char* cqs_hip_version(void) CQS_ABI_TRY { return "cqs-hip 0.1.0 (gfx950)"; } CQS_ABI_CATCH_VAL("cqs-hip")
 
-int32_t cqs_hip_device_count(void) {
+int32_t cqs_hip_device_count(void) CQS_ABI_TRY {
     int cnt = 0;
     if (hipGetDeviceCount(&cnt) != hipSuccess) return 0;
     return cnt;
-}
+} CQS_ABI_CATCH_NOHANDLE
 
-int32_t cqs_hip_device_mem(int32_t device, uint64_t* free_bytes, uint64_t* total_bytes) {
+int32_t cqs_hip_device_mem(int32_t device, uint64_t* free_bytes, uint64_t* total_bytes) CQS_ABI_TRY {
     if (hipSetDevice(device) != hipSuccess) return CQS_HIP_ERR_NO_DEVICE;
     size_t f = 0, t = 0;
     if (hipMemGetInfo(&f, &t) != hipSuccess) return CQS_HIP_ERR_DEVICE;
     if (free_bytes) *free_bytes = f;
     if (total_bytes) *total_bytes = t;
     return CQS_HIP_OK;
-}
+} CQS_ABI_CATCH_NOHANDLE
 
 int32_t cqs_hip_index_create(const float* rows, uint64_t n, uint32_t dim, uint32_t metric, int32_t device,
-                             uint64_t row_base, cqs_hip_index** out) {
+                             uint64_t row_base, cqs_hip_index** out) CQS_ABI_TRY {
     if (n > 0 && !rows) return CQS_HIP_ERR_INVALID;
     cqs_hip_index* x = nullptr;
     int32_t rc = create_common(n, dim, metric, device, row_base, out, &x);
@@ -234,10 +235,10 @@ int32_t cqs_hip_index_create(const float* rows, uint64_t n, uint32_t dim, uint32
     }
     *out = x;
     return CQS_HIP_OK;
-}
+} CQS_ABI_CATCH_NOHANDLE
 
 int32_t cqs_hip_index_create_device(const void* d_rows, uint64_t n, uint32_t dim, uint32_t metric, int32_t device,
-                                    uint64_t row_base, int32_t borrow, cqs_hip_index** out) {
+                                    uint64_t row_base, int32_t borrow, cqs_hip_index** out) CQS_ABI_TRY {
     if (n > 0 && !d_rows) return CQS_HIP_ERR_INVALID;
     if (((uintptr_t)d_rows & 15u) != 0) return CQS_HIP_ERR_INVALID;  // 16-B row loads
     cqs_hip_index* x = nullptr;
@@ -260,9 +261,9 @@ int32_t cqs_hip_index_create_device(const void* d_rows, uint64_t n, uint32_t dim
     }
     *out = x;
     return CQS_HIP_OK;
-}
+} CQS_ABI_CATCH_NOHANDLE
 
-int32_t cqs_hip_index_extend(cqs_hip_index* x, const float* rows, uint64_t n_new) {
+int32_t cqs_hip_index_extend(cqs_hip_index* x, const float* rows, uint64_t n_new) CQS_ABI_TRY {
     if (!x) return CQS_HIP_ERR_INVALID;
     if (x->sh) return cqs_sharded::extend(x, rows, n_new);
     std::lock_guard<std::mutex> g(x->mu);
@@ -293,7 +294,7 @@ int32_t cqs_hip_index_extend(cqs_hip_index* x, const float* rows, uint64_t n_new
     HIP_TRY(x, hipStreamSynchronize(x->stream));
     x->n += n_new;
     return CQS_HIP_OK;
-}
+} CQS_ABI_CATCH(x)
 
 }  // extern "C"
 
@@ -504,7 +505,7 @@ int32_t read_blob_into(int fd, uint64_t checksum, uint32_t dim, const std::vecto
 
 extern "C" {
 
-int32_t cqs_hip_index_save(cqs_hip_index* x, const char* path, uint64_t* out_checksum) {
+int32_t cqs_hip_index_save(cqs_hip_index* x, const char* path, uint64_t* out_checksum) CQS_ABI_TRY {
     if (!x || !path) return CQS_HIP_ERR_INVALID;
     if (x->sh) return cqs_sharded::save(x, path, out_checksum);
     std::lock_guard<std::mutex> g(x->mu);
@@ -512,10 +513,10 @@ int32_t cqs_hip_index_save(cqs_hip_index* x, const char* path, uint64_t* out_che
     HIP_TRY(x, hipSetDevice(x->device));
     HIP_TRY(x, quiesce(x));
     return save_segments(x, {Segment{x->device, x->d_rows, x->n, x->stream}}, x->dim, x->metric, path, out_checksum);
-}
+} CQS_ABI_CATCH(x)
 
 int32_t cqs_hip_index_load(const char* path, uint32_t expected_dim, uint64_t expected_rows, int32_t device,
-                           uint64_t row_base, cqs_hip_index** out) {
+                           uint64_t row_base, cqs_hip_index** out) CQS_ABI_TRY {
     if (!path || !out) return CQS_HIP_ERR_INVALID;
     *out = nullptr;
     int fd = -1;
@@ -536,9 +537,9 @@ int32_t cqs_hip_index_load(const char* path, uint32_t expected_dim, uint64_t exp
     if (rc != CQS_HIP_OK) { cqs_hip_index_destroy(x); return rc; }
     *out = x;
     return CQS_HIP_OK;
-}
+} CQS_ABI_CATCH_NOHANDLE
 
-void cqs_hip_index_destroy(cqs_hip_index* x) {
+void cqs_hip_index_destroy(cqs_hip_index* x) CQS_ABI_TRY {
     if (!x) return;
     if (x->sh) { cqs_sharded::destroy(x); return; }
     hipSetDevice(x->device);
@@ -551,20 +552,20 @@ void cqs_hip_index_destroy(cqs_hip_index* x) {
     if (x->done) hipEventDestroy(x->done);
     if (x->stream) hipStreamDestroy(x->stream);
     delete x;
-}
+} CQS_ABI_CATCH_VOID
 
-uint64_t cqs_hip_index_len(const cqs_hip_index* x) { return x ? (x->sh ? cqs_sharded::len(x) : x->n) : 0; }
-uint32_t cqs_hip_index_dim(const cqs_hip_index* x) { return x ? x->dim : 0; }
-uint32_t cqs_hip_index_metric(const cqs_hip_index* x) { return x ? x->metric : 0; }
-uint32_t cqs_hip_index_max_k(const cqs_hip_index* x) { (void)x; return kMaxK; }
-int32_t cqs_hip_index_poisoned(const cqs_hip_index* x) {
+uint64_t cqs_hip_index_len(const cqs_hip_index* x) CQS_ABI_TRY { return x ? (x->sh ? cqs_sharded::len(x) : x->n) : 0; } CQS_ABI_CATCH_VAL(0)
+uint32_t cqs_hip_index_dim(const cqs_hip_index* x) CQS_ABI_TRY { return x ? x->dim : 0; } CQS_ABI_CATCH_VAL(0)
+uint32_t cqs_hip_index_metric(const cqs_hip_index* x) CQS_ABI_TRY { return x ? x->metric : 0; } CQS_ABI_CATCH_VAL(0)
+uint32_t cqs_hip_index_max_k(const cqs_hip_index* x) CQS_ABI_TRY { (void)x; return kMaxK; } CQS_ABI_CATCH_VAL(0)
+int32_t cqs_hip_index_poisoned(const cqs_hip_index* x) CQS_ABI_TRY {
     if (x && x->sh) return cqs_sharded::poisoned(x);
     return x && x->poisoned.load(std::memory_order_acquire) ? 1 : 0;
-}
-int32_t cqs_hip_index_device(const cqs_hip_index* x) { return x ? x->device : -1; }
-uint64_t cqs_hip_index_row_base(const cqs_hip_index* x) { return x ? x->row_base : 0; }
+} CQS_ABI_CATCH_NOHANDLE
+int32_t cqs_hip_index_device(const cqs_hip_index* x) CQS_ABI_TRY { return x ? x->device : -1; } CQS_ABI_CATCH_NOHANDLE
+uint64_t cqs_hip_index_row_base(const cqs_hip_index* x) CQS_ABI_TRY { return x ? x->row_base : 0; } CQS_ABI_CATCH_VAL(0)
 
-size_t cqs_hip_index_last_error(const cqs_hip_index* x, char* buf, size_t cap) {
+size_t cqs_hip_index_last_error(const cqs_hip_index* x, char* buf, size_t cap) CQS_ABI_TRY {
     if (!x || !buf || cap == 0) return 0;
     if (x->sh) return cqs_sharded::last_error(x, buf, cap);
     std::lock_guard<std::mutex> g(x->mu);
@@ -572,9 +573,9 @@ size_t cqs_hip_index_last_error(const cqs_hip_index* x, char* buf, size_t cap) {
     memcpy(buf, x->last_error.data(), m);
     buf[m] = 0;
     return m;
-}
+} CQS_ABI_CATCH_VAL(0)
 
-void cqs_hip_unpack_keys(const uint64_t* keys, size_t count, uint64_t* rows, float* scores) {
+void cqs_hip_unpack_keys(const uint64_t* keys, size_t count, uint64_t* rows, float* scores) CQS_ABI_TRY {
     for (size_t i = 0; i < count; ++i) {
         const uint32_t ok = (uint32_t)(keys[i] >> 32);
         const uint32_t bits = (ok & 0x80000000u) ? (ok ^ 0x80000000u) : ~ok;
@@ -583,10 +584,10 @@ void cqs_hip_unpack_keys(const uint64_t* keys, size_t count, uint64_t* rows, flo
         if (scores) scores[i] = f;
         if (rows) rows[i] = (uint64_t)(0xFFFFFFFFu - (uint32_t)keys[i]);
     }
-}
+} CQS_ABI_CATCH_VOID
 
 size_t cqs_hip_merge_keys(const uint64_t* lists, const uint32_t* counts, size_t n_lists, size_t stride, size_t k,
-                          uint64_t* out_keys) {
+                          uint64_t* out_keys) CQS_ABI_TRY {
     // k-way merge of descending lists; n_lists is small (<= #GPUs), so a
     // linear scan over the list heads is cheaper than a heap.
     std::vector<size_t> pos(n_lists, 0);
@@ -605,11 +606,11 @@ size_t cqs_hip_merge_keys(const uint64_t* lists, const uint32_t* counts, size_t 
         pos[best]++;
     }
     return outc;
-}
+} CQS_ABI_CATCH_VAL(0)
 
 int32_t cqs_hip_index_search_device(cqs_hip_index* x, const float* d_queries, uint32_t b, uint32_t k,
                                     const uint32_t* d_keep_bitset, uint32_t mode, float threshold,
-                                    uint64_t* d_out_keys, uint32_t* d_out_counts, void* stream) {
+                                    uint64_t* d_out_keys, uint32_t* d_out_counts, void* stream) CQS_ABI_TRY {
     if (!x) return CQS_HIP_ERR_INVALID;
     if (x->sh) return CQS_HIP_ERR_INVALID;   // a row-sharded handle spans devices: host-buffer API only
     std::lock_guard<std::mutex> g(x->mu);
@@ -628,11 +629,11 @@ int32_t cqs_hip_index_search_device(cqs_hip_index* x, const float* d_queries, ui
     int32_t rc = ensure_scratch(x, b, k);
     if (rc != CQS_HIP_OK) return rc;
     return enqueue_search(x, d_queries, b, k, d_keep_bitset, mode, threshold, d_out_keys, d_out_counts, st);
-}
+} CQS_ABI_CATCH(x)
 
 int32_t cqs_hip_index_search(cqs_hip_index* x, const float* queries, uint32_t b, uint32_t query_dim, uint32_t k,
                              const uint32_t* keep_bitset, uint32_t mode, float threshold, uint64_t* out_rows,
-                             float* out_scores, uint32_t* out_counts) {
+                             float* out_scores, uint32_t* out_counts) CQS_ABI_TRY {
     if (!x) return CQS_HIP_ERR_INVALID;
     if (x->sh) return cqs_sharded::search(x, queries, b, query_dim, k, keep_bitset, mode, threshold, out_rows, out_scores, out_counts);
     std::lock_guard<std::mutex> g(x->mu);
@@ -730,14 +731,14 @@ int32_t cqs_hip_index_search(cqs_hip_index* x, const float* queries, uint32_t b,
         done += nb;
     }
     return CQS_HIP_OK;
-}
+} CQS_ABI_CATCH(x)
 
 // `find_neighbors` (src/cli/commands/search/neighbors.rs:86-132) for a row of this index: the query is the
 // target row where it already lies in HBM (no H2D), the scan asks for limit + 1 and the target itself is
 // dropped from the answer: top-(limit+1) of all rows minus the target = top-limit of all rows but the target
 // under the same total order (score desc, row asc; neighbors.rs:131), duplicates of the target included.
 int32_t cqs_hip_index_neighbors(cqs_hip_index* x, uint64_t target_row, uint32_t limit, uint64_t* out_rows,
-                                float* out_scores, uint32_t* out_count) {
+                                float* out_scores, uint32_t* out_count) CQS_ABI_TRY {
     if (!x || !out_count) return CQS_HIP_ERR_INVALID;
     if (x->sh) return cqs_sharded::neighbors(x, target_row, limit, out_rows, out_scores, out_count);
     std::lock_guard<std::mutex> g(x->mu);
@@ -772,17 +773,17 @@ int32_t cqs_hip_index_neighbors(cqs_hip_index* x, uint64_t target_row, uint32_t 
     }
     *out_count = outc;
     return CQS_HIP_OK;
-}
+} CQS_ABI_CATCH(x)
 
-void cqs_hip_index_set_timing(cqs_hip_index* x, int32_t enable) {
+void cqs_hip_index_set_timing(cqs_hip_index* x, int32_t enable) CQS_ABI_TRY {
     if (!x) return;
     if (x->sh) { cqs_sharded::set_timing(x, enable); return; }
     std::lock_guard<std::mutex> g(x->mu);
     x->timing = enable != 0;
     x->ev_used = 0;
-}
+} CQS_ABI_CATCH_VOID
 
-int32_t cqs_hip_index_scan_time(cqs_hip_index* x, uint32_t* launches, double* total_ms) {
+int32_t cqs_hip_index_scan_time(cqs_hip_index* x, uint32_t* launches, double* total_ms) CQS_ABI_TRY {
     if (!x || !launches || !total_ms) return CQS_HIP_ERR_INVALID;
     if (x->sh) return cqs_sharded::scan_time(x, launches, total_ms);
     std::lock_guard<std::mutex> g(x->mu);
@@ -798,6 +799,6 @@ int32_t cqs_hip_index_scan_time(cqs_hip_index* x, uint32_t* launches, double* to
     }
     x->ev_used = 0;
     return CQS_HIP_OK;
-}
+} CQS_ABI_CATCH(x)
 
 }  // extern "C"

@@ -22,6 +22,7 @@
 #include <cstring>
 #include <set>
 
+#include "abi_guard.h"
 #include "index_internal.h"
 
 using namespace cqs_idx;
@@ -465,7 +466,7 @@ static int32_t finish(cqs_hip_index* p, const int32_t* devices) {
 extern "C" {
 
 int32_t cqs_hip_index_create_sharded(const float* rows, uint64_t n, uint32_t dim, uint32_t metric, const int32_t* devices,
-                                     uint32_t n_devices, uint64_t row_base, cqs_hip_index** out) {
+                                     uint32_t n_devices, uint64_t row_base, cqs_hip_index** out) CQS_ABI_TRY {
     if (!out) return CQS_HIP_ERR_INVALID;
     *out = nullptr;
     if (!devices || n_devices == 0 || n_devices > 64 || (n > 0 && !rows)) return CQS_HIP_ERR_INVALID;
@@ -492,10 +493,10 @@ int32_t cqs_hip_index_create_sharded(const float* rows, uint64_t n, uint32_t dim
     }
     *out = p;
     return CQS_HIP_OK;
-}
+} CQS_ABI_CATCH_NOHANDLE
 
 int32_t cqs_hip_index_load_sharded(const char* path, uint32_t expected_dim, uint64_t expected_rows, const int32_t* devices,
-                                   uint32_t n_devices, uint64_t row_base, cqs_hip_index** out) {
+                                   uint32_t n_devices, uint64_t row_base, cqs_hip_index** out) CQS_ABI_TRY {
     if (!path || !out) return CQS_HIP_ERR_INVALID;
     *out = nullptr;
     if (!devices || n_devices == 0 || n_devices > 64) return CQS_HIP_ERR_INVALID;
@@ -529,13 +530,13 @@ int32_t cqs_hip_index_load_sharded(const char* path, uint32_t expected_dim, uint
     if (rc != CQS_HIP_OK) { cqs_sharded::destroy(p); return rc; }
     *out = p;
     return CQS_HIP_OK;
-}
+} CQS_ABI_CATCH_NOHANDLE
 
-uint32_t cqs_hip_index_shards(const cqs_hip_index* x) { return x ? (x->sh ? (uint32_t)x->sh->shard.size() : 1u) : 0u; }
+uint32_t cqs_hip_index_shards(const cqs_hip_index* x) CQS_ABI_TRY { return x ? (x->sh ? (uint32_t)x->sh->shard.size() : 1u) : 0u; } CQS_ABI_CATCH_VAL(0)
 
 // Rows and device of shard s (a single-device handle is its own shard 0).  Returns CQS_HIP_ERR_INVALID past the end.
 int32_t cqs_hip_index_shard_info(const cqs_hip_index* x, uint32_t s, int32_t* device, uint64_t* first_row, uint64_t* rows,
-                                 int32_t* gathers_with_rccl) {
+                                 int32_t* gathers_with_rccl) CQS_ABI_TRY {
     if (!x) return CQS_HIP_ERR_INVALID;
     if (!x->sh) {
         if (s != 0) return CQS_HIP_ERR_INVALID;
@@ -552,6 +553,6 @@ int32_t cqs_hip_index_shard_info(const cqs_hip_index* x, uint32_t s, int32_t* de
     if (rows) *rows = c->n;
     if (gathers_with_rccl) *gathers_with_rccl = x->sh->use_rccl ? 1 : 0;
     return CQS_HIP_OK;
-}
+} CQS_ABI_CATCH_NOHANDLE
 
 }  // extern "C"
