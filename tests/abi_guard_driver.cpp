@@ -1,7 +1,7 @@
 // Driver for tests/test_abi.py::test_exception_barrier_turns_bad_alloc_into_a_status: an `extern "C"` entry point
 // written exactly like the library's (CQS_ABI_TRY / CQS_ABI_CATCH around a body that runs the untrusted-file readers,
 // i.e. the body of cqs_hip_embedder_load_dir without the device), with a TEST HOOK in place of the allocator: the
-// replaced global operator new throws std::bad_alloc from its N-th call on.  Built for the CPU with
+// replaced global operator new throws std::bad_alloc at its N-th call.  Built for the CPU with
 // -fsanitize=address,undefined; every N must end in "rc=<status>", never in an abort / terminate.
 #include <cstdio>
 #include <cstdlib>
@@ -16,7 +16,7 @@
 static long g_allocs_left = -1;   // < 0: never fail
 
 void* operator new(size_t n) {
-    if (g_allocs_left == 0) throw std::bad_alloc();
+    if (g_allocs_left == 0) { g_allocs_left = -1; throw std::bad_alloc(); }   // one failed allocation, then memory is back
     if (g_allocs_left > 0) --g_allocs_left;
     void* p = malloc(n ? n : 1);
     if (!p) throw std::bad_alloc();
