@@ -617,7 +617,7 @@ int32_t cqs_hip_embed_collect(cqs_hip_embedder* e, uint64_t ticket, float* out) 
     cqs_hip_embedder::Slot* sl = nullptr;
     {
         std::lock_guard<std::mutex> lk(e->mu);
-        if (!out || ticket == 0) return efail(e, CQS_HIP_ERR_INVALID, "collect: null buffer / ticket");
+        if (ticket == 0) return efail(e, CQS_HIP_ERR_INVALID, "collect: null ticket");
         for (cqs_hip_embedder::Slot& c : e->slot)
             if (c.ticket == ticket) { sl = &c; break; }
         if (!sl) return efail(e, CQS_HIP_ERR_INVALID, "collect: unknown ticket");
@@ -628,10 +628,12 @@ int32_t cqs_hip_embed_collect(cqs_hip_embedder* e, uint64_t ticket, float* out) 
     std::lock_guard<std::mutex> lk(e->mu);
     if (he != hipSuccess) { sl->ticket = 0; return efail(e, CQS_HIP_ERR_DEVICE, "collect: device failure", he); }
     const uint32_t H = e->g.hidden, B = sl->B;
-    memcpy(out, sl->out, (size_t)B * H * sizeof(float));
-    const int32_t* seq_len = sl->meta + (size_t)2 * sl->M + B;
-    for (uint32_t b = 0; b < B; ++b)   // empty rows: exact zeros, like the reference's zero-mask pooling
-        if (seq_len[b] == 0) memset(out + (size_t)b * H, 0, (size_t)H * sizeof(float));
+    if (out) {                         // out == NULL: abandon the ticket (wait, release the slot, drop the rows)
+        memcpy(out, sl->out, (size_t)B * H * sizeof(float));
+        const int32_t* seq_len = sl->meta + (size_t)2 * sl->M + B;
+        for (uint32_t b = 0; b < B; ++b)   // empty rows: exact zeros, like the reference's zero-mask pooling
+            if (seq_len[b] == 0) memset(out + (size_t)b * H, 0, (size_t)H * sizeof(float));
+    }
     float ms = -1.f;
     if (hipEventElapsedTime(&ms, sl->ev0, sl->ev1) == hipSuccess) e->last_ms = ms;
     sl->ticket = 0;

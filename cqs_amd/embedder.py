@@ -170,6 +170,12 @@ class HipEmbedEngine:
             raise EmbedderError(f"InferenceFailed: {self.last_error()} ({rc})")
         return out
 
+    def abandon(self, ticket: int) -> None:
+        """`cqs_hip_embed_collect(ticket, NULL)`: wait for the ticket, release its submission slot, drop the rows."""
+        rc = self._lib.cqs_hip_embed_collect(self._h, ticket, None)
+        if rc != _lib.OK:
+            raise EmbedderError(f"InferenceFailed: {self.last_error()} ({rc})")
+
     def run_hidden(self, input_ids: np.ndarray, attention_mask: np.ndarray) -> np.ndarray:
         ids = np.ascontiguousarray(input_ids, dtype=np.int64)
         mask = np.ascontiguousarray(attention_mask, dtype=np.int64)

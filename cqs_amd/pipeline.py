@@ -66,6 +66,14 @@ class EmbedPipeline:
         self.max_seq = engine.max_seq()
         self._stats = {"batches": 0, "chunks": 0, "tokens": 0, "submit_s": 0.0, "collect_wait_s": 0.0}
 
+    def abandon(self, tickets) -> None:
+        """Give the library's submission slots of `tickets` back (results discarded, errors ignored)."""
+        for t in tickets:
+            try:
+                self.engine.abandon(t)
+            except EmbedderError:
+                pass                                       # a failed collect releases its slot as well
+
     def stats(self) -> dict:
         s = dict(self._stats)
         s.update(token_budget=self.token_budget, max_seqs=self.max_seqs, depth=self.DEPTH)
@@ -86,23 +94,31 @@ class EmbedPipeline:
         batches = plan_batches(lens, self.token_budget, self.max_seqs)
         inflight = []                                     # (ticket, index array)
         nxt = 0
-        while nxt < len(batches) or inflight:
-            while nxt < len(batches) and len(inflight) < self.DEPTH:
-                sel = batches[nxt]
+        try:
+            while nxt < len(batches) or inflight:
+                while nxt < len(batches) and len(inflight) < self.DEPTH:
+                    sel = batches[nxt]
+                    t0 = time.perf_counter()
+                    cat = np.concatenate([toks[i] for i in sel]) if len(sel) else np.zeros(0, np.int32)
+                    ticket = self.engine.submit_ragged(cat, lens[sel].astype(np.uint32))
+                    self._stats["submit_s"] += time.perf_counter() - t0
+                    inflight.append((ticket, sel))
+                    nxt += 1
+                ticket, sel = inflight.pop(0)
                 t0 = time.perf_counter()
-                cat = np.concatenate([toks[i] for i in sel]) if len(sel) else np.zeros(0, np.int32)
-                ticket = self.engine.submit_ragged(cat, lens[sel].astype(np.uint32))
-                self._stats["submit_s"] += time.perf_counter() - t0
-                inflight.append((ticket, sel))
-                nxt += 1
-            ticket, sel = inflight.pop(0)
-            t0 = time.perf_counter()
-            rows = self.engine.collect(ticket, len(sel))
-            self._stats["collect_wait_s"] += time.perf_counter() - t0
-            out[sel] = rows
-            self._stats["batches"] += 1
-            self._stats["chunks"] += len(sel)
-            self._stats["tokens"] += int(lens[sel].sum())
+                rows = self.engine.collect(ticket, len(sel))
+                self._stats["collect_wait_s"] += time.perf_counter() - t0
+                out[sel] = rows
+                self._stats["batches"] += 1
+                self._stats["chunks"] += len(sel)
+                self._stats["tokens"] += int(lens[sel].sum())
+        except BaseException:
+            # A submission slot is freed only when its ticket is collected (embedder.hip: submit_locked / collect), and a
+            # non-device failure (a token id out of range in ONE batch) does not poison the engine: without this drain
+            # the tickets still in flight would strand their slots and every later call would fail with "every
+            # submission slot is in flight" on an engine that still looks healthy.
+            self.abandon([t for t, _ in inflight])
+            raise
         return normalize_l2_rows(out) if normalize else out
 
 

@@ -287,7 +287,9 @@ int32_t cqs_hip_embed(cqs_hip_embedder* e, const int64_t* input_ids, const int64
  * without waiting; collect waits for that ticket and copies its [batch, hidden] rows out.  Up to 3 tickets may be in
  * flight: while the device runs batches i and i+1 the host packs batch i+2.  A 4th submit without a collect ->
  * CQS_HIP_ERR_INVALID.  Tickets may be collected in any order (and may finish out of order); results do not depend
- * on what else is in flight.
+ * on what else is in flight.  A slot is released only by collecting its ticket: a caller that gives up on a batch
+ * (an error in a LATER submit, a cancelled index run) must still collect every ticket it holds - `out` = NULL
+ * abandons one (waits for it, releases the slot, drops the rows).
  * submit_ragged takes the batch without padding: `tokens` = the sequences' ids back to back (i32), lens[b] = length
  * of sequence b (0 allowed -> zero vector) - what a length-sorted scheduler holds anyway. */
 int32_t cqs_hip_embed_submit(cqs_hip_embedder* e, const int64_t* input_ids, const int64_t* attention_mask,

@@ -199,6 +199,14 @@ impl HipEmbedSession {
         }
         Ok(out)
     }
+
+    /// Give a ticket's submission slot back without taking its rows (`out` = NULL): what a caller that bails out of
+    /// an index run - an `Err` from a later `submit`, a cancelled pipeline - owes every ticket it still holds; a slot
+    /// is released only by a collect, and a non-device failure does not poison the engine.
+    pub fn abandon(&mut self, ticket: (u64, usize)) {
+        // SAFETY: NULL `out` is the documented abandon form; the status is irrelevant (a failed collect frees the slot too).
+        let _ = unsafe { cqs_hip_embed_collect(self.handle, ticket.0, std::ptr::null_mut()) };
+    }
 }
 
 impl Drop for HipEmbedSession {

@@ -57,6 +57,9 @@ class _FakeEngine:
     def collect(self, ticket, batch):
         return self.pending.pop(ticket)
 
+    def abandon(self, ticket):                      # cqs_hip_embed_collect(ticket, NULL): the slot comes back
+        self.pending.pop(ticket)
+
 
 def test_pipeline_keeps_input_order_truncates_and_pipelines():
     eng = _FakeEngine()
@@ -91,6 +94,47 @@ def test_gpu_stage_failure_contract():
     assert [len(b.chunk_embeddings) for b in sent] == [3, 1, 2]
     assert sent[0].chunk_embeddings[1][0] == "a" and isinstance(sent[0], EmbeddedBatch)
     assert stage.embedded_count == 3 + 1 + 2
+
+
+def test_failed_submit_gives_every_slot_back():
+    """a submit that fails while earlier tickets are in flight must not strand their slots (a slot is
+    released only by collecting its ticket; the fake engine keeps the library's 3-slot accounting)."""
+    eng = _FakeEngine(fail_after=2)                                   # batch 3 of the call fails, 2 tickets in flight
+    pipe = EmbedPipeline(eng, token_budget=4, max_seqs=1)
+    chunks = [np.arange(1, 4) + i for i in range(6)]
+    with pytest.raises(EmbedderError):
+        pipe.embed_token_lists(chunks)
+    assert not eng.pending, "tickets stranded after a failed submit"
+    eng.fail_after = None
+    out = pipe.embed_token_lists(chunks, normalize=False)             # the same engine keeps working
+    assert [r[0] for r in out] == [float(c.sum()) for c in chunks] and not eng.pending
+
+
+@pytest.mark.gpu
+def test_failed_batch_does_not_strand_submission_slots(hip):
+    """The same on the real engine: an out-of-range token id in batch 2 of 3 fails that submit (not a device error:
+    the engine stays healthy); the tickets in flight are abandoned and the next call on the engine succeeds."""
+    from oracle import gemma3_ref as G
+    from test_embed_gpu import SMALL, batch, cos, make
+    eng, w = make(SMALL, seed=23)
+    lens = [40, 30, 20, 10, 5, 3]
+    ids, mask = batch(SMALL, lens, seed=24)
+    chunks = [ids[i, :lens[i]].copy() for i in range(len(lens))]
+    ref = G.forward(SMALL, w, ids, mask)
+    pipe = EmbedPipeline(eng, token_budget=40, max_seqs=2)            # batches: [40] [30] [20, 10] [5, 3]
+    poisoned = [c.copy() for c in chunks]
+    poisoned[1][3] = SMALL.vocab_size + 7                             # lands in batch 2
+    for _ in range(4):                                                # > 3 slots' worth of failures
+        with pytest.raises(EmbedderError):
+            pipe.embed_token_lists(poisoned)
+    emb = pipe.embed_token_lists(chunks)
+    for i in range(len(lens)):
+        assert cos(emb[i], ref[i]) > 0.999
+    t = eng.submit(ids[:1], mask[:1])                                 # abandon = collect without a buffer
+    eng.abandon(t)
+    with pytest.raises(EmbedderError):
+        eng.collect(t, 1)                                             # the ticket is gone
+    eng.close()
 
 
 @pytest.mark.gpu
