@@ -49,6 +49,8 @@ def parse():
     ap.add_argument("--embed-batch", type=int, default=32, help="sequences per embedding batch (reference: embed_batch_size() = 32)")
     ap.add_argument("--embed-len", type=int, default=512, help="tokens per sequence of the fixed-length embed leg")
     ap.add_argument("--e2e-chunks", type=int, default=100_000, help="configs[3]: chunks embedded + indexed end to end (0 = skip)")
+    ap.add_argument("--abi-after", type=int, default=1, help="N>1 (RCCL) only: after the timed region rank 0 also runs the "
+                    "single-process sharded handle over devices 0..N-1 into `abi_sharded` (0 = skip)")
     ap.add_argument("--abi-devices", type=str, default="", help="N=1 only: also run the single-process sharded index "
                     "(cqs_hip_index_create_sharded) over this comma-separated device list, e.g. 0,1,2,3 (or 0,0 on one GPU)")
     return ap.parse_args()
@@ -598,6 +600,35 @@ def abi_sharded_leg(a, torch, np, rows, queries, k, dim):
             "build_s": round(t_build, 2), "checked_vs_single_device": True}
 
 
+def abi_after_group_leg(a, torch, np, world, k, dim, rows_per_device=250_000, budget_s=150.0):
+    """Rank 0, after the process group is gone: cqs_hip_index_create_sharded over devices 0..world-1 (RCCL clique inside
+    the library), checked against the single-device answer, timed through the blocking host API.  Runs in a thread
+    with a wall-clock budget; any failure becomes an `error` field, never a lost bench line."""
+    import threading
+    box = {}
+
+    def work():
+        try:
+            dev0 = torch.device("cuda", 0)
+            torch.cuda.set_device(0)
+            n = rows_per_device * world
+            rows = make_unit_rows(torch, n, dim, 0xC950011, dev0)
+            queries = make_unit_rows(torch, 64, dim, 0xC950012, dev0).view(64, 1, dim)
+            ns = argparse.Namespace(abi_devices=",".join(str(d) for d in range(world)))
+            box["res"] = abi_sharded_leg(ns, torch, np, rows, queries, k, dim)
+            box["res"]["rows"] = n
+        except BaseException as e:      # noqa: BLE001 - the line must survive
+            box["res"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+
+    t = threading.Thread(target=work, daemon=True)
+    t.start()
+    t.join(budget_s)
+    if t.is_alive():
+        return {"error": "abi sharded leg exceeded its %.0f s budget (left running in a daemon thread)" % budget_s,
+                "_hung": True}
+    return box.get("res")
+
+
 def main():
     a = parse()
     import numpy as np
@@ -628,6 +659,23 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
+    # Self-proving N > 1 record: the size of the group as the COLLECTIVE saw it (an all-reduce of ones over the backend that
+    # carries the data path) and the physical device behind every rank (ordinal + PCI bus id, gathered the same way).
+    ranks_seen, rank_devices, collective = None, None, None
+    if dist is not None:
+        cdev = "cpu" if rehearsal else dev
+        ones = torch.ones(1, dtype=torch.int64, device=cdev)
+        dist.all_reduce(ones)
+        ranks_seen = int(ones.item())
+        props = torch.cuda.get_device_properties(local_rank)
+        me = torch.tensor([local_rank, int(getattr(props, "pci_domain_id", -1)), int(getattr(props, "pci_bus_id", -1)),
+                           int(getattr(props, "pci_device_id", -1))], dtype=torch.int64, device=cdev)
+        allp = torch.zeros(world * 4, dtype=torch.int64, device=cdev)
+        dist.all_gather_into_tensor(allp, me)
+        rank_devices = [{"rank": r, "device": int(v[0]), "pci": "%04x:%02x:%02x" % (int(v[1]) & 0xFFFF, int(v[2]) & 0xFF, int(v[3]) & 0xFF)}
+                        for r, v in enumerate(allp.view(world, 4).cpu().tolist())]
+        collective = "gloo-host (rehearsal)" if rehearsal else "rccl (torch.distributed backend nccl)"
+        assert ranks_seen == dist.get_world_size() == world, (ranks_seen, world)
     mode = a.mode
     if mode == "auto":
         mode = "strong" if (world > 1 or force_dist) else "single"
@@ -766,7 +814,8 @@ def main():
 
     # untimed pre-warm beyond the driver's W (clocks, caches, lazy allocations): with a small K the first steps after a
     # cold start would otherwise be the measurement; step 0 is simply repeated, its outputs are rewritten below
-    for _ in range(200 if dist is None else 20):     # (a FIXED count: every rank must issue the same collectives)
+    prewarm_steps = 200 if dist is None else 20       # (a FIXED count: every rank must issue the same collectives)
+    for _ in range(prewarm_steps):
         step(0)
         finish(0, 1)
     for i in range(W):
@@ -869,6 +918,9 @@ def main():
     abi = None
     if rank == 0 and world == 1 and mode == "single" and a.abi_devices:
         abi = abi_sharded_leg(a, torch, np, rows, queries[W:], k, dim)
+    # N > 1 under RCCL: the C ABI's single-process sharded handle (what the Rust daemon binds) gets its first
+    # multi-device run here, on rank 0, after every rank has let go of its shard and left the group - see below.
+    abi_after_group = dist is not None and not rehearsal and a.abi_after and torch.cuda.device_count() >= world
 
     embed = e2e = None
     if a.embed_steps > 0:
@@ -884,6 +936,21 @@ def main():
     if rank == 0 and world == 1 and mode == "single" and a.extras and a.embed_steps > 0:
         aux = aux_models_leg(a, np)
 
+    if abi_after_group:
+        # every rank drops its shard, the group dissolves, ranks != 0 leave; rank 0 then builds ONE handle over
+        # devices 0..N-1 with a corpus of its own (250k rows per device), checks it against the single-device answer
+        # and times it through the blocking host API - in a watchdog thread: whatever happens in there (an RCCL clique
+        # that cannot form, a hang), the line above is still printed.
+        if a.embed_steps <= 0:               # (the embed leg has closed the index and dropped the rows already)
+            idx.close()
+            del rows
+        del queries
+        torch.cuda.empty_cache()
+        dist.barrier()
+        dist.destroy_process_group()
+        dist = None
+        if rank == 0:
+            abi = abi_after_group_leg(a, torch, np, world, k, dim)
     if rank == 0:
         if mode == "weak":
             total_q = K * bq * world
@@ -905,6 +972,7 @@ def main():
             "n_gpus": world,
             "steps": K,
             "warmup": W,
+            "prewarm_steps": prewarm_steps,          # untimed repeats of step 0 before the W warm-ups (clocks, caches)
             "ms_per_step": round(elapsed / K * 1e3, 5),
             "higher_is_better": True,
             "scaling": "weak" if mode in ("weak", "single") else "strong",
@@ -913,8 +981,11 @@ def main():
             "data": "synthetic",
             "config": {"workload": workload, "mode": mode, "rows_per_gpu": n, "total_rows": total_rows, "dim": dim, "k": k,
                        "queries_per_step": bq * (world if mode == "weak" else 1),
-                       "parallelism": "row-sharded x%d, RCCL all-gather of per-shard candidates, host merge" % world
-                       if world > 1 else "single GPU"},
+                       "parallelism": ("row-sharded x%d, %s all-gather of per-shard candidates, host merge"
+                                       % (world, "gloo (host-staged, REHEARSAL)" if rehearsal else "RCCL")) if world > 1 else "single GPU",
+                       "ranks_seen": ranks_seen if ranks_seen is not None else 1,     # group size as the collective's all-reduce saw it
+                       "rank_devices": rank_devices if rank_devices is not None else [{"rank": 0, "device": local_rank}],
+                       "collective": collective},
             "roofline": roofline,
             "cpu_baseline": cpu,
             "latency_host_api": latency,
@@ -924,8 +995,13 @@ def main():
             "e2e": e2e,
             "aux_models": aux,
         }
+        if rehearsal or (force_dist and world == 1):
+            # all ranks on one GPU over gloo, or a 1-rank RCCL group: the N > 1 LOGIC ran, nothing here measures N GPUs
+            line["rehearsal"] = True
+            line["metric"] = "REHEARSAL (logic check, not a measurement): " + line["metric"]
+            line["vs_baseline"] = None
         print(json.dumps(line), flush=True)
-    if a.embed_steps <= 0:
+    if a.embed_steps <= 0 and not abi_after_group:
         idx.close()
     if dist is not None:
         dist.barrier()

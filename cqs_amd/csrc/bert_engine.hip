@@ -5,6 +5,7 @@
 // oracle/bert_ref.py.  No CPU fallback: without a GPU `cqs_hip_bert_create` fails.
 #include "../../include/cqs_hip.h"
 #include "abi_guard.h"
+#include "roctx.h"
 #include "bert_kernels.h"
 #include "onnx_reader.h"
 #include "safetensors_reader.h"
@@ -386,6 +387,7 @@ int32_t splade_forward(cqs_hip_bert* e, const int32_t* tokens, const uint32_t* l
 // [batch, vocab] f32 = ln(1 + max(0, max over the sequence's tokens of the MLM logits)) - the model's pre-pooled
 // `sparse_vector` output form (src/splade/mod.rs:960-978); the caller keeps entries > threshold.
 int32_t cqs_hip_splade_encode(cqs_hip_bert* e, const int32_t* tokens, const uint32_t* lens, uint32_t batch, float* out_dense) CQS_ABI_TRY {
+    CQS_ROCTX_RANGE("cqs_hip_splade_encode");
     if (!e) return CQS_HIP_ERR_INVALID;
     std::lock_guard<std::mutex> lk(e->mu);
     int32_t rc = check_ready(e, CQS_HIP_BERT_HEAD_MLM);
@@ -409,6 +411,7 @@ int32_t cqs_hip_splade_encode(cqs_hip_bert* e, const int32_t* tokens, const uint
 // cqs_hip_splade_encode (trained models keep 100-300 entries, src/splade/mod.rs:44).
 int32_t cqs_hip_splade_encode_sparse(cqs_hip_bert* e, const int32_t* tokens, const uint32_t* lens, uint32_t batch,
                                      float threshold, uint32_t cap, uint32_t* out_ids, float* out_weights, uint32_t* out_counts) CQS_ABI_TRY {
+    CQS_ROCTX_RANGE("cqs_hip_splade_encode_sparse");
     if (!e) return CQS_HIP_ERR_INVALID;
     std::lock_guard<std::mutex> lk(e->mu);
     int32_t rc = check_ready(e, CQS_HIP_BERT_HEAD_MLM);
@@ -444,6 +447,7 @@ int32_t cqs_hip_splade_encode_sparse(cqs_hip_bert* e, const int32_t* tokens, con
 // token type ids; out_logits [batch, num_labels] f32 (the caller applies sigmoid to column 0).
 int32_t cqs_hip_rerank_logits(cqs_hip_bert* e, const int32_t* tokens, const int32_t* type_ids, const uint32_t* lens,
                               uint32_t batch, float* out_logits) CQS_ABI_TRY {
+    CQS_ROCTX_RANGE("cqs_hip_rerank_logits");
     if (!e) return CQS_HIP_ERR_INVALID;
     std::lock_guard<std::mutex> lk(e->mu);
     int32_t rc = check_ready(e, CQS_HIP_BERT_HEAD_CLASSIFIER);
@@ -477,6 +481,7 @@ int32_t cqs_hip_rerank_logits(cqs_hip_bert* e, const int32_t* tokens, const int3
 // device.  out [batch, hidden] f32, NOT normalised (the caller's `normalize_l2`, core.rs:1196-1203).
 int32_t cqs_hip_bert_embed(cqs_hip_bert* e, const int32_t* tokens, const int32_t* type_ids, const uint32_t* lens, uint32_t batch,
                            uint32_t pooling, float* out) CQS_ABI_TRY {
+    CQS_ROCTX_RANGE("cqs_hip_bert_embed");
     if (!e) return CQS_HIP_ERR_INVALID;
     std::lock_guard<std::mutex> lk(e->mu);
     int32_t rc = check_ready(e, CQS_HIP_BERT_HEAD_NONE);

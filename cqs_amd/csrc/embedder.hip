@@ -22,6 +22,7 @@
 
 #include "../../include/cqs_hip.h"
 #include "abi_guard.h"
+#include "roctx.h"
 #include "embed_kernels.h"
 #include "onnx_reader.h"
 #include "safetensors_reader.h"
@@ -598,6 +599,7 @@ int32_t submit_locked(cqs_hip_embedder* e, uint32_t B, const std::function<int32
 
 int32_t cqs_hip_embed_submit(cqs_hip_embedder* e, const int64_t* ids, const int64_t* mask, uint32_t B, uint32_t L,
                              uint64_t* ticket) CQS_ABI_TRY {
+    CQS_ROCTX_RANGE("cqs_hip_embed_submit");
     if (!e) return CQS_HIP_ERR_INVALID;
     std::lock_guard<std::mutex> lk(e->mu);
     if (!ids || !mask || L == 0) return efail(e, CQS_HIP_ERR_INVALID, "embed: null buffer / empty sequence");
@@ -606,6 +608,7 @@ int32_t cqs_hip_embed_submit(cqs_hip_embedder* e, const int64_t* ids, const int6
 
 int32_t cqs_hip_embed_submit_ragged(cqs_hip_embedder* e, const int32_t* tokens, const uint32_t* lens, uint32_t B,
                                     uint64_t* ticket) CQS_ABI_TRY {
+    CQS_ROCTX_RANGE("cqs_hip_embed_submit_ragged");
     if (!e) return CQS_HIP_ERR_INVALID;
     std::lock_guard<std::mutex> lk(e->mu);
     if (!lens || (!tokens && B)) return efail(e, CQS_HIP_ERR_INVALID, "embed: null buffer");
@@ -613,6 +616,7 @@ int32_t cqs_hip_embed_submit_ragged(cqs_hip_embedder* e, const int32_t* tokens, 
 } CQS_ABI_CATCH(e)
 
 int32_t cqs_hip_embed_collect(cqs_hip_embedder* e, uint64_t ticket, float* out) CQS_ABI_TRY {
+    CQS_ROCTX_RANGE("cqs_hip_embed_collect");
     if (!e) return CQS_HIP_ERR_INVALID;
     cqs_hip_embedder::Slot* sl = nullptr;
     {
@@ -642,6 +646,7 @@ int32_t cqs_hip_embed_collect(cqs_hip_embedder* e, uint64_t ticket, float* out) 
 
 // `session.run` (src/embedder/core.rs:1097): submit + collect.
 int32_t cqs_hip_embed(cqs_hip_embedder* e, const int64_t* ids, const int64_t* mask, uint32_t B, uint32_t L, float* out) CQS_ABI_TRY {
+    CQS_ROCTX_RANGE("cqs_hip_embed");
     if (!e) return CQS_HIP_ERR_INVALID;
     if (B == 0) return CQS_HIP_OK;
     if (!out) { std::lock_guard<std::mutex> lk(e->mu); return efail(e, CQS_HIP_ERR_INVALID, "embed: null buffer / empty sequence"); }

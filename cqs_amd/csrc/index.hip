@@ -25,6 +25,7 @@
 #include <unistd.h>
 
 #include "abi_guard.h"
+#include "roctx.h"
 #include "index_internal.h"
 
 using cqs::kMaxK;
@@ -611,6 +612,7 @@ size_t cqs_hip_merge_keys(const uint64_t* lists, const uint32_t* counts, size_t 
 int32_t cqs_hip_index_search_device(cqs_hip_index* x, const float* d_queries, uint32_t b, uint32_t k,
                                     const uint32_t* d_keep_bitset, uint32_t mode, float threshold,
                                     uint64_t* d_out_keys, uint32_t* d_out_counts, void* stream) CQS_ABI_TRY {
+    CQS_ROCTX_RANGE("cqs_hip_index_search_device");
     if (!x) return CQS_HIP_ERR_INVALID;
     if (x->sh) return CQS_HIP_ERR_INVALID;   // a row-sharded handle spans devices: host-buffer API only
     std::lock_guard<std::mutex> g(x->mu);
@@ -634,6 +636,7 @@ int32_t cqs_hip_index_search_device(cqs_hip_index* x, const float* d_queries, ui
 int32_t cqs_hip_index_search(cqs_hip_index* x, const float* queries, uint32_t b, uint32_t query_dim, uint32_t k,
                              const uint32_t* keep_bitset, uint32_t mode, float threshold, uint64_t* out_rows,
                              float* out_scores, uint32_t* out_counts) CQS_ABI_TRY {
+    CQS_ROCTX_RANGE("cqs_hip_index_search");
     if (!x) return CQS_HIP_ERR_INVALID;
     if (x->sh) return cqs_sharded::search(x, queries, b, query_dim, k, keep_bitset, mode, threshold, out_rows, out_scores, out_counts);
     std::lock_guard<std::mutex> g(x->mu);
@@ -739,6 +742,7 @@ int32_t cqs_hip_index_search(cqs_hip_index* x, const float* queries, uint32_t b,
 // under the same total order (score desc, row asc; neighbors.rs:131), duplicates of the target included.
 int32_t cqs_hip_index_neighbors(cqs_hip_index* x, uint64_t target_row, uint32_t limit, uint64_t* out_rows,
                                 float* out_scores, uint32_t* out_count) CQS_ABI_TRY {
+    CQS_ROCTX_RANGE("cqs_hip_index_neighbors");
     if (!x || !out_count) return CQS_HIP_ERR_INVALID;
     if (x->sh) return cqs_sharded::neighbors(x, target_row, limit, out_rows, out_scores, out_count);
     std::lock_guard<std::mutex> g(x->mu);

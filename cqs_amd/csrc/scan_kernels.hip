@@ -20,6 +20,7 @@
 //
 // Wave = 64 lanes.  gfx950 only.
 #include "scan_kernels.h"
+#include "launch_util.h"
 
 namespace cqs {
 
@@ -690,8 +691,8 @@ static hipError_t launch_gemv(const ScanArgs& a, uint32_t q0, uint32_t nq, uint3
     do {                                                                                                     \
         auto kern = scan_gemv_kernel<NCH, BQ, RI, NTV, FULLV, PIPE, OCCV>;                                   \
         if (occ_lds > 64u * 1024u) {                                                                         \
-            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                               (int)occ_lds);                                                \
+            static DynLdsOnce once;   /* per instantiation: the attribute is set once per device, not per launch */ \
+            hipError_t e = once.ensure((const void*)kern, occ_lds);                                          \
             if (e != hipSuccess) return e;                                                                   \
         }                                                                                                    \
         hipLaunchKernelGGL(kern, grid, block, occ_lds, st, p);                                               \

@@ -23,6 +23,7 @@
 // Roofline: compute.  flops = 2*B*n*dim per batch (393 GFLOP at 256 x 1M x 768) against the
 // 157.3 TF f32-MFMA peak; HBM traffic = corpus once + B*n*4 B of scores.
 #include "scan_kernels.h"
+#include "launch_util.h"
 
 namespace cqs {
 
@@ -243,7 +244,8 @@ static hipError_t launch_mfma_cfg(const ScanArgs& a, uint32_t q0, uint32_t nq, u
     const size_t lds = (size_t)2 * (QT + RT) * kLDK * sizeof(float);
     uint32_t blocks = a.n_cu < p.n_tasks ? a.n_cu : p.n_tasks;
     auto kern = a.nontemporal ? scan_mfma_kernel<QW, WQ, RW, WR, true> : scan_mfma_kernel<QW, WQ, RW, WR, false>;
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static DynLdsOnce once[2];   // per instantiation x {nt, default}: set once per device, not per launch
+    hipError_t e = once[a.nontemporal ? 1 : 0].ensure((const void*)kern, lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, st, p);
     return hipGetLastError();

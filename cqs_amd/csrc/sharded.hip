@@ -23,6 +23,7 @@
 #include <set>
 
 #include "abi_guard.h"
+#include "roctx.h"
 #include "index_internal.h"
 
 using namespace cqs_idx;
@@ -184,6 +185,7 @@ int32_t search_block(cqs_hip_index* p, uint32_t nb, uint32_t k_eff, const uint32
         }
     }
     // 2. gather every shard's keys on every device (RCCL all-gather over xGMI), or by copies into device 0's buffer
+    CQS_ROCTX_RANGE("cqs_hip.shard_gather");
     if (ss->use_rccl) {
         RcclApi* api = rccl_api();
         ncclResult_t nr = api->GroupStart();

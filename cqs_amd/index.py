@@ -519,12 +519,15 @@ class HipBackend:
             return None
         dim = ctx.store.dim
         free, total = C.c_uint64(), C.c_uint64()
-        if lib.cqs_hip_device_mem(ctx.device, C.byref(free), C.byref(total)) != _lib.OK:
-            return None
-        n_dev = len(ctx.devices) if ctx.devices else 1
-        if n * dim * 4 * 1.25 / n_dev > free.value:  # gpu_available_for (src/cagra.rs:336-376), per shard
-            log.warning("HIP backend: corpus does not fit device memory, falling through")
-            return None
+        devs = list(ctx.devices) if ctx.devices else [ctx.device]
+        # gpu_available_for (src/cagra.rs:336-376) for EVERY device that will hold a shard: a device counted twice
+        # (two shards on one GPU) must have room for both
+        for d in sorted(set(devs)):
+            if lib.cqs_hip_device_mem(d, C.byref(free), C.byref(total)) != _lib.OK:
+                return None
+            if n * dim * 4 * 1.25 * devs.count(d) / len(devs) > free.value:
+                log.warning("HIP backend: corpus does not fit the memory of device %d, falling through", d)
+                return None
         import os
         path = os.path.join(ctx.cqs_dir, "index.hipflat")
         if ctx.persist and os.path.exists(path):           # persisted first (src/cagra.rs:1726-1752)

@@ -111,13 +111,18 @@ class HipBertEngine:
                     "splade_encode_sparse")
         return ids, wts, cnt
 
+    def _pack_types(self, type_ids, lens):
+        """token_type_ids packed like the ids; the C side reads one per token, so the lengths must line up."""
+        if type_ids is None:
+            return None
+        tt, tl = self._pack(type_ids)
+        if not np.array_equal(tl, lens):
+            raise BertError("token_type_ids do not line up with input_ids")
+        return tt
+
     def rerank_logits(self, seqs: Sequence[np.ndarray], type_ids: Optional[Sequence[np.ndarray]]) -> np.ndarray:
         toks, lens = self._pack(seqs)
-        tt = None
-        if type_ids is not None:
-            tt, tl = self._pack(type_ids)
-            if not np.array_equal(tl, lens):
-                raise BertError("token_type_ids do not line up with input_ids")
+        tt = self._pack_types(type_ids, lens)
         out = np.empty((len(seqs), int(self.cfg.num_labels)), np.float32)
         self._check(self._lib.cqs_hip_rerank_logits(self._h, toks.ctypes.data_as(C.c_void_p),
                                                     tt.ctypes.data_as(C.c_void_p) if tt is not None else None,
@@ -128,7 +133,7 @@ class HipBertEngine:
     def embed(self, seqs: Sequence[np.ndarray], type_ids: Optional[Sequence[np.ndarray]] = None, pooling: str = "mean") -> np.ndarray:
         """`cqs_hip_bert_embed`: pooled sentence vectors f32 [B, hidden], not normalised (head = NONE engines)."""
         toks, lens = self._pack(seqs)
-        tt = self._pack(type_ids)[0] if type_ids is not None else None
+        tt = self._pack_types(type_ids, lens)
         out = np.empty((len(seqs), int(self.cfg.hidden)), np.float32)
         self._check(self._lib.cqs_hip_bert_embed(self._h, toks.ctypes.data_as(C.c_void_p),
                                                  tt.ctypes.data_as(C.c_void_p) if tt is not None else None,
@@ -138,7 +143,7 @@ class HipBertEngine:
 
     def hidden(self, seqs: Sequence[np.ndarray], type_ids: Optional[Sequence[np.ndarray]] = None) -> np.ndarray:
         toks, lens = self._pack(seqs)
-        tt = self._pack(type_ids)[0] if type_ids is not None else None
+        tt = self._pack_types(type_ids, lens)
         out = np.empty((int(lens.sum()), int(self.cfg.hidden)), np.float32)
         self._check(self._lib.cqs_hip_bert_hidden(self._h, toks.ctypes.data_as(C.c_void_p),
                                                   tt.ctypes.data_as(C.c_void_p) if tt is not None else None,

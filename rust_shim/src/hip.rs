@@ -19,7 +19,6 @@
 //! returns an empty Vec; `try_open` returns `Ok(None)` to fall through to the next
 //! backend and `Err` only for store errors.
 
-use std::ffi::c_void;
 use std::os::raw::c_char;
 use std::sync::atomic::{AtomicBool, Ordering};
 
@@ -536,6 +535,3 @@ impl<Mode: ClearHnswDirty> IndexBackend<Mode> for HipBackend {
         }
     }
 }
-
-#[allow(dead_code)]
-fn _abi_types(_: *mut c_void) {}

@@ -31,6 +31,10 @@ def test_strong_mode_two_ranks(hip):
     assert d["scaling"] == "strong" and d["n_gpus"] == 2 and d["config"]["mode"] == "strong"
     assert d["config"]["total_rows"] == 300000 and d["config"]["rows_per_gpu"] == 150000
     assert "configs[4]" in d["config"]["workload"] and d["value"] > 0
+    # a rehearsal line can not be mistaken for a multi-GPU measurement
+    assert d["rehearsal"] is True and d["metric"].startswith("REHEARSAL") and "gloo" in d["config"]["collective"]
+    assert d["config"]["ranks_seen"] == 2 and [r["device"] for r in d["config"]["rank_devices"]] == [0, 0]
+    assert d["prewarm_steps"] == 20
 
 
 def test_weak_mode_two_ranks(hip):
@@ -41,3 +45,20 @@ def test_weak_mode_two_ranks(hip):
 def test_strong_mode_one_rank_rccl(hip):
     d = _run(1, 29623, ["--total-rows", "300000"], {"CQS_BENCH_FORCE_DIST": "1"})
     assert d["scaling"] == "strong" and d["n_gpus"] == 1 and d["roofline"]["bound"] == "hbm"
+    # the self-proving keys of the first real N > 1 run, rehearsed with the 1-rank RCCL group: group size as an
+    # all-reduce over the backend saw it, the device behind every rank, and the C ABI's sharded handle run by rank 0
+    # after the group is gone (devices 0..N-1 = [0] here; RCCL calls inside the library with one rank)
+    assert d["config"]["ranks_seen"] == 1 and d["config"]["collective"].startswith("rccl") and d["rehearsal"] is True
+    assert d["config"]["rank_devices"][0]["device"] == 0 and ":" in d["config"]["rank_devices"][0]["pci"]
+    ab = d["abi_sharded"]
+    assert ab and "error" not in ab, ab
+    assert ab["devices"] == [0] and ab["checked_vs_single_device"] and ab["rows"] == 250000 and ab["queries_per_sec_host_api"] > 0
+
+
+def test_single_gpu_line_carries_the_same_keys(hip):
+    env = dict(os.environ)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--rows", "200000", "--steps", "5", "--warmup", "2"] + COMMON[4:],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    assert d["config"]["ranks_seen"] == 1 and d["prewarm_steps"] == 200 and "rehearsal" not in d and d["n_gpus"] == 1
