@@ -255,7 +255,65 @@ __device__ __forceinline__ void gemm_pp_body(const bf16_t* __restrict__ A, const
     // bf16 / GeGLU: through LDS, so that the workgroup writes WHOLE rows of its tile (a lane's 8 bytes of a 16 x 16
     // accumulator tile are a quarter of a 32-byte segment: stored directly, every 128-byte line is written in four
     // pieces by four instructions - measured: the store phase was 25-35 % of these K = 768 GEMMs).
-    if (OUT == GEMM_OUT_BF16 || OUT == GEMM_OUT_BF16_GELU || OUT == GEMM_OUT_ROWMAX) {
+    if (OUT == GEMM_OUT_ROWMAX) {
+        // Column maxima per sequence instead of the tile (SPLADE pooling, src/splade/mod.rs:1026-1043, folded into the
+        // decoder GEMM: the [tokens, vocab] logits never reach HBM).  The reference pools F32 logits (max, then
+        // ln(1 + max(0, x)), then `> threshold`), so the f32 accumulators (+ bias) are staged as they are - a bf16
+        // stage would add a 2^-9 relative rounding on top of the GEMM's own error and flip entries at the threshold.
+        // Four passes of 64 rows (m-tiles 2p, 2p+1 of both wave rows), LDS row = BN f32 + 16 bytes.  Thread = one
+        // column x one of the pass's two 32-row runs; the running maximum of max(0, x) is flushed with an atomic max
+        // on the bits (non-negative floats order like unsigned integers; x <= 0 and NaN never pass `> 0`, which is the
+        // reference's strict `>` from -inf followed by max(., 0)) whenever the row's sequence changes.
+        f4 bv[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+            bv[j] = bias ? *(const f4*)(bias + n0 + (uint32_t)(wn * 16 * TN + j * 16 + 4 * lg)) : (f4)(0.f);
+        constexpr int kStride = BN + 4;                             // floats
+        float* const stage = (float*)p8smem;                        // 64 x kStride floats <= 66 KiB
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                float* rowp = stage + (size_t)(wm * 32 + t * 16 + l15) * kStride;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) *(f4*)(rowp + wn * 16 * TN + j * 16 + 4 * lg) = acc[2 * p + t][j] + bv[j];
+            }
+            __syncthreads();
+            if (tid < 2 * BN) {
+                const uint32_t col = (uint32_t)tid % (uint32_t)BN, run = (uint32_t)tid / (uint32_t)BN;
+                const uint32_t v = n0 + col;
+                const uint32_t row0 = m0 + run * 128u + (uint32_t)(2 * p) * 16u;
+                if (v < n_valid && row0 < M) {
+                    uint32_t* const outp = (uint32_t*)Cv + v;
+                    const uint32_t cnt = M - row0 < 32u ? M - row0 : 32u;
+                    const float* const sp = stage + (size_t)(run * 32u) * kStride + col;
+                    int32_t cur = row_seq[row0];
+                    float best = 0.f;
+                    if (cur == row_seq[row0 + cnt - 1u]) {             // rows are in sequence order: the run is ONE sequence
+                        for (uint32_t i = 0; i < cnt; ++i) {
+                            const float x = sp[(size_t)i * kStride];
+                            if (x > best) best = x;
+                        }
+                    } else {
+                        for (uint32_t i = 0; i < cnt; ++i) {
+                            const int32_t sq = row_seq[row0 + i];
+                            if (sq != cur) {
+                                if (best > 0.f) atomicMax(outp + (size_t)cur * ldc, __float_as_uint(best));
+                                cur = sq;
+                                best = 0.f;
+                            }
+                            const float x = sp[(size_t)i * kStride];
+                            if (x > best) best = x;
+                        }
+                    }
+                    if (best > 0.f) atomicMax(outp + (size_t)cur * ldc, __float_as_uint(best));
+                }
+            }
+            if (p < 3) __syncthreads();
+        }
+        return;
+    }
+    if (OUT == GEMM_OUT_BF16 || OUT == GEMM_OUT_BF16_GELU) {
         f4 bv[TN];                                                  // this lane's 4 columns of each n-tile
 #pragma unroll
         for (int j = 0; j < TN; ++j)
@@ -283,43 +341,7 @@ __device__ __forceinline__ void gemm_pp_body(const bf16_t* __restrict__ A, const
                 }
             }
             __syncthreads();
-            if (OUT == GEMM_OUT_ROWMAX) {
-                // Column maxima per sequence instead of the tile (SPLADE pooling, src/splade/mod.rs:1026-1043, folded
-                // into the decoder GEMM: the [tokens, vocab] logits never reach HBM).  Thread = one column x one of the
-                // pass's two 64-row runs; the running maximum of max(0, x) is flushed with an atomic max on the bits
-                // (non-negative floats order like unsigned integers; x <= 0 and NaN never pass `> 0`, which is the
-                // reference's strict `>` from -inf followed by max(., 0)) whenever the row's sequence changes.
-                if (tid < 2 * BN) {
-                    const uint32_t col = (uint32_t)tid % (uint32_t)BN, run = (uint32_t)tid / (uint32_t)BN;
-                    const uint32_t v = n0 + col;
-                    const uint32_t row0 = m0 + run * 128u + (uint32_t)(4 * p) * 16u;
-                    if (v < n_valid && row0 < M) {
-                        uint32_t* const outp = (uint32_t*)Cv + v;
-                        const uint32_t cnt = M - row0 < 64u ? M - row0 : 64u;
-                        const bf16_t* const sp = stage + (size_t)(run * 64u) * kStride + col;
-                        int32_t cur = row_seq[row0];
-                        float best = 0.f;
-                        if (cur == row_seq[row0 + cnt - 1u]) {             // rows are in sequence order: the run is ONE sequence
-                            for (uint32_t i = 0; i < cnt; ++i) {
-                                const float x = (float)sp[(size_t)i * kStride];
-                                if (x > best) best = x;
-                            }
-                        } else {
-                            for (uint32_t i = 0; i < cnt; ++i) {
-                                const int32_t sq = row_seq[row0 + i];
-                                if (sq != cur) {
-                                    if (best > 0.f) atomicMax(outp + (size_t)cur * ldc, __float_as_uint(best));
-                                    cur = sq;
-                                    best = 0.f;
-                                }
-                                const float x = (float)sp[(size_t)i * kStride];
-                                if (x > best) best = x;
-                            }
-                        }
-                        if (best > 0.f) atomicMax(outp + (size_t)cur * ldc, __float_as_uint(best));
-                    }
-                }
-            } else {
+            {
                 for (uint32_t c = (uint32_t)tid; c < 128u * (uint32_t)kCPR; c += 512u) {
                     const uint32_t r = c / (uint32_t)kCPR, cc = c % (uint32_t)kCPR;
                     const uint32_t row = m0 + (r >> 6) * 128u + (uint32_t)(4 * p) * 16u + (r & 63u);
