@@ -578,6 +578,49 @@ def _property_check(torch, rows, q, r, s, k, planted=None):
     assert np.max(np.abs(direct - s)) <= 1e-5, float(np.max(np.abs(direct - s)))
 
 
+def test_full_size_against_the_oracle_1m(hip, oracle):
+    """the ORACLE itself at BASELINE's full sizes, beside the property tests.  configs[1]:
+    1M x 768 fp32, one query, k = 20 and k = 500 (the production k, src/limits.rs:315-320); configs[2]: four queries
+    of one 256-query block (matrix-core kernel, work-queue regime) - each against `oracle.index_search` over the same
+    rows with the usual parity rule (identical ids wherever oracle scores are > 2e-6 apart, |score diff| <= 1e-5).
+    ~0.1-0.5 s of CPU per oracle query, 3 GB of host RAM."""
+    import torch
+    n, dim, b = 1_000_000, 768, 256
+    g = torch.Generator(device="cuda"); g.manual_seed(20260)
+    d_rows = torch.empty((n, dim), device="cuda", dtype=torch.float32)
+    for lo in range(0, n, 1 << 18):
+        hi = min(n, lo + (1 << 18))
+        x = torch.randn((hi - lo, dim), generator=g, device="cuda"); x /= x.norm(dim=1, keepdim=True); d_rows[lo:hi] = x
+    d_qs = torch.randn((b, dim), generator=g, device="cuda"); d_qs /= d_qs.norm(dim=1, keepdim=True)
+    rows = d_rows.cpu().numpy()
+    qs = d_qs.cpu().numpy()
+    idx = HipIndex.build_from_device(None, d_rows.data_ptr(), n, dim, borrow=True, keepalive=d_rows)
+    st = torch.cuda.current_stream().cuda_stream
+    for k in (20, 500):                                                  # configs[1]: the HBM-streaming kernel
+        keys = torch.zeros((1, k), dtype=torch.int64, device="cuda"); cnt = torch.zeros((1,), dtype=torch.int32, device="cuda")
+        idx.search_device(d_qs[3].data_ptr(), 1, k, keys.data_ptr(), cnt.data_ptr(), stream=st)
+        torch.cuda.synchronize()
+        assert cnt.item() == k
+        r, s = unpack_keys(keys.cpu().numpy().view(np.uint64)[0])
+        ext_ids, ext_scores = oracle.index_search(rows, qs[3], k + MARGIN)
+        assert_topk_parity(r, s, ext_ids, ext_scores, k)
+    k = 20                                                                # configs[2]: one 256-query block
+    keys = torch.zeros((b, k), dtype=torch.int64, device="cuda"); cnt = torch.zeros((b,), dtype=torch.int32, device="cuda")
+    idx.search_device(d_qs.data_ptr(), b, k, keys.data_ptr(), cnt.data_ptr(), stream=st)
+    torch.cuda.synchronize()
+    hk = keys.cpu().numpy().view(np.uint64)
+    for qi in (0, 77, 128, 255):
+        assert int(cnt[qi].item()) == k
+        r, s = unpack_keys(hk[qi])
+        ext_ids, ext_scores = oracle.index_search(rows, qs[qi], k + MARGIN)
+        assert_topk_parity(r, s, ext_ids, ext_scores, k)
+    # and through the blocking host API (what VectorIndex::search calls: host query in, host results out)
+    got_rows, got_scores, counts = idx.search_batch(qs[9], 20)
+    ext_ids, ext_scores = oracle.index_search(rows, qs[9], 20 + MARGIN)
+    assert_topk_parity(got_rows[0, :counts[0]], got_scores[0, :counts[0]], ext_ids, ext_scores, 20)
+    idx.close()
+
+
 def test_full_size_properties_1m_x_256_queries(hip):
     """BASELINE configs[2] at full size (1M x 768, 256-query block = 7 813 row tiles through the matrix-core
     kernel's work queue): for every query sortedness + direct fp64 dot of the returned rows <= 1e-5; planted rows
