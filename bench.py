@@ -276,13 +276,36 @@ def embed_leg(a, rank, world, dist, torch, np, dev, all_reduce_max):
         ceiling = round(2.0 * 8192 * 4096 * 4096 / ms / 1e9, 1) if ms > 0 else None
     except Exception:
         ceiling = None
+    # search-time latency: ONE short sequence through the blocking call = what `embed_query` costs before every search
+    # (src/embedder/core.rs:768-856 -> src/cli/commands/search/query.rs:595).  Roofline of this shape = weight streaming:
+    # the non-embedding parameters + the Dense head read once (bf16) against the 8 TB/s HBM peak.
+    qlat = None
+    if rank == 0:
+        wbytes = 2.0 * sum(int(np.prod(t.shape)) for n, t in weights.items() if n != "embed_tokens.weight" and t.ndim == 2)
+        qlat = {"what": "blocking cqs_hip_embed of ONE sequence, wall clock per call incl. H2D / D2H / sync; device_ms = HIP events around the chain",
+                "weight_bytes_streamed": wbytes, "by_tokens": {}}
+        for n in (8, 16, 32, 64, 65):
+            ids = rng.integers(1, V, size=(1, n)).astype(np.int64)
+            mask = np.ones((1, n), np.int64)
+            for _ in range(6):
+                eng.run(ids, mask)                   # (both contexts: eager run, capture, replays)
+            reps = 40
+            t0 = time.perf_counter()
+            dms = 0.0
+            for _ in range(reps):
+                eng.run(ids, mask)
+                dms += eng.last_ms()
+            dt = (time.perf_counter() - t0) / reps
+            qlat["by_tokens"][str(n)] = {"ms": round(dt * 1e3, 4), "device_ms": round(dms / reps, 4),
+                                         "path": "query kernels (5 launches / layer, hipGraph)" if n <= 64 else "batch chain",
+                                         "weight_stream_frac_of_hbm_peak": round(wbytes / (dms / reps / 1e3) / 1e9 / HBM_PEAK_GBS, 4)}
     cpu = None
     if rank == 0 and world == 1 and a.cpu_seconds > 0:
         cpu = embed_cpu_baseline(np, cfg, weights, a.cpu_seconds, a.embed_len)
     out = {"model": "EmbeddingGemma-300m geometry (24 x [768 | 3x256 q, 1 kv | 1152], vocab 262144), seeded weights",
            "steps": a.embed_steps, "fixed_len_%d" % a.embed_len: fixed, "lognormal_len": ragged,
            "fixed_len_%d_batch%d" % (a.embed_len, 4 * a.embed_batch): big,
-           "gemm_kernel_ceiling_tflops": ceiling, "cpu_baseline": cpu,
+           "gemm_kernel_ceiling_tflops": ceiling, "cpu_baseline": cpu, "query_latency": qlat,
            "note": "host-buffer API (ids in, embeddings out per batch, PCIe-inclusive); timed wall-clock, max over ranks; "
                    "chunks_per_sec = submit/collect with 3 tickets in flight, sync_api = one blocking call per batch"}
     return out, eng, cfg, weights

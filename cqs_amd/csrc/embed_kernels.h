@@ -121,6 +121,32 @@ hipError_t launch_attention(const bf16_t* qkv, const bf16_t* vt, bf16_t* out, co
 hipError_t launch_mean_pool(const float* hidden, const int32_t* seq_start, const int32_t* seq_len, bf16_t* pooled,
                             uint32_t B, uint32_t H, hipStream_t st);
 
+// ---- the search-time forward (query_kernels.hip): ONE sequence of <= 64 tokens, 5 launches per layer + 2 for the head ----
+struct QueryFwdLayer {
+    const bf16_t *wqkv, *wo, *wgu, *wd;
+    const float *n_in, *n_post_attn, *n_pre_ffw, *n_post_ffw, *n_q, *n_k;
+};
+struct QueryFwd {
+    const int32_t* meta;              // device: [0] = T (1..64), [1 + i] = token id i   (T is NOT a launch parameter: one hipGraph serves every length)
+    const bf16_t* emb;
+    float embed_scale;
+    const QueryFwdLayer* layer;       // host array [layers]
+    uint32_t layers;
+    const float* n_final;
+    const bf16_t *dense1, *dense2;
+    const float *rope_global, *rope_local;
+    uint32_t hidden, heads, kv_heads, inter, dense_hidden, window, sliding_pattern;
+    float eps, q_scale;
+    // scratch, all for 64 rows: x0 / x1 [64, hidden] f32 (the residual stream alternates), qkv [64, (heads + 2 kv) 256],
+    // attn [64, heads 256], y [64, hidden], h [64, inter] bf16, d1 [dense_hidden] bf16, out [hidden] f32
+    float *x0, *x1;
+    bf16_t *qkv, *attn, *y, *h, *d1;
+    float* out;
+};
+constexpr uint32_t kQueryFwdMaxTokens = 64;
+bool query_forward_supported(const EmbedGeom& g);
+hipError_t launch_query_forward(const QueryFwd& f, hipStream_t st);
+
 // f32 -> bf16 (round to nearest even), n elements
 hipError_t launch_f32_to_bf16(const float* in, bf16_t* out, size_t n, hipStream_t st);
 

@@ -54,6 +54,9 @@ struct cqs_hip_embedder {
     float* n_final = nullptr;
     bf16_t *dense1 = nullptr, *dense2 = nullptr;
     std::vector<LayerW> L;
+    std::vector<cqs::QueryFwdLayer> QL;   // the same pointers in the query path's layout (filled by finalize)
+    bool query_path = false;              // geometry supported and not disabled by CQS_HIP_QUERY_PATH=0
+    bool query_graph = true;              // CQS_HIP_QUERY_GRAPH=0: launch the query chain eagerly
     float *rope_global = nullptr, *rope_local = nullptr;  // [max_seq][128][2]
     std::map<std::string, bool> seen;
     bool finalized = false;
@@ -74,6 +77,15 @@ struct cqs_hip_embedder {
         size_t meta_cap = 0;   // int32 elements
         int32_t *d_tok = nullptr, *d_pos = nullptr, *d_seq_start = nullptr, *d_seq_len = nullptr,
                 *d_vt_start = nullptr, *d_blk = nullptr;
+        // search-time path (query_kernels.hip): fixed 64-row scratch, allocated once and never moved, so that the
+        // captured graph's kernel arguments stay valid; [T, tok 0..63] arrives in q_meta by one H2D per query
+        int32_t* q_meta = nullptr;
+        float *q_x0 = nullptr, *q_x1 = nullptr, *q_out = nullptr;
+        bf16_t *q_qkv = nullptr, *q_attn = nullptr, *q_y = nullptr, *q_h = nullptr, *q_d1 = nullptr;
+        hipGraph_t q_graph = nullptr;
+        hipGraphExec_t q_exec = nullptr;
+        uint32_t q_runs = 0;          // eager runs so far (the first sets the kernels' LDS attributes; the second is captured)
+        bool q_graph_failed = false;  // capture / instantiate refused once: stay eager
     };
     static constexpr int kCtx = 2;
     Ctx ctx[kCtx];
@@ -85,6 +97,7 @@ struct cqs_hip_embedder {
         size_t meta_cap = 0;
         float* out = nullptr;      // pinned [B, hidden]
         size_t out_cap = 0;        // floats
+        int32_t* q_meta = nullptr; // pinned [1 + 64]: the query path's [T, tokens]
         uint32_t B = 0, M = 0, vt_cols = 0, nblk = 0;
         hipEvent_t ev0 = nullptr, ev1 = nullptr;   // forward start / end (timing), ev_done after the D2H
         hipEvent_t done = nullptr;
@@ -133,6 +146,15 @@ int32_t upload_f32(cqs_hip_embedder* e, float* dst, const float* src, size_t cou
 }
 
 using Ctx = cqs_hip_embedder::Ctx;
+
+void free_query_scratch(Ctx& c) {
+    if (c.q_exec) (void)hipGraphExecDestroy(c.q_exec);
+    if (c.q_graph) (void)hipGraphDestroy(c.q_graph);
+    c.q_exec = nullptr; c.q_graph = nullptr;
+    void** all[] = {(void**)&c.q_meta, (void**)&c.q_x0, (void**)&c.q_x1, (void**)&c.q_out, (void**)&c.q_qkv, (void**)&c.q_attn,
+                    (void**)&c.q_y, (void**)&c.q_h, (void**)&c.q_d1};
+    for (void** p : all) { (void)hipFree(*p); *p = nullptr; }
+}
 
 void free_scratch(Ctx& c) {
     void** all[] = {(void**)&c.x, (void**)&c.y, (void**)&c.hidden, (void**)&c.out, (void**)&c.xn, (void**)&c.qkv,
@@ -298,6 +320,76 @@ int32_t run_layers(cqs_hip_embedder* e, Ctx& c, Slot& sl) {
     return CQS_HIP_OK;
 }
 
+// ---- the search-time path: ONE sequence of <= 64 tokens (`embed_query`, src/embedder/core.rs:768-856) ---------------
+// 122 launches (5 per layer + 2) of query_kernels.hip instead of the batch chain's ~230, replayed from a hipGraph
+// captured on the context's second query (eager launches of 2-3 us kernels are host-bound: ~3.5 us of host time each).
+bool slot_takes_query_path(const cqs_hip_embedder* e, const Slot& sl) {
+    return e->query_path && sl.B == 1 && sl.M >= 1 && sl.M <= cqs::kQueryFwdMaxTokens;
+}
+
+int32_t ensure_query_scratch(cqs_hip_embedder* e, Ctx& c) {
+    if (c.q_meta) return CQS_HIP_OK;
+    const cqs::EmbedGeom& g = e->g;
+    const size_t R = cqs::kQueryFwdMaxTokens, H = g.hidden;
+    hipError_t he = hipSuccess;
+    auto grab = [&](auto** p, size_t count) { if (he == hipSuccess) he = dmalloc(p, count); };
+    grab(&c.q_meta, R + 1); grab(&c.q_x0, R * H); grab(&c.q_x1, R * H); grab(&c.q_out, H);
+    grab(&c.q_qkv, R * nqkv(g)); grab(&c.q_attn, R * g.heads * g.head_dim); grab(&c.q_y, R * H); grab(&c.q_h, R * g.inter);
+    grab(&c.q_d1, (size_t)g.dense_hidden);
+    if (he != hipSuccess) {
+        free_query_scratch(c);
+        return efail(e, he == hipErrorOutOfMemory ? CQS_HIP_ERR_NOMEM : CQS_HIP_ERR_DEVICE, "query scratch", he);
+    }
+    return CQS_HIP_OK;
+}
+
+// Enqueue on the context's stream: [T, tokens] H2D, the chain (graph replay once captured); leaves the sentence
+// vector (f32 [hidden], not normalised) in c.q_out.
+int32_t run_query(cqs_hip_embedder* e, Ctx& c, Slot& sl) {
+    const cqs::EmbedGeom& g = e->g;
+    hipStream_t st = c.stream;
+    int32_t rc = ensure_query_scratch(e, c);
+    if (rc != CQS_HIP_OK) return rc;
+    if (!sl.q_meta) E_TRY(e, hipHostMalloc((void**)&sl.q_meta, (cqs::kQueryFwdMaxTokens + 1) * sizeof(int32_t), hipHostMallocDefault));
+    sl.q_meta[0] = (int32_t)sl.M;
+    memcpy(sl.q_meta + 1, sl.meta, (size_t)sl.M * sizeof(int32_t));       // slot_fill: tokens first
+    E_TRY(e, hipMemcpyAsync(c.q_meta, sl.q_meta, (size_t)(sl.M + 1) * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    E_TRY(e, hipEventRecord(sl.ev0, st));
+    cqs::QueryFwd f{};
+    f.meta = c.q_meta; f.emb = e->emb; f.embed_scale = sqrtf((float)g.hidden); f.layer = e->QL.data(); f.layers = g.layers;
+    f.n_final = e->n_final; f.dense1 = e->dense1; f.dense2 = e->dense2; f.rope_global = e->rope_global; f.rope_local = e->rope_local;
+    f.hidden = g.hidden; f.heads = g.heads; f.kv_heads = g.kv_heads; f.inter = g.inter; f.dense_hidden = g.dense_hidden;
+    f.window = g.window; f.sliding_pattern = g.sliding_pattern; f.eps = g.rms_eps; f.q_scale = g.q_scale;
+    f.x0 = c.q_x0; f.x1 = c.q_x1; f.qkv = c.q_qkv; f.attn = c.q_attn; f.y = c.q_y; f.h = c.q_h; f.d1 = c.q_d1; f.out = c.q_out;
+    if (c.q_exec) {
+        E_TRY(e, hipGraphLaunch(c.q_exec, st));
+        return CQS_HIP_OK;
+    }
+    if (e->query_graph && !c.q_graph_failed && c.q_runs >= 1) {
+        // capture the chain (kernel launches only; every argument is a fixed device address), instantiate, replay
+        hipError_t he = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+        if (he == hipSuccess) {
+            const hipError_t le = cqs::launch_query_forward(f, st);
+            hipGraph_t gr = nullptr;
+            he = hipStreamEndCapture(st, &gr);
+            if (he == hipSuccess && le != hipSuccess) he = le;
+            if (he == hipSuccess) he = hipGraphInstantiate(&c.q_exec, gr, nullptr, nullptr, 0);
+            if (he == hipSuccess) {
+                c.q_graph = gr;
+                E_TRY(e, hipGraphLaunch(c.q_exec, st));
+                return CQS_HIP_OK;
+            }
+            if (gr) (void)hipGraphDestroy(gr);
+            c.q_exec = nullptr;
+        }
+        (void)hipGetLastError();
+        c.q_graph_failed = true;        // not a device failure: the eager chain below computes the same thing
+    }
+    E_TRY(e, cqs::launch_query_forward(f, st));
+    c.q_runs++;
+    return CQS_HIP_OK;
+}
+
 const char* kLayerTensors[] = {"input_layernorm.weight", "self_attn.q_proj.weight", "self_attn.k_proj.weight",
                                "self_attn.v_proj.weight", "self_attn.o_proj.weight", "self_attn.q_norm.weight",
                                "self_attn.k_norm.weight", "post_attention_layernorm.weight",
@@ -458,6 +550,15 @@ int32_t cqs_hip_embedder_finalize(cqs_hip_embedder* e) CQS_ABI_TRY {
         for (const char* t : kLayerTensors) need.push_back("layers." + std::to_string(l) + "." + t);
     for (const std::string& n : need)
         if (!e->seen.count(n)) return efail(e, CQS_HIP_ERR_INVALID, "finalize: missing tensor " + n);
+    e->QL.resize(e->L.size());
+    for (size_t l = 0; l < e->L.size(); ++l) {
+        const LayerW& w = e->L[l];
+        e->QL[l] = cqs::QueryFwdLayer{w.wqkv, w.wo, w.wgu, w.wd, w.n_in, w.n_post_attn, w.n_pre_ffw, w.n_post_ffw, w.n_q, w.n_k};
+    }
+    const char* qp = getenv("CQS_HIP_QUERY_PATH");
+    const char* qg = getenv("CQS_HIP_QUERY_GRAPH");
+    e->query_path = cqs::query_forward_supported(e->g) && !(qp && qp[0] == '0');
+    e->query_graph = !(qg && qg[0] == '0');
     e->finalized = true;
     return CQS_HIP_OK;
 } CQS_ABI_CATCH(e)
@@ -518,8 +619,9 @@ void cqs_hip_embedder_destroy(cqs_hip_embedder* e) CQS_ABI_TRY {
         if (c.stream) (void)hipStreamSynchronize(c.stream);
     void* g[] = {e->emb, e->n_final, e->dense1, e->dense2, e->rope_global, e->rope_local};
     for (void* p : g) (void)hipFree(p);
-    for (Ctx& c : e->ctx) free_scratch(c);
+    for (Ctx& c : e->ctx) { free_scratch(c); free_query_scratch(c); }
     for (cqs_hip_embedder::Slot& sl : e->slot) {
+        if (sl.q_meta) (void)hipHostFree(sl.q_meta);
         if (sl.meta) (void)hipHostFree(sl.meta);
         if (sl.out) (void)hipHostFree(sl.out);
         if (sl.ev0) (void)hipEventDestroy(sl.ev0);
@@ -578,6 +680,12 @@ int32_t submit_locked(cqs_hip_embedder* e, uint32_t B, const std::function<int32
         memset(sl->out, 0, (size_t)B * H * sizeof(float));
         E_TRY(e, hipEventRecord(sl->ev0, st));
         E_TRY(e, hipEventRecord(sl->ev1, st));
+        E_TRY(e, hipEventRecord(sl->done, st));
+    } else if (slot_takes_query_path(e, *sl)) {
+        rc = run_query(e, c, *sl);
+        if (rc != CQS_HIP_OK) return rc;
+        E_TRY(e, hipEventRecord(sl->ev1, st));
+        E_TRY(e, hipMemcpyAsync(sl->out, c.q_out, (size_t)H * sizeof(float), hipMemcpyDeviceToHost, st));
         E_TRY(e, hipEventRecord(sl->done, st));
     } else {
         rc = run_layers(e, c, *sl);

@@ -1,0 +1,85 @@
+"""The search-time forward (cqs_amd/csrc/query_kernels.hip): ONE sequence of <= 64 tokens runs 5 launches per layer +
+2 for the head, replayed from a hipGraph - what `Embedder::embed_query` (src/embedder/core.rs:768-856) costs on every
+search.  Checked: (1) against the fp32 oracle (oracle/gemma3_ref.py) at lengths {1, 8, 33, 64}, tiny and full
+geometry - the reference holds no golden vector for the forward, so numerics stay "parity unpinned" as everywhere on
+the embedding path; (2) against the batch path of the same engine build (CQS_HIP_QUERY_PATH=0): cosine >= 0.9999 -
+NOT bit-identical, by design: the query kernels split K over a workgroup's four waves, so f32 sums associate
+differently (the batch path's own alone-vs-batched bit-identity is tested in test_embed_gpu.py for rows that take the
+same path); (3) graph replay == eager launches bit for bit, across changing lengths on one captured graph."""
+import numpy as np
+import pytest
+
+from oracle import gemma3_ref as G
+from test_embed_gpu import SMALL, batch, cos, make
+
+pytestmark = pytest.mark.gpu
+
+LENS = [1, 8, 33, 64]
+
+
+def _one(cfg, n, seed):
+    ids, mask = batch(cfg, [n], seed=seed)
+    return ids, mask
+
+
+def test_query_path_matches_the_oracle_and_the_batch_path(hip, monkeypatch):
+    eng_q, w = make(SMALL, seed=31)                      # query path on (default)
+    monkeypatch.setenv("CQS_HIP_QUERY_PATH", "0")
+    eng_b, _ = make(SMALL, seed=31)                      # the same weights through the batch chain only
+    monkeypatch.delenv("CQS_HIP_QUERY_PATH")
+    for n in LENS + [2, 15, 16, 17, 48, 63]:
+        ids, mask = _one(SMALL, n, seed=100 + n)
+        got = eng_q.run(ids, mask)[0]
+        ref = G.forward(SMALL, w, ids, mask)[0]
+        bat = eng_b.run(ids, mask)[0]
+        assert np.all(np.isfinite(got))
+        assert cos(got, ref) > 0.999, (n, cos(got, ref))          # bf16 matrix-core operands vs an fp32 oracle
+        assert cos(got, bat) > 0.9999, (n, cos(got, bat))         # same operands, different f32 association
+        assert np.max(np.abs(got - bat)) < 3e-2 * np.abs(bat).max(), (n, float(np.max(np.abs(got - bat))))
+    # 65 tokens and 2-row batches stay on the batch chain: both engines agree bit for bit there
+    ids, mask = _one(SMALL, 65, seed=9)
+    assert np.array_equal(eng_q.run(ids, mask), eng_b.run(ids, mask))
+    ids, mask = batch(SMALL, [8, 33], seed=10)
+    assert np.array_equal(eng_q.run(ids, mask), eng_b.run(ids, mask))
+    eng_q.close(); eng_b.close()
+
+
+def test_graph_replay_equals_eager_across_lengths(hip, monkeypatch):
+    """One graph per execution context, captured on the context's second query; T is read from device memory, so the
+    same graph must serve every length.  Tickets alternate contexts: 12 queries = 6 per context (1 eager, 1 capture +
+    replay, 4 replays).  Eager engine (CQS_HIP_QUERY_GRAPH=0) = the reference answer, bit for bit."""
+    eng_g, w = make(SMALL, seed=33)
+    monkeypatch.setenv("CQS_HIP_QUERY_GRAPH", "0")
+    eng_e, _ = make(SMALL, seed=33)
+    monkeypatch.delenv("CQS_HIP_QUERY_GRAPH")
+    order = [8, 64, 1, 33, 5, 17, 64, 2, 40, 16, 1, 50]
+    for j, n in enumerate(order):
+        ids, mask = _one(SMALL, n, seed=200 + j)
+        a, b = eng_g.run(ids, mask), eng_e.run(ids, mask)
+        assert np.array_equal(a, b), (j, n, float(np.max(np.abs(a - b))))
+    # a long row in between (batch chain on the same stream / scratch), then the graph again
+    ids, mask = _one(SMALL, 200, seed=7)
+    assert np.array_equal(eng_g.run(ids, mask), eng_e.run(ids, mask))
+    ids, mask = _one(SMALL, 12, seed=8)
+    assert np.array_equal(eng_g.run(ids, mask), eng_e.run(ids, mask))
+    # three tickets in flight, all on the query path (two contexts, each with its own graph + scratch)
+    qs = [_one(SMALL, n, seed=300 + n) for n in (9, 30, 64)]
+    want = [eng_e.run(i, m) for i, m in qs]
+    tickets = [eng_g.submit(i, m) for i, m in qs]
+    for t, wv in zip(reversed(tickets), reversed(want)):
+        assert np.array_equal(eng_g.collect(t, 1), wv)
+    eng_g.close(); eng_e.close()
+
+
+def test_query_path_full_geometry(hip):
+    """EmbeddingGemma's real per-layer geometry (768 | 3 x 256 q, 1 kv | 1152 | Dense 3072), 4 layers incl. one
+    full-attention layer, the 262 144-row vocabulary left out (a 4 096-row table): vs the fp32 oracle."""
+    cfg = G.GemmaConfig(vocab_size=4096, hidden=768, layers=4, heads=3, kv_heads=1, head_dim=256, intermediate=1152,
+                        dense_hidden=3072, sliding_window=512, sliding_pattern=2, max_seq=2048)
+    eng, w = make(cfg, seed=35)
+    for n in LENS:
+        ids, mask = _one(cfg, n, seed=400 + n)
+        got = eng.run(ids, mask)[0]
+        ref = G.forward(cfg, w, ids, mask)[0]
+        assert cos(got, ref) > 0.999, (n, cos(got, ref))
+    eng.close()
