@@ -127,7 +127,8 @@ struct QueryFwdLayer {
     const float *n_in, *n_post_attn, *n_pre_ffw, *n_post_ffw, *n_q, *n_k;
 };
 struct QueryFwd {
-    const int32_t* meta;              // device: [0] = T (1..64), [1 + i] = token id i   (T is NOT a launch parameter: one hipGraph serves every length)
+    const int32_t* tok;               // device: token ids [T]
+    uint32_t T;                       // tokens, 1..64: a launch parameter (the engine keeps one captured hipGraph per length)
     const bf16_t* emb;
     float embed_scale;
     const QueryFwdLayer* layer;       // host array [layers]
@@ -142,6 +143,7 @@ struct QueryFwd {
     float *x0, *x1;
     bf16_t *qkv, *attn, *y, *h, *d1;
     float* out;
+    unsigned long long* dbg;          // nullable: [5 layers + 2 kernel slots][256 workgroups][8] diagnostic stamps (query_kernels.hip)
 };
 constexpr uint32_t kQueryFwdMaxTokens = 64;
 bool query_forward_supported(const EmbedGeom& g);

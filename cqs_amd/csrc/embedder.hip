@@ -78,14 +78,17 @@ struct cqs_hip_embedder {
         int32_t *d_tok = nullptr, *d_pos = nullptr, *d_seq_start = nullptr, *d_seq_len = nullptr,
                 *d_vt_start = nullptr, *d_blk = nullptr;
         // search-time path (query_kernels.hip): fixed 64-row scratch, allocated once and never moved, so that the
-        // captured graph's kernel arguments stay valid; [T, tok 0..63] arrives in q_meta by one H2D per query
+        // captured graphs' kernel arguments stay valid; the token ids arrive in q_meta by one H2D per query
         int32_t* q_meta = nullptr;
         float *q_x0 = nullptr, *q_x1 = nullptr, *q_out = nullptr;
         bf16_t *q_qkv = nullptr, *q_attn = nullptr, *q_y = nullptr, *q_h = nullptr, *q_d1 = nullptr;
-        hipGraph_t q_graph = nullptr;
-        hipGraphExec_t q_exec = nullptr;
-        uint32_t q_runs = 0;          // eager runs so far (the first sets the kernels' LDS attributes; the second is captured)
+        // one captured chain per query length T = 1..64 (T is a launch parameter of every kernel: no load waits for a
+        // length read from memory, no row past T is touched), captured the first time a length is seen
+        hipGraph_t q_graph[64] = {};
+        hipGraphExec_t q_exec[64] = {};
+        uint32_t q_runs = 0;          // eager runs so far (the first sets the kernels' LDS attributes; graphs are captured after it)
         bool q_graph_failed = false;  // capture / instantiate refused once: stay eager
+        unsigned long long* q_dbg = nullptr;   // CQS_HIP_QUERY_STAMPS=1: per-kernel, per-workgroup stamps of the last query
     };
     static constexpr int kCtx = 2;
     Ctx ctx[kCtx];
@@ -97,7 +100,6 @@ struct cqs_hip_embedder {
         size_t meta_cap = 0;
         float* out = nullptr;      // pinned [B, hidden]
         size_t out_cap = 0;        // floats
-        int32_t* q_meta = nullptr; // pinned [1 + 64]: the query path's [T, tokens]
         uint32_t B = 0, M = 0, vt_cols = 0, nblk = 0;
         hipEvent_t ev0 = nullptr, ev1 = nullptr;   // forward start / end (timing), ev_done after the D2H
         hipEvent_t done = nullptr;
@@ -148,10 +150,12 @@ int32_t upload_f32(cqs_hip_embedder* e, float* dst, const float* src, size_t cou
 using Ctx = cqs_hip_embedder::Ctx;
 
 void free_query_scratch(Ctx& c) {
-    if (c.q_exec) (void)hipGraphExecDestroy(c.q_exec);
-    if (c.q_graph) (void)hipGraphDestroy(c.q_graph);
-    c.q_exec = nullptr; c.q_graph = nullptr;
-    void** all[] = {(void**)&c.q_meta, (void**)&c.q_x0, (void**)&c.q_x1, (void**)&c.q_out, (void**)&c.q_qkv, (void**)&c.q_attn,
+    for (int i = 0; i < 64; ++i) {
+        if (c.q_exec[i]) (void)hipGraphExecDestroy(c.q_exec[i]);
+        if (c.q_graph[i]) (void)hipGraphDestroy(c.q_graph[i]);
+        c.q_exec[i] = nullptr; c.q_graph[i] = nullptr;
+    }
+    void** all[] = {(void**)&c.q_dbg, (void**)&c.q_meta, (void**)&c.q_x0, (void**)&c.q_x1, (void**)&c.q_out, (void**)&c.q_qkv, (void**)&c.q_attn,
                     (void**)&c.q_y, (void**)&c.q_h, (void**)&c.q_d1};
     for (void** p : all) { (void)hipFree(*p); *p = nullptr; }
 }
@@ -336,6 +340,18 @@ int32_t ensure_query_scratch(cqs_hip_embedder* e, Ctx& c) {
     grab(&c.q_meta, R + 1); grab(&c.q_x0, R * H); grab(&c.q_x1, R * H); grab(&c.q_out, H);
     grab(&c.q_qkv, R * nqkv(g)); grab(&c.q_attn, R * g.heads * g.head_dim); grab(&c.q_y, R * H); grab(&c.q_h, R * g.inter);
     grab(&c.q_d1, (size_t)g.dense_hidden);
+    // rows past a query's length are read (never used): keep them finite from the start
+    if (he == hipSuccess && getenv("CQS_HIP_QUERY_STAMPS")) {
+        const size_t words = ((size_t)g.layers * 5 + 2) * 256 * 8 * 2;   // x 2: CQS_HIP_QUERY_DEBUG_REPEAT=2
+        grab(&c.q_dbg, words);
+        if (he == hipSuccess) he = hipMemsetAsync(c.q_dbg, 0, words * 8, c.stream);
+    }
+    if (he == hipSuccess) he = hipMemsetAsync(c.q_x0, 0, R * H * 4, c.stream);
+    if (he == hipSuccess) he = hipMemsetAsync(c.q_x1, 0, R * H * 4, c.stream);
+    if (he == hipSuccess) he = hipMemsetAsync(c.q_qkv, 0, R * nqkv(g) * 2, c.stream);
+    if (he == hipSuccess) he = hipMemsetAsync(c.q_attn, 0, R * g.heads * g.head_dim * 2, c.stream);
+    if (he == hipSuccess) he = hipMemsetAsync(c.q_y, 0, R * H * 2, c.stream);
+    if (he == hipSuccess) he = hipMemsetAsync(c.q_h, 0, R * g.inter * 2, c.stream);
     if (he != hipSuccess) {
         free_query_scratch(c);
         return efail(e, he == hipErrorOutOfMemory ? CQS_HIP_ERR_NOMEM : CQS_HIP_ERR_DEVICE, "query scratch", he);
@@ -350,19 +366,18 @@ int32_t run_query(cqs_hip_embedder* e, Ctx& c, Slot& sl) {
     hipStream_t st = c.stream;
     int32_t rc = ensure_query_scratch(e, c);
     if (rc != CQS_HIP_OK) return rc;
-    if (!sl.q_meta) E_TRY(e, hipHostMalloc((void**)&sl.q_meta, (cqs::kQueryFwdMaxTokens + 1) * sizeof(int32_t), hipHostMallocDefault));
-    sl.q_meta[0] = (int32_t)sl.M;
-    memcpy(sl.q_meta + 1, sl.meta, (size_t)sl.M * sizeof(int32_t));       // slot_fill: tokens first
-    E_TRY(e, hipMemcpyAsync(c.q_meta, sl.q_meta, (size_t)(sl.M + 1) * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    E_TRY(e, hipMemcpyAsync(c.q_meta, sl.meta, (size_t)sl.M * sizeof(int32_t), hipMemcpyHostToDevice, st));   // slot_fill: the token ids come first
     E_TRY(e, hipEventRecord(sl.ev0, st));
     cqs::QueryFwd f{};
-    f.meta = c.q_meta; f.emb = e->emb; f.embed_scale = sqrtf((float)g.hidden); f.layer = e->QL.data(); f.layers = g.layers;
+    f.tok = c.q_meta; f.T = sl.M; f.emb = e->emb; f.embed_scale = sqrtf((float)g.hidden); f.layer = e->QL.data(); f.layers = g.layers;
     f.n_final = e->n_final; f.dense1 = e->dense1; f.dense2 = e->dense2; f.rope_global = e->rope_global; f.rope_local = e->rope_local;
     f.hidden = g.hidden; f.heads = g.heads; f.kv_heads = g.kv_heads; f.inter = g.inter; f.dense_hidden = g.dense_hidden;
     f.window = g.window; f.sliding_pattern = g.sliding_pattern; f.eps = g.rms_eps; f.q_scale = g.q_scale;
+    f.dbg = c.q_dbg;
     f.x0 = c.q_x0; f.x1 = c.q_x1; f.qkv = c.q_qkv; f.attn = c.q_attn; f.y = c.q_y; f.h = c.q_h; f.d1 = c.q_d1; f.out = c.q_out;
-    if (c.q_exec) {
-        E_TRY(e, hipGraphLaunch(c.q_exec, st));
+    const int gi = (int)sl.M - 1;
+    if (c.q_exec[gi]) {
+        E_TRY(e, hipGraphLaunch(c.q_exec[gi], st));
         return CQS_HIP_OK;
     }
     if (e->query_graph && !c.q_graph_failed && c.q_runs >= 1) {
@@ -373,14 +388,14 @@ int32_t run_query(cqs_hip_embedder* e, Ctx& c, Slot& sl) {
             hipGraph_t gr = nullptr;
             he = hipStreamEndCapture(st, &gr);
             if (he == hipSuccess && le != hipSuccess) he = le;
-            if (he == hipSuccess) he = hipGraphInstantiate(&c.q_exec, gr, nullptr, nullptr, 0);
+            if (he == hipSuccess) he = hipGraphInstantiate(&c.q_exec[gi], gr, nullptr, nullptr, 0);
             if (he == hipSuccess) {
-                c.q_graph = gr;
-                E_TRY(e, hipGraphLaunch(c.q_exec, st));
+                c.q_graph[gi] = gr;
+                E_TRY(e, hipGraphLaunch(c.q_exec[gi], st));
                 return CQS_HIP_OK;
             }
             if (gr) (void)hipGraphDestroy(gr);
-            c.q_exec = nullptr;
+            c.q_exec[gi] = nullptr;
         }
         (void)hipGetLastError();
         c.q_graph_failed = true;        // not a device failure: the eager chain below computes the same thing
@@ -621,7 +636,6 @@ void cqs_hip_embedder_destroy(cqs_hip_embedder* e) CQS_ABI_TRY {
     for (void* p : g) (void)hipFree(p);
     for (Ctx& c : e->ctx) { free_scratch(c); free_query_scratch(c); }
     for (cqs_hip_embedder::Slot& sl : e->slot) {
-        if (sl.q_meta) (void)hipHostFree(sl.q_meta);
         if (sl.meta) (void)hipHostFree(sl.meta);
         if (sl.out) (void)hipHostFree(sl.out);
         if (sl.ev0) (void)hipEventDestroy(sl.ev0);
@@ -814,6 +828,19 @@ void cqs_hip_normalize_l2_rows(float* rows, uint64_t n, uint32_t dim) CQS_ABI_TR
         }
     }
 } CQS_ABI_CATCH_VOID
+
+// Diagnostic (not part of the public header; CQS_HIP_QUERY_STAMPS=1 at engine creation): the stamps the query chain's
+// workgroups left in context `ctx` ([kernel slot][256][8] u64).  Returns the number of u64 copied.
+uint64_t cqs_hip_debug_query_stamps(cqs_hip_embedder* e, uint32_t ctx, unsigned long long* out, uint64_t cap) CQS_ABI_TRY {
+    if (!e || !out || ctx >= (uint32_t)cqs_hip_embedder::kCtx) return 0;
+    std::lock_guard<std::mutex> lk(e->mu);
+    Ctx& c = e->ctx[ctx];
+    if (!c.q_dbg) return 0;
+    const uint64_t words = std::min<uint64_t>(cap, ((uint64_t)e->g.layers * 5 + 2) * 256 * 8 * 2);
+    if (hipSetDevice(e->device) != hipSuccess || hipStreamSynchronize(c.stream) != hipSuccess ||
+        hipMemcpy(out, c.q_dbg, words * 8, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    return words;
+} CQS_ABI_CATCH_VAL(0)
 
 // Test / tuning aid (not part of the public header): one GEMM launch on caller-provided device buffers
 // (bf16 A [M,K], bf16 W [N,K], C per out_kind) on `stream`; the kernel is chosen like in the forward

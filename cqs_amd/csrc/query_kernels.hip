@@ -24,30 +24,64 @@
 //     latency hides under the activation round trip + norm; v_mfma_f32_16x16x32_bf16 with the weight rows as the A
 //     operand (a lane ends with 4 consecutive output columns of one token row), partial tiles summed through LDS;
 //   * the head (final add + norm, mean pool, Dense 768 -> 3072 -> 768) is two more launches of the same kernel;
-//   * the sequence length T lives in DEVICE memory (meta[0]): grids do not depend on it, so one captured hipGraph
-//     serves every query (embedder.hip).
+//   * measured (in-kernel stamps, tools/query_stamps.py): a workgroup's memory pipeline retires ~28 KB per microsecond
+//     in this regime (12 dwordx4 loads per lane of 4 waves take 0.9 us to ISSUE and 0.8 us more to return), a launch
+//     boundary costs 1.3 us - so a kernel's time is its bytes PER WORKGROUP: weight tiles are 4-8 rows wide (the MFMA's
+//     other rows are zeros: 200-300 workgroups instead of 48-80), no row past the query's length is loaded (T is a
+//     launch parameter; the engine keeps one captured hipGraph per length), reductions are DPP + readlane;
 // K order differs from the batch kernels (4-way K split) -> results agree with the batch path to bf16 rounding noise
 // (cosine >= 0.9999, tests/test_query_path_gpu.py), not bit for bit.
 #include "embed_kernels.h"
 #include "launch_util.h"
 
 #include <cmath>
+#include <cstdlib>
 
 namespace cqs {
 
 typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
 typedef float f4 __attribute__((ext_vector_type(4)));
+typedef unsigned qf_u2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
-constexpr int kQfRows = 64;          // max tokens
 constexpr int kQfPad = 8;            // bf16 elements of row padding in the LDS activation tile
 
+template <int CTRL>
+__device__ __forceinline__ float qf_dpp(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+// sum over the wave: four DPP steps inside each 16-lane row (quad_perm xor 1, xor 2, row_half_mirror, row_mirror),
+// then the four row sums through v_readlane (uniform result; no LDS round trip as with ds_bpermute shuffles)
 __device__ __forceinline__ float qf_wave_sum(float v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
+    v += qf_dpp<0xB1>(v);
+    v += qf_dpp<0x4E>(v);
+    v += qf_dpp<0x141>(v);
+    v += qf_dpp<0x140>(v);
+    const int b = __builtin_bit_cast(int, v);
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16)) +
+           __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+}
+__device__ __forceinline__ float qf_xor32(float v, int lane) {       // the value of lane ^ 32
+    const qf_u2 a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(lane < 32 ? a[1] : a[0]);
+}
+__device__ __forceinline__ float qf_xor16_max(float v) {
+    const qf_u2 a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+}
+__device__ __forceinline__ float qf_xor32_max(float v) {
+    const qf_u2 a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+}
+__device__ __forceinline__ float qf_xor16_sum(float v) {
+    const qf_u2 a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(a[0]) + __uint_as_float(a[1]);
+}
+__device__ __forceinline__ float qf_xor32_sum(float v) {
+    const qf_u2 a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(a[0]) + __uint_as_float(a[1]);
 }
 __device__ __forceinline__ float qf_gelu_tanh(float x) {      // as gelu_tanh (embed_kernels.hip)
     const float k0 = 0.7978845608028654f, k1 = 0.044715f;
@@ -55,12 +89,19 @@ __device__ __forceinline__ float qf_gelu_tanh(float x) {      // as gelu_tanh (e
     return x * __frcp_rn(1.0f + __expf(-u2));
 }
 
+// Diagnostic stamps (off unless the engine was created under CQS_HIP_QUERY_STAMPS=1): workgroup b (< 256) of chain
+// kernel `slot` writes the 100 MHz realtime counter at phase i - where a 4 us kernel that moves 30 KB spends its time.
+#define QF_STAMP(P, i)                                                                                      \
+    do {                                                                                                    \
+        if ((P).dbg && threadIdx.x == 0 && blockIdx.x < 256u)                                               \
+            (P).dbg[((size_t)(P).dbg_slot * 256u + blockIdx.x) * 8u + (i)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+
 enum { QF_PRO_NONE = 0, QF_PRO_EMBED = 1, QF_PRO_ADDNORM = 2, QF_PRO_POOL = 3 };
 enum { QF_EPI_BF16 = 0, QF_EPI_GEGLU = 1, QF_EPI_F32 = 2 };
 
 struct QfGemmParams {
-    const int32_t* meta;      // [0] = T (1..64), [1 + i] = token id of row i
-    // prologue inputs
+    const int32_t* tok;       // EMBED: token ids [T]
     const bf16_t* emb;        // EMBED: token table [vocab, H]
     float scale;              // EMBED: sqrt(H)
     const float* x_in;        // ADDNORM / POOL: residual stream [64, H] f32
@@ -69,350 +110,421 @@ struct QfGemmParams {
     const float* w_next;      // next pre-norm weight [H] (POOL: the model's final norm)
     float* x_out;             // EMBED / ADDNORM: new residual stream [64, H] (written by workgroup 0; != x_in)
     float eps;
-    // GEMM
-    const bf16_t* A;          // PRO_NONE: activations [64, K] bf16
+    const bf16_t* A;          // PRO_NONE: activations [64, K] bf16 (one_row: [K])
     const bf16_t* W;          // [N, K] bf16
     void* C;                  // [64, ldc] bf16 / f32 (POOL and its successor: one row)
     uint32_t K, ldc;
-    int32_t one_row;          // 1: the activations are ONE row (the pooled vector), whatever T says
+    uint32_t T;               // tokens, 1..64: a LAUNCH parameter (the engine keeps one captured graph per length)
+    int32_t one_row;          // 1: the GEMM's activations are ONE row (the pooled vector)
+    unsigned long long* dbg;  // nullable (CQS_HIP_QUERY_STAMPS=1): [kernel slot][workgroup < 256][8] realtime stamps
+    uint32_t dbg_slot;
 };
 
-// C[rows, 16 (x2 for GeGLU)] of one workgroup.  NCH = H / 256 (prologue variants: K = H).
-template <int NCH, int PRO, int EPI>
+// What these kernels are built around (measured with the stamps below, then read off the ISA): at one wave per SIMD a
+// wave issues one instruction per ~4-5 clocks and every launch runs its code exactly once, so a kernel's time is its
+// EXECUTED INSTRUCTION COUNT.  The first versions (runtime row / tile counts behind guards inside unrolled loops) were
+// 10-16 KB of straight-line code, 2 000 instructions of which ~1 100 were register copies at the guards' joins: 3-5 us
+// per kernel whatever the bytes.  Hence: row-tile count MT, rows per wave RB and k-steps per batch CH are TEMPLATE
+// parameters (no guards, no copies), dead slots re-do a real row instead of being predicated (same address: no extra
+// bytes; same value stored to the same place), weight rows past NC repeat a real row (their output columns are never
+// stored).
+
+// ---- C = A W^T for activations that already exist as bf16 rows (o_proj, down, Dense 2) -------------------------------
+// One workgroup = NC output columns x all rows; its 4 waves split K; a wave walks its K range in `nb` batches of CH
+// k-steps, every load of a batch in flight before the first MFMA (K <= 1152: one batch).
+template <int MT, int CH, int EPI, int NC>
+__global__ __launch_bounds__(256) void qf_gemm_plain_kernel(const QfGemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char qf_smem[];
+    float* const red = (float*)qf_smem;                            // [4 waves][MT][64 lanes] f4
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, lg = lane >> 4;
+    QF_STAMP(p, 0);
+    const uint32_t rows = p.one_row ? 1u : p.T;
+    const uint32_t K = p.K, kw = K / 4u, nb = kw / (32u * (uint32_t)CH);
+    const uint32_t koff = (uint32_t)wid * kw + 8u * (uint32_t)lg;
+    const bf16_t* wp = p.W + (size_t)(blockIdx.x * (uint32_t)NC + (uint32_t)(l15 % NC)) * K + koff;
+    const bf16_t* ap[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const uint32_t r = 16u * (uint32_t)m + (uint32_t)l15;
+        ap[m] = p.A + (size_t)(r < rows ? r : rows - 1u) * K + koff;
+    }
+    f4 acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[m] = (f4)(0.f);
+    for (uint32_t b = 0; b < nb; ++b) {
+        bf8 wf[CH], af[MT][CH];
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+            wf[u] = *(const bf8*)(wp + 32 * u);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) af[m][u] = *(const bf8*)(ap[m] + 32 * u);
+        }
+#pragma unroll
+        for (int u = 0; u < CH; ++u)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u], af[m][u], acc[m], 0, 0, 0);
+        wp += 32 * CH;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) ap[m] += 32 * CH;
+    }
+    QF_STAMP(p, 1);
+    // sum the four K-quarters through LDS; wave w finishes m-tile w.  acc[m][r] = C[row 16 m + l15][col 4 lg + r]
+#pragma unroll
+    for (int m = 0; m < MT; ++m) *(f4*)(red + ((size_t)(wid * MT + m) * 64 + lane) * 4) = acc[m];
+    __syncthreads();
+    QF_STAMP(p, 2);
+    if (wid >= MT) return;
+    f4 v = *(const f4*)(red + ((size_t)wid * 64 + lane) * 4);
+#pragma unroll
+    for (int w = 1; w < 4; ++w) v += *(const f4*)(red + ((size_t)(w * MT + wid) * 64 + lane) * 4);
+    const uint32_t row = 16u * (uint32_t)wid + (uint32_t)l15;
+    if (row >= rows || 4 * lg >= NC) return;                       // columns 4 lg .. 4 lg + 3 of the tile: real iff < NC
+    const size_t off = (size_t)row * p.ldc + blockIdx.x * (uint32_t)NC + 4u * (uint32_t)lg;
+    if (EPI == QF_EPI_F32) {
+        *(f4*)((float*)p.C + off) = v;
+    } else {
+        bf4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = (bf16_t)v[r];
+        *(bf4*)((bf16_t*)p.C + off) = o;
+    }
+    if (p.dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); QF_STAMP(p, 3); }
+}
+
+// ---- GEMMs whose activations are made on the way in: embedding gather / add + RMSNorm pair (/ + mean pool) ---------
+// NCH = H / 256, K = H.  Rows: one WAVE per row, wave w takes rows w, w + 4, ... in batches of RB rows (RB = 1, 2, 4
+// by T for T <= 16: one batch; longer queries loop over batches of 4, the next batch's loads issued before the current
+// one is reduced).  A batch slot past T re-does row T - 1.
+template <int NCH, int PRO, int EPI, int NC, int RB, int MT>
 __global__ __launch_bounds__(256) void qf_gemm_kernel(const QfGemmParams p) {
     constexpr int H = NCH * 256;
-    constexpr int NT = EPI == QF_EPI_GEGLU ? 2 : 1;               // 16-row weight tiles per workgroup
+    constexpr int NT = EPI == QF_EPI_GEGLU ? 2 : 1;               // weight tiles per workgroup
     constexpr int LDA = H + kQfPad;                                // LDS activation row stride (elements)
+    constexpr int GT = PRO == QF_PRO_POOL ? 1 : MT;                // row tiles of the GEMM (POOL: the one pooled row)
     extern __shared__ __attribute__((aligned(16))) unsigned char qf_smem[];
-    bf16_t* const sA = (bf16_t*)qf_smem;                           // [64][LDA] (prologue variants only)
-    float* const red = (float*)(qf_smem + (PRO != QF_PRO_NONE ? (size_t)kQfRows * LDA * sizeof(bf16_t) : 0));   // [4 waves][NT][4 mt][64 lanes] f4
-    float* const pool = red + 4 * NT * 4 * 64 * 4;                 // POOL: [4 waves][H] column sums
+    bf16_t* const sA = (bf16_t*)qf_smem;                           // [16 GT][LDA]
+    float* const red = (float*)(qf_smem + (size_t)16 * GT * LDA * sizeof(bf16_t));   // [4 waves][NT][GT][64 lanes] f4
+    float* const pool = red + 4 * NT * GT * 64 * 4;                // POOL: [4 waves][H] column sums
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, lg = lane >> 4;
-    const uint32_t T = (uint32_t)p.meta[0];
-    const uint32_t rows = p.one_row ? 1u : T;
-    const uint32_t mtiles = (rows + 15u) / 16u;
-    const uint32_t K = PRO != QF_PRO_NONE ? (uint32_t)H : p.K;
-    const uint32_t kw = K / 4u;                                    // this wave's K range: [wid kw, (wid + 1) kw)
-    const uint32_t steps = kw / 32u;
+    QF_STAMP(p, 0);
+    const uint32_t T = p.T;
+    constexpr uint32_t kw = H / 4;                                 // this wave's K range: [wid kw, (wid + 1) kw)
+    constexpr int S = 2 * NCH;                                     // k-steps of 32 per wave
 
-    // weight rows of the workgroup's tiles.  GeGLU: W rows are interleaved per 64 (32 gate rows, then the same
-    // channels' 32 up rows; embedder.hip set_tensor) -> channels [16 b, 16 b + 16) = gate rows 64 (b / 2) + 16 (b % 2) + r.
-    uint32_t wrow[NT];
-    if (EPI == QF_EPI_GEGLU) {
-        wrow[0] = 64u * (blockIdx.x >> 1) + 16u * (blockIdx.x & 1u);
-        wrow[NT - 1] = wrow[0] + 32u;
-    } else {
-        wrow[0] = blockIdx.x * 16u;
-    }
-    const bf16_t* wp[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) wp[t] = p.W + (size_t)(wrow[t] + (uint32_t)l15) * K + (size_t)wid * kw + 8u * (uint32_t)lg;
-
-    f4 acc[NT][4];
+    // weight rows of the workgroup's tile(s).  GeGLU: W rows are interleaved per 64 (32 gate rows, then the same
+    // channels' 32 up rows; embedder.hip set_tensor) -> channels [NC b, NC b + NC) = gate rows 64 (c / 32) + c % 32.
+    uint32_t wrow0 = blockIdx.x * (uint32_t)NC;
+    if (EPI == QF_EPI_GEGLU) wrow0 = 64u * (wrow0 >> 5) + (wrow0 & 31u);
+    const bf16_t* wp = p.W + (size_t)(wrow0 + (uint32_t)(l15 % NC)) * H + (uint32_t)wid * kw + 8u * (uint32_t)lg;
+    bf8 wf[NT][S];                                                 // requested first: they land while the rows are normalised
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int m = 0; m < 4; ++m) acc[t][m] = (f4)(0.f);
+        for (int s = 0; s < S; ++s) wf[t][s] = *(const bf8*)(wp + (size_t)t * 32 * H + 32 * s);
 
-    if constexpr (PRO != QF_PRO_NONE) {
-        // ---- weights first: the wave's whole K range of its tile(s) is 2 NCH fragments per tile, requested now ----
-        constexpr int S = 2 * NCH;                                  // k-steps of 32 per wave (H / 4 / 32)
-        bf8 wf[NT][S];
+    // lane owns 4 consecutive floats of each 256-chunk of a row
+    f4 wn1[NCH], wp1[NCH];                                         // 1 + w
+    const uint32_t c0 = (uint32_t)lane * 4u;
+    auto load_row = [&](uint32_t row, f4 (&xv)[NCH], f4 (&yv)[NCH]) {
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+        for (int c = 0; c < NCH; ++c) {
+            if (PRO == QF_PRO_EMBED) {
+                const bf4 e = *(const bf4*)(p.emb + (size_t)(uint32_t)p.tok[row] * H + c * 256 + c0);
 #pragma unroll
-            for (int s = 0; s < S; ++s) wf[t][s] = *(const bf8*)(wp[t] + 32 * s);
-
-        // ---- prologue: rows wid, wid + 4, ... of the activation tile; lane owns 4 consecutive floats of each 256-chunk ----
-        f4 psum[NCH];                                               // POOL: this wave's column sums
+                for (int i = 0; i < 4; ++i) xv[c][i] = (float)e[i] * p.scale;
+            } else {
+                xv[c] = *(const f4*)(p.x_in + (size_t)row * H + c * 256 + c0);
+                const bf4 yb = *(const bf4*)(p.y + (size_t)row * H + c * 256 + c0);
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) psum[c] = (f4)(0.f);
-        constexpr int RB = 4;                                       // rows in flight per wave
-        for (uint32_t r0 = (uint32_t)wid; r0 < T; r0 += 4u * RB) {
-            f4 xv[RB][NCH];
-            f4 yv[RB][NCH];
+                for (int i = 0; i < 4; ++i) yv[c][i] = (float)yb[i];
+            }
+        }
+    };
+    f4 psum[NCH];                                                  // POOL: this wave's column sums
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) psum[c] = (f4)(0.f);
+    auto finish_row = [&](uint32_t row, bool count, f4 (&xv)[NCH], f4 (&yv)[NCH]) {
+        if (PRO != QF_PRO_EMBED) {                                   // x += norm(y) (1 + w_post)   (add_norm_kernel's arithmetic)
+            float ss = 0.f;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ss += yv[c][i] * yv[c][i];
+            const float invy = rsqrtf(qf_wave_sum(ss) / (float)H + p.eps);
+#pragma unroll
+            for (int c = 0; c < NCH; ++c)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) xv[c][i] += yv[c][i] * invy * wp1[c][i];
+        }
+        float sx = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sx += xv[c][i] * xv[c][i];
+        const float invx = rsqrtf(qf_wave_sum(sx) / (float)H + p.eps);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            if (PRO == QF_PRO_POOL) {
+                if (count) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) psum[c][i] += xv[c][i] * invx * wn1[c][i];     // f32 hidden state, summed
+                }
+            } else {
+                bf4 o;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i] = (bf16_t)(xv[c][i] * invx * wn1[c][i]);
+                *(bf4*)(sA + (size_t)row * LDA + c * 256 + c0) = o;
+                if (blockIdx.x == 0) *(f4*)(p.x_out + (size_t)row * H + c * 256 + c0) = xv[c];
+            }
+        }
+    };
+    f4 xv[RB][NCH], yv[RB][NCH];
+    const uint32_t last = T - 1u;
+#pragma unroll
+    for (int b = 0; b < RB; ++b) {
+        const uint32_t r = (uint32_t)wid + 4u * (uint32_t)b;
+        load_row(r < T ? r : last, xv[b], yv[b]);
+    }
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const f4 a = *(const f4*)(p.w_next + c * 256 + c0);
+        wn1[c] = a + 1.0f;
+        if (PRO != QF_PRO_EMBED) wp1[c] = *(const f4*)(p.w_post + c * 256 + c0) + 1.0f;
+    }
+    if (MT == 1) {
+#pragma unroll
+        for (int b = 0; b < RB; ++b) {
+            const uint32_t r = (uint32_t)wid + 4u * (uint32_t)b;
+            finish_row(r < T ? r : last, r < T, xv[b], yv[b]);
+        }
+    } else {                                                        // RB = 4; 16 rows per batch of the workgroup
+        for (uint32_t r0 = (uint32_t)wid; r0 < T; r0 += 16u) {
+            f4 xn[RB][NCH], yn[RB][NCH];
+            const bool more = r0 + 16u < T;                          // wave-uniform
+            if (more) {
+#pragma unroll
+                for (int b = 0; b < RB; ++b) {
+                    const uint32_t r = r0 + 16u + 4u * (uint32_t)b;
+                    load_row(r < T ? r : last, xn[b], yn[b]);
+                }
+            }
 #pragma unroll
             for (int b = 0; b < RB; ++b) {
-                const uint32_t row = r0 + 4u * (uint32_t)b < T ? r0 + 4u * (uint32_t)b : T - 1u;   // clamped: loaded, not used
-#pragma unroll
-                for (int c = 0; c < NCH; ++c) {
-                    const uint32_t col = (uint32_t)c * 256u + (uint32_t)lane * 4u;
-                    if (PRO == QF_PRO_EMBED) {
-                        const bf4 e = *(const bf4*)(p.emb + (size_t)(uint32_t)p.meta[1u + row] * H + col);
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) xv[b][c][i] = (float)e[i] * p.scale;
-                    } else {
-                        xv[b][c] = *(const f4*)(p.x_in + (size_t)row * H + col);
-                        const bf4 yb = *(const bf4*)(p.y + (size_t)row * H + col);
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) yv[b][c][i] = (float)yb[i];
-                    }
-                }
+                const uint32_t r = r0 + 4u * (uint32_t)b;
+                finish_row(r < T ? r : last, r < T, xv[b], yv[b]);
             }
+            if (more) {
 #pragma unroll
-            for (int b = 0; b < RB; ++b) {
-                const uint32_t row = r0 + 4u * (uint32_t)b;
-                if (row >= T) break;                                 // wave-uniform
-                if (PRO != QF_PRO_EMBED) {                           // x += norm(y) (1 + w_post)   (add_norm_kernel's arithmetic)
-                    float ss = 0.f;
+                for (int b = 0; b < RB; ++b)
 #pragma unroll
-                    for (int c = 0; c < NCH; ++c)
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) ss += yv[b][c][i] * yv[b][c][i];
-                    const float invy = rsqrtf(qf_wave_sum(ss) / (float)H + p.eps);
-#pragma unroll
-                    for (int c = 0; c < NCH; ++c) {
-                        const f4 w = *(const f4*)(p.w_post + c * 256 + lane * 4);
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) xv[b][c][i] += yv[b][c][i] * invy * (1.0f + w[i]);
-                    }
-                }
-                float sx = 0.f;
-#pragma unroll
-                for (int c = 0; c < NCH; ++c)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) sx += xv[b][c][i] * xv[b][c][i];
-                const float invx = rsqrtf(qf_wave_sum(sx) / (float)H + p.eps);
-#pragma unroll
-                for (int c = 0; c < NCH; ++c) {
-                    const uint32_t col = (uint32_t)c * 256u + (uint32_t)lane * 4u;
-                    const f4 w = *(const f4*)(p.w_next + col);
-                    if (PRO == QF_PRO_POOL) {
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) psum[c][i] += xv[b][c][i] * invx * (1.0f + w[i]);    // f32 hidden state, summed
-                    } else {
-                        bf4 o;
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) o[i] = (bf16_t)(xv[b][c][i] * invx * (1.0f + w[i]));
-                        *(bf4*)(sA + (size_t)row * LDA + col) = o;
-                        if (blockIdx.x == 0) *(f4*)(p.x_out + (size_t)row * H + col) = xv[b][c];
-                    }
-                }
-            }
-        }
-        if (PRO == QF_PRO_POOL) {
-            // masked mean pool (src/embedder/pooling.rs:87-128) of the final-norm rows -> ONE activation row (bf16, as
-            // mean_pool_kernel hands it to the Dense head)
-#pragma unroll
-            for (int c = 0; c < NCH; ++c) *(f4*)(pool + (size_t)wid * H + c * 256 + lane * 4) = psum[c];
-            __syncthreads();
-            for (uint32_t col = (uint32_t)tid; col < (uint32_t)H; col += 256u) {
-                const float s = pool[col] + pool[H + col] + pool[2 * H + col] + pool[3 * H + col];
-                sA[col] = (bf16_t)(s / (float)T);
-            }
-            for (uint32_t i = (uint32_t)tid; i < 15u * (uint32_t)H; i += 256u) sA[(size_t)(1u + i / H) * LDA + i % H] = (bf16_t)0.f;   // rows 1..15 of the m-tile
-        } else {
-            // rows [T, 16 mtiles) feed the MFMA's B operand too: keep them finite
-            for (uint32_t i = (uint32_t)tid; i < (mtiles * 16u - T) * (uint32_t)H; i += 256u) sA[(size_t)(T + i / H) * LDA + i % H] = (bf16_t)0.f;
-        }
-        __syncthreads();
-        // ---- multiply: B operand (activations) from LDS: lane feeds row 16 m + l15, k = wid kw + 32 s + 8 lg .. + 7 ----
-        const bf16_t* la = sA + (size_t)l15 * LDA + (size_t)wid * kw + 8u * (uint32_t)lg;
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            if ((uint32_t)m >= mtiles) break;                        // wave-uniform
-#pragma unroll
-            for (int s = 0; s < S; ++s) {
-                const bf8 a = *(const bf8*)(la + (size_t)(16 * m) * LDA + 32 * s);
-#pragma unroll
-                for (int t = 0; t < NT; ++t) acc[t][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t][s], a, acc[t][m], 0, 0, 0);
-            }
-        }
-    } else {
-        // ---- activations straight from global memory (o_proj, down, Dense 2): U k-steps of both operands in flight ----
-        constexpr int U = 6;
-        const bf16_t* ap[4];
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            const uint32_t r = 16u * (uint32_t)m + (uint32_t)l15;
-            ap[m] = p.A + (size_t)(r < rows ? r : rows - 1u) * K + (size_t)wid * kw + 8u * (uint32_t)lg;   // rows past the end: any real row
-        }
-        for (uint32_t s0 = 0; s0 < steps; s0 += U) {
-            bf8 wf[NT][U], af[4][U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const uint32_t s = s0 + (uint32_t)u < steps ? s0 + (uint32_t)u : steps - 1u;            // (tail: re-read, not accumulated)
-#pragma unroll
-                for (int t = 0; t < NT; ++t) wf[t][u] = *(const bf8*)(wp[t] + (size_t)s * 32u);
-#pragma unroll
-                for (int m = 0; m < 4; ++m)
-                    if ((uint32_t)m < mtiles) af[m][u] = *(const bf8*)(ap[m] + (size_t)s * 32u);
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                if (s0 + (uint32_t)u >= steps) break;
-#pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    if ((uint32_t)m >= mtiles) break;
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) acc[t][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t][u], af[m][u], acc[t][m], 0, 0, 0);
-                }
+                    for (int c = 0; c < NCH; ++c) { xv[b][c] = xn[b][c]; yv[b][c] = yn[b][c]; }
             }
         }
     }
-
+    if (PRO == QF_PRO_POOL) {
+        // masked mean pool (src/embedder/pooling.rs:87-128) of the final-norm rows -> ONE activation row (bf16, as
+        // mean_pool_kernel hands it to the Dense head)
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) *(f4*)(pool + (size_t)wid * H + c * 256 + c0) = psum[c];
+        __syncthreads();
+        for (uint32_t col = (uint32_t)tid; col < (uint32_t)H; col += 256u) {
+            const float sm = pool[col] + pool[H + col] + pool[2 * H + col] + pool[3 * H + col];
+            sA[col] = (bf16_t)(sm / (float)T);
+        }
+        // (rows 1..15 of the m-tile stay whatever LDS held: an activation row only feeds its own output column of the
+        // MFMA, and columns past the real rows are never stored)
+    }
+    // rows [T, 16 MT) of the tile are not initialised either, for the same reason
+    __syncthreads();
+    QF_STAMP(p, 1);
+    // ---- multiply: B operand (activations) from LDS: lane feeds row 16 m + l15, k = wid kw + 32 s + 8 lg .. + 7 ----
+    f4 acc[NT][GT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int m = 0; m < GT; ++m) acc[t][m] = (f4)(0.f);
+    const bf16_t* la = sA + (size_t)l15 * LDA + (uint32_t)wid * kw + 8u * (uint32_t)lg;
+#pragma unroll
+    for (int m = 0; m < GT; ++m)
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const bf8 a = *(const bf8*)(la + (size_t)(16 * m) * LDA + 32 * s);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t][s], a, acc[t][m], 0, 0, 0);
+        }
     // ---- sum the four K-quarters through LDS; wave w finishes m-tile w.  acc[t][m][r] = C[row 16 m + l15][col 4 lg + r] ----
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
-            if ((uint32_t)m < mtiles) *(f4*)(red + ((size_t)((wid * NT + t) * 4 + m) * 64 + lane) * 4) = acc[t][m];
+        for (int m = 0; m < GT; ++m) *(f4*)(red + ((size_t)((wid * NT + t) * GT + m) * 64 + lane) * 4) = acc[t][m];
     __syncthreads();
-    if ((uint32_t)wid >= mtiles) return;
+    QF_STAMP(p, 2);
+    if (wid >= GT) return;
     f4 v[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        v[t] = *(const f4*)(red + ((size_t)((0 * NT + t) * 4 + wid) * 64 + lane) * 4);
+        v[t] = *(const f4*)(red + ((size_t)((0 * NT + t) * GT + wid) * 64 + lane) * 4);
 #pragma unroll
-        for (int w = 1; w < 4; ++w) v[t] += *(const f4*)(red + ((size_t)((w * NT + t) * 4 + wid) * 64 + lane) * 4);
+        for (int w = 1; w < 4; ++w) v[t] += *(const f4*)(red + ((size_t)((w * NT + t) * GT + wid) * 64 + lane) * 4);
     }
+    const uint32_t rows = PRO == QF_PRO_POOL ? 1u : T;
     const uint32_t row = 16u * (uint32_t)wid + (uint32_t)l15;
-    if (row >= rows) return;
+    if (row >= rows || 4 * lg >= NC) return;                       // columns 4 lg .. 4 lg + 3 of the tile: real iff < NC
+    const size_t off = (size_t)row * p.ldc + blockIdx.x * (uint32_t)NC + 4u * (uint32_t)lg;
+    bf4 o;
     if (EPI == QF_EPI_GEGLU) {
-        bf4 o;
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[r] = (bf16_t)(qf_gelu_tanh(v[0][r]) * v[NT - 1][r]);
-        *(bf4*)((bf16_t*)p.C + (size_t)row * p.ldc + blockIdx.x * 16u + 4u * (uint32_t)lg) = o;
-    } else if (EPI == QF_EPI_F32) {
-        *(f4*)((float*)p.C + (size_t)row * p.ldc + blockIdx.x * 16u + 4u * (uint32_t)lg) = v[0];
     } else {
-        bf4 o;
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[r] = (bf16_t)v[0][r];
-        *(bf4*)((bf16_t*)p.C + (size_t)row * p.ldc + blockIdx.x * 16u + 4u * (uint32_t)lg) = o;
     }
+    *(bf4*)((bf16_t*)p.C + off) = o;
+    if (p.dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); QF_STAMP(p, 3); }
 }
 
-// ---- attention over <= 64 keys: one workgroup per q head, wave w = queries [16 w, 16 w + 16) ---------------------------
-// K rows (k-head RMSNorm + RoPE applied on the way, the arithmetic of qk_norm_rope_block) and V^T are staged once in LDS;
-// S^T = K Q^T with keys on MFMA rows (softmax lane-local + two cross-lane steps), O^T = V^T P^T with the S^T
-// accumulators as the B operand (embed_kernels.hip's key permutation: lane group g holds keys {4g..4g+3} of each 16-key
-// tile, so the 8 slots of a 32-key step are keys {4g.., 16 + 4g..} and V^T is read in that order).
+// ---- attention over <= 64 keys ------------------------------------------------------------------------------------------
+// Staging (one WAVE per token row; lane owns dims [4 lane, 4 lane + 4), rotate_half partner = lane ^ 32 - the arithmetic
+// of qk_norm_rope_block): per row the k head and the NH q heads are RMS-normalised, rotated (q also scaled) and written
+// to LDS as bf16 rows, V is written transposed.  S^T = K Q^T with keys on MFMA rows (softmax lane-local + two
+// cross-lane steps), O^T = V^T P^T with the S^T accumulators as the B operand (embed_kernels.hip's key permutation: lane
+// group g holds keys {4g..4g+3} of each 16-key tile, so the 8 slots of a 32-key step are keys {4g.., 16 + 4g..} and V^T
+// is read in that order).  Two users: qf_attention_kernel (one workgroup per q head; queries of 49-64 tokens) and
+// qf_attn_oproj_kernel (every o_proj workgroup redoes the attention of all heads in its own LDS: one launch and one
+// round trip through memory less per layer; the redundant work is ~100 MFMAs per workgroup at 8-16 tokens).
 constexpr int kQfHD = 256;
-constexpr int kQfKRow = kQfHD + 8;          // sK row stride (elements)
-constexpr int kQfVRow = kQfRows + 8;        // sVt row stride (elements)
+constexpr int kQfKRow = kQfHD + 8;          // sQ / sK row stride (elements)
 
 struct QfAttnParams {
-    const int32_t* meta;
     const bf16_t* qkv;        // [64, (heads + 2 kv) 256] bf16, as the QKV projection wrote it
-    bf16_t* out;              // [64, heads 256] bf16
+    bf16_t* out;              // qf_attention_kernel: [64, heads 256] bf16
     const float* wq;          // q-head norm weight [256]
     const float* wk;          // k-head norm weight [256]
     const float* cos_sin;     // [max_seq][128][2] of the layer type
     float eps, q_scale;
     uint32_t heads, kv_heads;
     uint32_t window;          // 0 = full attention; else |q - k| < window
+    uint32_t T;               // launch parameter (see QfGemmParams)
+    // qf_attn_oproj_kernel only: y = attn Wo^T
+    const bf16_t* wo;         // [H, heads 256] bf16
+    bf16_t* y;                // [64, H] bf16
+    uint32_t H;
+    unsigned long long* dbg;
+    uint32_t dbg_slot;
 };
 
-__global__ __launch_bounds__(256) void qf_attention_kernel(const QfAttnParams p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char qf_smem[];
-    bf16_t* const sK = (bf16_t*)qf_smem;                                  // [64][kQfKRow]
-    bf16_t* const sVt = sK + (size_t)kQfRows * kQfKRow;                   // [256][kQfVRow]
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l15 = lane & 15, lg = lane >> 4;
-    const uint32_t T = (uint32_t)p.meta[0];
-    const uint32_t mtiles = (T + 15u) / 16u;
-    const uint32_t h = blockIdx.x, g = h / (p.heads / p.kv_heads);
+template <int MT> constexpr int qf_vrow() { return 32 * ((MT + 1) / 2) + 8; }   // sVt row stride: keys padded to 32, + 8
+
+// Stage rows [0, T) of kv head g and q heads [h0, h0 + NH): sQ [NH][16 MT][kQfKRow], sK [16 MT][kQfKRow], sVt [256][vrow].
+template <int MT, int RB, int NH>
+__device__ __forceinline__ void qf_attn_stage(const QfAttnParams& p, uint32_t h0, uint32_t g, bf16_t* sQ, bf16_t* sK, bf16_t* sVt,
+                                              int wid, int lane) {
+    constexpr int VR = qf_vrow<MT>();
+    const uint32_t T = p.T, last = T - 1u;
     const uint32_t ld = (p.heads + 2u * p.kv_heads) * (uint32_t)kQfHD;
-    const bf16_t* kbase = p.qkv + (size_t)(p.heads + g) * kQfHD;
-    const bf16_t* vbase = p.qkv + (size_t)(p.heads + p.kv_heads + g) * kQfHD;
-
-    // ---- stage K (norm + rope) and V^T: wave w takes keys w, w + 4, ...; lane owns dims [4 lane, 4 lane + 4) ----
-    const f4 wkv = *(const f4*)(p.wk + lane * 4);
-    for (uint32_t key = (uint32_t)wid; key < mtiles * 16u; key += 4u) {
-        if (key < T) {
-            const bf4 kin = *(const bf4*)(kbase + (size_t)key * ld + lane * 4);
-            const bf4 vin = *(const bf4*)(vbase + (size_t)key * ld + lane * 4);
-            const float* cs = p.cos_sin + ((size_t)key * 128u + (uint32_t)(lane & 31) * 4u) * 2u;
-            const f4 cs0 = *(const f4*)cs, cs1 = *(const f4*)(cs + 4);
-            const float c4[4] = {cs0[0], cs0[2], cs1[0], cs1[2]};
-            const float s4[4] = {cs0[1], cs0[3], cs1[1], cs1[3]};
-            float kv[4];
-            float ss = 0.f;
+    const bf16_t* qb = p.qkv + (size_t)h0 * kQfHD + lane * 4;
+    const bf16_t* kb = p.qkv + (size_t)(p.heads + g) * kQfHD + lane * 4;
+    const bf16_t* vb = p.qkv + (size_t)(p.heads + p.kv_heads + g) * kQfHD + lane * 4;
+    const float* csb = p.cos_sin + (uint32_t)(lane & 31) * 8u;
+    struct Row { bf4 q[NH], k, v; f4 c0, c1; };
+    auto load = [&](uint32_t row, Row& r) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { kv[i] = (float)kin[i]; ss += kv[i] * kv[i]; }
-            const float inv = rsqrtf(qf_wave_sum(ss) / (float)kQfHD + p.eps);
-            bf4 o;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float n = kv[i] * inv * (1.0f + wkv[i]);
-                const float other = __shfl_xor(n, 32, 64);            // rotate_half partner: dim +/- 128 = lane ^ 32
-                o[i] = (bf16_t)((lane < 32) ? (n * c4[i] - other * s4[i]) : (n * c4[i] + other * s4[i]));
-            }
-            *(bf4*)(sK + (size_t)key * kQfKRow + lane * 4) = o;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) sVt[(size_t)(lane * 4 + i) * kQfVRow + key] = vin[i];
-        } else {                                                      // padding keys: finite (their P is 0)
-            *(bf4*)(sK + (size_t)key * kQfKRow + lane * 4) = (bf4)(0.f);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) sVt[(size_t)(lane * 4 + i) * kQfVRow + key] = (bf16_t)0.f;
-        }
-    }
-    // a 32-key PV step past the last 16-key tile reads 16 more V^T columns: zero them too
-    if (mtiles & 1u)
-        for (uint32_t i = (uint32_t)tid; i < 16u * (uint32_t)kQfHD; i += 256u) sVt[(size_t)(i >> 4) * kQfVRow + mtiles * 16u + (i & 15u)] = (bf16_t)0.f;
-
-    // ---- this wave's Q^T fragments (B operand of S^T): q norm + rope + scale on the wave's own fragments ----
-    const bool active = (uint32_t)wid < mtiles;
-    bf8 qf[8];
-    const uint32_t q = 16u * (uint32_t)wid + (uint32_t)l15;
-    const uint32_t qc = q < T ? q : T - 1u;
-    if (active) {
-        const bf16_t* qrow = p.qkv + (size_t)qc * ld + (size_t)h * kQfHD;
-#pragma unroll
-        for (int s = 0; s < 8; ++s) qf[s] = *(const bf8*)(qrow + 32 * s + 8 * lg);
+        for (int h = 0; h < NH; ++h) r.q[h] = *(const bf4*)(qb + (size_t)row * ld + h * kQfHD);
+        r.k = *(const bf4*)(kb + (size_t)row * ld);
+        r.v = *(const bf4*)(vb + (size_t)row * ld);
+        r.c0 = *(const f4*)(csb + (size_t)row * 256u);
+        r.c1 = *(const f4*)(csb + (size_t)row * 256u + 4);
+    };
+    f4 wq1, wk1;
+    auto rot = [&](const bf4& in, const f4& w1, const Row& r, float scale) -> bf4 {
+        const float c4[4] = {r.c0[0], r.c0[2], r.c1[0], r.c1[2]};
+        const float s4[4] = {r.c0[1], r.c0[3], r.c1[1], r.c1[3]};
+        float x[4];
         float ss = 0.f;
 #pragma unroll
-        for (int s = 0; s < 8; ++s)
+        for (int i = 0; i < 4; ++i) { x[i] = (float)in[i]; ss += x[i] * x[i]; }
+        const float inv = rsqrtf(qf_wave_sum(ss) / (float)kQfHD + p.eps);
+        bf4 o;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { const float v = (float)qf[s][j]; ss += v * v; }
-        ss += __shfl_xor(ss, 16, 64);
-        ss += __shfl_xor(ss, 32, 64);
-        const float inv = rsqrtf(ss / (float)kQfHD + p.eps);
-        const float* cs = p.cos_sin + (size_t)qc * 256u;
+        for (int i = 0; i < 4; ++i) {
+            const float n = x[i] * inv * w1[i];
+            const float other = qf_xor32(n, lane);                    // rotate_half partner: dim +/- 128
+            o[i] = (bf16_t)(((lane < 32) ? (n * c4[i] - other * s4[i]) : (n * c4[i] + other * s4[i])) * scale);
+        }
+        return o;
+    };
+    auto put = [&](uint32_t row, const Row& r) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const uint32_t d0 = (uint32_t)(32 * s + 8 * lg);        // dims d0 .. d0 + 7 (< 128) and their partners d0 + 128
-            f4 c[4], wlo[2], whi[2];
+        for (int h = 0; h < NH; ++h)
+            *(bf4*)(sQ + ((size_t)h * 16 * MT + row) * kQfKRow + lane * 4) = rot(r.q[h], wq1, r, p.q_scale);
+        *(bf4*)(sK + (size_t)row * kQfKRow + lane * 4) = rot(r.k, wk1, r, 1.0f);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) c[u] = *(const f4*)(cs + 2u * d0 + 4u * (uint32_t)u);
+        for (int i = 0; i < 4; ++i) sVt[(size_t)(lane * 4 + i) * VR + row] = r.v[i];
+    };
+    Row rows[RB];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) { wlo[u] = *(const f4*)(p.wq + d0 + 4 * u); whi[u] = *(const f4*)(p.wq + 128u + d0 + 4 * u); }
-            bf8 lo, hi;
+    for (int b = 0; b < RB; ++b) {
+        const uint32_t r = (uint32_t)wid + 4u * (uint32_t)b;
+        load(r < T ? r : last, rows[b]);                              // a slot past T re-does row T - 1
+    }
+    wq1 = *(const f4*)(p.wq + lane * 4) + 1.0f;
+    wk1 = *(const f4*)(p.wk + lane * 4) + 1.0f;
+    if (MT == 1) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float co = c[j >> 1][2 * (j & 1)], si = c[j >> 1][2 * (j & 1) + 1];
-                const float nlo = (float)qf[s][j] * inv * (1.0f + wlo[j >> 2][j & 3]);
-                const float nhi = (float)qf[s + 4][j] * inv * (1.0f + whi[j >> 2][j & 3]);
-                lo[j] = (bf16_t)((nlo * co - nhi * si) * p.q_scale);
-                hi[j] = (bf16_t)((nhi * co + nlo * si) * p.q_scale);
+        for (int b = 0; b < RB; ++b) {
+            const uint32_t r = (uint32_t)wid + 4u * (uint32_t)b;
+            put(r < T ? r : last, rows[b]);
+        }
+    } else {                                                          // RB = 4: 16 rows per pass of the workgroup
+        for (uint32_t r0 = (uint32_t)wid;;) {
+#pragma unroll
+            for (int b = 0; b < RB; ++b) {
+                const uint32_t r = r0 + 4u * (uint32_t)b;
+                put(r < T ? r : last, rows[b]);
             }
-            qf[s] = lo;
-            qf[s + 4] = hi;
+            r0 += 16u;
+            if (r0 >= T) break;
+#pragma unroll
+            for (int b = 0; b < RB; ++b) {
+                const uint32_t r = r0 + 4u * (uint32_t)b;
+                load(r < T ? r : last, rows[b]);
+            }
         }
     }
-    __syncthreads();
-    if (!active) return;
+    // V^T columns [T, 32 ceil(MT / 2)) multiply P = 0 in the last 32-key step: zeros (K rows past T may hold anything:
+    // their scores are replaced, not multiplied).  Thread = one head dim.
+    bf16_t* vz = sVt + (size_t)threadIdx.x * VR;
+    for (uint32_t key = T; key < 32u * ((MT + 1) / 2); ++key) vz[key] = (bf16_t)0.f;
+}
 
-    // ---- S^T tiles: sc[kt][r] = S[key 16 kt + 4 lg + r][query l15] ----
-    f4 sc[4];
+// One (q head, 16-query tile) unit on one wave: o[j][r] = O[query 16 qt + l15][dim 16 (dt0 + j) + 4 lg + r], unnormalised;
+// returns 1 / sum.  sQh = the head's Q rows.
+template <int MT, int NDT>
+__device__ __forceinline__ float qf_attn_unit(const QfAttnParams& p, const bf16_t* sQh, const bf16_t* sK, const bf16_t* sVt,
+                                              uint32_t qt, uint32_t dt0, int l15, int lg, f4 (&o)[NDT]) {
+    constexpr int VR = qf_vrow<MT>();
+    const uint32_t T = p.T;
+    const uint32_t q = 16u * qt + (uint32_t)l15;
+    f4 sc[MT];
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt) {
-        sc[kt] = (f4)(0.f);
-        if ((uint32_t)kt >= mtiles) continue;
+    for (int kt = 0; kt < MT; ++kt) sc[kt] = (f4)(0.f);
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
+    for (int s = 0; s < 8; ++s) {
+        const bf8 qf = *(const bf8*)(sQh + (size_t)q * kQfKRow + 32 * s + 8 * lg);
+#pragma unroll
+        for (int kt = 0; kt < MT; ++kt) {
             const bf8 kf = *(const bf8*)(sK + (size_t)(16 * kt + l15) * kQfKRow + 32 * s + 8 * lg);
-            sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[s], sc[kt], 0, 0, 0);
+            sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, sc[kt], 0, 0, 0);
         }
     }
     float mx = -INFINITY;
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt)
+    for (int kt = 0; kt < MT; ++kt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const uint32_t key = (uint32_t)(16 * kt + 4 * lg + r);
@@ -421,122 +533,324 @@ __global__ __launch_bounds__(256) void qf_attention_kernel(const QfAttnParams p)
             sc[kt][r] = ok ? sc[kt][r] : -INFINITY;
             mx = fmaxf(mx, sc[kt][r]);
         }
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = qf_xor16_max(mx);
+    mx = qf_xor32_max(mx);
     float sum = 0.f;
-    bf4 pb[4];
+    constexpr int KT2 = 2 * ((MT + 1) / 2);
+    bf4 pb[KT2];
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt)
+    for (int kt = 0; kt < KT2; ++kt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float e = __expf(sc[kt][r] - mx);                   // masked: exp(-inf) = 0 (a query always sees itself: mx is finite)
+            const float e = kt < MT ? __expf(sc[kt < MT ? kt : 0][r] - mx) : 0.f;   // masked: exp(-inf) = 0 (a live query sees itself: mx is finite)
             pb[kt][r] = (bf16_t)e;
             sum += (float)pb[kt][r];                                   // the rounded weights are what multiplies V
         }
-    sum += __shfl_xor(sum, 16, 64);
-    sum += __shfl_xor(sum, 32, 64);
-    const float rinv = 1.0f / sum;
-
-    // ---- O^T = V^T P^T over 32-key steps; o[dt][r] = O[query l15][dim 16 dt + 4 lg + r] ----
-    f4 o[16];
+    sum = qf_xor16_sum(sum);
+    sum = qf_xor32_sum(sum);
 #pragma unroll
-    for (int dt = 0; dt < 16; ++dt) o[dt] = (f4)(0.f);
+    for (int j = 0; j < NDT; ++j) o[j] = (f4)(0.f);
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-        if ((uint32_t)(2 * kb) >= mtiles) break;
+    for (int kb = 0; kb < (MT + 1) / 2; ++kb) {
         bf8 pf;
 #pragma unroll
         for (int r = 0; r < 4; ++r) { pf[r] = pb[2 * kb][r]; pf[4 + r] = pb[2 * kb + 1][r]; }
 #pragma unroll
-        for (int dt = 0; dt < 16; ++dt) {
-            const bf16_t* vr = sVt + (size_t)(16 * dt + l15) * kQfVRow + 32 * kb + 4 * lg;
+        for (int j = 0; j < NDT; ++j) {
+            const bf16_t* vr = sVt + (size_t)(16u * (dt0 + (uint32_t)j) + (uint32_t)l15) * VR + 32 * kb + 4 * lg;
             const bf4 v0 = *(const bf4*)vr, v1 = *(const bf4*)(vr + 16);
             bf8 vf;
 #pragma unroll
             for (int r = 0; r < 4; ++r) { vf[r] = v0[r]; vf[4 + r] = v1[r]; }
-            o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[dt], 0, 0, 0);
+            o[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[j], 0, 0, 0);
         }
     }
-    if (q >= T) return;
-    bf16_t* orow = p.out + (size_t)q * (p.heads * (uint32_t)kQfHD) + (size_t)h * kQfHD + 4 * lg;
-#pragma unroll
-    for (int dt = 0; dt < 16; ++dt) {
-        bf4 ob;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) ob[r] = (bf16_t)(o[dt][r] * rinv);
-        *(bf4*)(orow + 16 * dt) = ob;
-    }
+    return 1.0f / sum;
 }
 
-template <int NCH, int PRO, int EPI>
-hipError_t qf_launch_gemm_t(const QfGemmParams& p, uint32_t n_out_cols, hipStream_t st) {
-    constexpr int NT = EPI == QF_EPI_GEGLU ? 2 : 1;
-    size_t lds = (size_t)4 * NT * 4 * 64 * 16;                                     // K-split partial tiles
-    if (PRO != QF_PRO_NONE) lds += (size_t)kQfRows * (NCH * 256 + kQfPad) * sizeof(bf16_t);
-    if (PRO == QF_PRO_POOL) lds += (size_t)4 * NCH * 256 * sizeof(float);
-    auto kern = qf_gemm_kernel<NCH, PRO, EPI>;
-    static DynLdsOnce once;
+template <int MT> constexpr size_t qf_attn_lds(int nh) {
+    return ((size_t)(nh + 1) * 16 * MT * kQfKRow + (size_t)kQfHD * qf_vrow<MT>()) * sizeof(bf16_t);
+}
+
+// Standalone: one workgroup per q head.  Up to 16 queries the 4 waves split the 16 output tiles of the one query tile
+// (each recomputes S and the softmax: 8 MFMAs); 17-32 queries: 2 waves per query tile; more: one wave per tile.
+template <int MT, int RB>
+__global__ __launch_bounds__(256) void qf_attention_kernel(const QfAttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char qf_smem[];
+    bf16_t* const sQ = (bf16_t*)qf_smem;
+    bf16_t* const sK = sQ + (size_t)16 * MT * kQfKRow;
+    bf16_t* const sVt = sK + (size_t)16 * MT * kQfKRow;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, lg = lane >> 4;
+    QF_STAMP(p, 0);
+    const uint32_t h = blockIdx.x, g = h / (p.heads / p.kv_heads);
+    qf_attn_stage<MT, RB, 1>(p, h, g, sQ, sK, sVt, wid, lane);
+    __syncthreads();
+    QF_STAMP(p, 1);
+    constexpr int G = MT == 1 ? 4 : (MT == 2 ? 2 : 1);                    // waves per query tile
+    constexpr int NDT = 16 / G;
+    const uint32_t qt = (uint32_t)wid / G, dgrp = (uint32_t)wid % G;
+    if (qt >= (uint32_t)MT) return;
+    f4 o[NDT];
+    const float rinv = qf_attn_unit<MT, NDT>(p, sQ, sK, sVt, qt, dgrp * (uint32_t)NDT, l15, lg, o);
+    QF_STAMP(p, 2);
+    const uint32_t q = 16u * qt + (uint32_t)l15;
+    if (q >= p.T) return;
+    bf16_t* orow = p.out + (size_t)q * (p.heads * (uint32_t)kQfHD) + (size_t)h * kQfHD + 4 * lg + 16u * dgrp * (uint32_t)NDT;
+#pragma unroll
+    for (int j = 0; j < NDT; ++j) {
+        bf4 ob;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ob[r] = (bf16_t)(o[j][r] * rinv);
+        *(bf4*)(orow + 16 * j) = ob;
+    }
+    if (p.dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); QF_STAMP(p, 3); }
+}
+
+// Fused: attention of ALL heads (NH = heads, one kv head) in the workgroup's LDS, then y[:, NC columns] = attn Wo^T.
+// The attention output of (head, query tile) overwrites that tile's Q rows (the unit's own wave is their only reader).
+template <int MT, int RB, int NH, int NC>
+__global__ __launch_bounds__(256) void qf_attn_oproj_kernel(const QfAttnParams p) {
+    constexpr int K = NH * kQfHD, kw = K / 4, S = kw / 32;           // o_proj's K = heads x 256; this wave's K range and k-steps
+    extern __shared__ __attribute__((aligned(16))) unsigned char qf_smem[];
+    bf16_t* const sQ = (bf16_t*)qf_smem;                               // [NH][16 MT][kQfKRow]: Q, then O
+    bf16_t* const sK = sQ + (size_t)NH * 16 * MT * kQfKRow;
+    bf16_t* const sVt = sK + (size_t)16 * MT * kQfKRow;
+    float* const red = (float*)(sVt + (size_t)kQfHD * qf_vrow<MT>());  // [4 waves][MT][64 lanes] f4
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, lg = lane >> 4;
+    QF_STAMP(p, 0);
+    // o_proj weights first: they land while the attention runs
+    const bf16_t* wp = p.wo + (size_t)(blockIdx.x * (uint32_t)NC + (uint32_t)(l15 % NC)) * K + wid * kw + 8 * lg;
+    bf8 wf[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) wf[s] = *(const bf8*)(wp + 32 * s);
+    qf_attn_stage<MT, RB, NH>(p, 0u, 0u, sQ, sK, sVt, wid, lane);
+    __syncthreads();
+    QF_STAMP(p, 1);
+    for (uint32_t u = (uint32_t)wid; u < (uint32_t)(NH * MT); u += 4u) {   // (head, query tile) units over the 4 waves
+        const uint32_t h = u / (uint32_t)MT, qt = u % (uint32_t)MT;
+        bf16_t* sQh = sQ + (size_t)h * 16 * MT * kQfKRow;
+        f4 o[16];
+        const float rinv = qf_attn_unit<MT, 16>(p, sQh, sK, sVt, qt, 0u, l15, lg, o);
+        bf16_t* orow = sQh + (size_t)(16u * qt + (uint32_t)l15) * kQfKRow + 4 * lg;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            bf4 ob;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ob[r] = (bf16_t)(o[j][r] * rinv);
+            *(bf4*)(orow + 16 * j) = ob;
+        }
+    }
+    __syncthreads();
+    QF_STAMP(p, 2);
+    // y tile: B operand (attention rows) from LDS: row 16 m + l15, k = wid kw + 32 s + 8 lg -> head k / 256, dim k % 256
+    f4 acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[m] = (f4)(0.f);
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const int k = wid * kw + 32 * s;                               // wave-uniform; a 32-wide step never straddles a head
+        const bf16_t* src = sQ + (size_t)(k / kQfHD) * 16 * MT * kQfKRow + (k % kQfHD) + 8 * lg;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const bf8 a = *(const bf8*)(src + (size_t)(16 * m + l15) * kQfKRow);
+            acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s], a, acc[m], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m) *(f4*)(red + ((size_t)(wid * MT + m) * 64 + lane) * 4) = acc[m];
+    __syncthreads();
+    if (wid >= MT) return;
+    f4 v = *(const f4*)(red + ((size_t)wid * 64 + lane) * 4);
+#pragma unroll
+    for (int w = 1; w < 4; ++w) v += *(const f4*)(red + ((size_t)(w * MT + wid) * 64 + lane) * 4);
+    const uint32_t row = 16u * (uint32_t)wid + (uint32_t)l15;
+    if (row >= p.T || 4 * lg >= NC) return;
+    bf4 ob;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ob[r] = (bf16_t)v[r];
+    *(bf4*)(p.y + (size_t)row * p.H + blockIdx.x * (uint32_t)NC + 4u * (uint32_t)lg) = ob;
+    if (p.dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); QF_STAMP(p, 3); }
+}
+
+int qf_debug_repeat() {
+    static const int r = [] { const char* e = getenv("CQS_HIP_QUERY_DEBUG_REPEAT"); return e && e[0] == '2' ? 2 : 1; }();
+    return r;
+}
+
+template <class Kern, class P>
+hipError_t qf_launch(Kern kern, DynLdsOnce& once, const P& p0, uint32_t grid, size_t lds, hipStream_t st) {
     const hipError_t e = once.ensure((const void*)kern, lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(n_out_cols / 16u), dim3(256), lds, st, p);
+    if (qf_debug_repeat() == 2 && p0.dbg) {       // diagnostic: every kernel twice (cold vs warm operands), slots 2 s and 2 s + 1
+        P q = p0;
+        q.dbg_slot = 2 * p0.dbg_slot;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, q);
+        q.dbg_slot++;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, q);
+    } else {
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, p0);
+    }
     return hipGetLastError();
 }
 
+// (rows per wave in the first batch, row tiles) by query length
+#define QF_BY_T(T, CALL)                                  \
+    do {                                                  \
+        if ((T) <= 4u) return CALL(1, 1);                 \
+        if ((T) <= 8u) return CALL(2, 1);                 \
+        if ((T) <= 16u) return CALL(4, 1);                \
+        if ((T) <= 32u) return CALL(4, 2);                \
+        if ((T) <= 48u) return CALL(4, 3);                \
+        return CALL(4, 4);                                \
+    } while (0)
+
+template <int NCH, int PRO, int EPI, int NC>
+hipError_t qf_launch_pro(const QfGemmParams& p, uint32_t n_out_cols, hipStream_t st) {
+    constexpr int NT = EPI == QF_EPI_GEGLU ? 2 : 1;
+#define QF_CALL(RBV, MTV)                                                                                                   \
+    [&]() {                                                                                                                 \
+        constexpr int GT = PRO == QF_PRO_POOL ? 1 : MTV;                                                                    \
+        const size_t lds = (size_t)16 * GT * (NCH * 256 + kQfPad) * sizeof(bf16_t) + (size_t)4 * NT * GT * 64 * 16 +        \
+                           (PRO == QF_PRO_POOL ? (size_t)4 * NCH * 256 * sizeof(float) : 0);                                \
+        static DynLdsOnce once;                                                                                             \
+        return qf_launch(qf_gemm_kernel<NCH, PRO, EPI, NC, RBV, MTV>, once, p, n_out_cols / (uint32_t)NC, lds, st);         \
+    }()
+    QF_BY_T(p.T, QF_CALL);
+#undef QF_CALL
+}
+
+template <int MT, int EPI, int NC>
+hipError_t qf_launch_plain_ch(const QfGemmParams& p, uint32_t n_out_cols, hipStream_t st) {
+    const uint32_t steps = p.K / 128u;                               // k-steps of 32 per wave
+    const size_t lds = (size_t)4 * MT * 64 * 16;
+#define QF_PLAIN(CHV)                                                                                          \
+    do {                                                                                                       \
+        static DynLdsOnce once;                                                                                \
+        return qf_launch(qf_gemm_plain_kernel<MT, CHV, EPI, NC>, once, p, n_out_cols / (uint32_t)NC, lds, st); \
+    } while (0)
+    if (steps == 9u) QF_PLAIN(9);
+    if (steps % 6u == 0u && (MT <= 2 || steps == 6u)) QF_PLAIN(6);   // (batches of 6 x 4 row tiles would not fit the registers twice over)
+    if (steps % 4u == 0u) QF_PLAIN(4);
+    if (steps % 3u == 0u) QF_PLAIN(3);
+    if (steps % 2u == 0u) QF_PLAIN(2);
+    QF_PLAIN(1);
+#undef QF_PLAIN
+}
+
+template <int EPI, int NC>
+hipError_t qf_launch_plain(const QfGemmParams& p, uint32_t n_out_cols, hipStream_t st) {
+    const uint32_t rows = p.one_row ? 1u : p.T;
+    if (rows <= 16u) return qf_launch_plain_ch<1, EPI, NC>(p, n_out_cols, st);
+    if (rows <= 32u) return qf_launch_plain_ch<2, EPI, NC>(p, n_out_cols, st);
+    if (rows <= 48u) return qf_launch_plain_ch<3, EPI, NC>(p, n_out_cols, st);
+    return qf_launch_plain_ch<4, EPI, NC>(p, n_out_cols, st);
+}
+
+hipError_t qf_launch_attention(const QfAttnParams& a, hipStream_t st) {
+#define QF_ATT(RBV, MTV)                                                                                   \
+    [&]() {                                                                                                \
+        static DynLdsOnce once;                                                                            \
+        return qf_launch(qf_attention_kernel<MTV, RBV>, once, a, a.heads, qf_attn_lds<MTV>(1), st);        \
+    }()
+    QF_BY_T(a.T, QF_ATT);
+#undef QF_ATT
+}
+
+// attention + o_proj in one launch: heads in {2, 3}, one kv head, <= 48 tokens (LDS); else hipErrorNotSupported
+template <int NH, int NC>
+hipError_t qf_launch_attn_oproj_h(const QfAttnParams& a, hipStream_t st) {
+#define QF_AO(RBV, MTV)                                                                                                     \
+    [&]() {                                                                                                                 \
+        static DynLdsOnce once;                                                                                             \
+        return qf_launch(qf_attn_oproj_kernel<MTV, RBV, NH, NC>, once, a, a.H / (uint32_t)NC,                               \
+                         qf_attn_lds<MTV>(NH) + (size_t)4 * MTV * 64 * 16, st);                                             \
+    }()
+    if (a.T <= 4u) return QF_AO(1, 1);
+    if (a.T <= 8u) return QF_AO(2, 1);
+    if (a.T <= 16u) return QF_AO(4, 1);
+    if (a.T <= 32u) return QF_AO(4, 2);
+    if (a.T <= 48u) return QF_AO(4, 3);
+    return hipErrorNotSupported;
+#undef QF_AO
+}
+hipError_t qf_launch_attn_oproj(const QfAttnParams& a, hipStream_t st) {
+    static const bool off = [] { const char* e = getenv("CQS_HIP_QUERY_FUSE_ATTN"); return e && e[0] == '0'; }();
+    if (off || a.kv_heads != 1u || a.H % 8u) return hipErrorNotSupported;
+    if (a.heads == 3u) return qf_launch_attn_oproj_h<3, 8>(a, st);
+    if (a.heads == 2u) return qf_launch_attn_oproj_h<2, 8>(a, st);
+    return hipErrorNotSupported;
+}
+
+// Weight-tile width by projection (NC = 8: EmbeddingGemma's QKV 160, o_proj / down 96, GeGLU 144, Dense 1 384 (NC 8),
+// Dense 2 96 workgroups): the kernels are instruction-bound, not byte-bound - a narrower tile adds workgroups, not speed.
 template <int NCH>
 hipError_t qf_forward_t(const QueryFwd& f, hipStream_t st) {
     const uint32_t H = f.hidden, NQ = (f.heads + 2u * f.kv_heads) * 256u, HQ = f.heads * 256u;
     float* xb[2] = {f.x0, f.x1};
     int cur = 0;                                     // the residual stream lives in xb[cur]
-    const size_t att_lds = ((size_t)kQfRows * kQfKRow + (size_t)kQfHD * kQfVRow) * sizeof(bf16_t);
-    static DynLdsOnce att_once;
-    hipError_t e = att_once.ensure((const void*)qf_attention_kernel, att_lds);
-    if (e != hipSuccess) return e;
+    hipError_t e = hipSuccess;
+    uint32_t slot = 0;
     for (uint32_t l = 0; l < f.layers; ++l) {
         const QueryFwdLayer& w = f.layer[l];
         QfGemmParams p{};
-        p.meta = f.meta; p.eps = f.eps;
+        p.dbg = f.dbg; p.dbg_slot = slot++;
+        p.T = f.T; p.eps = f.eps;
         // QKV (+ embedding gather / the previous layer's post-ffw add + this layer's input norm)
         p.W = w.wqkv; p.C = f.qkv; p.ldc = NQ; p.w_next = w.n_in; p.x_out = xb[cur ^ (l == 0 ? 0 : 1)];
         if (l == 0) {
-            p.emb = f.emb; p.scale = f.embed_scale;
-            e = qf_launch_gemm_t<NCH, QF_PRO_EMBED, QF_EPI_BF16>(p, NQ, st);
+            p.tok = f.tok; p.emb = f.emb; p.scale = f.embed_scale;
+            e = qf_launch_pro<NCH, QF_PRO_EMBED, QF_EPI_BF16, 8>(p, NQ, st);
         } else {
             p.x_in = xb[cur]; p.y = f.y; p.w_post = f.layer[l - 1].n_post_ffw;
-            e = qf_launch_gemm_t<NCH, QF_PRO_ADDNORM, QF_EPI_BF16>(p, NQ, st);
+            e = qf_launch_pro<NCH, QF_PRO_ADDNORM, QF_EPI_BF16, 8>(p, NQ, st);
             cur ^= 1;
         }
         if (e != hipSuccess) return e;
         // attention
         QfAttnParams a{};
-        a.meta = f.meta; a.qkv = f.qkv; a.out = f.attn; a.wq = w.n_q; a.wk = w.n_k;
+        a.dbg = f.dbg; a.dbg_slot = slot++;
+        a.T = f.T; a.qkv = f.qkv; a.out = f.attn; a.wq = w.n_q; a.wk = w.n_k;
         const bool full = ((l + 1u) % f.sliding_pattern) == 0u;
         a.cos_sin = full ? f.rope_global : f.rope_local;
         a.eps = f.eps; a.q_scale = f.q_scale; a.heads = f.heads; a.kv_heads = f.kv_heads; a.window = full ? 0u : f.window;
-        hipLaunchKernelGGL(qf_attention_kernel, dim3(f.heads), dim3(256), att_lds, st, a);
-        if ((e = hipGetLastError()) != hipSuccess) return e;
-        // o_proj
-        QfGemmParams po{};
-        po.meta = f.meta; po.A = f.attn; po.K = HQ; po.W = w.wo; po.C = f.y; po.ldc = H;
-        if ((e = qf_launch_gemm_t<NCH, QF_PRO_NONE, QF_EPI_BF16>(po, H, st)) != hipSuccess) return e;
+        a.wo = w.wo; a.y = f.y; a.H = H;
+        e = qf_launch_attn_oproj(a, st);                 // attention + o_proj in one launch where it fits ...
+        if (e == hipErrorNotSupported) {                 // ... else two
+            if ((e = qf_launch_attention(a, st)) != hipSuccess) return e;
+            QfGemmParams po{};
+            po.dbg = f.dbg; po.dbg_slot = slot;
+            po.T = f.T; po.A = f.attn; po.K = HQ; po.W = w.wo; po.C = f.y; po.ldc = H;
+            e = qf_launch_plain<QF_EPI_BF16, 8>(po, H, st);
+        }
+        slot++;
+        if (e != hipSuccess) return e;
         // GeGLU (+ post-attention add, pre-ffw norm)
         QfGemmParams pg{};
-        pg.meta = f.meta; pg.eps = f.eps; pg.x_in = xb[cur]; pg.y = f.y; pg.w_post = w.n_post_attn; pg.w_next = w.n_pre_ffw;
+        pg.dbg = f.dbg; pg.dbg_slot = slot++;
+        pg.T = f.T; pg.eps = f.eps; pg.x_in = xb[cur]; pg.y = f.y; pg.w_post = w.n_post_attn; pg.w_next = w.n_pre_ffw;
         pg.x_out = xb[cur ^ 1]; pg.W = w.wgu; pg.C = f.h; pg.ldc = f.inter;
-        if ((e = qf_launch_gemm_t<NCH, QF_PRO_ADDNORM, QF_EPI_GEGLU>(pg, f.inter, st)) != hipSuccess) return e;
+        if ((e = qf_launch_pro<NCH, QF_PRO_ADDNORM, QF_EPI_GEGLU, 8>(pg, f.inter, st)) != hipSuccess) return e;
         cur ^= 1;
         // down
         QfGemmParams pd{};
-        pd.meta = f.meta; pd.A = f.h; pd.K = f.inter; pd.W = w.wd; pd.C = f.y; pd.ldc = H;
-        if ((e = qf_launch_gemm_t<NCH, QF_PRO_NONE, QF_EPI_BF16>(pd, H, st)) != hipSuccess) return e;
+        pd.dbg = f.dbg; pd.dbg_slot = slot++;
+        pd.T = f.T; pd.A = f.h; pd.K = f.inter; pd.W = w.wd; pd.C = f.y; pd.ldc = H;
+        if ((e = qf_launch_plain<QF_EPI_BF16, 8>(pd, H, st)) != hipSuccess) return e;
     }
     // head: last post-ffw add + final norm + mean pool -> Dense 1 ; Dense 2
     QfGemmParams p1{};
-    p1.meta = f.meta; p1.eps = f.eps; p1.x_in = xb[cur]; p1.y = f.y; p1.w_post = f.layer[f.layers - 1].n_post_ffw; p1.w_next = f.n_final;
+    p1.dbg = f.dbg; p1.dbg_slot = slot++;
+    p1.T = f.T; p1.eps = f.eps; p1.x_in = xb[cur]; p1.y = f.y; p1.w_post = f.layer[f.layers - 1].n_post_ffw; p1.w_next = f.n_final;
     p1.W = f.dense1; p1.C = f.d1; p1.ldc = f.dense_hidden; p1.one_row = 1;
-    if ((e = qf_launch_gemm_t<NCH, QF_PRO_POOL, QF_EPI_BF16>(p1, f.dense_hidden, st)) != hipSuccess) return e;
+    if ((e = qf_launch_pro<NCH, QF_PRO_POOL, QF_EPI_BF16, 8>(p1, f.dense_hidden, st)) != hipSuccess) return e;
     QfGemmParams p2{};
-    p2.meta = f.meta; p2.A = f.d1; p2.K = f.dense_hidden; p2.W = f.dense2; p2.C = f.out; p2.ldc = H; p2.one_row = 1;
-    return qf_launch_gemm_t<NCH, QF_PRO_NONE, QF_EPI_F32>(p2, H, st);
+    p2.dbg = f.dbg; p2.dbg_slot = slot++;
+    p2.T = f.T; p2.A = f.d1; p2.K = f.dense_hidden; p2.W = f.dense2; p2.C = f.out; p2.ldc = H; p2.one_row = 1;
+    return qf_launch_plain<QF_EPI_F32, 8>(p2, H, st);
 }
 
 }  // namespace
@@ -548,7 +862,7 @@ bool query_forward_supported(const EmbedGeom& g) {
 }
 
 hipError_t launch_query_forward(const QueryFwd& f, hipStream_t st) {
-    if (!f.layer || f.layers == 0) return hipErrorInvalidValue;
+    if (!f.layer || f.layers == 0 || f.T < 1u || f.T > kQueryFwdMaxTokens) return hipErrorInvalidValue;
     if (f.hidden == 768u) return qf_forward_t<3>(f, st);
     if (f.hidden == 256u) return qf_forward_t<1>(f, st);
     return hipErrorInvalidValue;
