@@ -302,27 +302,19 @@ __global__ __launch_bounds__(256) void qf_gemm_kernel(const QfGemmParams p) {
             const uint32_t r = (uint32_t)wid + 4u * (uint32_t)b;
             finish_row(r < T ? r : last, r < T, xv[b], yv[b]);
         }
-    } else {                                                        // RB = 4; 16 rows per batch of the workgroup
-        for (uint32_t r0 = (uint32_t)wid; r0 < T; r0 += 16u) {
-            f4 xn[RB][NCH], yn[RB][NCH];
-            const bool more = r0 + 16u < T;                          // wave-uniform
-            if (more) {
-#pragma unroll
-                for (int b = 0; b < RB; ++b) {
-                    const uint32_t r = r0 + 16u + 4u * (uint32_t)b;
-                    load_row(r < T ? r : last, xn[b], yn[b]);
-                }
-            }
+    } else {                                                        // RB = 4; 16 rows per pass of the workgroup, passes one after
+        for (uint32_t r0 = (uint32_t)wid;;) {                        // the other (a second set of rows in flight spills the registers)
 #pragma unroll
             for (int b = 0; b < RB; ++b) {
                 const uint32_t r = r0 + 4u * (uint32_t)b;
                 finish_row(r < T ? r : last, r < T, xv[b], yv[b]);
             }
-            if (more) {
+            r0 += 16u;
+            if (r0 >= T) break;
 #pragma unroll
-                for (int b = 0; b < RB; ++b)
-#pragma unroll
-                    for (int c = 0; c < NCH; ++c) { xv[b][c] = xn[b][c]; yv[b][c] = yn[b][c]; }
+            for (int b = 0; b < RB; ++b) {
+                const uint32_t r = r0 + 4u * (uint32_t)b;
+                load_row(r < T ? r : last, xv[b], yv[b]);
             }
         }
     }
