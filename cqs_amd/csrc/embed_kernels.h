@@ -43,6 +43,13 @@ hipError_t launch_embed_norm(const int32_t* tok, const bf16_t* emb, float scale,
 hipError_t launch_add_norm(float* x, const bf16_t* y, const float* w_post, const float* w_next, float eps,
                            bf16_t* xn, float* out, int final, uint32_t M, uint32_t H, hipStream_t st);
 
+// launch_gemm_bf16(A, W, y, GEMM_OUT_BF16) + launch_add_norm(x, y, ...) in ONE launch (gemm_rowfuse.hip): a workgroup owns
+// 64 whole rows x all H = 768 columns, so y never leaves the CU.  Same bits as the two-launch chain.  H must be 768.
+bool gemm_addnorm_supported(uint32_t M, uint32_t H, uint32_t K);     // shape + CQS_HIP_GEMM_FUSE_NORM / _MIN_ROWS
+hipError_t launch_gemm_addnorm(const bf16_t* A, const bf16_t* W, float* x, const float* w_post, const float* w_next,
+                               float eps, bf16_t* xn, float* out, int final, uint32_t M, uint32_t H, uint32_t K,
+                               hipStream_t st);
+
 // C[M,N] = A[M,K] (bf16, row-major) x W[N,K]^T (bf16, row-major), f32 accumulate on the matrix cores.
 //   GEMM_OUT_BF16 : C bf16 [M, ldc]
 //   GEMM_OUT_F32  : C f32  [M, ldc]

@@ -313,13 +313,23 @@ int32_t run_layers(cqs_hip_embedder* e, Ctx& c, Slot& sl) {
         E_TRY(e, cqs::launch_attention(c.qkv, c.vt, c.attn, c.d_blk, nblk, c.d_seq_start, c.d_seq_len,
                                        c.d_vt_start, c.vt_ld, g.heads, g.kv_heads, full ? 0u : g.window, w.n_q, rope,
                                        g.rms_eps, g.q_scale, st));
-        E_TRY(e, cqs::launch_gemm_bf16(c.attn, w.wo, c.y, M, H, g.heads * g.head_dim, H, cqs::GEMM_OUT_BF16, st));
-        E_TRY(e, cqs::launch_add_norm(c.x, c.y, w.n_post_attn, w.n_pre_ffw, g.rms_eps, c.xn, nullptr, 0, M, H, st));
+        // o_proj, then x += norm(y)(1 + w); xn = norm(x)(1 + w'): one launch where a workgroup can own whole rows
+        if (cqs::gemm_addnorm_supported(M, H, g.heads * g.head_dim)) {
+            E_TRY(e, cqs::launch_gemm_addnorm(c.attn, w.wo, c.x, w.n_post_attn, w.n_pre_ffw, g.rms_eps, c.xn, nullptr, 0, M, H,
+                                              g.heads * g.head_dim, st));
+        } else {
+            E_TRY(e, cqs::launch_gemm_bf16(c.attn, w.wo, c.y, M, H, g.heads * g.head_dim, H, cqs::GEMM_OUT_BF16, st));
+            E_TRY(e, cqs::launch_add_norm(c.x, c.y, w.n_post_attn, w.n_pre_ffw, g.rms_eps, c.xn, nullptr, 0, M, H, st));
+        }
         E_TRY(e, cqs::launch_gemm_bf16(c.xn, w.wgu, c.h, M, 2u * g.inter, H, g.inter, cqs::GEMM_OUT_GEGLU, st));
-        E_TRY(e, cqs::launch_gemm_bf16(c.h, w.wd, c.y, M, H, g.inter, H, cqs::GEMM_OUT_BF16, st));
         const bool last = (l + 1u == g.layers);
-        E_TRY(e, cqs::launch_add_norm(c.x, c.y, w.n_post_ffw, last ? e->n_final : e->L[l + 1].n_in, g.rms_eps, c.xn,
-                                      c.hidden, last ? 1 : 0, M, H, st));
+        const float* w_next = last ? e->n_final : e->L[l + 1].n_in;
+        if (cqs::gemm_addnorm_supported(M, H, g.inter)) {
+            E_TRY(e, cqs::launch_gemm_addnorm(c.h, w.wd, c.x, w.n_post_ffw, w_next, g.rms_eps, c.xn, c.hidden, last ? 1 : 0, M, H, g.inter, st));
+        } else {
+            E_TRY(e, cqs::launch_gemm_bf16(c.h, w.wd, c.y, M, H, g.inter, H, cqs::GEMM_OUT_BF16, st));
+            E_TRY(e, cqs::launch_add_norm(c.x, c.y, w.n_post_ffw, w_next, g.rms_eps, c.xn, c.hidden, last ? 1 : 0, M, H, st));
+        }
     }
     return CQS_HIP_OK;
 }

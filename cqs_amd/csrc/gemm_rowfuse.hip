@@ -1,0 +1,283 @@
+// gemm_rowfuse.hip — a branch's output projection FUSED with the residual add and the two RMSNorms around it:
+//
+//     y      = A W^T                                (o_proj: A = attention rows; down: A = GeGLU rows)
+//     x     += rmsnorm(bf16(y)) (1 + w_post)        (the f32 residual stream, in place)
+//     xn     = bf16(rmsnorm(x) (1 + w_next))        (FINAL: out = f32 of the same, the model's final norm)
+//
+// i.e. `gemm_pp_kernel<.., GEMM_OUT_BF16>` + `add_norm_kernel` of the unfused chain in ONE launch, bit for bit the same
+// numbers (same MFMA, same k order -> the same bf16 y; the row phase is add_norm_kernel's arithmetic on y rows that
+// never left the CU).  Why: VERDICT r02 / profiles/r02_embed_rocprofv3.txt - the two add_norm launches of a layer move
+// 302 of the layer's 731 MB (41 %) and take 46 of its 254 us at the HBM roof, and every GEMM launch idles the matrix
+// pipe ~60 % around its main loop.  Fused, the y round trip (a 25 MB write + a 25 MB read per projection) and two
+// launches per layer disappear; what remains of the add_norm traffic (x in / x out / xn out) is the residual stream.
+//
+// A row norm needs the whole row, so a workgroup must own whole rows: tile = 64 token rows x ALL 768 columns, 256
+// workgroups at 16 384 tokens = one per CU.  8 waves; wave w owns columns [96 w, 96 w + 96) = 6 n-tiles x 4 m-tiles of
+// 16 x 16 (96 accumulator registers).  Per 32-deep k-step a workgroup needs 64 x 32 of A (4 KB) and ALL of W's 768 x 32
+// (48 KB): the W panel (1.18 / 1.77 MB) stays in every XCD's L2 and streams through every CU once per launch - that
+// stream, ~52 KB per 768 MFMA clocks = 68 B/clk/CU against the ~56 B/clk an XCD's L2 delivers, bounds the main loop
+// (~11 us at K = 768, ~16 us at K = 1152; the 256-row tiles of gemm_kernels.hip need a quarter of that per flop).
+//   * operands by LDS-DMA (global_load_lds_dwordx4 from inline asm, counted vmcnt) into a ring of THREE stages (156 KB):
+//     the DMA runs two k-steps ahead of the MFMAs;
+//   * a wave DMAs and reads its OWN 96 W rows: only the 4 KB A tile is shared, so one barrier per k-step;
+//   * 64-byte LDS rows (32 bf16), 16-byte chunk c of row R stored at chunk c ^ f[(R >> 2) & 3], f = {0, 2, 3, 1}:
+//     the 16 lanes a ds_read_b128 serves per cycle ({0-3, 12-15, 20-27}, ...) then hit 16 distinct 16-byte bank slots;
+//     the swizzle is applied to the DMA's SOURCE address (its LDS side is linear);
+//   * epilogue: accumulators -> bf16 -> LDS [64][776] (reusing the ring), barrier, then wave w takes rows w, w + 8, ...
+//     exactly like add_norm_kernel (lane owns 4 consecutive floats of each 256-chunk), x loads issued before the barrier.
+#include "embed_kernels.h"
+#include "launch_util.h"
+
+#include <cstdlib>
+#include <type_traits>
+
+namespace cqs {
+
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int kRfRows = 64;                              // token rows per workgroup
+constexpr int kRfH = 768;                                // output columns = hidden
+constexpr int kRfSlot = 16 * 128;                        // one W slot: 16 rows x 64 k (128-byte rows) = 2 KB
+constexpr int kRfWRing = 8 * 6 * kRfSlot;                // 8 waves x 6 private slots = 96 KB
+constexpr int kRfATile = kRfRows * 128;                  // the shared A tile of one k-step: 8 KB, double-buffered
+constexpr int kRfLds = kRfWRing + 2 * kRfATile;          // 112 KB
+constexpr int kRfLdy = kRfH + 8;                         // epilogue row stride (elements): 64 x 776 x 2 B = 97 KB <= kRfLds
+
+__device__ __forceinline__ float rf_wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+#define RF_WAIT_VM(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
+
+// Time structure of the main loop (64-deep k-steps; every LDS row is one full 128-byte line of its matrix - 64-byte rows
+// made every DMA instruction a 16-segment gather, ~44 clocks of address processing each: 3 000 clocks per k-step):
+//   * W: wave w streams its OWN 96 rows through 6 private slots (slot j = n-tile j: 16 rows x 64 k, two DMA
+//     instructions of 8 rows x 128 B).  Step (kt, j): wait for slot (kt, j), read its two fragments, refill the slot with
+//     (kt + 1, j), 8 MFMAs.  Nobody else touches a wave's slots: no barrier on the W stream, 5 slots (10 KB) always in flight.
+//   * A: the 64 x 64 tile of a k-step is shared: one DMA instruction per wave into a double buffer at the top of the
+//     step before (right behind that step's barrier), one barrier per k-step.
+//   * counted waits, constant through the whole loop because the tail keeps issuing (harmless) refills of the last
+//     k-step: DMA completes in issue order, and between the DMA of slot (kt, j) and its use this wave issues slots
+//     (kt, j+1..5), A (kt + 1) and slots (kt + 1, 0..j-1) = 2 (5 - j) + 1 + 2 j = 11 instructions -> vmcnt(11); behind A (kt)
+//     come the 12 refill instructions of step kt - 1 -> vmcnt(12) at the top of step kt.
+template <int FINAL>
+__global__ __launch_bounds__(512, 2) void gemm_rowfuse_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
+                                                              float* __restrict__ x, const float* __restrict__ w_post,
+                                                              const float* __restrict__ w_next, float eps,
+                                                              bf16_t* __restrict__ xn, float* __restrict__ out,
+                                                              uint32_t M, uint32_t K) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char rf_smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, lg = lane >> 4;
+    const uint32_t m0 = blockIdx.x * (uint32_t)kRfRows;
+    const uint32_t rows_left = M - m0;                   // >= 1
+    const uint32_t nk = K / 64u;
+
+    // ---- DMA sources.  One instruction = 8 LDS rows x 128 B: lane -> row (lane >> 3), physical chunk (lane & 7) ->
+    // logical chunk (lane & 7) ^ ((R >> 1) & 7), R = the row's index inside its 16-row group (embed_kernels.hip swz()).
+    const uint32_t r8 = (uint32_t)lane >> 3;
+    const uint32_t pc = (uint32_t)lane & 7u;
+    // W slot j, half hf (rows 8 hf + r8 of n-tile j): row 96 wid + 16 j + 8 hf + r8; the (j, hf, kt) parts are scalar
+    uint32_t voffW[2];
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+        const uint32_t R = (uint32_t)(8 * hf) + r8;
+        voffW[hf] = (((uint32_t)(96 * wid) + R) * K + ((pc ^ ((R >> 1) & 7u)) * 8u)) * 2u;
+    }
+    // A: wave w covers tile rows 8 w + r8 (R = that row & 15)
+    uint32_t arow = (uint32_t)(8 * wid) + r8;
+    const uint32_t aR = arow & 15u;
+    if (arow >= rows_left) arow = rows_left - 1u;        // rows past M: any real row (their outputs are never stored)
+    const uint32_t voffA = (arow * K + ((pc ^ ((aR >> 1) & 7u)) * 8u)) * 2u;
+    const char* const gA = (const char*)(A + (size_t)m0 * K);
+    const char* const gW = (const char*)W;
+    const size_t rowK16 = (size_t)K * 32u;               // bytes of 16 rows
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)rf_smem;
+    auto dma = [&](const char* sbase, uint32_t voff, uint32_t lds_byte) {
+        const uint32_t m0v = lds0 + lds_byte;
+        asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                     :: "s"(m0v), "v"(voff), "s"(sbase) : "memory");
+    };
+    const uint32_t wring = (uint32_t)(wid * 6 * kRfSlot);
+    auto fill_w = [&](uint32_t kt, int j) {               // slot j <- k-step kt (two instructions)
+        const char* src = gW + (size_t)kt * 128u + (size_t)j * rowK16;
+        dma(src, voffW[0], wring + (uint32_t)(j * kRfSlot));
+        dma(src, voffW[1], wring + (uint32_t)(j * kRfSlot + 1024));
+    };
+    auto fill_a = [&](uint32_t kt, uint32_t buf) {        // this wave's 8 rows of A tile kt (one instruction) into buffer buf
+        dma(gA + (size_t)kt * 128u, voffA, (uint32_t)kRfWRing + buf * (uint32_t)kRfATile + (uint32_t)(wid * 1024));
+    };
+
+    // ---- fragment read offsets: row l15 of a 16-row group, k-sub s: logical chunk 4 s + lg
+    const uint32_t swr = ((uint32_t)l15 >> 1) & 7u;
+    uint32_t foff[2];
+#pragma unroll
+    for (int sb = 0; sb < 2; ++sb) foff[sb] = (uint32_t)l15 * 128u + ((((uint32_t)(4 * sb + lg)) ^ swr) * 16u);
+
+    f4 acc[6][4];
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[j][t] = (f4)(0.f);
+
+    // x rows of the epilogue (wave w: rows w, w + 8, ...; lane owns floats [256 c + 4 lane, + 4)): requested before the LAST
+    // k-step, so that their HBM latency (the main loop runs out of L2: HBM is idle) hides under it
+    f4 xv[8][3];
+    auto load_x = [&]() {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const uint32_t r = (uint32_t)(wid + 8 * i);
+            const uint32_t row = m0 + (r < rows_left ? r : rows_left - 1u);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) xv[i][c] = *(const f4*)(x + (size_t)row * kRfH + c * 256 + lane * 4);
+        }
+    };
+    const uint32_t klast = nk - 1u;
+    // One k-step.  Fragments of slot j + 1 are read while slot j multiplies (the LDS latency hides behind 8 MFMAs); between
+    // the DMA of slot (kt, j + 1) and that read this wave issued 2 (4 - j) + 1 + 2 j = 9 instructions -> vmcnt(9); slot (kt, 0)
+    // is read at the top behind 10 + 1 = 11.
+    // XTRA: vector-memory instructions of the compiler's own (the 24 x loads before the last step) that sit in the same
+    // in-order queue between the DMAs being waited for and the ones issued since
+    auto kstep = [&](uint32_t kt, auto xtra_c) {
+        constexpr int XTRA = decltype(xtra_c)::value;
+        RF_WAIT_VM(12 + XTRA);                            // this wave's part of A (kt) has landed (behind it: 12 W instructions)
+        asm volatile("s_barrier" ::: "memory");          // ... and everybody's; everybody is done reading A (kt - 1)
+        const uint32_t kn = kt < klast ? kt + 1u : klast; // (the last step re-requests itself: keeps the wait counts constant)
+        fill_a(kn, (kt + 1u) & 1u);                       // into the buffer A (kt - 1) lived in
+        const unsigned char* sa = rf_smem + kRfWRing + (kt & 1u) * (uint32_t)kRfATile;
+        const unsigned char* sw = rf_smem + wring;
+        bf8 af[4][2], wf[2], wn[2];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int sb = 0; sb < 2; ++sb) af[t][sb] = *(const bf8*)(sa + (uint32_t)(t * 2048) + foff[sb]);
+        RF_WAIT_VM(11 + XTRA);                            // slot (kt, 0)
+#pragma unroll
+        for (int sb = 0; sb < 2; ++sb) wf[sb] = *(const bf8*)(sw + foff[sb]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            if (j < 5) {
+                RF_WAIT_VM(9 + XTRA);                     // slot (kt, j + 1)
+#pragma unroll
+                for (int sb = 0; sb < 2; ++sb) wn[sb] = *(const bf8*)(sw + (uint32_t)((j + 1) * kRfSlot) + foff[sb]);
+            }
+            fill_w(kn, j);                                // slot j is in registers: refill it
+#pragma unroll
+            for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[j][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[sb], af[t][sb], acc[j][t], 0, 0, 0);
+            if (j < 5) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                wf[0] = wn[0]; wf[1] = wn[1];
+            }
+        }
+    };
+    fill_a(0u, 0u);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) fill_w(0u, j);
+    for (uint32_t kt = 0; kt < klast; ++kt) kstep(kt, std::integral_constant<int, 0>{});
+    load_x();
+    kstep(klast, std::integral_constant<int, 24>{});
+    RF_WAIT_VM(0);                                        // the tail's surplus refills are done before LDS is reused
+
+    // ---- epilogue ----
+    __syncthreads();                                      // every wave is out of the ring
+    bf16_t* const sY = (bf16_t*)rf_smem;                  // [64][kRfLdy]
+    // acc[j][t][r] = y[token 16 t + l15][column 96 wid + 16 j + 4 lg + r]
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            bf4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = (bf16_t)acc[j][t][r];
+            *(bf4*)(sY + (size_t)(16 * t + l15) * kRfLdy + 96 * wid + 16 * j + 4 * lg) = o;
+        }
+    __syncthreads();
+    f4 wpo[3], wne[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        wpo[c] = *(const f4*)(w_post + c * 256 + lane * 4);
+        wne[c] = *(const f4*)(w_next + c * 256 + lane * 4);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const uint32_t r = (uint32_t)(wid + 8 * i);
+        if (r >= rows_left) continue;                     // wave-uniform (a guard, not a break: the loop must unroll)
+        const size_t row = (size_t)(m0 + r);
+        f4 yv[3];
+        float ss = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const bf4 yb = *(const bf4*)(sY + (size_t)r * kRfLdy + c * 256 + lane * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { yv[c][e] = (float)yb[e]; ss += yv[c][e] * yv[c][e]; }
+        }
+        const float invy = rsqrtf(rf_wave_sum(ss) / (float)kRfH + eps);
+        float sx = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                xv[i][c][e] += yv[c][e] * invy * (1.0f + wpo[c][e]);
+                sx += xv[i][c][e] * xv[i][c][e];
+            }
+            *(f4*)(x + row * kRfH + c * 256 + lane * 4) = xv[i][c];
+        }
+        const float invx = rsqrtf(rf_wave_sum(sx) / (float)kRfH + eps);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            if (FINAL) {
+                f4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = xv[i][c][e] * invx * (1.0f + wne[c][e]);
+                *(f4*)(out + row * kRfH + c * 256 + lane * 4) = o;
+            } else {
+                bf4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (bf16_t)(xv[i][c][e] * invx * (1.0f + wne[c][e]));
+                *(bf4*)(xn + row * kRfH + c * 256 + lane * 4) = o;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+bool gemm_addnorm_supported(uint32_t M, uint32_t H, uint32_t K) {
+    const char* e0 = getenv("CQS_HIP_GEMM_FUSE_NORM");                  // (read per call: tests flip it inside one process)
+    const char* e1 = getenv("CQS_HIP_GEMM_FUSE_NORM_MIN_ROWS");
+    const bool off = e0 && e0[0] == '0';
+    const uint32_t min_rows = e1 ? (uint32_t)atoi(e1) : 4096u;
+    return !off && H == (uint32_t)kRfH && K % 64u == 0 && K >= 64u && M >= min_rows && (uint64_t)M * K < (1ull << 31) &&
+           (uint64_t)H * K < (1ull << 31);
+}
+
+hipError_t launch_gemm_addnorm(const bf16_t* A, const bf16_t* W, float* x, const float* w_post, const float* w_next,
+                               float eps, bf16_t* xn, float* out, int final, uint32_t M, uint32_t H, uint32_t K,
+                               hipStream_t st) {
+    if (M == 0) return hipSuccess;
+    if (H != (uint32_t)kRfH || K % 64u || K < 64u || (uint64_t)M * K >= (1ull << 31)) return hipErrorInvalidValue;
+    const dim3 grid((M + (uint32_t)kRfRows - 1u) / (uint32_t)kRfRows);
+    static DynLdsOnce once[2];
+    if (final) {
+        const hipError_t e = once[1].ensure((const void*)gemm_rowfuse_kernel<1>, (size_t)kRfLds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(gemm_rowfuse_kernel<1>, grid, dim3(512), (size_t)kRfLds, st, A, W, x, w_post, w_next, eps, xn, out, M, K);
+    } else {
+        const hipError_t e = once[0].ensure((const void*)gemm_rowfuse_kernel<0>, (size_t)kRfLds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(gemm_rowfuse_kernel<0>, grid, dim3(512), (size_t)kRfLds, st, A, W, x, w_post, w_next, eps, xn, out, M, K);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace cqs

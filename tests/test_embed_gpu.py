@@ -496,3 +496,29 @@ def test_fewrows_gemm_is_bit_identical_to_the_tiled_kernel(hip, monkeypatch):
             if kind == 1:
                 ref = A.float() @ W.float().T
                 assert float((a - ref).abs().max()) < 2e-2
+
+
+def test_fused_projection_addnorm_is_bit_identical_to_the_two_launch_chain(hip, monkeypatch):
+    """gemm_rowfuse.hip: o_proj / down + residual add + both RMSNorms in one launch (a workgroup owns 64 whole rows x
+    768 columns).  Same MFMA and k order as the 256-row GEMM, the row phase is add_norm_kernel's arithmetic -> the
+    embeddings must equal the two-launch chain's BIT FOR BIT; ragged token counts (last tile partly filled), both the
+    xn and the final-norm output forms (4 layers: the last `down` runs FINAL).  Also against the fp32 oracle."""
+    cfg = G.GemmaConfig(vocab_size=4096, hidden=768, layers=4, heads=3, kv_heads=1, head_dim=256, intermediate=1152,
+                        dense_hidden=3072, sliding_window=512, sliding_pattern=2, max_seq=2048)
+    eng, w = make(cfg, seed=41)
+    for lens in ([700, 650, 33, 517], [64] * 20, [1000, 3]):             # 1900, 1280 and 1003 tokens
+        ids, mask = batch(cfg, lens, seed=sum(lens))
+        monkeypatch.setenv("CQS_HIP_GEMM_FUSE_NORM", "0")
+        plain = eng.run(ids, mask)
+        monkeypatch.setenv("CQS_HIP_GEMM_FUSE_NORM", "1")
+        monkeypatch.setenv("CQS_HIP_GEMM_FUSE_NORM_MIN_ROWS", "256")     # (default 4096: the test batches are smaller)
+        fused = eng.run(ids, mask)
+        monkeypatch.delenv("CQS_HIP_GEMM_FUSE_NORM_MIN_ROWS")
+        assert np.array_equal(fused, plain), float(np.max(np.abs(fused - plain)))
+    ids, mask = batch(cfg, [300, 41], seed=5)
+    monkeypatch.setenv("CQS_HIP_GEMM_FUSE_NORM_MIN_ROWS", "64")
+    got = eng.run(ids, mask)
+    ref = G.forward(cfg, w, ids, mask)
+    for i in range(2):
+        assert cos(got[i], ref[i]) > 0.999
+    eng.close()
