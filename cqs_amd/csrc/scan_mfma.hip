@@ -25,6 +25,9 @@
 #include "scan_kernels.h"
 #include "launch_util.h"
 
+#include <cstdlib>
+#include <type_traits>
+
 namespace cqs {
 
 typedef float f4 __attribute__((ext_vector_type(4)));
@@ -44,17 +47,20 @@ struct MfmaParams {
     uint32_t mode;
     float thr;
     uint32_t* work;
-    uint32_t n_tasks;    // n_pad / RT
+    uint32_t n_tasks;    // n_pad / RT  (scan_mfma16_kernel: x q_blocks)
+    uint32_t q_blocks;   // scan_mfma16_kernel: query blocks of QT per row tile (task = row tile * q_blocks + query block)
 };
 
 template <int QW, int WQ, int RW, int WR, bool NT>
-__global__ __launch_bounds__(256, 1) void scan_mfma_kernel(const MfmaParams p) {
+__global__ __launch_bounds__(64 * WQ * WR, WQ * WR / 4) void scan_mfma_kernel(const MfmaParams p) {
     constexpr int QT = 32 * QW * WQ, RT = 32 * RW * WR;
-    static_assert(WQ * WR == 4, "4 waves per workgroup");
-    static_assert(RT % 64 == 0, "row tile covers whole 64-row groups");
+    constexpr int NTHR = 64 * WQ * WR;           // 4 waves (one per SIMD) or 8 (two per SIMD: while one wave waits on LDS or
+                                                 // at the stage barrier its SIMD partner keeps the f32 matrix pipe fed)
+    static_assert(WQ * WR == 4 || WQ * WR == 8, "4 or 8 waves per workgroup");
+    static_assert(RW % 2 == 0, "a wave covers whole 64-row groups");
     constexpr int NF4 = (QT + RT) * (kBK / 4);   // float4 per stage
-    constexpr int PER_T = NF4 / 256;             // float4 per thread per stage
-    static_assert(NF4 % 256 == 0, "stage divides over the workgroup");
+    constexpr int PER_T = NF4 / NTHR;            // float4 per thread per stage
+    static_assert(NF4 % NTHR == 0, "stage divides over the workgroup");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sQ = smem;                            // [2][QT][kLDK]
     float* sR = smem + 2 * QT * kLDK;            // [2][RT][kLDK]
@@ -72,7 +78,7 @@ __global__ __launch_bounds__(256, 1) void scan_mfma_kernel(const MfmaParams p) {
     uint32_t st_row[PER_T], st_c4[PER_T];
 #pragma unroll
     for (int u = 0; u < PER_T; ++u) {
-        const uint32_t f = (uint32_t)u * 256u + (uint32_t)tid;
+        const uint32_t f = (uint32_t)u * (uint32_t)NTHR + (uint32_t)tid;
         st_row[u] = f >> 3;
         st_c4[u] = f & 7u;
     }
@@ -229,6 +235,215 @@ __global__ __launch_bounds__(256, 1) void scan_mfma_kernel(const MfmaParams p) {
     }
 }
 
+// ---- the same tile with TWO workgroups per CU ---------------------------------------------------------------------------
+// One workgroup per CU (above) leaves the matrix pipe idle whenever its four waves are all in the same non-MFMA phase:
+// the tile epilogue (128 KB of score stores + 128 shuffle-maxima per lane: ~10 % of a 256 x 128 tile), the hand-over
+// to the next tile, every stage barrier.  Two co-resident workgroups (one wave of each per SIMD) are in different phases
+// most of the time.  For both to fit, K is staged 16 floats at a time (LDS 2 x 384 rows x 20 floats = 60 KB per
+// workgroup; 20-float rows keep the 16 lanes of a ds_read_b128 cycle on 16 distinct 4-bank slots) and the registers
+// stay under 256 (acc 128 + fragments 48 + two staging sets 48).  A stage is 2 k-groups of 8: the global loads of stage
+// s + 2 are issued in k-group 0 of stage s into the register set that stage s - 1 has just written out; their data goes
+// to LDS one stage later (a whole stage of MFMAs = 4 096 clocks covers the HBM latency).
+constexpr int kBK16 = 16, kLDK16 = 20;
+
+template <int QW, int WQ, int RW, int WR, bool NT>
+__global__ __launch_bounds__(256, 2) void scan_mfma16_kernel(const MfmaParams p) {
+    constexpr int QT = 32 * QW * WQ, RT = 32 * RW * WR;
+    static_assert(WQ * WR == 4, "4 waves per workgroup");
+    constexpr int NF4 = (QT + RT) * (kBK16 / 4);
+    constexpr int PER_T = NF4 / 256;
+    static_assert(NF4 % 256 == 0, "stage divides over the workgroup");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sQ = smem;                            // [2][QT][kLDK16]
+    float* sR = smem + 2 * QT * kLDK16;          // [2][RT][kLDK16]
+    __shared__ uint32_t s_task;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wq = wid / WR, wr = wid % WR;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const uint32_t dim = p.dim, n = p.n;
+    const uint32_t stages = dim / kBK16;         // even (dim % 32 == 0)
+    const uint32_t last_row = n - 1u;
+
+    uint32_t st_row[PER_T], st_c4[PER_T];        // float4 f of a stage -> (tile row, 16-B column): 4 threads per row
+#pragma unroll
+    for (int u = 0; u < PER_T; ++u) {
+        const uint32_t f = (uint32_t)u * 256u + (uint32_t)tid;
+        st_row[u] = f >> 2;
+        st_c4[u] = f & 3u;
+    }
+
+    uint32_t task = blockIdx.x;
+    for (;; ) {
+        if (task >= p.n_tasks) break;
+        // consecutive tasks = the query blocks of ONE row tile: they run at about the same time on neighbouring workgroups,
+        // so the tile's corpus rows come from HBM once and from L2 after that
+        const uint32_t rtile = task / p.q_blocks, qblk = task % p.q_blocks;
+        const uint32_t row0 = rtile * (uint32_t)RT;
+        const float* const qbase = p.q + (size_t)qblk * QT * dim;
+        const uint32_t b_live = p.b - qblk * (uint32_t)QT < (uint32_t)QT ? p.b - qblk * (uint32_t)QT : (uint32_t)QT;
+        float* const scores = p.scores + (size_t)qblk * QT * p.n_pad;
+        float* const gmax = p.gmax + (size_t)qblk * QT * (p.n_pad / 64u);
+        uint32_t next_task = 0;
+        if (tid == 0) next_task = gridDim.x + atomicAdd(p.work, 1u);
+        const float* src[PER_T];
+#pragma unroll
+        for (int u = 0; u < PER_T; ++u) {
+            if (st_row[u] < (uint32_t)QT) {
+                src[u] = qbase + (size_t)st_row[u] * dim + st_c4[u] * 4u;
+            } else {
+                uint32_t r = row0 + (st_row[u] - (uint32_t)QT);
+                r = r > last_row ? last_row : r;
+                src[u] = p.rows + (size_t)r * dim + st_c4[u] * 4u;
+            }
+        }
+        auto stage_load = [&](uint32_t s, f4 (&reg)[PER_T]) {
+#pragma unroll
+            for (int u = 0; u < PER_T; ++u) {
+                const float* a = src[u] + (size_t)s * kBK16;
+                if (NT && st_row[u] >= (uint32_t)QT) reg[u] = __builtin_nontemporal_load((const f4*)a);
+                else reg[u] = *(const f4*)a;
+            }
+        };
+        auto stage_write = [&](int buf, const f4 (&reg)[PER_T]) {
+#pragma unroll
+            for (int u = 0; u < PER_T; ++u) {
+                float* dst = (st_row[u] < (uint32_t)QT)
+                                 ? sQ + ((size_t)buf * QT + st_row[u]) * kLDK16 + st_c4[u] * 4u
+                                 : sR + ((size_t)buf * RT + (st_row[u] - (uint32_t)QT)) * kLDK16 + st_c4[u] * 4u;
+                *(f4*)dst = reg[u];
+            }
+        };
+        f16v acc[QW][RW];
+#pragma unroll
+        for (int a = 0; a < QW; ++a)
+#pragma unroll
+            for (int b = 0; b < RW; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+        f4 regs[2][PER_T];
+        stage_load(0, regs[0]);
+        stage_load(1, regs[1]);
+        stage_write(0, regs[0]);
+        __syncthreads();
+        f4 af[2][QW], bf[2][RW];
+        auto read_frags = [&](int buf, int kg, int set) {
+            const float* aQ = sQ + ((size_t)buf * QT + (size_t)(wq * QW) * 32 + l31) * kLDK16 + 4 * lh;
+            const float* aR = sR + ((size_t)buf * RT + (size_t)(wr * RW) * 32 + l31) * kLDK16 + 4 * lh;
+#pragma unroll
+            for (int a = 0; a < QW; ++a) af[set][a] = *(const f4*)(aQ + (size_t)a * 32 * kLDK16 + kg * 8);
+#pragma unroll
+            for (int b = 0; b < RW; ++b) bf[set][b] = *(const f4*)(aR + (size_t)b * 32 * kLDK16 + kg * 8);
+        };
+        auto mma = [&](int cur) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int a = 0; a < QW; ++a)
+#pragma unroll
+                    for (int b = 0; b < RW; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][a][c], bf[cur][b][c], acc[a][b], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4 * QW * RW; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x0b0, 1, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        read_frags(0, 0, 0);
+        // one stage: buffer `buf` multiplies; k-group 0 writes stage s + 1 (register set (s + 1) & 1, loaded a stage ago) into
+        // the other buffer and requests stage s + 2 into the set stage s came from; k-group 1 crosses the barrier
+        auto stage = [&](uint32_t s, auto par_c) {
+            constexpr int par = decltype(par_c)::value;     // s & 1
+            const bool more = s + 1u < stages;
+            if (more) stage_write(par ^ 1, regs[par ^ 1]);
+            if (s + 2u < stages) stage_load(s + 2u, regs[par]);
+            read_frags(par, 1, 1);
+            mma(0);
+            __syncthreads();                                 // stage s + 1 is in place; everyone is done reading buffer par
+            if (more) read_frags(par ^ 1, 0, 0);
+            mma(1);
+        };
+        for (uint32_t s = 0; s < stages; s += 2u) {
+            stage(s, std::integral_constant<int, 0>{});
+            stage(s + 1u, std::integral_constant<int, 1>{});
+        }
+        __syncthreads();
+
+        // ---- epilogue (as scan_mfma_kernel): lane&31 <-> corpus row, register <-> query ----
+        const uint32_t nwords = (n + 31u) / 32u;
+        const uint32_t gpt = (uint32_t)RT / 64u;
+#pragma unroll
+        for (int b = 0; b < RW; ++b) {
+            const uint32_t row = row0 + (uint32_t)((wr * RW + b) * 32 + l31);
+            bool live = row < n;
+            if (p.keep && live) {
+                const uint32_t w = row >> 5;
+                live = w < nwords && ((p.keep[w] >> (row & 31u)) & 1u);
+            }
+#pragma unroll
+            for (int a = 0; a < QW; ++a) {
+                const uint32_t q_lo = (uint32_t)((wq * QW + a) * 32 + 4 * lh);
+                float* const sp = scores + (size_t)q_lo * p.n_pad + row;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const uint32_t dq = (uint32_t)((r & 3) + 8 * (r >> 2));
+                    float sv = acc[a][b][r];
+                    if (!live || !(__builtin_fabsf(sv) <= 3.4028234664e38f)) sv = -INFINITY;
+                    else if (p.mode == 1u) {
+                        sv = sv < 0.f ? 0.f : (sv > 1.f ? 1.f : sv);
+                        if (!(sv >= p.thr)) sv = -INFINITY;
+                    }
+                    acc[a][b][r] = sv;
+                    if (q_lo + dq < b_live) sp[(size_t)dq * p.n_pad] = sv;
+                }
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < RW / 2; ++g)
+#pragma unroll
+            for (int a = 0; a < QW; ++a)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float m = fmaxf(acc[a][2 * g][r], acc[a][2 * g + 1][r]);
+#pragma unroll
+                    for (int off = 16; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+                    const uint32_t qi = (uint32_t)((wq * QW + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh);
+                    if (l31 == 0 && qi < b_live)
+                        gmax[(size_t)qi * (p.n_pad / 64u) + rtile * gpt + (uint32_t)(wr * (RW / 2) + g)] = m;
+                }
+        if (tid == 0) s_task = next_task;
+        __syncthreads();
+        task = s_task;
+        __syncthreads();
+    }
+}
+
+template <int QW, int WQ, int RW, int WR>
+static hipError_t launch_mfma16_cfg(const ScanArgs& a, uint32_t q0, uint32_t nq, uint32_t slot, hipStream_t st) {
+    constexpr int QT = 32 * QW * WQ, RT = 32 * RW * WR;
+    MfmaParams p;
+    p.rows = a.rows; p.n = a.n; p.n_pad = a.n_pad; p.dim = a.dim;
+    p.q = a.q + (size_t)q0 * a.dim;
+    p.b = nq;
+    p.scores = a.scores + (size_t)q0 * a.n_pad;
+    p.gmax = a.gmax + (size_t)q0 * (a.n_pad / kTaskRows);
+    p.keep = a.keep; p.mode = a.mode; p.thr = a.threshold;
+    p.work = a.work + slot;
+    p.q_blocks = (nq + (uint32_t)QT - 1u) / (uint32_t)QT;
+    p.n_tasks = (a.n_pad / (uint32_t)RT) * p.q_blocks;
+    const size_t lds = (size_t)2 * (QT + RT) * kLDK16 * sizeof(float);
+    const uint32_t want = 2u * a.n_cu;                      // two workgroups per CU
+    uint32_t blocks = want < p.n_tasks ? want : p.n_tasks;
+    auto kern = a.nontemporal ? scan_mfma16_kernel<QW, WQ, RW, WR, true> : scan_mfma16_kernel<QW, WQ, RW, WR, false>;
+    static DynLdsOnce once[2];
+    hipError_t e = once[a.nontemporal ? 1 : 0].ensure((const void*)kern, lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, st, p);
+    return hipGetLastError();
+}
+
 template <int QW, int WQ, int RW, int WR>
 static hipError_t launch_mfma_cfg(const ScanArgs& a, uint32_t q0, uint32_t nq, uint32_t slot, hipStream_t st) {
     constexpr int QT = 32 * QW * WQ, RT = 32 * RW * WR;
@@ -247,13 +462,23 @@ static hipError_t launch_mfma_cfg(const ScanArgs& a, uint32_t q0, uint32_t nq, u
     static DynLdsOnce once[2];   // per instantiation x {nt, default}: set once per device, not per launch
     hipError_t e = once[a.nontemporal ? 1 : 0].ensure((const void*)kern, lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, st, p);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * WQ * WR), lds, st, p);
     return hipGetLastError();
 }
 
 // Query block [q0, q0+nq) (nq <= 256) through the MFMA kernel.  a.q must be readable (zero
 // padded) up to the next multiple of the chosen query tile.
 hipError_t launch_scan_mfma(const ScanArgs& a, uint32_t q0, uint32_t nq, uint32_t slot, hipStream_t st) {
+    static const int waves = [] { const char* e = getenv("CQS_HIP_SCAN_MFMA_WAVES"); return e ? atoi(e) : 16; }();   // A/B hook: 4 = round-2 kernels, 8 = one 8-wave workgroup per CU
+    if (waves == 16) {                                       // 2 workgroups of 4 waves per CU, K staged 16 at a time
+        if (nq > 64) return launch_mfma16_cfg<2, 2, 2, 2>(a, q0, nq, slot, st);   // 128 q x 128 rows (x 2 query blocks for 129-256)
+        if (nq > 32) return launch_mfma16_cfg<2, 1, 2, 4>(a, q0, nq, slot, st);   //  64 q x 256 rows
+    }
+    if (waves == 8) {
+        if (nq > 128) return launch_mfma_cfg<2, 4, 2, 2>(a, q0, nq, slot, st);   // 256 q x 128 rows, 8 waves of 64 q x 64 rows
+        if (nq > 64) return launch_mfma_cfg<2, 2, 2, 4>(a, q0, nq, slot, st);    // 128 q x 256 rows
+        if (nq > 32) return launch_mfma_cfg<1, 2, 2, 4>(a, q0, nq, slot, st);    //  64 q x 256 rows (row tiles must divide n_pad: <= 256)
+    }
     if (nq > 128) return launch_mfma_cfg<2, 4, 4, 1>(a, q0, nq, slot, st);   // 256 q x 128 rows
     if (nq > 64) return launch_mfma_cfg<2, 2, 2, 2>(a, q0, nq, slot, st);    // 128 q x 128 rows
     if (nq > 32) return launch_mfma_cfg<2, 1, 2, 4>(a, q0, nq, slot, st);    //  64 q x 256 rows
