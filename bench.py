@@ -424,7 +424,7 @@ def other_configs(torch, np, HipIndex, idx, rows, queries, dim, dev, st):
     check_topk(torch, np, rows, q1, hk[0], hc[0], 500, what="k500_1M")
     out["k500_1M"] = {"queries_per_sec": round(1.0 / t, 1), "ms_per_query": round(t * 1e3, 4), "checked": True}
     qb = make_unit_rows(torch, 256, dim, 0xC950003, dev)
-    t, hk, hc = timed(idx, qb, 256, 20, 10, 2)                # configs[2]: 256-query blocks on the f32 matrix cores
+    t, hk, hc = timed(idx, qb, 256, 20, 60, 15)               # configs[2]: 256-query blocks on the f32 matrix cores
     allsc = rows @ qb.T                                       # exhaustive threshold count for all 256 queries at once
     kth = torch.empty((256,), device=dev)
     for qi in range(256):
@@ -510,7 +510,12 @@ def aux_models_leg(a, np):
     t0 = time.perf_counter()
     for _ in range(steps):
         sv = enc.encode_batch_arrays(seqs)
-    dt = (time.perf_counter() - t0) / steps
+    dt_sync = (time.perf_counter() - t0) / steps                       # one blocking encode_batch at a time
+    enc.encode_batches_arrays([seqs] * 3)
+    t0 = time.perf_counter()
+    piped = enc.encode_batches_arrays([seqs] * (2 * steps))             # the index pipeline's form: 3 tickets in flight
+    dt = (time.perf_counter() - t0) / (2 * steps)
+    assert all(np.array_equal(piped[0][b][0], sv[b][0]) and np.array_equal(piped[-1][b][1], sv[b][1]) for b in range(B)), "tickets != blocking call"
     t0 = time.perf_counter()
     for _ in range(steps):
         eng.splade_dense(seqs)
@@ -519,12 +524,14 @@ def aux_models_leg(a, np):
                            + cfg.hidden * cfg.vocab_size) + 4.0 * B * cfg.layers * L * L * cfg.hidden
     out["splade"] = {"model": "BERT-base masked-LM geometry (12 x [768 | 12 x 64 | 3072], vocab 30522), seeded weights",
                      "batch": B, "tokens_per_doc": L, "docs_per_sec": round(B / dt, 1), "tokens_per_sec": round(B * L / dt, 1),
-                     "ms_per_batch": round(dt * 1e3, 3), "ms_per_batch_device_side": round(dt_dense * 1e3, 3),
+                     "ms_per_batch": round(dt * 1e3, 3), "sync_api": {"docs_per_sec": round(B / dt_sync, 1), "ms_per_batch": round(dt_sync * 1e3, 3)},
+                     "ms_per_batch_device_side": round(dt_dense * 1e3, 3),
                      "tflops": round(flops / dt_dense / 1e12, 1), "nnz_per_doc": round(float(np.mean([len(v[0]) for v in sv])), 1),
                      "checked": {"max_abs_err_vs_fp32_oracle": round(err, 4)},
                      "cpu_baseline": {"docs_per_sec": round(3 / cpu_s, 2), "kind": "port", "sample": "oracle/bert_ref (torch CPU fp32), 3 docs / 255 tokens"},
                      "threshold": round(thr, 4),
-                     "note": "host API: token ids in, sparse vectors out (threshold filter of src/splade/mod.rs:1049-1062 on the device, cqs_hip_splade_encode_sparse); "
+                     "note": "host API: token ids in, sparse vectors out (threshold filter of src/splade/mod.rs:1049-1062 on the device), 3 tickets in flight "
+                             "(cqs_hip_splade_submit_sparse / _collect_sparse; sync_api = one blocking cqs_hip_splade_encode_sparse per batch); "
                              "threshold set where ~200 entries per document survive (seeded weights are not sparse)"}
     eng.close()
 
@@ -548,13 +555,25 @@ def aux_models_leg(a, np):
         steps = max(4, a.embed_steps)
         t0 = time.perf_counter()
         for _ in range(steps):
-            eng.embed(seqs, None, "mean")
-        dt = (time.perf_counter() - t0) / steps
+            ref_out = eng.embed(seqs, None, "mean")
+        dt_sync = (time.perf_counter() - t0) / steps
+        pend, last = [], None
+        t0 = time.perf_counter()
+        for _ in range(2 * steps):                                        # tickets: 3 in flight
+            pend.append(eng.embed_submit(seqs, None, "mean"))
+            if len(pend) == 3:
+                last = eng.embed_collect(pend.pop(0))
+        for h in pend:
+            last = eng.embed_collect(h)
+        dt = (time.perf_counter() - t0) / (2 * steps)
+        assert np.array_equal(last, ref_out), "tickets != blocking call"
         flops = 2.0 * B * L * cfg.layers * (4 * cfg.hidden * cfg.hidden + 2 * cfg.hidden * cfg.intermediate) + 4.0 * B * cfg.layers * L * L * cfg.hidden
         out["embedder_" + name] = {"model": "%s geometry (%d x [%d | %d x 64 | %d]), seeded weights, mean pooling" % (
                                        name.replace("_", "-"), cfg.layers, cfg.hidden, cfg.heads, cfg.intermediate),
                                    "batch": B, "tokens_per_chunk": L, "chunks_per_sec": round(B / dt, 1), "tokens_per_sec": round(B * L / dt, 1),
                                    "ms_per_batch": round(dt * 1e3, 3), "tflops": round(flops / dt / 1e12, 1),
+                                   "sync_api": {"chunks_per_sec": round(B / dt_sync, 1), "ms_per_batch": round(dt_sync * 1e3, 3)},
+                                   "note": "3 tickets in flight (cqs_hip_bert_embed_submit / _collect); sync_api = one blocking cqs_hip_bert_embed per batch",
                                    "checked": {"min_cosine_vs_fp32_oracle": round(cs, 6)},
                                    "cpu_baseline": {"chunks_per_sec": round(2 / cpu_s, 2), "kind": "port", "sample": "oracle/bert_ref (torch CPU fp32), 2 chunks / 170 tokens"}}
         eng.close()

@@ -97,6 +97,10 @@ SIGNATURES = [
     ("cqs_hip_splade_encode", C.c_int32, [_c_idx, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
     ("cqs_hip_splade_encode_sparse", C.c_int32,
      [_c_idx, C.c_void_p, C.c_void_p, C.c_uint32, C.c_float, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("cqs_hip_splade_submit_sparse", C.c_int32, [_c_idx, C.c_void_p, C.c_void_p, C.c_uint32, C.c_float, C.c_uint32, C.c_void_p]),
+    ("cqs_hip_splade_collect_sparse", C.c_int32, [_c_idx, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("cqs_hip_bert_embed_submit", C.c_int32, [_c_idx, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
+    ("cqs_hip_bert_embed_collect", C.c_int32, [_c_idx, C.c_uint64, C.c_void_p]),
     ("cqs_hip_rerank_logits", C.c_int32, [_c_idx, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
     ("cqs_hip_bert_embed", C.c_int32, [_c_idx, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
     ("cqs_hip_bert_hidden", C.c_int32, [_c_idx, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),

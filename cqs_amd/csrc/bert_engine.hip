@@ -47,7 +47,6 @@ struct cqs_hip_bert {
     int device = 0;
     cqs_hip_bert_config cfg{};
     uint32_t vpad = 0;                       // vocab rounded up to a multiple of 192 (decoder N tile)
-    hipStream_t stream = nullptr;
     std::map<std::string, std::vector<float>> pending;    // host copies until finalize
     bool finalized = false;
 
@@ -62,15 +61,37 @@ struct cqs_hip_bert {
     float *bp = nullptr, *bc = nullptr;
     std::vector<void*> owned;                // every device allocation of the weights
 
-    // scratch (one batch at a time; the engine is serialised by `mu`)
-    uint32_t tok_cap = 0, seq_cap = 0, blk_cap = 0;
-    bf16_t *x = nullptr, *y = nullptr, *qkv = nullptr, *att = nullptr, *h = nullptr, *pooled = nullptr;
-    float *dense = nullptr, *cls = nullptr;
-    uint32_t *sp_ids = nullptr, *sp_cnt = nullptr;      // device-side threshold filter: [sp_rows * sp_cap] ids / weights, [sp_rows] counts
-    float* sp_w = nullptr;
-    size_t sp_rows = 0, sp_cap = 0;
-    int32_t* d_meta = nullptr;
-    std::vector<int32_t> h_meta;
+    // Execution contexts (a HIP stream + the activation scratch of one batch each; weights shared): consecutive tickets
+    // alternate, so batch i + 1's kernel chain fills the CUs batch i's leaves idle and its H2D / host packing overlap
+    // batch i's compute - the submit / collect scheme of the EmbeddingGemma engine (embedder.hip), which the reference's
+    // index pipeline needs from the SPLADE encoder just as well (src/splade/mod.rs:774-1075 is called per batch from it).
+    struct Ctx {
+        hipStream_t stream = nullptr;
+        uint32_t tok_cap = 0, seq_cap = 0, blk_cap = 0;
+        bf16_t *x = nullptr, *y = nullptr, *qkv = nullptr, *att = nullptr, *h = nullptr, *pooled = nullptr;
+        float *dense = nullptr, *cls = nullptr;
+        uint32_t *sp_ids = nullptr, *sp_cnt = nullptr;  // device-side threshold filter: [sp_rows * sp_cap] ids / weights, [sp_rows] counts
+        float* sp_w = nullptr;
+        size_t sp_rows = 0, sp_cap = 0;
+        int32_t* d_meta = nullptr;
+    };
+    static constexpr int kCtx = 2;
+    Ctx ctx[kCtx];
+    // Submission slots: pinned tables (packed on the host while earlier tickets run) + pinned results + a completion event.
+    struct Slot {
+        uint64_t ticket = 0;         // 0 = free
+        int kind = 0;                // 1 = sparse SPLADE vectors, 2 = pooled embeddings
+        int ctx = 0;
+        uint32_t B = 0, M = 0, cap = 0, nblk = 0;
+        int32_t* meta = nullptr;     // pinned: [tok M][pos M][tt M][seq_start B][seq_len B][blk 2 nblk][row_seq M]
+        size_t meta_cap = 0;         // int32 elements
+        void* out = nullptr;         // pinned results: kind 1: ids [B cap] u32 | weights [B cap] f32 | counts [B] u32; kind 2: [B, H] f32
+        size_t out_cap = 0;          // bytes
+        hipEvent_t done = nullptr;
+    };
+    static constexpr int kSlots = 3;
+    Slot slot[kSlots];
+    uint64_t next_ticket = 1;
 
     std::mutex mu;
     std::atomic<bool> poisoned{false};
@@ -119,58 +140,69 @@ int32_t up_f32(cqs_hip_bert* e, float** dst, const float* src, size_t count, siz
     return CQS_HIP_OK;
 }
 
-void free_scratch(cqs_hip_bert* e) {
-    void** all[] = {(void**)&e->x, (void**)&e->y, (void**)&e->qkv, (void**)&e->att, (void**)&e->h,
-                    (void**)&e->pooled, (void**)&e->dense, (void**)&e->cls, (void**)&e->d_meta};
+using BCtx = cqs_hip_bert::Ctx;
+using BSlot = cqs_hip_bert::Slot;
+
+void free_scratch(BCtx& c) {
+    void** all[] = {(void**)&c.x, (void**)&c.y, (void**)&c.qkv, (void**)&c.att, (void**)&c.h,
+                    (void**)&c.pooled, (void**)&c.dense, (void**)&c.cls, (void**)&c.d_meta};
     for (void** p : all) { (void)hipFree(*p); *p = nullptr; }
-    (void)hipFree(e->sp_ids); (void)hipFree(e->sp_w); (void)hipFree(e->sp_cnt);
-    e->sp_ids = e->sp_cnt = nullptr; e->sp_w = nullptr; e->sp_rows = e->sp_cap = 0;
-    e->tok_cap = e->seq_cap = e->blk_cap = 0;
+    (void)hipFree(c.sp_ids); (void)hipFree(c.sp_w); (void)hipFree(c.sp_cnt);
+    c.sp_ids = c.sp_cnt = nullptr; c.sp_w = nullptr; c.sp_rows = c.sp_cap = 0;
+    c.tok_cap = c.seq_cap = c.blk_cap = 0;
 }
 
-int32_t ensure_scratch(cqs_hip_bert* e, uint32_t M, uint32_t B, uint32_t nblk) {
-    if (M <= e->tok_cap && B <= e->seq_cap && nblk <= e->blk_cap) return CQS_HIP_OK;
-    B_TRY(e, hipStreamSynchronize(e->stream));
-    const uint32_t Mc = std::max(M, e->tok_cap), Bc = std::max(B, e->seq_cap), bc = std::max(nblk, e->blk_cap);
-    free_scratch(e);
-    const cqs_hip_bert_config& c = e->cfg;
-    const size_t H = c.hidden;
-    B_TRY(e, hipMalloc((void**)&e->x, (size_t)Mc * H * 2));
-    B_TRY(e, hipMalloc((void**)&e->y, (size_t)Mc * H * 2));
-    B_TRY(e, hipMalloc((void**)&e->qkv, (size_t)Mc * 3 * H * 2));
-    B_TRY(e, hipMalloc((void**)&e->att, (size_t)Mc * H * 2));
-    B_TRY(e, hipMalloc((void**)&e->h, (size_t)Mc * c.intermediate * 2));
-    if (c.head == CQS_HIP_BERT_HEAD_MLM) {
-        B_TRY(e, hipMalloc((void**)&e->dense, (size_t)Bc * c.vocab_size * 4));
-    } else if (c.head == CQS_HIP_BERT_HEAD_NONE) {
-        B_TRY(e, hipMalloc((void**)&e->dense, (size_t)Bc * H * 4));            // pooled embeddings
+int32_t ensure_scratch(cqs_hip_bert* e, BCtx& c, uint32_t M, uint32_t B, uint32_t nblk) {
+    if (M <= c.tok_cap && B <= c.seq_cap && nblk <= c.blk_cap) return CQS_HIP_OK;
+    B_TRY(e, hipStreamSynchronize(c.stream));
+    const uint32_t Mc = std::max(M, c.tok_cap), Bc = std::max(B, c.seq_cap), bc = std::max(nblk, c.blk_cap);
+    free_scratch(c);
+    const cqs_hip_bert_config& cf = e->cfg;
+    const size_t H = cf.hidden;
+    B_TRY(e, hipMalloc((void**)&c.x, (size_t)Mc * H * 2));
+    B_TRY(e, hipMalloc((void**)&c.y, (size_t)Mc * H * 2));
+    B_TRY(e, hipMalloc((void**)&c.qkv, (size_t)Mc * 3 * H * 2));
+    B_TRY(e, hipMalloc((void**)&c.att, (size_t)Mc * H * 2));
+    B_TRY(e, hipMalloc((void**)&c.h, (size_t)Mc * cf.intermediate * 2));
+    if (cf.head == CQS_HIP_BERT_HEAD_MLM) {
+        B_TRY(e, hipMalloc((void**)&c.dense, (size_t)Bc * cf.vocab_size * 4));
+    } else if (cf.head == CQS_HIP_BERT_HEAD_NONE) {
+        B_TRY(e, hipMalloc((void**)&c.dense, (size_t)Bc * H * 4));            // pooled embeddings
     } else {
-        B_TRY(e, hipMalloc((void**)&e->pooled, (size_t)Bc * H * 2));
-        B_TRY(e, hipMalloc((void**)&e->cls, (size_t)Bc * 16 * 4));
+        B_TRY(e, hipMalloc((void**)&c.pooled, (size_t)Bc * H * 2));
+        B_TRY(e, hipMalloc((void**)&c.cls, (size_t)Bc * 16 * 4));
     }
-    B_TRY(e, hipMalloc((void**)&e->d_meta, ((size_t)4 * Mc + (size_t)2 * Bc + (size_t)2 * bc) * 4));
-    e->tok_cap = Mc; e->seq_cap = Bc; e->blk_cap = bc;
+    B_TRY(e, hipMalloc((void**)&c.d_meta, ((size_t)4 * Mc + (size_t)2 * Bc + (size_t)2 * bc) * 4));
+    c.tok_cap = Mc; c.seq_cap = Bc; c.blk_cap = bc;
     return CQS_HIP_OK;
 }
 
-// Validate + pack a ragged batch, upload its tables, run the encoder; leaves the final hidden states in e->x.
-int32_t run_encoder(cqs_hip_bert* e, const int32_t* tokens, const int32_t* type_ids, const uint32_t* lens, uint32_t B,
+// Validate + pack a ragged batch into the slot's pinned tables, upload them, run the encoder on context `c`; leaves the
+// final hidden states in c.x.
+int32_t run_encoder(cqs_hip_bert* e, BCtx& c, BSlot& sl, const int32_t* tokens, const int32_t* type_ids, const uint32_t* lens, uint32_t B,
                     uint32_t* M_out) {
-    const cqs_hip_bert_config& c = e->cfg;
+    const cqs_hip_bert_config& cf = e->cfg;
     uint64_t M64 = 0, nblk64 = 0;
     for (uint32_t b = 0; b < B; ++b) {
-        if (lens[b] > c.max_pos) return bfail(e, CQS_HIP_ERR_INVALID, "bert: sequence longer than max_position_embeddings");
+        if (lens[b] > cf.max_pos) return bfail(e, CQS_HIP_ERR_INVALID, "bert: sequence longer than max_position_embeddings");
         M64 += lens[b];
         nblk64 += (lens[b] + 63u) / 64u;
     }
     if (M64 > 0x7FFFFFFFull) return bfail(e, CQS_HIP_ERR_INVALID, "bert: batch holds too many tokens");
     const uint32_t M = (uint32_t)M64, nblk = (uint32_t)nblk64;
     *M_out = M;
+    sl.B = B; sl.M = M; sl.nblk = nblk;
     if (M == 0) return CQS_HIP_OK;
     // tables: [tok M][pos M][tt M][seq_start B][seq_len B][blk 2 nblk][row_seq M]
-    std::vector<int32_t>& t = e->h_meta;
-    t.assign((size_t)4 * M + (size_t)2 * B + (size_t)2 * nblk, 0);
-    int32_t *tok = t.data(), *pos = tok + M, *tt = pos + M, *seq_start = tt + M, *seq_len = seq_start + B, *blk = seq_len + B;
+    const size_t words = (size_t)4 * M + (size_t)2 * B + (size_t)2 * nblk;
+    if (words > sl.meta_cap) {
+        if (sl.meta) (void)hipHostFree(sl.meta);
+        sl.meta = nullptr; sl.meta_cap = 0;
+        const size_t cap = words + words / 4 + 64;
+        B_TRY(e, hipHostMalloc((void**)&sl.meta, cap * sizeof(int32_t), hipHostMallocDefault));
+        sl.meta_cap = cap;
+    }
+    int32_t *tok = sl.meta, *pos = tok + M, *tt = pos + M, *seq_start = tt + M, *seq_len = seq_start + B, *blk = seq_len + B;
     int32_t* row_seq = blk + (size_t)2 * nblk;
     uint32_t m = 0, nb = 0;
     for (uint32_t b = 0; b < B; ++b) {
@@ -178,33 +210,61 @@ int32_t run_encoder(cqs_hip_bert* e, const int32_t* tokens, const int32_t* type_
         seq_len[b] = (int32_t)lens[b];
         for (uint32_t j = 0; j < lens[b]; ++j) {
             const int32_t id = tokens[m + j];
-            if (id < 0 || (uint32_t)id >= c.vocab_size) return bfail(e, CQS_HIP_ERR_INVALID, "bert: token id out of range");
+            if (id < 0 || (uint32_t)id >= cf.vocab_size) return bfail(e, CQS_HIP_ERR_INVALID, "bert: token id out of range");
             const int32_t ty = type_ids ? type_ids[m + j] : 0;
-            if (ty < 0 || (uint32_t)ty >= c.type_vocab) return bfail(e, CQS_HIP_ERR_INVALID, "bert: token type id out of range");
+            if (ty < 0 || (uint32_t)ty >= cf.type_vocab) return bfail(e, CQS_HIP_ERR_INVALID, "bert: token type id out of range");
             tok[m + j] = id; pos[m + j] = (int32_t)j; tt[m + j] = ty; row_seq[m + j] = (int32_t)b;
         }
         for (uint32_t q = 0; q * 64u < lens[b]; ++q) { blk[2 * nb] = (int32_t)b; blk[2 * nb + 1] = (int32_t)q; ++nb; }
         m += lens[b];
     }
-    int32_t rc = ensure_scratch(e, M, B, nblk);
+    int32_t rc = ensure_scratch(e, c, M, B, nblk);
     if (rc != CQS_HIP_OK) return rc;
-    hipStream_t st = e->stream;
-    B_TRY(e, hipMemcpyAsync(e->d_meta, t.data(), t.size() * 4, hipMemcpyHostToDevice, st));
-    const int32_t *d_tok = e->d_meta, *d_pos = d_tok + M, *d_tt = d_pos + M, *d_start = d_tt + M, *d_len = d_start + B,
+    hipStream_t st = c.stream;
+    B_TRY(e, hipMemcpyAsync(c.d_meta, sl.meta, words * 4, hipMemcpyHostToDevice, st));
+    const int32_t *d_tok = c.d_meta, *d_pos = d_tok + M, *d_tt = d_pos + M, *d_start = d_tt + M, *d_len = d_start + B,
                   *d_blk = d_len + B;
-    const uint32_t H = c.hidden, I = c.intermediate;
-    B_TRY(e, cqs::launch_bert_embed_ln(d_tok, d_pos, d_tt, e->word, e->posw, e->typew, e->emb_g, e->emb_b, c.ln_eps, e->x, M, H, st));
-    for (uint32_t l = 0; l < c.layers; ++l) {
+    const uint32_t H = cf.hidden, I = cf.intermediate;
+    B_TRY(e, cqs::launch_bert_embed_ln(d_tok, d_pos, d_tt, e->word, e->posw, e->typew, e->emb_g, e->emb_b, cf.ln_eps, c.x, M, H, st));
+    for (uint32_t l = 0; l < cf.layers; ++l) {
         const BertLayer& w = e->L[l];
-        B_TRY(e, cqs::launch_gemm_bias(e->x, w.wqkv, w.bqkv, e->qkv, M, 3u * H, H, 3u * H, cqs::GEMM_OUT_BF16, st));
-        B_TRY(e, cqs::launch_bert_attention(e->qkv, e->att, d_blk, nblk, d_start, d_len, c.heads, H / c.heads, st));
-        B_TRY(e, cqs::launch_gemm_bias(e->att, w.wo, w.bo, e->y, M, H, H, H, cqs::GEMM_OUT_BF16, st));
-        B_TRY(e, cqs::launch_bert_add_ln(e->x, e->y, w.ln1_g, w.ln1_b, c.ln_eps, e->x, M, H, st));
-        B_TRY(e, cqs::launch_gemm_bias(e->x, w.w1, w.b1, e->h, M, I, H, I, cqs::GEMM_OUT_BF16_GELU, st));
-        B_TRY(e, cqs::launch_gemm_bias(e->h, w.w2, w.b2, e->y, M, H, I, H, cqs::GEMM_OUT_BF16, st));
-        B_TRY(e, cqs::launch_bert_add_ln(e->x, e->y, w.ln2_g, w.ln2_b, c.ln_eps, e->x, M, H, st));
+        B_TRY(e, cqs::launch_gemm_bias(c.x, w.wqkv, w.bqkv, c.qkv, M, 3u * H, H, 3u * H, cqs::GEMM_OUT_BF16, st));
+        B_TRY(e, cqs::launch_bert_attention(c.qkv, c.att, d_blk, nblk, d_start, d_len, cf.heads, H / cf.heads, st));
+        B_TRY(e, cqs::launch_gemm_bias(c.att, w.wo, w.bo, c.y, M, H, H, H, cqs::GEMM_OUT_BF16, st));
+        B_TRY(e, cqs::launch_bert_add_ln(c.x, c.y, w.ln1_g, w.ln1_b, cf.ln_eps, c.x, M, H, st));
+        B_TRY(e, cqs::launch_gemm_bias(c.x, w.w1, w.b1, c.h, M, I, H, I, cqs::GEMM_OUT_BF16_GELU, st));
+        B_TRY(e, cqs::launch_gemm_bias(c.h, w.w2, w.b2, c.y, M, H, I, H, cqs::GEMM_OUT_BF16, st));
+        B_TRY(e, cqs::launch_bert_add_ln(c.x, c.y, w.ln2_g, w.ln2_b, cf.ln_eps, c.x, M, H, st));
     }
     return CQS_HIP_OK;
+}
+
+// A free submission slot + the context the next ticket runs on (consecutive tickets alternate).
+int32_t take_slot(cqs_hip_bert* e, BSlot** sl, BCtx** c) {
+    *sl = nullptr;
+    for (BSlot& s : e->slot)
+        if (s.ticket == 0) { *sl = &s; break; }
+    if (!*sl) return bfail(e, CQS_HIP_ERR_INVALID, "bert: every submission slot is in flight (collect a ticket first)");
+    const int ci = (int)(e->next_ticket % (uint64_t)cqs_hip_bert::kCtx);
+    (*sl)->ctx = ci;
+    *c = &e->ctx[ci];
+    if (!(*sl)->done) B_TRY(e, hipEventCreateWithFlags(&(*sl)->done, hipEventDisableTiming));
+    return CQS_HIP_OK;
+}
+int32_t slot_out_reserve(cqs_hip_bert* e, BSlot& sl, size_t bytes) {
+    if (bytes <= sl.out_cap) return CQS_HIP_OK;
+    if (sl.out) (void)hipHostFree(sl.out);
+    sl.out = nullptr; sl.out_cap = 0;
+    const size_t cap = bytes + bytes / 4 + 256;
+    B_TRY(e, hipHostMalloc(&sl.out, cap, hipHostMallocDefault));
+    sl.out_cap = cap;
+    return CQS_HIP_OK;
+}
+BSlot* find_ticket(cqs_hip_bert* e, uint64_t ticket, int kind) {
+    if (ticket == 0) return nullptr;
+    for (BSlot& s : e->slot)
+        if (s.ticket == ticket && s.kind == kind) return &s;
+    return nullptr;
 }
 
 int32_t check_ready(cqs_hip_bert* e, uint32_t head) {
@@ -249,13 +309,14 @@ int32_t cqs_hip_bert_create(const cqs_hip_bert_config* cfg, int32_t device, cqs_
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return CQS_HIP_ERR_NO_DEVICE;
     cqs_hip_bert* e = new (std::nothrow) cqs_hip_bert();
     if (!e) return CQS_HIP_ERR_NOMEM;
-    std::unique_ptr<cqs_hip_bert> owner(e);     // a throwing resize below must not leak the handle
+    std::unique_ptr<cqs_hip_bert, void (*)(cqs_hip_bert*)> owner(e, cqs_hip_bert_destroy);   // every failing exit gives the handle (and its streams) back
     e->device = device;
     e->cfg = c;
     e->vpad = (c.vocab_size + 191u) / 192u * 192u;
     e->L.resize(c.layers);
-    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess)
-        return CQS_HIP_ERR_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return CQS_HIP_ERR_DEVICE;
+    for (cqs_hip_bert::Ctx& cx : e->ctx)
+        if (hipStreamCreateWithFlags(&cx.stream, hipStreamNonBlocking) != hipSuccess) return CQS_HIP_ERR_DEVICE;
     *out = owner.release();
     return CQS_HIP_OK;
 } CQS_ABI_CATCH_NOHANDLE
@@ -353,31 +414,30 @@ int32_t cqs_hip_bert_finalize(cqs_hip_bert* e) CQS_ABI_TRY {
 
 namespace {
 
-// Encoder + masked-LM head + pooling + activation: leaves the [batch, vocab] activations in e->dense (device).
+// Encoder + masked-LM head + pooling + activation: leaves the [batch, vocab] activations in c.dense (device).
 // *M_out == 0: every sequence empty (nothing was launched; the activations are all ln(1 + 0) = 0).
-int32_t splade_forward(cqs_hip_bert* e, const int32_t* tokens, const uint32_t* lens, uint32_t batch, uint32_t* M_out) {
+int32_t splade_forward(cqs_hip_bert* e, BCtx& c, BSlot& sl, const int32_t* tokens, const uint32_t* lens, uint32_t batch, uint32_t* M_out) {
     uint64_t tot = 0;
     for (uint32_t b = 0; b < batch; ++b) tot += lens[b];
     if (tot && !tokens) return bfail(e, CQS_HIP_ERR_INVALID, "splade: null tokens");
-    int32_t rc = run_encoder(e, tokens, nullptr, lens, batch, M_out);
+    int32_t rc = run_encoder(e, c, sl, tokens, nullptr, lens, batch, M_out);
     if (rc != CQS_HIP_OK) return rc;
     const uint32_t M = *M_out;
     if (M == 0) return CQS_HIP_OK;
-    const cqs_hip_bert_config& c = e->cfg;
-    const size_t V = c.vocab_size;
-    hipStream_t st = e->stream;
-    const uint32_t H = c.hidden;
-    const int32_t* d_len = e->d_meta + (size_t)3 * M + batch;
+    const cqs_hip_bert_config& cf = e->cfg;
+    const size_t V = cf.vocab_size;
+    hipStream_t st = c.stream;
+    const uint32_t H = cf.hidden;
+    const int32_t* d_len = c.d_meta + (size_t)3 * M + batch;
     // BertLMPredictionHead: LayerNorm(gelu(x Wt^T + bt)) E^T + b, decoder tied to the (zero-padded) word embeddings.
     // The [tokens, vocab] logits are never stored: the decoder GEMM's epilogue keeps, per sequence and vocabulary
     // entry, the maximum of max(0, logit) (atomic max on the float bits), then one small pass takes ln(1 + .).
-    const uint32_t nblk = (uint32_t)((e->h_meta.size() - (size_t)4 * M - (size_t)2 * batch) / 2);
-    const int32_t* d_rowseq = d_len + batch + (size_t)2 * nblk;
-    B_TRY(e, cqs::launch_gemm_bias(e->x, e->wt, e->bt, e->y, M, H, H, H, cqs::GEMM_OUT_BF16_GELU, st));
-    B_TRY(e, cqs::launch_bert_add_ln(e->y, nullptr, e->lnt_g, e->lnt_b, c.ln_eps, e->y, M, H, st));
-    B_TRY(e, hipMemsetAsync(e->dense, 0, (size_t)batch * V * 4, st));
-    B_TRY(e, cqs::launch_gemm_rowmax(e->y, e->word, e->bdec, (uint32_t*)e->dense, M, e->vpad, H, (uint32_t)V, d_rowseq, (uint32_t)V, st));
-    B_TRY(e, cqs::launch_splade_activate(e->dense, (size_t)batch * V, st));
+    const int32_t* d_rowseq = d_len + batch + (size_t)2 * sl.nblk;
+    B_TRY(e, cqs::launch_gemm_bias(c.x, e->wt, e->bt, c.y, M, H, H, H, cqs::GEMM_OUT_BF16_GELU, st));
+    B_TRY(e, cqs::launch_bert_add_ln(c.y, nullptr, e->lnt_g, e->lnt_b, cf.ln_eps, c.y, M, H, st));
+    B_TRY(e, hipMemsetAsync(c.dense, 0, (size_t)batch * V * 4, st));
+    B_TRY(e, cqs::launch_gemm_rowmax(c.y, e->word, e->bdec, (uint32_t*)c.dense, M, e->vpad, H, (uint32_t)V, d_rowseq, (uint32_t)V, st));
+    B_TRY(e, cqs::launch_splade_activate(c.dense, (size_t)batch * V, st));
     return CQS_HIP_OK;
 }
 
@@ -395,52 +455,107 @@ int32_t cqs_hip_splade_encode(cqs_hip_bert* e, const int32_t* tokens, const uint
     if (batch == 0) return CQS_HIP_OK;
     if (!lens || !out_dense) return bfail(e, CQS_HIP_ERR_INVALID, "splade: null buffer");
     B_TRY(e, hipSetDevice(e->device));
+    BSlot* sl; BCtx* c;
+    if ((rc = take_slot(e, &sl, &c)) != CQS_HIP_OK) return rc;
     uint32_t M = 0;
-    rc = splade_forward(e, tokens, lens, batch, &M);
+    rc = splade_forward(e, *c, *sl, tokens, lens, batch, &M);
     if (rc != CQS_HIP_OK) return rc;
     const size_t V = e->cfg.vocab_size;
     if (M == 0) { memset(out_dense, 0, (size_t)batch * V * 4); return CQS_HIP_OK; }   // all empty: ln(1 + 0) = 0 everywhere
-    B_TRY(e, hipMemcpyAsync(out_dense, e->dense, (size_t)batch * V * 4, hipMemcpyDeviceToHost, e->stream));
-    B_TRY(e, hipStreamSynchronize(e->stream));
+    B_TRY(e, hipMemcpyAsync(out_dense, c->dense, (size_t)batch * V * 4, hipMemcpyDeviceToHost, c->stream));
+    B_TRY(e, hipStreamSynchronize(c->stream));
     return CQS_HIP_OK;
 } CQS_ABI_CATCH(e)
 
-// The same with the threshold filter of src/splade/mod.rs:1049-1062 on the device: sequence b's entries > threshold
-// as (id, weight), ascending id, at out_ids / out_weights [b * cap ..]; out_counts[b] = how many passed.  A count above
+// The same with the threshold filter of src/splade/mod.rs:1049-1062 on the device, as a TICKET: submit packs the batch
+// into a free slot's pinned tables, enqueues H2D + encoder + head + filter + D2H on one of the two execution contexts
+// and returns without waiting; collect waits for that ticket and hands out sequence b's entries > threshold as
+// (id, weight), ascending id, at out_ids / out_weights [b * cap ..], out_counts[b] = how many passed.  A count above
 // `cap` means the row was cut off after its first `cap` entries: the caller re-encodes that sequence through
-// cqs_hip_splade_encode (trained models keep 100-300 entries, src/splade/mod.rs:44).
-int32_t cqs_hip_splade_encode_sparse(cqs_hip_bert* e, const int32_t* tokens, const uint32_t* lens, uint32_t batch,
-                                     float threshold, uint32_t cap, uint32_t* out_ids, float* out_weights, uint32_t* out_counts) CQS_ABI_TRY {
-    CQS_ROCTX_RANGE("cqs_hip_splade_encode_sparse");
+// cqs_hip_splade_encode (trained models keep 100-300 entries, src/splade/mod.rs:44).  Up to 3 tickets in flight; a
+// ticket is released only by collecting it (out_ids = NULL: abandon).
+int32_t cqs_hip_splade_submit_sparse(cqs_hip_bert* e, const int32_t* tokens, const uint32_t* lens, uint32_t batch, float threshold,
+                                     uint32_t cap, uint64_t* ticket) CQS_ABI_TRY {
+    CQS_ROCTX_RANGE("cqs_hip_splade_submit_sparse");
     if (!e) return CQS_HIP_ERR_INVALID;
     std::lock_guard<std::mutex> lk(e->mu);
     int32_t rc = check_ready(e, CQS_HIP_BERT_HEAD_MLM);
     if (rc != CQS_HIP_OK) return rc;
-    if (batch == 0) return CQS_HIP_OK;
-    if (!lens || !out_ids || !out_weights || !out_counts || cap == 0) return bfail(e, CQS_HIP_ERR_INVALID, "splade: null buffer / zero cap");
+    if (!ticket) return bfail(e, CQS_HIP_ERR_INVALID, "splade: null ticket");
+    *ticket = 0;
+    if (batch == 0 || !lens || cap == 0) return bfail(e, CQS_HIP_ERR_INVALID, "splade: empty batch / null buffer / zero cap");
     B_TRY(e, hipSetDevice(e->device));
+    BSlot* sl; BCtx* c;
+    if ((rc = take_slot(e, &sl, &c)) != CQS_HIP_OK) return rc;
     uint32_t M = 0;
-    rc = splade_forward(e, tokens, lens, batch, &M);
+    rc = splade_forward(e, *c, *sl, tokens, lens, batch, &M);
     if (rc != CQS_HIP_OK) return rc;
-    if (M == 0) { memset(out_counts, 0, (size_t)batch * 4); return CQS_HIP_OK; }      // activations all 0: nothing passes `>`
-    if ((size_t)batch > e->sp_rows || (size_t)cap > e->sp_cap) {
-        B_TRY(e, hipStreamSynchronize(e->stream));
-        (void)hipFree(e->sp_ids); (void)hipFree(e->sp_w); (void)hipFree(e->sp_cnt);
-        e->sp_ids = e->sp_cnt = nullptr; e->sp_w = nullptr;
-        const size_t rows = std::max<size_t>(batch, e->sp_rows), cp = std::max<size_t>(cap, e->sp_cap);
-        e->sp_rows = e->sp_cap = 0;
-        B_TRY(e, hipMalloc((void**)&e->sp_ids, rows * cp * 4));
-        B_TRY(e, hipMalloc((void**)&e->sp_w, rows * cp * 4));
-        B_TRY(e, hipMalloc((void**)&e->sp_cnt, rows * 4));
-        e->sp_rows = rows; e->sp_cap = cp;
+    const size_t n = (size_t)batch * cap;
+    if ((rc = slot_out_reserve(e, *sl, n * 8 + (size_t)batch * 4)) != CQS_HIP_OK) return rc;
+    hipStream_t st = c->stream;
+    if (M == 0) {
+        memset((char*)sl->out + n * 8, 0, (size_t)batch * 4);                      // activations all 0: nothing passes `>`
+    } else {
+        if ((size_t)batch > c->sp_rows || (size_t)cap > c->sp_cap) {
+            B_TRY(e, hipStreamSynchronize(st));
+            (void)hipFree(c->sp_ids); (void)hipFree(c->sp_w); (void)hipFree(c->sp_cnt);
+            c->sp_ids = c->sp_cnt = nullptr; c->sp_w = nullptr;
+            const size_t rows = std::max<size_t>(batch, c->sp_rows), cp = std::max<size_t>(cap, c->sp_cap);
+            c->sp_rows = c->sp_cap = 0;
+            B_TRY(e, hipMalloc((void**)&c->sp_ids, rows * cp * 4));
+            B_TRY(e, hipMalloc((void**)&c->sp_w, rows * cp * 4));
+            B_TRY(e, hipMalloc((void**)&c->sp_cnt, rows * 4));
+            c->sp_rows = rows; c->sp_cap = cp;
+        }
+        B_TRY(e, cqs::launch_splade_sparsify(c->dense, batch, e->cfg.vocab_size, threshold, cap, c->sp_ids, c->sp_w, c->sp_cnt, st));
+        B_TRY(e, hipMemcpyAsync(sl->out, c->sp_ids, n * 4, hipMemcpyDeviceToHost, st));
+        B_TRY(e, hipMemcpyAsync((char*)sl->out + n * 4, c->sp_w, n * 4, hipMemcpyDeviceToHost, st));
+        B_TRY(e, hipMemcpyAsync((char*)sl->out + n * 8, c->sp_cnt, (size_t)batch * 4, hipMemcpyDeviceToHost, st));
     }
-    hipStream_t st = e->stream;
-    B_TRY(e, cqs::launch_splade_sparsify(e->dense, batch, e->cfg.vocab_size, threshold, cap, e->sp_ids, e->sp_w, e->sp_cnt, st));
-    B_TRY(e, hipMemcpyAsync(out_ids, e->sp_ids, (size_t)batch * cap * 4, hipMemcpyDeviceToHost, st));
-    B_TRY(e, hipMemcpyAsync(out_weights, e->sp_w, (size_t)batch * cap * 4, hipMemcpyDeviceToHost, st));
-    B_TRY(e, hipMemcpyAsync(out_counts, e->sp_cnt, (size_t)batch * 4, hipMemcpyDeviceToHost, st));
-    B_TRY(e, hipStreamSynchronize(st));
+    B_TRY(e, hipEventRecord(sl->done, st));
+    sl->kind = 1; sl->cap = cap;
+    sl->ticket = e->next_ticket++;
+    *ticket = sl->ticket;
     return CQS_HIP_OK;
+} CQS_ABI_CATCH(e)
+
+int32_t cqs_hip_splade_collect_sparse(cqs_hip_bert* e, uint64_t ticket, uint32_t* out_ids, float* out_weights, uint32_t* out_counts) CQS_ABI_TRY {
+    if (!e) return CQS_HIP_ERR_INVALID;
+    BSlot* sl = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(e->mu);
+        sl = find_ticket(e, ticket, 1);
+        if (!sl) return bfail(e, CQS_HIP_ERR_INVALID, "splade collect: unknown ticket");
+    }
+    (void)hipSetDevice(e->device);
+    const hipError_t he = hipEventSynchronize(sl->done);     // outside the lock: other threads may submit meanwhile
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (he != hipSuccess) { sl->ticket = 0; return bfail(e, CQS_HIP_ERR_DEVICE, "splade collect: device failure", he); }
+    if (out_ids) {                                           // NULL: abandon the ticket
+        if (!out_weights || !out_counts) { sl->ticket = 0; return bfail(e, CQS_HIP_ERR_INVALID, "splade collect: null buffer"); }
+        const size_t n = (size_t)sl->B * sl->cap;
+        memcpy(out_ids, sl->out, n * 4);
+        memcpy(out_weights, (char*)sl->out + n * 4, n * 4);
+        memcpy(out_counts, (char*)sl->out + n * 8, (size_t)sl->B * 4);
+    }
+    sl->ticket = 0;
+    return CQS_HIP_OK;
+} CQS_ABI_CATCH(e)
+
+// blocking form: submit + collect
+int32_t cqs_hip_splade_encode_sparse(cqs_hip_bert* e, const int32_t* tokens, const uint32_t* lens, uint32_t batch,
+                                     float threshold, uint32_t cap, uint32_t* out_ids, float* out_weights, uint32_t* out_counts) CQS_ABI_TRY {
+    CQS_ROCTX_RANGE("cqs_hip_splade_encode_sparse");
+    if (!e) return CQS_HIP_ERR_INVALID;
+    if (batch == 0) {
+        std::lock_guard<std::mutex> lk(e->mu);
+        return check_ready(e, CQS_HIP_BERT_HEAD_MLM);
+    }
+    if (!out_ids || !out_weights || !out_counts) { std::lock_guard<std::mutex> lk(e->mu); return bfail(e, CQS_HIP_ERR_INVALID, "splade: null buffer / zero cap"); }
+    uint64_t t = 0;
+    const int32_t rc = cqs_hip_splade_submit_sparse(e, tokens, lens, batch, threshold, cap, &t);
+    if (rc != CQS_HIP_OK) return rc;
+    return cqs_hip_splade_collect_sparse(e, t, out_ids, out_weights, out_counts);
 } CQS_ABI_CATCH(e)
 
 // `compute_scores_opt` below the tokenizer (src/reranker.rs:343-533): (query, passage) pairs already encoded as ids +
@@ -457,54 +572,99 @@ int32_t cqs_hip_rerank_logits(cqs_hip_bert* e, const int32_t* tokens, const int3
     for (uint32_t b = 0; b < batch; ++b)
         if (lens[b] == 0) return bfail(e, CQS_HIP_ERR_INVALID, "rerank: empty sequence (no [CLS] row to pool)");
     B_TRY(e, hipSetDevice(e->device));
+    BSlot* sl; BCtx* c;
+    if ((rc = take_slot(e, &sl, &c)) != CQS_HIP_OK) return rc;
     uint32_t M = 0;
-    rc = run_encoder(e, tokens, type_ids, lens, batch, &M);
+    rc = run_encoder(e, *c, *sl, tokens, type_ids, lens, batch, &M);
     if (rc != CQS_HIP_OK) return rc;
-    const cqs_hip_bert_config& c = e->cfg;
-    hipStream_t st = e->stream;
-    const uint32_t H = c.hidden;
+    const cqs_hip_bert_config& cf = e->cfg;
+    hipStream_t st = c->stream;
+    const uint32_t H = cf.hidden;
     // BertPooler on every sequence's first token (row seq_start[b] of the packed hidden states: the skinny GEMM reads its
     // rows through that table), dense + tanh, then the classifier (labels padded to 16).
-    const int32_t* d_start = e->d_meta + (size_t)3 * M;
-    B_TRY(e, cqs::launch_gemm_rows(e->x, H, e->wp, e->bp, 1, e->att, batch, H, H, H, cqs::GEMM_OUT_BF16, st, d_start));
-    B_TRY(e, cqs::launch_gemm_rows(e->att, H, e->wc, e->bc, 0, e->cls, batch, 16, H, 16, cqs::GEMM_OUT_F32, st));
+    const int32_t* d_start = c->d_meta + (size_t)3 * M;
+    B_TRY(e, cqs::launch_gemm_rows(c->x, H, e->wp, e->bp, 1, c->att, batch, H, H, H, cqs::GEMM_OUT_BF16, st, d_start));
+    B_TRY(e, cqs::launch_gemm_rows(c->att, H, e->wc, e->bc, 0, c->cls, batch, 16, H, 16, cqs::GEMM_OUT_F32, st));
     std::vector<float> tmp((size_t)batch * 16);
-    B_TRY(e, hipMemcpyAsync(tmp.data(), e->cls, tmp.size() * 4, hipMemcpyDeviceToHost, st));
+    B_TRY(e, hipMemcpyAsync(tmp.data(), c->cls, tmp.size() * 4, hipMemcpyDeviceToHost, st));
     B_TRY(e, hipStreamSynchronize(st));
     for (uint32_t b = 0; b < batch; ++b)
-        for (uint32_t j = 0; j < c.num_labels; ++j) out_logits[(size_t)b * c.num_labels + j] = tmp[(size_t)b * 16 + j];
+        for (uint32_t j = 0; j < cf.num_labels; ++j) out_logits[(size_t)b * cf.num_labels + j] = tmp[(size_t)b * 16 + j];
     return CQS_HIP_OK;
 } CQS_ABI_CATCH(e)
 
 // The BERT-family EMBEDDER presets (e5-base, v9-200k, bge-large, bge-large-ft: src/embedder/models.rs:346-405) below the
 // tokenizer: `session.run` -> last_hidden_state -> `mean_pool` / `cls_pool` (src/embedder/pooling.rs:87-128), all on the
-// device.  out [batch, hidden] f32, NOT normalised (the caller's `normalize_l2`, core.rs:1196-1203).
-int32_t cqs_hip_bert_embed(cqs_hip_bert* e, const int32_t* tokens, const int32_t* type_ids, const uint32_t* lens, uint32_t batch,
-                           uint32_t pooling, float* out) CQS_ABI_TRY {
-    CQS_ROCTX_RANGE("cqs_hip_bert_embed");
+// device.  out [batch, hidden] f32, NOT normalised (the caller's `normalize_l2`, core.rs:1196-1203).  Ticket form (what
+// the index pipeline's embed stage uses, src/cli/pipeline/embedding.rs:226-421) + the blocking `session.run` form.
+int32_t cqs_hip_bert_embed_submit(cqs_hip_bert* e, const int32_t* tokens, const int32_t* type_ids, const uint32_t* lens, uint32_t batch,
+                                  uint32_t pooling, uint64_t* ticket) CQS_ABI_TRY {
+    CQS_ROCTX_RANGE("cqs_hip_bert_embed_submit");
     if (!e) return CQS_HIP_ERR_INVALID;
     std::lock_guard<std::mutex> lk(e->mu);
     int32_t rc = check_ready(e, CQS_HIP_BERT_HEAD_NONE);
     if (rc != CQS_HIP_OK) return rc;
-    if (batch == 0) return CQS_HIP_OK;
-    if (!lens || !out || pooling > 1u) return bfail(e, CQS_HIP_ERR_INVALID, "bert_embed: null buffer / unknown pooling");
+    if (!ticket) return bfail(e, CQS_HIP_ERR_INVALID, "bert_embed: null ticket");
+    *ticket = 0;
+    if (batch == 0 || !lens || pooling > 1u) return bfail(e, CQS_HIP_ERR_INVALID, "bert_embed: empty batch / null buffer / unknown pooling");
     {
         uint64_t tot = 0;
         for (uint32_t b = 0; b < batch; ++b) tot += lens[b];
         if (tot && !tokens) return bfail(e, CQS_HIP_ERR_INVALID, "bert_embed: null tokens");
     }
     B_TRY(e, hipSetDevice(e->device));
+    BSlot* sl; BCtx* c;
+    if ((rc = take_slot(e, &sl, &c)) != CQS_HIP_OK) return rc;
     uint32_t M = 0;
-    rc = run_encoder(e, tokens, type_ids, lens, batch, &M);
+    rc = run_encoder(e, *c, *sl, tokens, type_ids, lens, batch, &M);
     if (rc != CQS_HIP_OK) return rc;
     const uint32_t H = e->cfg.hidden;
-    if (M == 0) { memset(out, 0, (size_t)batch * H * 4); return CQS_HIP_OK; }      // every sequence empty: zero vectors
-    const int32_t *d_start = e->d_meta + (size_t)3 * M, *d_len = d_start + batch;
-    hipStream_t st = e->stream;
-    B_TRY(e, cqs::launch_bert_pool(e->x, d_start, d_len, e->dense, batch, H, (int)pooling, st));
-    B_TRY(e, hipMemcpyAsync(out, e->dense, (size_t)batch * H * 4, hipMemcpyDeviceToHost, st));
-    B_TRY(e, hipStreamSynchronize(st));
+    if ((rc = slot_out_reserve(e, *sl, (size_t)batch * H * 4)) != CQS_HIP_OK) return rc;
+    hipStream_t st = c->stream;
+    if (M == 0) {
+        memset(sl->out, 0, (size_t)batch * H * 4);                                   // every sequence empty: zero vectors
+    } else {
+        const int32_t *d_start = c->d_meta + (size_t)3 * M, *d_len = d_start + batch;
+        B_TRY(e, cqs::launch_bert_pool(c->x, d_start, d_len, c->dense, batch, H, (int)pooling, st));
+        B_TRY(e, hipMemcpyAsync(sl->out, c->dense, (size_t)batch * H * 4, hipMemcpyDeviceToHost, st));
+    }
+    B_TRY(e, hipEventRecord(sl->done, st));
+    sl->kind = 2;
+    sl->ticket = e->next_ticket++;
+    *ticket = sl->ticket;
     return CQS_HIP_OK;
+} CQS_ABI_CATCH(e)
+
+int32_t cqs_hip_bert_embed_collect(cqs_hip_bert* e, uint64_t ticket, float* out) CQS_ABI_TRY {
+    if (!e) return CQS_HIP_ERR_INVALID;
+    BSlot* sl = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(e->mu);
+        sl = find_ticket(e, ticket, 2);
+        if (!sl) return bfail(e, CQS_HIP_ERR_INVALID, "bert_embed collect: unknown ticket");
+    }
+    (void)hipSetDevice(e->device);
+    const hipError_t he = hipEventSynchronize(sl->done);
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (he != hipSuccess) { sl->ticket = 0; return bfail(e, CQS_HIP_ERR_DEVICE, "bert_embed collect: device failure", he); }
+    if (out) memcpy(out, sl->out, (size_t)sl->B * e->cfg.hidden * 4);               // NULL: abandon the ticket
+    sl->ticket = 0;
+    return CQS_HIP_OK;
+} CQS_ABI_CATCH(e)
+
+int32_t cqs_hip_bert_embed(cqs_hip_bert* e, const int32_t* tokens, const int32_t* type_ids, const uint32_t* lens, uint32_t batch,
+                           uint32_t pooling, float* out) CQS_ABI_TRY {
+    CQS_ROCTX_RANGE("cqs_hip_bert_embed");
+    if (!e) return CQS_HIP_ERR_INVALID;
+    if (batch == 0) {
+        std::lock_guard<std::mutex> lk(e->mu);
+        return check_ready(e, CQS_HIP_BERT_HEAD_NONE);
+    }
+    if (!out) { std::lock_guard<std::mutex> lk(e->mu); return bfail(e, CQS_HIP_ERR_INVALID, "bert_embed: null buffer / unknown pooling"); }
+    uint64_t t = 0;
+    const int32_t rc = cqs_hip_bert_embed_submit(e, tokens, type_ids, lens, batch, pooling, &t);
+    if (rc != CQS_HIP_OK) return rc;
+    return cqs_hip_bert_embed_collect(e, t, out);
 } CQS_ABI_CATCH(e)
 
 // Diagnostic: final hidden states of the packed tokens, f32 [sum(lens), hidden].
@@ -517,12 +677,14 @@ int32_t cqs_hip_bert_hidden(cqs_hip_bert* e, const int32_t* tokens, const int32_
     if (batch == 0) return CQS_HIP_OK;
     if (!lens || !out_hidden || !tokens) return bfail(e, CQS_HIP_ERR_INVALID, "bert: null buffer");
     B_TRY(e, hipSetDevice(e->device));
+    BSlot* sl; BCtx* c;
+    if ((rc = take_slot(e, &sl, &c)) != CQS_HIP_OK) return rc;
     uint32_t M = 0;
-    rc = run_encoder(e, tokens, type_ids, lens, batch, &M);
+    rc = run_encoder(e, *c, *sl, tokens, type_ids, lens, batch, &M);
     if (rc != CQS_HIP_OK || M == 0) return rc;
     std::vector<uint16_t> tmp((size_t)M * e->cfg.hidden);
-    B_TRY(e, hipMemcpyAsync(tmp.data(), e->x, tmp.size() * 2, hipMemcpyDeviceToHost, e->stream));
-    B_TRY(e, hipStreamSynchronize(e->stream));
+    B_TRY(e, hipMemcpyAsync(tmp.data(), c->x, tmp.size() * 2, hipMemcpyDeviceToHost, c->stream));
+    B_TRY(e, hipStreamSynchronize(c->stream));
     for (size_t i = 0; i < tmp.size(); ++i) {
         const uint32_t u = (uint32_t)tmp[i] << 16;
         memcpy(&out_hidden[i], &u, 4);
@@ -595,10 +757,18 @@ int32_t cqs_hip_bert_load_dir(const char* model_dir, const cqs_hip_bert_config* 
 void cqs_hip_bert_destroy(cqs_hip_bert* e) CQS_ABI_TRY {
     if (!e) return;
     (void)hipSetDevice(e->device);
-    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    for (cqs_hip_bert::Ctx& c : e->ctx)
+        if (c.stream) (void)hipStreamSynchronize(c.stream);
     for (void* p : e->owned) (void)hipFree(p);
-    free_scratch(e);
-    if (e->stream) (void)hipStreamDestroy(e->stream);
+    for (cqs_hip_bert::Ctx& c : e->ctx) {
+        free_scratch(c);
+        if (c.stream) (void)hipStreamDestroy(c.stream);
+    }
+    for (cqs_hip_bert::Slot& sl : e->slot) {
+        if (sl.meta) (void)hipHostFree(sl.meta);
+        if (sl.out) (void)hipHostFree(sl.out);
+        if (sl.done) (void)hipEventDestroy(sl.done);
+    }
     delete e;
 } CQS_ABI_CATCH_VOID
 

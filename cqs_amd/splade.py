@@ -120,6 +120,45 @@ class HipBertEngine:
             raise BertError("token_type_ids do not line up with input_ids")
         return tt
 
+    # ---- tickets: submit returns at once, collect waits (up to 3 in flight; consecutive tickets alternate between the
+    # engine's two execution contexts) - the overlap the index pipeline wants from its SPLADE / BERT embed stages
+    def submit_sparse(self, seqs: Sequence[np.ndarray], threshold: float, cap: int = 2048) -> Tuple[int, int, int]:
+        """`cqs_hip_splade_submit_sparse` -> ticket handle (ticket, batch, cap) for `collect_sparse`."""
+        toks, lens = self._pack(seqs)
+        t = C.c_uint64()
+        self._check(self._lib.cqs_hip_splade_submit_sparse(self._h, toks.ctypes.data_as(C.c_void_p), lens.ctypes.data_as(C.c_void_p),
+                                                           len(seqs), C.c_float(threshold), cap, C.byref(t)), "splade_submit_sparse")
+        return int(t.value), len(seqs), int(cap)
+
+    def collect_sparse(self, handle: Tuple[int, int, int]):
+        ticket, B, cap = handle
+        ids = np.empty((B, cap), np.uint32); wts = np.empty((B, cap), np.float32); cnt = np.empty(B, np.uint32)
+        self._check(self._lib.cqs_hip_splade_collect_sparse(self._h, ticket, ids.ctypes.data_as(C.c_void_p),
+                                                            wts.ctypes.data_as(C.c_void_p), cnt.ctypes.data_as(C.c_void_p)),
+                    "splade_collect_sparse")
+        return ids, wts, cnt
+
+    def abandon_sparse(self, handle: Tuple[int, int, int]) -> None:
+        self._lib.cqs_hip_splade_collect_sparse(self._h, handle[0], None, None, None)
+
+    def embed_submit(self, seqs: Sequence[np.ndarray], type_ids: Optional[Sequence[np.ndarray]] = None, pooling: str = "mean") -> Tuple[int, int]:
+        toks, lens = self._pack(seqs)
+        tt = self._pack_types(type_ids, lens)
+        t = C.c_uint64()
+        self._check(self._lib.cqs_hip_bert_embed_submit(self._h, toks.ctypes.data_as(C.c_void_p),
+                                                        tt.ctypes.data_as(C.c_void_p) if tt is not None else None,
+                                                        lens.ctypes.data_as(C.c_void_p), len(seqs), {"mean": 0, "cls": 1}[pooling],
+                                                        C.byref(t)), "bert_embed_submit")
+        return int(t.value), len(seqs)
+
+    def embed_collect(self, handle: Tuple[int, int]) -> np.ndarray:
+        out = np.empty((handle[1], int(self.cfg.hidden)), np.float32)
+        self._check(self._lib.cqs_hip_bert_embed_collect(self._h, handle[0], out.ctypes.data_as(C.c_void_p)), "bert_embed_collect")
+        return out
+
+    def embed_abandon(self, handle: Tuple[int, int]) -> None:
+        self._lib.cqs_hip_bert_embed_collect(self._h, handle[0], None)
+
     def rerank_logits(self, seqs: Sequence[np.ndarray], type_ids: Optional[Sequence[np.ndarray]]) -> np.ndarray:
         toks, lens = self._pack(seqs)
         tt = self._pack_types(type_ids, lens)
@@ -183,6 +222,41 @@ class SpladeEncoder:
         bounds = np.searchsorted(rows, np.arange(len(cut) + 1))
         vals = dense[rows, cols]
         return [(cols[bounds[b]:bounds[b + 1]].astype(np.uint32), vals[bounds[b]:bounds[b + 1]]) for b in range(len(cut))]
+
+    DEPTH = 3   # tickets in flight (= the library's submission slots)
+
+    def encode_batches_arrays(self, batches: Sequence[Sequence[Sequence[int]]]) -> List[List[Tuple[np.ndarray, np.ndarray]]]:
+        """The index pipeline's form: a stream of batches with up to three in flight (host packing and PCIe of batch
+        i + 1, i + 2 under batch i's kernels; two kernel chains interleaved on the device).  Same results as
+        `encode_batch_arrays` per batch, in order.  A failing batch abandons the tickets in flight (their slots come
+        back) before the error propagates."""
+        out: List = [None] * len(batches)
+        inflight = []                                         # (batch index, handle, cut)
+        nxt = 0
+        try:
+            while nxt < len(batches) or inflight:
+                while nxt < len(batches) and len(inflight) < self.DEPTH:
+                    cut = [np.asarray(s, np.int32)[: self.max_seq_len] for s in batches[nxt]]
+                    if len(cut):
+                        inflight.append((nxt, self.engine.submit_sparse(cut, self.threshold, self.sparse_cap), cut))
+                    else:
+                        out[nxt] = []
+                    nxt += 1
+                if not inflight:
+                    continue
+                bi, handle, cut = inflight.pop(0)
+                ids, wts, cnt = self.engine.collect_sparse(handle)
+                res = [(ids[b, :cnt[b]].copy(), wts[b, :cnt[b]].copy()) if cnt[b] <= self.sparse_cap else None for b in range(len(cut))]
+                over = [b for b, o in enumerate(res) if o is None]
+                if over:                                      # more survivors than the cap: that row through the dense form
+                    for b, o in zip(over, self._from_dense([cut[b] for b in over])):
+                        res[b] = o
+                out[bi] = res
+        except BaseException:
+            for _, handle, _ in inflight:
+                self.engine.abandon_sparse(handle)
+            raise
+        return out
 
     def encode_batch(self, seqs: Sequence[Sequence[int]]) -> List[SparseVector]:
         """`SpladeEncoder::encode_batch`: `Vec<SparseVector>`, a sparse vector = [(token id, weight)] ascending id."""

@@ -358,6 +358,14 @@ int32_t cqs_hip_splade_encode(cqs_hip_bert* e, const int32_t* tokens, const uint
  * through cqs_hip_splade_encode instead (trained models keep 100-300 entries, src/splade/mod.rs:44). */
 int32_t cqs_hip_splade_encode_sparse(cqs_hip_bert* e, const int32_t* tokens, const uint32_t* lens, uint32_t batch,
                                      float threshold, uint32_t cap, uint32_t* out_ids, float* out_weights, uint32_t* out_counts);
+/* Ticket form of the same (the index pipeline's SPLADE stage, src/splade/mod.rs:774-1075 called per batch): submit packs
+ * the batch into pinned staging and enqueues it on one of the engine's two execution contexts (consecutive tickets
+ * alternate) without waiting; collect waits for that ticket.  Up to 3 tickets in flight; a ticket is released only by
+ * collecting it (out_ids = NULL abandons it).  The blocking call above is submit + collect. */
+int32_t cqs_hip_splade_submit_sparse(cqs_hip_bert* e, const int32_t* tokens, const uint32_t* lens, uint32_t batch,
+                                     float threshold, uint32_t cap, uint64_t* ticket);
+int32_t cqs_hip_splade_collect_sparse(cqs_hip_bert* e, uint64_t ticket, uint32_t* out_ids, float* out_weights,
+                                      uint32_t* out_counts);
 /* Reranker: (query, passage) pairs as ids + token type ids (NULL = all zero), packed like the above; every sequence
  * non-empty.  out_logits [batch, num_labels] f32; score = sigmoid(out_logits[b * num_labels]) (src/reranker.rs:516-518). */
 int32_t cqs_hip_rerank_logits(cqs_hip_bert* e, const int32_t* tokens, const int32_t* type_ids, const uint32_t* lens,
@@ -367,6 +375,11 @@ int32_t cqs_hip_rerank_logits(cqs_hip_bert* e, const int32_t* tokens, const int3
  * an empty sequence gives zeros), 1 = first token (`PoolingStrategy::Cls`).  type_ids NULL = all zero. */
 int32_t cqs_hip_bert_embed(cqs_hip_bert* e, const int32_t* tokens, const int32_t* type_ids, const uint32_t* lens,
                            uint32_t batch, uint32_t pooling, float* out);
+/* Ticket form (the index pipeline's embed stage with a BERT-family preset, src/cli/pipeline/embedding.rs:226-421):
+ * as cqs_hip_embed_submit / _collect; out = NULL abandons the ticket. */
+int32_t cqs_hip_bert_embed_submit(cqs_hip_bert* e, const int32_t* tokens, const int32_t* type_ids, const uint32_t* lens,
+                                  uint32_t batch, uint32_t pooling, uint64_t* ticket);
+int32_t cqs_hip_bert_embed_collect(cqs_hip_bert* e, uint64_t ticket, float* out);
 /* Diagnostic: final encoder hidden states of the packed tokens, f32 [sum(lens), hidden]. */
 int32_t cqs_hip_bert_hidden(cqs_hip_bert* e, const int32_t* tokens, const int32_t* type_ids, const uint32_t* lens,
                             uint32_t batch, float* out_hidden);

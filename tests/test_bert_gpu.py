@@ -362,3 +362,54 @@ def test_bge_large_full_geometry(hip):
     for i in range(3):
         assert cos(got[i], want[i]) > 0.999, (i, cos(got[i], want[i]))
     eng.close()
+
+
+def test_tickets_match_blocking_calls_and_release_slots(hip):
+    """submit / collect of the BERT-family engines (the reference calls `SpladeEncoder::encode_batch` from
+    its index pipeline, src/splade/mod.rs:774-1075): three tickets in flight on two execution contexts, collected out of
+    order, equal the blocking call bit for bit; a 4th submit is refused; an abandoned or failed ticket gives its slot
+    back; the pipelined encoder returns per-batch results in order."""
+    from cqs_amd.splade import BertError, SpladeEncoder
+    cfg = R.BertConfig(vocab_size=1531, hidden=384, layers=2, heads=6, intermediate=768, max_pos=128)
+    eng, w = _engine(cfg, "mlm", seed=21)
+    batches = [_seqs(cfg, lens, seed=30 + i) for i, lens in enumerate(([40, 7, 128], [64, 1, 0, 90], [5], [100, 100]))]
+    thr = 0.3
+    want = [eng.splade_sparse(b, thr, 512) for b in batches]
+    hs = [eng.submit_sparse(b, thr, 512) for b in batches[:3]]
+    with pytest.raises(BertError):
+        eng.submit_sparse(batches[3], thr, 512)                      # every slot in flight
+    for j in (2, 0, 1):
+        ids, wts, cnt = eng.collect_sparse(hs[j])
+        assert np.array_equal(cnt, want[j][2])
+        for b in range(len(cnt)):
+            assert np.array_equal(ids[b, :cnt[b]], want[j][0][b, :cnt[b]]) and np.array_equal(wts[b, :cnt[b]], want[j][1][b, :cnt[b]])
+    with pytest.raises(BertError):
+        eng.collect_sparse(hs[0])                                     # the ticket is gone
+    h = eng.submit_sparse(batches[3], thr, 512)
+    eng.abandon_sparse(h)
+    bad = [np.array([1, 2, cfg.vocab_size + 3], np.int32)]
+    for _ in range(4):                                                # failed submits must not strand slots
+        with pytest.raises(BertError):
+            eng.submit_sparse(bad, thr, 512)
+    enc = SpladeEncoder(eng, threshold=thr, max_seq_len=128, sparse_cap=512)
+    piped = enc.encode_batches_arrays(batches * 2)
+    for i, res in enumerate(piped):
+        ref = enc.encode_batch_arrays(batches[i % 4])
+        assert len(res) == len(ref)
+        for (a_ids, a_w), (b_ids, b_w) in zip(res, ref):
+            assert np.array_equal(a_ids, b_ids) and np.array_equal(a_w, b_w)
+    with pytest.raises(BertError):
+        enc.encode_batches_arrays([batches[0], bad, batches[1]])      # the batch in flight is abandoned, then the error
+    assert len(enc.encode_batches_arrays([batches[0]])[0]) == 3      # ... and the engine still has all its slots
+    eng.close()
+    # pooled embeddings through tickets
+    cfg2 = R.BertConfig(vocab_size=997, hidden=384, layers=2, heads=6, intermediate=768, max_pos=128)
+    e2, _ = _engine(cfg2, "none", seed=22)
+    bs = [_seqs(cfg2, lens, seed=40 + i) for i, lens in enumerate(([33, 100], [5, 6, 7], [128]))]
+    want = [e2.embed(b, None, "mean") for b in bs]
+    hs = [e2.embed_submit(b, None, "mean") for b in bs]
+    for j in (1, 2, 0):
+        assert np.array_equal(e2.embed_collect(hs[j]), want[j])
+    e2.embed_abandon(e2.embed_submit(bs[0], None, "cls"))
+    assert np.array_equal(e2.embed(bs[2], None, "mean"), want[2])
+    e2.close()
