@@ -50,6 +50,13 @@ extern "C" {
     fn cqs_hip_splade_encode(e: *mut CqsHipBert, tokens: *const i32, lens: *const u32, batch: u32, out_dense: *mut f32) -> i32;
     fn cqs_hip_splade_encode_sparse(e: *mut CqsHipBert, tokens: *const i32, lens: *const u32, batch: u32, threshold: f32,
                                     cap: u32, out_ids: *mut u32, out_weights: *mut f32, out_counts: *mut u32) -> i32;
+    fn cqs_hip_splade_submit_sparse(e: *mut CqsHipBert, tokens: *const i32, lens: *const u32, batch: u32, threshold: f32,
+                                    cap: u32, ticket: *mut u64) -> i32;
+    fn cqs_hip_splade_collect_sparse(e: *mut CqsHipBert, ticket: u64, out_ids: *mut u32, out_weights: *mut f32,
+                                     out_counts: *mut u32) -> i32;
+    fn cqs_hip_bert_embed_submit(e: *mut CqsHipBert, tokens: *const i32, type_ids: *const i32, lens: *const u32, batch: u32,
+                                 pooling: u32, ticket: *mut u64) -> i32;
+    fn cqs_hip_bert_embed_collect(e: *mut CqsHipBert, ticket: u64, out: *mut f32) -> i32;
     fn cqs_hip_rerank_logits(e: *mut CqsHipBert, tokens: *const i32, type_ids: *const i32, lens: *const u32, batch: u32,
                              out_logits: *mut f32) -> i32;
     fn cqs_hip_bert_embed(e: *mut CqsHipBert, tokens: *const i32, type_ids: *const i32, lens: *const u32, batch: u32,
@@ -143,6 +150,67 @@ impl HipBert {
         Ok(out)
     }
 
+    /// Ticket form of `splade_sparse` for the index pipeline (src/splade/mod.rs:774-1075 is called per batch): `submit`
+    /// returns once the batch is packed into pinned staging and enqueued on one of the engine's two execution contexts;
+    /// keep at most 3 tickets in flight and `collect` (or `abandon`) every one of them - a slot is released only then.
+    pub fn splade_submit(&self, encodings: &[&[u32]], threshold: f32, cap: usize) -> Result<SpladeTicket, String> {
+        let (toks, lens) = Self::pack(encodings);
+        let mut t = 0u64;
+        let rc = unsafe {
+            cqs_hip_splade_submit_sparse(self.raw, toks.as_ptr(), lens.as_ptr(), lens.len() as u32, threshold, cap as u32, &mut t)
+        };
+        if rc != CQS_HIP_OK {
+            return Err(format!("cqs_hip_splade_submit_sparse: {} ({rc})", self.last_error()));
+        }
+        Ok(SpladeTicket { id: t, batch: encodings.len(), cap, threshold })
+    }
+
+    /// Rows with more than `cap` survivors come back as `None`: re-encode those through `splade_dense`.
+    pub fn splade_collect(&self, t: SpladeTicket) -> Result<Vec<Option<Vec<(u32, f32)>>>, String> {
+        let (b, cap) = (t.batch, t.cap);
+        let (mut ids, mut wts, mut cnt) = (vec![0u32; b * cap], vec![0f32; b * cap], vec![0u32; b]);
+        let rc = unsafe { cqs_hip_splade_collect_sparse(self.raw, t.id, ids.as_mut_ptr(), wts.as_mut_ptr(), cnt.as_mut_ptr()) };
+        if rc != CQS_HIP_OK {
+            return Err(format!("cqs_hip_splade_collect_sparse: {} ({rc})", self.last_error()));
+        }
+        Ok((0..b)
+            .map(|i| {
+                let n = cnt[i] as usize;
+                (n <= cap).then(|| (0..n).map(|j| (ids[i * cap + j], wts[i * cap + j])).collect())
+            })
+            .collect())
+    }
+
+    /// Give a ticket's slot back without its results (an `Err` from a later submit, a cancelled index run).
+    pub fn splade_abandon(&self, t: SpladeTicket) {
+        // SAFETY: NULL buffers are the documented abandon form.
+        let _ = unsafe { cqs_hip_splade_collect_sparse(self.raw, t.id, std::ptr::null_mut(), std::ptr::null_mut(), std::ptr::null_mut()) };
+    }
+
+    /// Ticket form of `embed` (the index pipeline's embed stage with a BERT-family preset).
+    pub fn embed_submit(&self, encodings: &[&[u32]], type_ids: &[&[u32]], cls: bool) -> Result<(u64, usize), String> {
+        let (toks, lens) = Self::pack(encodings);
+        let tt: Vec<i32> = type_ids.iter().flat_map(|e| e.iter().map(|&t| t as i32)).collect();
+        let mut t = 0u64;
+        let rc = unsafe {
+            cqs_hip_bert_embed_submit(self.raw, toks.as_ptr(), if tt.is_empty() { std::ptr::null() } else { tt.as_ptr() },
+                                      lens.as_ptr(), lens.len() as u32, cls as u32, &mut t)
+        };
+        if rc != CQS_HIP_OK {
+            return Err(format!("cqs_hip_bert_embed_submit: {} ({rc})", self.last_error()));
+        }
+        Ok((t, encodings.len()))
+    }
+
+    pub fn embed_collect(&self, ticket: (u64, usize)) -> Result<Vec<f32>, String> {
+        let mut out = vec![0f32; ticket.1 * self.cfg.hidden as usize];
+        let rc = unsafe { cqs_hip_bert_embed_collect(self.raw, ticket.0, out.as_mut_ptr()) };
+        if rc != CQS_HIP_OK {
+            return Err(format!("cqs_hip_bert_embed_collect: {} ({rc})", self.last_error()));
+        }
+        Ok(out)
+    }
+
     /// The BERT-family embedder presets (src/embedder/models.rs:346-405): `session.run` + `mean_pool` / `cls_pool`
     /// (src/embedder/pooling.rs:87-128) in one call; `[batch, hidden]`, not normalised - `Embedder::embed_batch` keeps its
     /// `normalize_l2` (core.rs:1196-1203).  `cls`: `PoolingStrategy::Cls`.
@@ -175,6 +243,15 @@ impl HipBert {
         }
         Ok(out)
     }
+}
+
+/// An in-flight `splade_submit` (see there).
+pub struct SpladeTicket {
+    id: u64,
+    batch: usize,
+    cap: usize,
+    #[allow(dead_code)]
+    threshold: f32,
 }
 
 impl Drop for HipBert {
