@@ -197,8 +197,8 @@ __global__ __launch_bounds__(256) void qf_gemm_plain_kernel(const QfGemmParams p
 // NCH = H / 256, K = H.  Rows: one WAVE per row, wave w takes rows w, w + 4, ... in batches of RB rows (RB = 1, 2, 4
 // by T for T <= 16: one batch; longer queries loop over batches of 4, the next batch's loads issued before the current
 // one is reduced).  A batch slot past T re-does row T - 1.
-template <int NCH, int PRO, int EPI, int NC, int RB, int MT>
-__global__ __launch_bounds__(256) void qf_gemm_kernel(const QfGemmParams p) {
+template <int NCH, int PRO, int EPI, int NC, int RB, int MT, int NW>
+__global__ __launch_bounds__(64 * NW) void qf_gemm_kernel(const QfGemmParams p) {
     constexpr int H = NCH * 256;
     constexpr int NT = EPI == QF_EPI_GEGLU ? 2 : 1;               // weight tiles per workgroup
     constexpr int LDA = H + kQfPad;                                // LDS activation row stride (elements)
@@ -206,15 +206,16 @@ __global__ __launch_bounds__(256) void qf_gemm_kernel(const QfGemmParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char qf_smem[];
     bf16_t* const sA = (bf16_t*)qf_smem;                           // [16 GT][LDA]
     float* const red = (float*)(qf_smem + (size_t)16 * GT * LDA * sizeof(bf16_t));   // [4 waves][NT][GT][64 lanes] f4
-    float* const pool = red + 4 * NT * GT * 64 * 4;                // POOL: [4 waves][H] column sums
+    float* const pool = red + NW * NT * GT * 64 * 4;               // POOL: [NW waves][H] column sums
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, lg = lane >> 4;
     QF_STAMP(p, 0);
     const uint32_t T = p.T;
-    constexpr uint32_t kw = H / 4;                                 // this wave's K range: [wid kw, (wid + 1) kw)
-    constexpr int S = 2 * NCH;                                     // k-steps of 32 per wave
+    constexpr uint32_t kw = H / NW;                                // this wave's K range: [wid kw, (wid + 1) kw)
+    constexpr int S = H / NW / 32;                                 // k-steps of 32 per wave
+    static_assert(H % (32 * NW) == 0, "the waves split K in whole 32-deep steps");
 
     // weight rows of the workgroup's tile(s).  GeGLU: W rows are interleaved per 64 (32 gate rows, then the same
     // channels' 32 up rows; embedder.hip set_tensor) -> channels [NC b, NC b + NC) = gate rows 64 (c / 32) + c % 32.
@@ -287,7 +288,7 @@ __global__ __launch_bounds__(256) void qf_gemm_kernel(const QfGemmParams p) {
     const uint32_t last = T - 1u;
 #pragma unroll
     for (int b = 0; b < RB; ++b) {
-        const uint32_t r = (uint32_t)wid + 4u * (uint32_t)b;
+        const uint32_t r = (uint32_t)wid + (uint32_t)NW * (uint32_t)b;
         load_row(r < T ? r : last, xv[b], yv[b]);
     }
 #pragma unroll
@@ -299,21 +300,21 @@ __global__ __launch_bounds__(256) void qf_gemm_kernel(const QfGemmParams p) {
     if (MT == 1) {
 #pragma unroll
         for (int b = 0; b < RB; ++b) {
-            const uint32_t r = (uint32_t)wid + 4u * (uint32_t)b;
+            const uint32_t r = (uint32_t)wid + (uint32_t)NW * (uint32_t)b;
             finish_row(r < T ? r : last, r < T, xv[b], yv[b]);
         }
     } else {                                                        // RB = 4; 16 rows per pass of the workgroup, passes one after
         for (uint32_t r0 = (uint32_t)wid;;) {                        // the other (a second set of rows in flight spills the registers)
 #pragma unroll
             for (int b = 0; b < RB; ++b) {
-                const uint32_t r = r0 + 4u * (uint32_t)b;
+                const uint32_t r = r0 + (uint32_t)NW * (uint32_t)b;
                 finish_row(r < T ? r : last, r < T, xv[b], yv[b]);
             }
-            r0 += 16u;
+            r0 += (uint32_t)(NW * RB);
             if (r0 >= T) break;
 #pragma unroll
             for (int b = 0; b < RB; ++b) {
-                const uint32_t r = r0 + 4u * (uint32_t)b;
+                const uint32_t r = r0 + (uint32_t)NW * (uint32_t)b;
                 load_row(r < T ? r : last, xv[b], yv[b]);
             }
         }
@@ -324,8 +325,10 @@ __global__ __launch_bounds__(256) void qf_gemm_kernel(const QfGemmParams p) {
 #pragma unroll
         for (int c = 0; c < NCH; ++c) *(f4*)(pool + (size_t)wid * H + c * 256 + c0) = psum[c];
         __syncthreads();
-        for (uint32_t col = (uint32_t)tid; col < (uint32_t)H; col += 256u) {
-            const float sm = pool[col] + pool[H + col] + pool[2 * H + col] + pool[3 * H + col];
+        for (uint32_t col = (uint32_t)tid; col < (uint32_t)H; col += (uint32_t)(64 * NW)) {
+            float sm = pool[col];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) sm += pool[(size_t)w * H + col];
             sA[col] = (bf16_t)(sm / (float)T);
         }
         // (rows 1..15 of the m-tile stay whatever LDS held: an activation row only feeds its own output column of the
@@ -362,7 +365,7 @@ __global__ __launch_bounds__(256) void qf_gemm_kernel(const QfGemmParams p) {
     for (int t = 0; t < NT; ++t) {
         v[t] = *(const f4*)(red + ((size_t)((0 * NT + t) * GT + wid) * 64 + lane) * 4);
 #pragma unroll
-        for (int w = 1; w < 4; ++w) v[t] += *(const f4*)(red + ((size_t)((w * NT + t) * GT + wid) * 64 + lane) * 4);
+        for (int w = 1; w < NW; ++w) v[t] += *(const f4*)(red + ((size_t)((w * NT + t) * GT + wid) * 64 + lane) * 4);
     }
     const uint32_t rows = PRO == QF_PRO_POOL ? 1u : T;
     const uint32_t row = 16u * (uint32_t)wid + (uint32_t)l15;
@@ -413,7 +416,7 @@ struct QfAttnParams {
 template <int MT> constexpr int qf_vrow() { return 32 * ((MT + 1) / 2) + 8; }   // sVt row stride: keys padded to 32, + 8
 
 // Stage rows [0, T) of kv head g and q heads [h0, h0 + NH): sQ [NH][16 MT][kQfKRow], sK [16 MT][kQfKRow], sVt [256][vrow].
-template <int MT, int RB, int NH>
+template <int MT, int RB, int NH, int NW>
 __device__ __forceinline__ void qf_attn_stage(const QfAttnParams& p, uint32_t h0, uint32_t g, bf16_t* sQ, bf16_t* sK, bf16_t* sVt,
                                               int wid, int lane) {
     constexpr int VR = qf_vrow<MT>();
@@ -461,7 +464,7 @@ __device__ __forceinline__ void qf_attn_stage(const QfAttnParams& p, uint32_t h0
     Row rows[RB];
 #pragma unroll
     for (int b = 0; b < RB; ++b) {
-        const uint32_t r = (uint32_t)wid + 4u * (uint32_t)b;
+        const uint32_t r = (uint32_t)wid + (uint32_t)NW * (uint32_t)b;
         load(r < T ? r : last, rows[b]);                              // a slot past T re-does row T - 1
     }
     wq1 = *(const f4*)(p.wq + lane * 4) + 1.0f;
@@ -469,29 +472,31 @@ __device__ __forceinline__ void qf_attn_stage(const QfAttnParams& p, uint32_t h0
     if (MT == 1) {
 #pragma unroll
         for (int b = 0; b < RB; ++b) {
-            const uint32_t r = (uint32_t)wid + 4u * (uint32_t)b;
+            const uint32_t r = (uint32_t)wid + (uint32_t)NW * (uint32_t)b;
             put(r < T ? r : last, rows[b]);
         }
     } else {                                                          // RB = 4: 16 rows per pass of the workgroup
         for (uint32_t r0 = (uint32_t)wid;;) {
 #pragma unroll
             for (int b = 0; b < RB; ++b) {
-                const uint32_t r = r0 + 4u * (uint32_t)b;
+                const uint32_t r = r0 + (uint32_t)NW * (uint32_t)b;
                 put(r < T ? r : last, rows[b]);
             }
-            r0 += 16u;
+            r0 += (uint32_t)(NW * RB);
             if (r0 >= T) break;
 #pragma unroll
             for (int b = 0; b < RB; ++b) {
-                const uint32_t r = r0 + 4u * (uint32_t)b;
+                const uint32_t r = r0 + (uint32_t)NW * (uint32_t)b;
                 load(r < T ? r : last, rows[b]);
             }
         }
     }
     // V^T columns [T, 32 ceil(MT / 2)) multiply P = 0 in the last 32-key step: zeros (K rows past T may hold anything:
     // their scores are replaced, not multiplied).  Thread = one head dim.
-    bf16_t* vz = sVt + (size_t)threadIdx.x * VR;
-    for (uint32_t key = T; key < 32u * ((MT + 1) / 2); ++key) vz[key] = (bf16_t)0.f;
+    if (threadIdx.x < (uint32_t)kQfHD) {
+        bf16_t* vz = sVt + (size_t)threadIdx.x * VR;
+        for (uint32_t key = T; key < 32u * ((MT + 1) / 2); ++key) vz[key] = (bf16_t)0.f;
+    }
 }
 
 // One (q head, 16-query tile) unit on one wave: o[j][r] = O[query 16 qt + l15][dim 16 (dt0 + j) + 4 lg + r], unnormalised;
@@ -577,7 +582,7 @@ __global__ __launch_bounds__(256) void qf_attention_kernel(const QfAttnParams p)
     const int l15 = lane & 15, lg = lane >> 4;
     QF_STAMP(p, 0);
     const uint32_t h = blockIdx.x, g = h / (p.heads / p.kv_heads);
-    qf_attn_stage<MT, RB, 1>(p, h, g, sQ, sK, sVt, wid, lane);
+    qf_attn_stage<MT, RB, 1, 4>(p, h, g, sQ, sK, sVt, wid, lane);
     __syncthreads();
     QF_STAMP(p, 1);
     constexpr int G = MT == 1 ? 4 : (MT == 2 ? 2 : 1);                    // waves per query tile
@@ -602,9 +607,10 @@ __global__ __launch_bounds__(256) void qf_attention_kernel(const QfAttnParams p)
 
 // Fused: attention of ALL heads (NH = heads, one kv head) in the workgroup's LDS, then y[:, NC columns] = attn Wo^T.
 // The attention output of (head, query tile) overwrites that tile's Q rows (the unit's own wave is their only reader).
-template <int MT, int RB, int NH, int NC>
-__global__ __launch_bounds__(256) void qf_attn_oproj_kernel(const QfAttnParams p) {
-    constexpr int K = NH * kQfHD, kw = K / 4, S = kw / 32;           // o_proj's K = heads x 256; this wave's K range and k-steps
+template <int MT, int RB, int NH, int NC, int NW>
+__global__ __launch_bounds__(64 * NW) void qf_attn_oproj_kernel(const QfAttnParams p) {
+    constexpr int K = NH * kQfHD, kw = K / NW, S = kw / 32;          // o_proj's K = heads x 256; this wave's K range and k-steps
+    static_assert(K % (32 * NW) == 0, "the waves split K in whole 32-deep steps");
     extern __shared__ __attribute__((aligned(16))) unsigned char qf_smem[];
     bf16_t* const sQ = (bf16_t*)qf_smem;                               // [NH][16 MT][kQfKRow]: Q, then O
     bf16_t* const sK = sQ + (size_t)NH * 16 * MT * kQfKRow;
@@ -619,10 +625,10 @@ __global__ __launch_bounds__(256) void qf_attn_oproj_kernel(const QfAttnParams p
     bf8 wf[S];
 #pragma unroll
     for (int s = 0; s < S; ++s) wf[s] = *(const bf8*)(wp + 32 * s);
-    qf_attn_stage<MT, RB, NH>(p, 0u, 0u, sQ, sK, sVt, wid, lane);
+    qf_attn_stage<MT, RB, NH, NW>(p, 0u, 0u, sQ, sK, sVt, wid, lane);
     __syncthreads();
     QF_STAMP(p, 1);
-    for (uint32_t u = (uint32_t)wid; u < (uint32_t)(NH * MT); u += 4u) {   // (head, query tile) units over the 4 waves
+    for (uint32_t u = (uint32_t)wid; u < (uint32_t)(NH * MT); u += (uint32_t)NW) {   // (head, query tile) units over the waves
         const uint32_t h = u / (uint32_t)MT, qt = u % (uint32_t)MT;
         bf16_t* sQh = sQ + (size_t)h * 16 * MT * kQfKRow;
         f4 o[16];
@@ -658,7 +664,7 @@ __global__ __launch_bounds__(256) void qf_attn_oproj_kernel(const QfAttnParams p
     if (wid >= MT) return;
     f4 v = *(const f4*)(red + ((size_t)wid * 64 + lane) * 4);
 #pragma unroll
-    for (int w = 1; w < 4; ++w) v += *(const f4*)(red + ((size_t)(w * MT + wid) * 64 + lane) * 4);
+    for (int w = 1; w < NW; ++w) v += *(const f4*)(red + ((size_t)(w * MT + wid) * 64 + lane) * 4);
     const uint32_t row = 16u * (uint32_t)wid + (uint32_t)l15;
     if (row >= p.T || 4 * lg >= NC) return;
     bf4 ob;
@@ -674,42 +680,47 @@ int qf_debug_repeat() {
 }
 
 template <class Kern, class P>
-hipError_t qf_launch(Kern kern, DynLdsOnce& once, const P& p0, uint32_t grid, size_t lds, hipStream_t st) {
+hipError_t qf_launch(Kern kern, DynLdsOnce& once, const P& p0, uint32_t grid, size_t lds, hipStream_t st, uint32_t threads = 256u) {
     const hipError_t e = once.ensure((const void*)kern, lds);
     if (e != hipSuccess) return e;
     if (qf_debug_repeat() == 2 && p0.dbg) {       // diagnostic: every kernel twice (cold vs warm operands), slots 2 s and 2 s + 1
         P q = p0;
         q.dbg_slot = 2 * p0.dbg_slot;
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, q);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, st, q);
         q.dbg_slot++;
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, q);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, st, q);
     } else {
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, p0);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, st, p0);
     }
     return hipGetLastError();
 }
 
-// (rows per wave in the first batch, row tiles) by query length
+// (rows per wave in the first batch, row tiles, waves per workgroup) by query length.  Past 8 tokens a workgroup has 8
+// waves: the per-row work of the prologue / the attention staging is what these kernels spend their time on.
 #define QF_BY_T(T, CALL)                                  \
     do {                                                  \
-        if ((T) <= 4u) return CALL(1, 1);                 \
-        if ((T) <= 8u) return CALL(2, 1);                 \
-        if ((T) <= 16u) return CALL(4, 1);                \
-        if ((T) <= 32u) return CALL(4, 2);                \
-        if ((T) <= 48u) return CALL(4, 3);                \
-        return CALL(4, 4);                                \
+        if ((T) <= 4u) return CALL(1, 1, 4);              \
+        if ((T) <= 8u) return CALL(2, 1, 4);              \
+        if ((T) <= 16u) return CALL(2, 1, 8);             \
+        if ((T) <= 32u) return CALL(4, 2, 8);             \
+        if ((T) <= 48u) return CALL(4, 3, 8);             \
+        return CALL(4, 4, 8);                             \
     } while (0)
 
 template <int NCH, int PRO, int EPI, int NC>
 hipError_t qf_launch_pro(const QfGemmParams& p, uint32_t n_out_cols, hipStream_t st) {
     constexpr int NT = EPI == QF_EPI_GEGLU ? 2 : 1;
-#define QF_CALL(RBV, MTV)                                                                                                   \
+    // queries over 16 tokens: 8 waves per workgroup (the per-row work of the prologue and of the attention staging is what
+    // these kernels spend their time on: half the rows per wave)
+#define QF_CALL(RBV, MTV, NWR)                                                                                              \
     [&]() {                                                                                                                 \
         constexpr int GT = PRO == QF_PRO_POOL ? 1 : MTV;                                                                    \
-        const size_t lds = (size_t)16 * GT * (NCH * 256 + kQfPad) * sizeof(bf16_t) + (size_t)4 * NT * GT * 64 * 16 +        \
-                           (PRO == QF_PRO_POOL ? (size_t)4 * NCH * 256 * sizeof(float) : 0);                                \
+        constexpr int NWV = (NT == 2 && MTV == 4) ? 4 : NWR;               /* (GeGLU x 4 row tiles at 8 waves: LDS) */       \
+        const size_t lds = (size_t)16 * GT * (NCH * 256 + kQfPad) * sizeof(bf16_t) + (size_t)NWV * NT * GT * 64 * 16 +      \
+                           (PRO == QF_PRO_POOL ? (size_t)NWV * NCH * 256 * sizeof(float) : 0);                              \
         static DynLdsOnce once;                                                                                             \
-        return qf_launch(qf_gemm_kernel<NCH, PRO, EPI, NC, RBV, MTV>, once, p, n_out_cols / (uint32_t)NC, lds, st);         \
+        return qf_launch(qf_gemm_kernel<NCH, PRO, EPI, NC, RBV, MTV, NWV>, once, p, n_out_cols / (uint32_t)NC, lds, st,     \
+                         64u * NWV);                                                                                        \
     }()
     QF_BY_T(p.T, QF_CALL);
 #undef QF_CALL
@@ -742,30 +753,35 @@ hipError_t qf_launch_plain(const QfGemmParams& p, uint32_t n_out_cols, hipStream
     return qf_launch_plain_ch<4, EPI, NC>(p, n_out_cols, st);
 }
 
-hipError_t qf_launch_attention(const QfAttnParams& a, hipStream_t st) {
+hipError_t qf_launch_attention(const QfAttnParams& a, hipStream_t st) {       // 4 waves: (rows per wave, row tiles) by length
 #define QF_ATT(RBV, MTV)                                                                                   \
     [&]() {                                                                                                \
         static DynLdsOnce once;                                                                            \
         return qf_launch(qf_attention_kernel<MTV, RBV>, once, a, a.heads, qf_attn_lds<MTV>(1), st);        \
     }()
-    QF_BY_T(a.T, QF_ATT);
+    if (a.T <= 4u) return QF_ATT(1, 1);
+    if (a.T <= 8u) return QF_ATT(2, 1);
+    if (a.T <= 16u) return QF_ATT(4, 1);
+    if (a.T <= 32u) return QF_ATT(4, 2);
+    if (a.T <= 48u) return QF_ATT(4, 3);
+    return QF_ATT(4, 4);
 #undef QF_ATT
 }
 
 // attention + o_proj in one launch: heads in {2, 3}, one kv head, <= 48 tokens (LDS); else hipErrorNotSupported
 template <int NH, int NC>
 hipError_t qf_launch_attn_oproj_h(const QfAttnParams& a, hipStream_t st) {
-#define QF_AO(RBV, MTV)                                                                                                     \
+#define QF_AO(RBV, MTV, NWV)                                                                                                \
     [&]() {                                                                                                                 \
         static DynLdsOnce once;                                                                                             \
-        return qf_launch(qf_attn_oproj_kernel<MTV, RBV, NH, NC>, once, a, a.H / (uint32_t)NC,                               \
-                         qf_attn_lds<MTV>(NH) + (size_t)4 * MTV * 64 * 16, st);                                             \
+        return qf_launch(qf_attn_oproj_kernel<MTV, RBV, NH, NC, NWV>, once, a, a.H / (uint32_t)NC,                          \
+                         qf_attn_lds<MTV>(NH) + (size_t)NWV * MTV * 64 * 16, st, 64u * NWV);                                \
     }()
-    if (a.T <= 4u) return QF_AO(1, 1);
-    if (a.T <= 8u) return QF_AO(2, 1);
-    if (a.T <= 16u) return QF_AO(4, 1);
-    if (a.T <= 32u) return QF_AO(4, 2);
-    if (a.T <= 48u) return QF_AO(4, 3);
+    if (a.T <= 4u) return QF_AO(1, 1, 4);
+    if (a.T <= 8u) return QF_AO(2, 1, 4);
+    if (a.T <= 16u) return QF_AO(2, 1, 8);
+    if (a.T <= 32u) return QF_AO(4, 2, 8);
+    if (a.T <= 48u) return QF_AO(4, 3, 8);
     return hipErrorNotSupported;
 #undef QF_AO
 }

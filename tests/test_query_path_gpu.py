@@ -83,3 +83,30 @@ def test_query_path_full_geometry(hip):
         ref = G.forward(cfg, w, ids, mask)[0]
         assert cos(got, ref) > 0.999, (n, cos(got, ref))
     eng.close()
+
+
+def test_unfused_attention_chain_in_a_child_process(hip):
+    """CQS_HIP_QUERY_FUSE_ATTN=0 (read once per process): attention and o_proj as two launches - the chain that queries of
+    49-64 tokens and models with other head counts take - against the fused default, every length class."""
+    import os, subprocess, sys, json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, json; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import numpy as np\n"
+        "from test_embed_gpu import SMALL, batch, make\n"
+        "eng, w = make(SMALL, seed=31)\n"
+        "out = {}\n"
+        "for n in (1, 5, 8, 9, 16, 17, 33, 48, 50, 64):\n"
+        "    ids, mask = batch(SMALL, [n], seed=100 + n)\n"
+        "    out[str(n)] = eng.run(ids, mask)[0].tolist()\n"
+        "print('RESULT' + json.dumps(out))\n" % (root, os.path.join(root, "tests")))
+    res = {}
+    for fuse in ("1", "0"):
+        env = dict(os.environ, CQS_HIP_QUERY_FUSE_ATTN=fuse)
+        p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        line = [l for l in p.stdout.splitlines() if l.startswith("RESULT")][0]
+        res[fuse] = json.loads(line[6:])
+    for n, v in res["1"].items():
+        a, b = np.array(v, np.float32), np.array(res["0"][n], np.float32)
+        assert cos(a, b) > 0.99999 and np.max(np.abs(a - b)) < 2e-2 * np.abs(b).max(), (n, cos(a, b))
