@@ -213,15 +213,17 @@ int32_t search_block(cqs_hip_index* p, uint32_t nb, uint32_t k_eff, const uint32
             P_TRY(p, hipMemcpyAsync(ss->d_gather[0] + s * keys, c->d_out_keys, keys * sizeof(uint64_t), hipMemcpyDefault, c0->stream));
         }
     }
-    // 3. one D2H from the first device, then every stream quiesces (the collective ends when all ranks are done)
+    // 3. one D2H from the first device and ONE host wait, on that device's stream: its copy of the gathered lists is
+    // complete only when every shard has produced and sent its part (RCCL: the all-gather's receive side; copy path: the
+    // per-shard events the copies waited on), i.e. when every shard's H2D of the pinned query block and its scan are
+    // done too.  What the other devices still run (their own, unused, receive side) is ordered on THEIR streams before
+    // anything the next search enqueues there; extend / save / destroy quiesce every stream themselves.  (Round 2 also
+    // synchronised the other G - 1 streams here: G - 1 host round trips per query for nothing.)
     {
         cqs_hip_index* c0 = ss->shard[0];
         P_TRY(p, hipSetDevice(c0->device));
         P_TRY(p, hipMemcpyAsync(ss->h_gather, ss->d_gather[0], G * keys * sizeof(uint64_t), hipMemcpyDeviceToHost, c0->stream));
-        for (size_t s = 0; s < G; ++s) {
-            P_TRY(p, hipSetDevice(ss->shard[s]->device));
-            P_TRY(p, hipStreamSynchronize(ss->shard[s]->stream));
-        }
+        P_TRY(p, hipStreamSynchronize(c0->stream));
     }
     // 4. host k-way merge per query (lists of query q: h_gather + s * keys + q * k_eff, zero padded)
     std::vector<uint32_t> counts(G);
