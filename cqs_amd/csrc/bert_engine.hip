@@ -92,6 +92,7 @@ struct cqs_hip_bert {
     static constexpr int kSlots = 3;
     Slot slot[kSlots];
     uint64_t next_ticket = 1;
+    int last_ctx = 1;                    // context of the previous ticket (ties alternate)
 
     std::mutex mu;
     std::atomic<bool> poisoned{false};
@@ -245,7 +246,13 @@ int32_t take_slot(cqs_hip_bert* e, BSlot** sl, BCtx** c) {
     for (BSlot& s : e->slot)
         if (s.ticket == 0) { *sl = &s; break; }
     if (!*sl) return bfail(e, CQS_HIP_ERR_INVALID, "bert: every submission slot is in flight (collect a ticket first)");
-    const int ci = (int)(e->next_ticket % (uint64_t)cqs_hip_bert::kCtx);
+    // the context with fewer tickets in flight; ties alternate, an idle engine takes context 0 (one blocking call at a time
+    // keeps re-using ONE set of activation scratch instead of two taking turns in L2 / the Infinity Cache)
+    int load[cqs_hip_bert::kCtx] = {0, 0};
+    for (const BSlot& s2 : e->slot)
+        if (s2.ticket != 0) load[s2.ctx]++;
+    const int ci = load[0] == load[1] ? (load[0] == 0 ? 0 : 1 - e->last_ctx) : (load[0] < load[1] ? 0 : 1);
+    e->last_ctx = ci;
     (*sl)->ctx = ci;
     *c = &e->ctx[ci];
     if (!(*sl)->done) B_TRY(e, hipEventCreateWithFlags(&(*sl)->done, hipEventDisableTiming));

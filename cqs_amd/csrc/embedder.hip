@@ -104,10 +104,12 @@ struct cqs_hip_embedder {
         hipEvent_t ev0 = nullptr, ev1 = nullptr;   // forward start / end (timing), ev_done after the D2H
         hipEvent_t done = nullptr;
         uint64_t ticket = 0;       // 0 = free
+        int ctx = 0;               // execution context the ticket runs on
     };
     static constexpr int kSlots = 3;
     Slot slot[kSlots];
     uint64_t next_ticket = 1;
+    int last_ctx = 1;              // context of the previous ticket (ties alternate)
 
     mutable std::mutex mu;
     std::atomic<bool> poisoned{false};
@@ -696,7 +698,16 @@ int32_t submit_locked(cqs_hip_embedder* e, uint32_t B, const std::function<int32
     E_TRY(e, hipSetDevice(e->device));
     int32_t rc = pack(*sl);
     if (rc != CQS_HIP_OK) return rc;
-    Ctx& c = e->ctx[e->next_ticket % (uint64_t)cqs_hip_embedder::kCtx];   // consecutive tickets alternate contexts
+    // The context with fewer tickets in flight; ties alternate - so pipelined callers interleave two kernel chains on the
+    // device as before, while ONE blocking call at a time always lands on context 0: the same 0.3 GB of activation scratch
+    // (and the same captured query graphs) call after call instead of two sets taking turns in L2 / the Infinity Cache.
+    int load[cqs_hip_embedder::kCtx] = {0, 0};
+    for (const cqs_hip_embedder::Slot& s2 : e->slot)
+        if (s2.ticket != 0) load[s2.ctx]++;
+    const int ci = load[0] == load[1] ? (load[0] == 0 ? 0 : 1 - e->last_ctx) : (load[0] < load[1] ? 0 : 1);
+    e->last_ctx = ci;
+    sl->ctx = ci;
+    Ctx& c = e->ctx[ci];
     hipStream_t st = c.stream;
     const uint32_t H = e->g.hidden;
     if (sl->M == 0) {
