@@ -193,6 +193,130 @@ __global__ __launch_bounds__(256) void qf_gemm_plain_kernel(const QfGemmParams p
     if (p.dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); QF_STAMP(p, 3); }
 }
 
+// ---- the same with both operands staged through LDS by COALESCED loads -----------------------------------------------------
+// The kernel above feeds the MFMA straight from global memory: every fragment load is a gather of 16 rows x 64 B, ~44
+// clocks of address processing per wave-instruction against ~16 for a contiguous 1 KB (measured with the stamps: with
+// the same number of loads made contiguous - wrong data, timing only - `down` went from 2.05 to 1.05 us at 8 tokens, 3.3 to
+// 2.0 at 32).  Here thread (row group rg = tid / 32, l32 = tid % 32) copies 16-byte chunks l32, l32 + 32, ... of rows rg,
+// rg + 8, ... of the weight slice (NC consecutive rows = one contiguous block) and of the activation rows: a wave-instruction
+// covers 2 rows x 512 contiguous bytes.  LDS rows are padded by 16 B (K % 128 == 0: consecutive rows land 4 banks apart).
+// Chunks / rows past the end re-copy the last real one (same data to the same place: no guards in the unrolled code).
+// KC32 = ceil(K / 8 / 32) chunk iterations per row, CH k-steps per batch (CH x batches = K / 4 / 32), ONE: the activations
+// are one row (Dense 2).
+template <int MT, int CH, int KC32, int EPI, int NC, int ONE>
+__global__ __launch_bounds__(256) void qf_gemm_staged_kernel(const QfGemmParams p) {
+    static_assert(NC == 8, "one 8-row weight slice per workgroup");
+    extern __shared__ __attribute__((aligned(16))) unsigned char qf_smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, lg = lane >> 4;
+    QF_STAMP(p, 0);
+    const uint32_t rows = ONE ? 1u : p.T;
+    const uint32_t K = p.K, kc = K / 8u, kw = K / 4u, nb = kw / (32u * (uint32_t)CH);
+    const uint32_t ldk = K + 8u;                                   // LDS row stride (elements)
+    bf16_t* const sW = (bf16_t*)qf_smem;                           // [NC][ldk]
+    bf16_t* const sA = sW + (size_t)NC * ldk;                      // [16 MT][ldk]  (ONE: [1][ldk])
+    constexpr int AR = ONE ? 1 : 16 * MT;
+    float* const red = (float*)(sA + (size_t)AR * ldk);            // [4 waves][MT][64 lanes] f4
+
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    const uint32_t rg = (uint32_t)tid >> 5, l32 = (uint32_t)tid & 31u;
+    constexpr int AI = ONE ? 0 : 2 * MT;                           // activation row iterations of 8 rows
+    u4 wreg[KC32], areg[AI > 0 ? AI : 1][KC32], oreg[ONE ? (KC32 + 7) / 8 : 1];
+    const bf16_t* wsrc = p.W + (size_t)(blockIdx.x * (uint32_t)NC + rg) * K;
+#pragma unroll
+    for (int j = 0; j < KC32; ++j) {
+        const uint32_t c = l32 + 32u * (uint32_t)j < kc ? l32 + 32u * (uint32_t)j : kc - 1u;
+        wreg[j] = *(const u4*)(wsrc + c * 8u);
+    }
+    if (ONE) {                                                      // the one activation row: chunk tid, tid + 256, ...
+#pragma unroll
+        for (int j = 0; j < (KC32 + 7) / 8; ++j) {
+            const uint32_t c = (uint32_t)tid + 256u * (uint32_t)j < kc ? (uint32_t)tid + 256u * (uint32_t)j : kc - 1u;
+            oreg[j] = *(const u4*)(p.A + c * 8u);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < AI; ++i) {
+            const uint32_t r = 8u * (uint32_t)i + rg;
+            const bf16_t* asrc = p.A + (size_t)(r < rows ? r : rows - 1u) * K;
+#pragma unroll
+            for (int j = 0; j < KC32; ++j) {
+                const uint32_t c = l32 + 32u * (uint32_t)j < kc ? l32 + 32u * (uint32_t)j : kc - 1u;
+                areg[i][j] = *(const u4*)(asrc + c * 8u);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < KC32; ++j) {
+        const uint32_t c = l32 + 32u * (uint32_t)j < kc ? l32 + 32u * (uint32_t)j : kc - 1u;
+        *(u4*)(sW + (size_t)rg * ldk + c * 8u) = wreg[j];
+    }
+    if (ONE) {
+#pragma unroll
+        for (int j = 0; j < (KC32 + 7) / 8; ++j) {
+            const uint32_t c = (uint32_t)tid + 256u * (uint32_t)j < kc ? (uint32_t)tid + 256u * (uint32_t)j : kc - 1u;
+            *(u4*)(sA + c * 8u) = oreg[j];
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < AI; ++i) {
+            const uint32_t r = 8u * (uint32_t)i + rg;
+            const uint32_t rr = r < rows ? r : rows - 1u;
+#pragma unroll
+            for (int j = 0; j < KC32; ++j) {
+                const uint32_t c = l32 + 32u * (uint32_t)j < kc ? l32 + 32u * (uint32_t)j : kc - 1u;
+                *(u4*)(sA + (size_t)rr * ldk + c * 8u) = areg[i][j];
+            }
+        }
+    }
+    __syncthreads();
+    QF_STAMP(p, 1);
+    // fragments: weight row l15 % NC (rows past NC repeat real rows: their output columns are never stored), activation
+    // row 16 m + l15 (rows past `rows` hold whatever LDS held: they only feed output columns that are never stored)
+    const uint32_t koff = (uint32_t)wid * kw + 8u * (uint32_t)lg;
+    const bf16_t* wp = sW + (size_t)(l15 % NC) * ldk + koff;
+    const bf16_t* ap = sA + (size_t)(ONE ? 0 : l15) * ldk + koff;
+    f4 acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[m] = (f4)(0.f);
+    for (uint32_t b = 0; b < nb; ++b) {
+        bf8 wf[CH], af[MT][CH];
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+            wf[u] = *(const bf8*)(wp + 32 * u);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) af[m][u] = *(const bf8*)(ap + (size_t)(ONE ? 0 : 16 * m) * ldk + 32 * u);
+        }
+#pragma unroll
+        for (int u = 0; u < CH; ++u)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u], af[m][u], acc[m], 0, 0, 0);
+        wp += 32 * CH;
+        ap += 32 * CH;
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m) *(f4*)(red + ((size_t)(wid * MT + m) * 64 + lane) * 4) = acc[m];
+    __syncthreads();
+    QF_STAMP(p, 2);
+    if (wid >= MT) return;
+    f4 v = *(const f4*)(red + ((size_t)wid * 64 + lane) * 4);
+#pragma unroll
+    for (int w = 1; w < 4; ++w) v += *(const f4*)(red + ((size_t)(w * MT + wid) * 64 + lane) * 4);
+    const uint32_t row = 16u * (uint32_t)wid + (uint32_t)l15;
+    if (row >= rows || 4 * lg >= NC) return;
+    const size_t off = (size_t)row * p.ldc + blockIdx.x * (uint32_t)NC + 4u * (uint32_t)lg;
+    if (EPI == QF_EPI_F32) {
+        *(f4*)((float*)p.C + off) = v;
+    } else {
+        bf4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = (bf16_t)v[r];
+        *(bf4*)((bf16_t*)p.C + off) = o;
+    }
+    if (p.dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); QF_STAMP(p, 3); }
+}
+
 // ---- GEMMs whose activations are made on the way in: embedding gather / add + RMSNorm pair (/ + mean pool) ---------
 // NCH = H / 256, K = H.  Rows: one WAVE per row, wave w takes rows w, w + 4, ... in batches of RB rows (RB = 1, 2, 4
 // by T for T <= 16: one batch; longer queries loop over batches of 4, the next batch's loads issued before the current
@@ -207,6 +331,7 @@ __global__ __launch_bounds__(64 * NW) void qf_gemm_kernel(const QfGemmParams p) 
     bf16_t* const sA = (bf16_t*)qf_smem;                           // [16 GT][LDA]
     float* const red = (float*)(qf_smem + (size_t)16 * GT * LDA * sizeof(bf16_t));   // [4 waves][NT][GT][64 lanes] f4
     float* const pool = red + NW * NT * GT * 64 * 4;               // POOL: [NW waves][H] column sums
+    bf16_t* const sW = (bf16_t*)(pool + (PRO == QF_PRO_POOL ? NW * H : 0));   // [NT][NC][LDA] weight slice
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -221,12 +346,23 @@ __global__ __launch_bounds__(64 * NW) void qf_gemm_kernel(const QfGemmParams p) 
     // channels' 32 up rows; embedder.hip set_tensor) -> channels [NC b, NC b + NC) = gate rows 64 (c / 32) + c % 32.
     uint32_t wrow0 = blockIdx.x * (uint32_t)NC;
     if (EPI == QF_EPI_GEGLU) wrow0 = 64u * (wrow0 >> 5) + (wrow0 & 31u);
-    const bf16_t* wp = p.W + (size_t)(wrow0 + (uint32_t)(l15 % NC)) * H + (uint32_t)wid * kw + 8u * (uint32_t)lg;
-    bf8 wf[NT][S];                                                 // requested first: they land while the rows are normalised
+    // The weight slice (NC consecutive rows per tile = one contiguous block) is requested first, with COALESCED loads
+    // (thread = row tid / 32 of the slice, 16-byte chunks tid % 32 + 32 j: a wave-instruction covers 2 rows x 512 B; a
+    // fragment gather of 16 rows x 64 B costs ~44 clocks of address processing per instruction against ~16), lands while
+    // the rows are normalised and goes through LDS: sW [NT][NC][LDA].
+    static_assert(NC == 8, "one 8-row weight slice per tile");
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    constexpr int WL = NW == 4 ? NT : 1;                           // slices per thread (8 waves: threads 256.. take the second tile)
+    const uint32_t wg = (uint32_t)tid >> 5, wl32 = (uint32_t)tid & 31u;
+    const bool wload = NW == 4 || (wg >> 3) < (uint32_t)NT;
+    u4 wreg[WL][NCH];
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int t = 0; t < WL; ++t) {
+        const uint32_t tile = NW == 4 ? (uint32_t)t : (wload ? wg >> 3 : 0u);
+        const bf16_t* src = p.W + (size_t)(wrow0 + 32u * tile + (wg & 7u)) * H + wl32 * 8u;
 #pragma unroll
-        for (int s = 0; s < S; ++s) wf[t][s] = *(const bf8*)(wp + (size_t)t * 32 * H + 32 * s);
+        for (int j = 0; j < NCH; ++j) wreg[t][j] = *(const u4*)(src + 256 * j);
+    }
 
     // lane owns 4 consecutive floats of each 256-chunk of a row
     f4 wn1[NCH], wp1[NCH];                                         // 1 + w
@@ -335,9 +471,22 @@ __global__ __launch_bounds__(64 * NW) void qf_gemm_kernel(const QfGemmParams p) 
         // MFMA, and columns past the real rows are never stored)
     }
     // rows [T, 16 MT) of the tile are not initialised either, for the same reason
+    if (wload) {
+#pragma unroll
+        for (int t = 0; t < WL; ++t) {
+            const uint32_t tile = NW == 4 ? (uint32_t)t : wg >> 3;
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) *(u4*)(sW + (size_t)(tile * (uint32_t)NC + (wg & 7u)) * LDA + wl32 * 8u + 256 * j) = wreg[t][j];
+        }
+    }
     __syncthreads();
     QF_STAMP(p, 1);
     // ---- multiply: B operand (activations) from LDS: lane feeds row 16 m + l15, k = wid kw + 32 s + 8 lg .. + 7 ----
+    bf8 wf[NT][S];                                                 // weight row l15 % NC (rows past NC repeat real rows)
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int s = 0; s < S; ++s) wf[t][s] = *(const bf8*)(sW + (size_t)(t * NC + l15 % NC) * LDA + (uint32_t)wid * kw + 8u * (uint32_t)lg + 32 * s);
     f4 acc[NT][GT];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -620,11 +769,28 @@ __global__ __launch_bounds__(64 * NW) void qf_attn_oproj_kernel(const QfAttnPara
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, lg = lane >> 4;
     QF_STAMP(p, 0);
-    // o_proj weights first: they land while the attention runs
-    const bf16_t* wp = p.wo + (size_t)(blockIdx.x * (uint32_t)NC + (uint32_t)(l15 % NC)) * K + wid * kw + 8 * lg;
+    // o_proj's weight slice (NC consecutive rows: one contiguous block) first, by coalesced loads (thread = row tid / 32,
+    // 16-byte chunks tid % 32 + 32 j); it lands while the attention runs and goes through LDS (sW [NC][K + 8]) - except
+    // at 3 row tiles, where LDS is full and the fragments are gathered from global memory as before
+    static_assert(NC == 8, "one 8-row weight slice per workgroup");
+    constexpr bool kStageW = MT < 3;
+    constexpr int LDW = K + 8;
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    bf16_t* const sW = (bf16_t*)(red + NW * MT * 64 * 4);
+    const uint32_t wg = (uint32_t)tid >> 5, wl32 = (uint32_t)tid & 31u;
+    u4 wreg[NH];
     bf8 wf[S];
+    if (kStageW) {
+        if (wg < 8u) {
+            const bf16_t* src = p.wo + (size_t)(blockIdx.x * (uint32_t)NC + wg) * K + wl32 * 8u;
 #pragma unroll
-    for (int s = 0; s < S; ++s) wf[s] = *(const bf8*)(wp + 32 * s);
+            for (int j = 0; j < NH; ++j) wreg[j] = *(const u4*)(src + 256 * j);
+        }
+    } else {
+        const bf16_t* wp = p.wo + (size_t)(blockIdx.x * (uint32_t)NC + (uint32_t)(l15 % NC)) * K + wid * kw + 8 * lg;
+#pragma unroll
+        for (int s = 0; s < S; ++s) wf[s] = *(const bf8*)(wp + 32 * s);
+    }
     qf_attn_stage<MT, RB, NH, NW>(p, 0u, 0u, sQ, sK, sVt, wid, lane);
     __syncthreads();
     QF_STAMP(p, 1);
@@ -642,8 +808,16 @@ __global__ __launch_bounds__(64 * NW) void qf_attn_oproj_kernel(const QfAttnPara
             *(bf4*)(orow + 16 * j) = ob;
         }
     }
+    if (kStageW && wg < 8u) {
+#pragma unroll
+        for (int j = 0; j < NH; ++j) *(u4*)(sW + (size_t)wg * LDW + wl32 * 8u + 256 * j) = wreg[j];
+    }
     __syncthreads();
     QF_STAMP(p, 2);
+    if (kStageW) {
+#pragma unroll
+        for (int s = 0; s < S; ++s) wf[s] = *(const bf8*)(sW + (size_t)(l15 % NC) * LDW + wid * kw + 8 * lg + 32 * s);
+    }
     // y tile: B operand (attention rows) from LDS: row 16 m + l15, k = wid kw + 32 s + 8 lg -> head k / 256, dim k % 256
     f4 acc[MT];
 #pragma unroll
@@ -716,7 +890,7 @@ hipError_t qf_launch_pro(const QfGemmParams& p, uint32_t n_out_cols, hipStream_t
     [&]() {                                                                                                                 \
         constexpr int GT = PRO == QF_PRO_POOL ? 1 : MTV;                                                                    \
         constexpr int NWV = (NT == 2 && MTV == 4) ? 4 : NWR;               /* (GeGLU x 4 row tiles at 8 waves: LDS) */       \
-        const size_t lds = (size_t)16 * GT * (NCH * 256 + kQfPad) * sizeof(bf16_t) + (size_t)NWV * NT * GT * 64 * 16 +      \
+        const size_t lds = (size_t)(16 * GT + NT * NC) * (NCH * 256 + kQfPad) * sizeof(bf16_t) + (size_t)NWV * NT * GT * 64 * 16 + \
                            (PRO == QF_PRO_POOL ? (size_t)NWV * NCH * 256 * sizeof(float) : 0);                              \
         static DynLdsOnce once;                                                                                             \
         return qf_launch(qf_gemm_kernel<NCH, PRO, EPI, NC, RBV, MTV, NWV>, once, p, n_out_cols / (uint32_t)NC, lds, st,     \
@@ -744,9 +918,42 @@ hipError_t qf_launch_plain_ch(const QfGemmParams& p, uint32_t n_out_cols, hipStr
 #undef QF_PLAIN
 }
 
+// K classes of the staged kernel: (k-steps per batch, chunk iterations per row).  Unknown K, 49-64 rows (LDS) or the
+// experiment switch CQS_HIP_QUERY_STAGED=0: the gather kernel.
+template <int MT, int EPI, int NC, int ONE>
+hipError_t qf_launch_staged(const QfGemmParams& p, uint32_t n_out_cols, hipStream_t st) {
+    static const bool off = [] { const char* e = getenv("CQS_HIP_QUERY_STAGED"); return e && e[0] == '0'; }();
+    if (off || NC != 8) return hipErrorNotSupported;
+    const size_t lds = (size_t)(NC + (ONE ? 1 : 16 * MT)) * (p.K + 8u) * sizeof(bf16_t) + (size_t)4 * MT * 64 * 16;
+    if (lds > 160u * 1024u) return hipErrorNotSupported;
+#define QF_ST(CHV, KCV)                                                                                                  \
+    do {                                                                                                                 \
+        static DynLdsOnce once;                                                                                          \
+        return qf_launch(qf_gemm_staged_kernel<MT, CHV, KCV, EPI, NC, ONE>, once, p, n_out_cols / (uint32_t)NC, lds, st); \
+    } while (0)
+    switch (p.K) {
+        case 768: QF_ST(6, 3);
+        case 1152: QF_ST(9, 5);
+        case 3072: QF_ST(8, 12);
+        case 512: QF_ST(4, 2);
+        case 384: QF_ST(3, 2);
+        case 256: QF_ST(2, 1);
+        default: return hipErrorNotSupported;
+    }
+#undef QF_ST
+}
+
 template <int EPI, int NC>
 hipError_t qf_launch_plain(const QfGemmParams& p, uint32_t n_out_cols, hipStream_t st) {
     const uint32_t rows = p.one_row ? 1u : p.T;
+    {
+        hipError_t e = hipErrorNotSupported;
+        if (p.one_row) e = qf_launch_staged<1, EPI, NC, 1>(p, n_out_cols, st);
+        else if (rows <= 16u) e = qf_launch_staged<1, EPI, NC, 0>(p, n_out_cols, st);
+        else if (rows <= 32u) e = qf_launch_staged<2, EPI, NC, 0>(p, n_out_cols, st);
+        else if (rows <= 48u) e = qf_launch_staged<3, EPI, NC, 0>(p, n_out_cols, st);
+        if (e != hipErrorNotSupported) return e;
+    }
     if (rows <= 16u) return qf_launch_plain_ch<1, EPI, NC>(p, n_out_cols, st);
     if (rows <= 32u) return qf_launch_plain_ch<2, EPI, NC>(p, n_out_cols, st);
     if (rows <= 48u) return qf_launch_plain_ch<3, EPI, NC>(p, n_out_cols, st);
@@ -775,7 +982,8 @@ hipError_t qf_launch_attn_oproj_h(const QfAttnParams& a, hipStream_t st) {
     [&]() {                                                                                                                 \
         static DynLdsOnce once;                                                                                             \
         return qf_launch(qf_attn_oproj_kernel<MTV, RBV, NH, NC, NWV>, once, a, a.H / (uint32_t)NC,                          \
-                         qf_attn_lds<MTV>(NH) + (size_t)NWV * MTV * 64 * 16, st, 64u * NWV);                                \
+                         qf_attn_lds<MTV>(NH) + (size_t)NWV * MTV * 64 * 16 +                                               \
+                             (MTV < 3 ? (size_t)NC * (NH * kQfHD + 8) * sizeof(bf16_t) : 0), st, 64u * NWV);                \
     }()
     if (a.T <= 4u) return QF_AO(1, 1, 4);
     if (a.T <= 8u) return QF_AO(2, 1, 4);
