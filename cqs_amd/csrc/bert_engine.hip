@@ -184,10 +184,12 @@ int32_t run_encoder(cqs_hip_bert* e, BCtx& c, BSlot& sl, const int32_t* tokens, 
                     uint32_t* M_out) {
     const cqs_hip_bert_config& cf = e->cfg;
     uint64_t M64 = 0, nblk64 = 0;
+    uint32_t max_len = 0;
     for (uint32_t b = 0; b < B; ++b) {
         if (lens[b] > cf.max_pos) return bfail(e, CQS_HIP_ERR_INVALID, "bert: sequence longer than max_position_embeddings");
         M64 += lens[b];
         nblk64 += (lens[b] + 63u) / 64u;
+        max_len = std::max(max_len, lens[b]);
     }
     if (M64 > 0x7FFFFFFFull) return bfail(e, CQS_HIP_ERR_INVALID, "bert: batch holds too many tokens");
     const uint32_t M = (uint32_t)M64, nblk = (uint32_t)nblk64;
@@ -230,7 +232,7 @@ int32_t run_encoder(cqs_hip_bert* e, BCtx& c, BSlot& sl, const int32_t* tokens, 
     for (uint32_t l = 0; l < cf.layers; ++l) {
         const BertLayer& w = e->L[l];
         B_TRY(e, cqs::launch_gemm_bias(c.x, w.wqkv, w.bqkv, c.qkv, M, 3u * H, H, 3u * H, cqs::GEMM_OUT_BF16, st));
-        B_TRY(e, cqs::launch_bert_attention(c.qkv, c.att, d_blk, nblk, d_start, d_len, cf.heads, H / cf.heads, st));
+        B_TRY(e, cqs::launch_bert_attention(c.qkv, c.att, d_blk, nblk, d_start, d_len, B, max_len, cf.heads, H / cf.heads, st));
         B_TRY(e, cqs::launch_gemm_bias(c.att, w.wo, w.bo, c.y, M, H, H, H, cqs::GEMM_OUT_BF16, st));
         B_TRY(e, cqs::launch_bert_add_ln(c.x, c.y, w.ln1_g, w.ln1_b, cf.ln_eps, c.x, M, H, st));
         B_TRY(e, cqs::launch_gemm_bias(c.x, w.w1, w.b1, c.h, M, I, H, I, cqs::GEMM_OUT_BF16_GELU, st));

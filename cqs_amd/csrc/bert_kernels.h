@@ -15,10 +15,13 @@ hipError_t launch_bert_add_ln(const bf16_t* a, const bf16_t* r, const float* gam
                               bf16_t* out, uint32_t M, uint32_t H, hipStream_t st);
 
 // Multi-head bidirectional attention over packed sequences.  qkv [M, 3 H] bf16 (q | k | v, heads contiguous, biases
-// already added), out [M, H]; blk[i] = {sequence, 64-query block}; head_dim 32 or 64; softmax(q k^T / sqrt(head_dim)) v.
+// already added), out [M, H]; head_dim 32 or 64; softmax(q k^T / sqrt(head_dim)) v.  Sequences of up to 512 tokens
+// (max_len = the batch's longest) take the resident-key kernel, one workgroup per (sequence, head) [part];
+// CQS_HIP_BERT_ATTN_RESIDENT=0 or a longer sequence takes the first-generation kernel, which walks
+// blk[i] = {sequence, 64-query block}.
 hipError_t launch_bert_attention(const bf16_t* qkv, bf16_t* out, const int32_t* blk /*[nblk][2]*/, uint32_t nblk,
-                                 const int32_t* seq_start, const int32_t* seq_len, uint32_t heads, uint32_t head_dim,
-                                 hipStream_t st);
+                                 const int32_t* seq_start, const int32_t* seq_len, uint32_t B, uint32_t max_len,
+                                 uint32_t heads, uint32_t head_dim, hipStream_t st);
 
 // out[b] = mean over the sequence's tokens of x (mode 0; empty sequence: zeros) or its first token (mode 1), f32 [B, H]
 hipError_t launch_bert_pool(const bf16_t* x, const int32_t* seq_start, const int32_t* seq_len, float* out, uint32_t B,

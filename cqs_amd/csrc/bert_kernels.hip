@@ -7,6 +7,9 @@
 // (the pooling itself is the decoder GEMM's epilogue, launch_gemm_rowmax).
 // Tokens are packed (no padding reaches a kernel); bf16 operands, f32 accumulation and statistics.
 #include "bert_kernels.h"
+#include "launch_util.h"
+#include <stdlib.h>
+#include <type_traits>
 
 namespace cqs {
 
@@ -276,6 +279,280 @@ __global__ __launch_bounds__(256) void bert_attention_kernel(const bf16_t* __res
     }
 }
 
+// ---- multi-head attention, second generation: a sequence's keys RESIDENT in LDS ----------------------------------
+// One workgroup = NW waves = one (sequence, head) pair - or one of `qsplit` parts of its queries.  The head's K and V
+// rows (HD * 2 bytes each, exactly as they lie in the qkv buffer) are fetched ONCE by LDS-DMA into images that hold the
+// whole sequence (NG groups of 128 keys), group by group; the workgroup then walks its queries in passes of 16 NW (one
+// 16-query tile per wave) over the resident keys.  The first pass starts on group 0 while groups 1.. are still in
+// flight (counted vmcnt + one barrier per group, first pass only); after that there is no barrier and no wait left.
+// Against bert_attention_kernel (64 queries / workgroup, 64-key tiles through registers, two barriers and one rescale of
+// O per 32 keys, K / V re-read per 64 queries): the running maximum moves once per 128 KEYS (32 scores per lane: exact
+// maximum first, then one exp per score), the row sums ride on the matrix cores (one more PV tile whose V^T rows are
+// all ones: sum_k P[k][q], from the same bf16 P the numerator uses), key masking is a branch only the sequence's last
+// group takes, no ds_write is issued, K / V cross L2 -> LDS once per (sequence, head).  The loop is VALU-bound by design:
+// per 128 keys and wave 33 v_exp (quarter rate) + 32 fma + 16 max3 + 16 cvt_pk against 36..40 MFMAs.
+// Same product layout as above (S^T = K Q^T, keys on MFMA rows in the order 32 t + 8 (i >> 2) + 4 kt + (i & 3); V^T
+// fragments by ds_read_b64_tr_b16 from the row-major V image).  The images are unpadded; the 16-byte chunk c of key
+// row r lives at position c ^ f(r) - applied to the DMA's SOURCE address - with
+//   HD = 64 (128-byte rows):  f(r) = r3 | r1 << 1 | r3 << 2        HD = 32 (64-byte rows):  f(r) = r3 | (r3 ^ r4) << 1
+// (r1, r3, r4: bits of r), so that the 16 rows of a ds_read_b128 lane group and the 8 rows x 32 B of a transposed
+// read's 32-lane half fall into distinct bank slots (MI355X_MICROARCH.md, LDS lane groups).
+template <int HD>
+__device__ __forceinline__ uint32_t res_swz(uint32_t r) {
+    if (HD == 64) return ((r >> 3) & 1u) * 5u ^ (((r >> 1) & 1u) << 1);
+    return ((r >> 3) & 1u) | ((((r >> 3) ^ (r >> 4)) & 1u) << 1);
+}
+
+template <int HD, int NW, int NG>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void bert_attention_res_kernel(
+    const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, const int32_t* __restrict__ seq_start,
+    const int32_t* __restrict__ seq_len, uint32_t heads, uint32_t qsplit, float scale) {
+    constexpr int kST = HD / 32, kDT = HD / 16;
+    constexpr int kCh = HD / 8;                                   // 16-byte chunks per row
+    constexpr int kRowsPerDma = 1024 / (HD * 2);                  // key rows one DMA instruction fills (8 or 16)
+    constexpr int kDmaPerGroup = 128 / kRowsPerDma;               // instructions per 128-key group of ONE image
+    constexpr int kPerWave = kDmaPerGroup / NW;                   // ... per wave (K; as many again for V)
+    static_assert(kDmaPerGroup % NW == 0 && kPerWave >= 1, "a group's fetch splits evenly over the waves");
+    constexpr int kOut = 2 * kPerWave;                            // DMA instructions in flight per wave and group
+    constexpr uint32_t kImg = (uint32_t)NG * 128u * HD * 2u;      // bytes of one image (K or V)
+    extern __shared__ __attribute__((aligned(1024))) bf16_t res_smem[];     // K image | V image
+    typedef short tr4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) tr4* lds_tr4;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, lg = lane >> 4;
+    // one contiguous run of the (sequence, head, part) list per XCD: the parts of one pair share an L2
+    const uint32_t nwg = gridDim.x, xcd = blockIdx.x % 8u, q8 = nwg / 8u, r8 = nwg % 8u;
+    const uint32_t wg = (xcd < r8 ? xcd * (q8 + 1u) : r8 * (q8 + 1u) + (xcd - r8) * q8) + blockIdx.x / 8u;
+    const uint32_t part = wg % qsplit, pair = wg / qsplit;
+    const uint32_t b = pair / heads, head = pair % heads;
+    const uint32_t s0 = (uint32_t)seq_start[b], L = (uint32_t)seq_len[b];
+    const uint32_t npass = (L + 16u * NW - 1u) / (16u * NW);
+    if (part >= npass) return;                                    // (uniform, before any barrier; covers L == 0)
+    const uint32_t ng = (L + 127u) / 128u;                        // <= NG: the host checked the longest sequence
+    const uint32_t H = heads * (uint32_t)HD, ld = 3u * H;
+
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) bf16_t*)res_smem;
+    const char* const gK = (const char*)(qkv + (size_t)s0 * ld + H + head * HD);
+    const uint32_t vrel = H * 2u;                                 // byte distance from a token's k head to its v head
+    auto dma = [&](uint32_t voff, uint32_t lds_byte) {
+        asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                     :: "s"(lds_byte), "v"(voff), "s"(gK) : "memory");
+    };
+    // group g: instruction i (1 KiB of each image) by wave i % NW; rows past the sequence read its last key (finite: V
+    // times P = 0; their scores are masked)
+    auto stage = [&](uint32_t g) {
+#pragma unroll
+        for (int j = 0; j < kPerWave; ++j) {
+            const uint32_t i = g * (uint32_t)kDmaPerGroup + (uint32_t)wid + (uint32_t)(NW * j);
+            const uint32_t r = (uint32_t)kRowsPerDma * i + (uint32_t)lane / (uint32_t)kCh;
+            const uint32_t key = r < L ? r : L - 1u;
+            const uint32_t c = ((uint32_t)lane % (uint32_t)kCh) ^ res_swz<HD>(r);
+            const uint32_t voff = key * ld * 2u + c * 16u;
+#if defined(CQS_BATT_NO_DMA)
+            if (voff == 0xFFFFFFFFu)
+#endif
+            {
+                dma(voff, lds0 + i * 1024u);
+                dma(voff + vrel, lds0 + kImg + i * 1024u);
+            }
+        }
+    };
+    // at most k groups of this wave's fetches still in flight
+    auto wait_groups = [&](uint32_t k) {
+        if (k == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (k == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kOut) : "memory");
+        else if (k == 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * kOut) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * kOut) : "memory");
+    };
+    static_assert(NG <= 4, "wait_groups covers four groups");
+
+    // fragment addresses.  K: row(l15) of tile (t, kt) = 32 t + 4 kt + 8 (l15 >> 2) + (l15 & 3), chunk 4 s + lg
+    const uint32_t krow = (uint32_t)(8 * (l15 >> 2) + (l15 & 3));
+    const bf16_t* kp[kST];
+#pragma unroll
+    for (int s = 0; s < kST; ++s) kp[s] = res_smem + krow * (uint32_t)HD + (((uint32_t)(4 * s + lg)) ^ res_swz<HD>(krow)) * 8u;
+    // V (transposed reads): lane 16 lg + 4 q + p addresses key row 8 lg + q (+ 4 h + 32 t), dims 16 dt + 4 p ..+3
+    const int tq = (lane >> 2) & 3, tp = lane & 3;
+    const uint32_t vrow = (uint32_t)(8 * lg + tq);
+    uint32_t vb[kDT];
+#pragma unroll
+    for (int dt = 0; dt < kDT; ++dt)
+        vb[dt] = lds0 + kImg + vrow * (uint32_t)(HD * 2) + ((((uint32_t)(2 * dt + (tp >> 1))) ^ res_swz<HD>(vrow)) * 16u) +
+                 (uint32_t)(tp & 1) * 8u;
+    bf8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (bf16_t)1.0f;
+    const float c = scale * 1.4426950408889634f;                  // scores enter exp2 as s * c
+
+    uint32_t q0 = part * (16u * NW) + (uint32_t)wid * 16u;        // this wave's first query of the pass
+    // first pass: group 0, then the Q fragments, then the other groups - in that order in the vmcnt queue, so that group 0
+    // and Q can be waited for with groups 1.. still in flight.  (The Q loads are asm: tracked by hipcc they would get a
+    // vmcnt(0) at their first use, which also drains every DMA; nothing touches qf between the loads and the wait.)
+    stage(0u);
+    bf8 qf[kST];
+    {
+        const uint32_t qi = q0 + (uint32_t)l15;
+        const bf16_t* qp = qkv + (size_t)(s0 + (qi < L ? qi : L - 1u)) * ld + head * HD + 8 * lg;
+#pragma unroll
+        for (int s = 0; s < kST; ++s)
+            asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=&v"(qf[s]) : "v"(qp), "n"(64 * s) : "memory");
+    }
+    for (uint32_t g = 1; g < ng; ++g) stage(g);
+    wait_groups(ng - 1u);                                         // this wave's share of group 0, and its Q, have landed
+#pragma unroll
+    for (int s = 0; s < kST; ++s) asm volatile("" : "+v"(qf[s]));
+    __syncthreads();                                              // everyone's share of group 0 has
+
+    for (uint32_t pi = 0;; ++pi) {
+        const bool wave_live = q0 < L;                            // waves past the sequence only help staging
+        const uint32_t qi = q0 + (uint32_t)l15;
+        f4 o[kDT], ls = (f4)(0.f);
+#pragma unroll
+        for (int d = 0; d < kDT; ++d) o[d] = (f4)(0.f);
+        float m_run = -INFINITY;
+
+        // 128 keys at LDS rows 128 g ..
+        auto group = [&](auto g_c) {
+            constexpr int g = decltype(g_c)::value;
+            const uint32_t kfirst = 128u * g;
+            f4 sc[4][2];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt) {
+                    sc[t][kt] = (f4)(0.f);
+#pragma unroll
+                    for (int s = 0; s < kST; ++s) {
+#if defined(CQS_BATT_NO_KREAD)
+                        const bf8 kf = qf[(s + t) % kST];
+#else
+                        const bf8 kf = *(const bf8*)(kp[s] + (128 * g + 32 * t + 4 * kt) * HD);
+#endif
+#if defined(CQS_BATT_NO_S)
+                        sc[t][kt][s] += (float)kf[0];
+#else
+                        sc[t][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[s], sc[t][kt], 0, 0, 0);
+#endif
+                    }
+                }
+            // sc[t][kt][r] = q . k for key kfirst + 32 t + 8 lg + 4 kt + r
+            if (kfirst + 127u >= L) {                             // (wave-uniform) the sequence's last, partial group
+                int lim = (int)L - (int)kfirst - 8 * lg;
+                asm volatile("" : "+v"(lim));                     // keep it a branch (full groups pay nothing), and keep the
+                                                                  // 32 compare masks out of the pass loop's SGPRs
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) sc[t][kt][r] = (32 * t + 4 * kt + r) < lim ? sc[t][kt][r] : -INFINITY;
+            }
+            float mloc = -INFINITY;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) mloc = fmaxf(mloc, sc[t][kt][r]);
+            mloc = xg_max(mloc);
+            const float m_new = fmaxf(m_run, mloc);               // finite: key kfirst < L is attendable for every query
+            const float a = __builtin_amdgcn_exp2f((m_run - m_new) * c);      // exp2(-inf) = 0 on the first group
+            ls *= a;
+#pragma unroll
+            for (int d = 0; d < kDT; ++d) o[d] *= a;
+            m_run = m_new;
+            const float mc = -m_new * c;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                bf8 pf;
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#if defined(CQS_BATT_NO_EXP)
+                        pf[kt * 4 + r] = (bf16_t)__builtin_fmaf(sc[t][kt][r], c, mc);
+#else
+                        pf[kt * 4 + r] = (bf16_t)__builtin_amdgcn_exp2f(__builtin_fmaf(sc[t][kt][r], c, mc));
+#endif
+                ls = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf, ls, 0, 0, 0);     // every row: sum_k P[k][query]
+#pragma unroll
+                for (int dt = 0; dt < kDT; ++dt) {
+#if defined(CQS_BATT_NO_VREAD)
+                    const bf8 vf = qf[dt % kST];
+#else
+                    const uint32_t ad = vb[dt] + (uint32_t)((128 * g + 32 * t) * HD * 2);
+                    const tr4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr4)(uintptr_t)ad);
+                    const tr4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr4)(uintptr_t)(ad + (uint32_t)(4 * HD * 2)));
+                    const bf8 vf = __builtin_bit_cast(bf8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+#endif
+#if defined(CQS_BATT_NO_PV)
+                    o[dt][0] += (float)vf[0] * (float)pf[dt];
+#else
+                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[dt], 0, 0, 0);
+#endif
+                }
+            }
+        };
+        auto step = [&](auto g_c) {
+            constexpr int g = decltype(g_c)::value;
+            if constexpr (g < NG) {
+                if ((uint32_t)g < ng) {                           // (uniform)
+                    if (g > 0 && pi == 0) {
+                        wait_groups(ng - 1u - (uint32_t)g);       // this wave's share of group g has landed
+                        __syncthreads();                          // everyone's has
+                    }
+                    if (wave_live) group(g_c);
+                }
+            }
+        };
+        step(std::integral_constant<int, 0>{});
+        step(std::integral_constant<int, 1>{});
+        step(std::integral_constant<int, 2>{});
+        step(std::integral_constant<int, 3>{});
+
+#if defined(CQS_BATT_NO_STORE)
+        if (wave_live && qi < L && o[0][0] == 1234.5f) {
+#else
+        if (wave_live && qi < L) {
+#endif
+            const float invl = ls[0] > 0.f ? 1.0f / ls[0] : 0.f;
+            bf16_t* op = out + (size_t)(s0 + qi) * H + head * HD;
+            // O^T[dim 16 d + 4 lg + e][query l15]: a lane holds 8-byte pieces 32 bytes apart.  One v_permlane16_swap per
+            // register of a tile pair (d, d + 1) turns them into 16 contiguous bytes per lane (lane groups 0 / 2 keep
+            // tile d's dims 8 lg' .. + 7, groups 1 / 3 tile d + 1's), so a store instruction writes 64 contiguous bytes
+            // of each of its 16 rows instead of 32
+            typedef unsigned pu2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+            for (int d = 0; d < kDT; d += 2) {
+                bf4 w0, w1;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { w0[e] = (bf16_t)(o[d][e] * invl); w1[e] = (bf16_t)(o[d + 1][e] * invl); }
+                const pu2 a = __builtin_bit_cast(pu2, w0), b2 = __builtin_bit_cast(pu2, w1);
+                const pu2 x = __builtin_amdgcn_permlane16_swap(a[0], b2[0], false, false);
+                const pu2 y = __builtin_amdgcn_permlane16_swap(a[1], b2[1], false, false);
+                // even lane groups: (own tile d, the next group's tile d); odd: (the previous group's tile d + 1, own)
+                u4 v;
+                v[0] = x[0]; v[1] = y[0]; v[2] = x[1]; v[3] = y[1];
+                const int col = 16 * d + ((lg & 1) ? 16 : 0) + 8 * (lg >> 1);
+                *(u4*)(op + col) = v;
+            }
+        }
+        q0 += qsplit * (16u * NW);
+        if (q0 - (uint32_t)wid * 16u >= L) break;                 // (uniform: the pass's first query) no pass left
+        // the next pass's Q fragments, waited for right here (by now nothing else is in flight; a wait that hipcc placed
+        // at their first use would sit in front of group 0 and, in the first pass, drain every DMA): the other waves
+        // of the SIMD cover the round trip
+        const uint32_t qx = q0 + (uint32_t)l15;
+        const bf16_t* qp = qkv + (size_t)(s0 + (qx < L ? qx : L - 1u)) * ld + head * HD + 8 * lg;
+#pragma unroll
+        for (int s = 0; s < kST; ++s) qf[s] = *(const bf8*)(qp + 32 * s);
+#pragma unroll
+        for (int s = 0; s < kST; ++s) asm volatile("" : "+v"(qf[s]));
+    }
+}
+
 // SPLADE activation (src/splade/mod.rs:1049-1053) over the pooled maxima the decoder GEMM left behind
 // (launch_gemm_rowmax: max(0, max_s logits), NaN never taken): x <- ln(1 + x), in place.
 __global__ __launch_bounds__(256) void splade_activate_kernel(float* __restrict__ x, size_t n) {
@@ -397,11 +674,51 @@ hipError_t launch_bert_add_ln(const bf16_t* a, const bf16_t* r, const float* gam
     return hipGetLastError();
 }
 
-hipError_t launch_bert_attention(const bf16_t* qkv, bf16_t* out, const int32_t* blk, uint32_t nblk,
-                                 const int32_t* seq_start, const int32_t* seq_len, uint32_t heads, uint32_t head_dim,
+namespace {
+template <int HD, int NW, int NG>
+hipError_t launch_res(const bf16_t* qkv, bf16_t* out, const int32_t* seq_start, const int32_t* seq_len, uint32_t B,
+                      uint32_t max_len, uint32_t heads, float scale, hipStream_t st) {
+    static DynLdsOnce once;
+    auto kern = bert_attention_res_kernel<HD, NW, NG>;
+    constexpr size_t lds = (size_t)2 * NG * 128 * HD * 2;
+    hipError_t e = once.ensure((const void*)kern, lds);
+    if (e != hipSuccess) return e;
+    // how many workgroups share one (sequence, head): each loads the whole K / V, so as few as fill the chip evenly.
+    // Model: workgroups on the busiest CU x (passes per workgroup + ~half a pass of exposed fetch)
+    const uint32_t pairs = B * heads, slots = 256u;             // (a CU's second workgroup shares its VALU: count CUs)
+    const uint32_t npass = (max_len + 16u * NW - 1u) / (16u * NW);
+    uint32_t qsplit = 1;
+    if (const char* v = getenv("CQS_HIP_BERT_ATTN_QSPLIT")) qsplit = (uint32_t)atoi(v);
+    else {
+        float best = 0.f;
+        for (uint32_t q = 1; q <= npass; q *= 2u) {
+            const uint32_t rounds = (pairs * q + slots - 1u) / slots;
+            const float cost = (float)rounds * ((float)((npass + q - 1u) / q) + 0.5f);
+            if (q == 1u || cost < best) { best = cost; qsplit = q; }
+        }
+    }
+    if (qsplit < 1u) qsplit = 1u;
+    if (qsplit > npass) qsplit = npass;
+    hipLaunchKernelGGL(kern, dim3(pairs * qsplit), dim3(64 * NW), lds, st, qkv, out, seq_start, seq_len, heads, qsplit, scale);
+    return hipGetLastError();
+}
+}  // namespace
+
+hipError_t launch_bert_attention(const bf16_t* qkv, bf16_t* out, const int32_t* blk, uint32_t nblk, const int32_t* seq_start,
+                                 const int32_t* seq_len, uint32_t B, uint32_t max_len, uint32_t heads, uint32_t head_dim,
                                  hipStream_t st) {
-    if (nblk == 0) return hipSuccess;
+    if (nblk == 0 || B == 0) return hipSuccess;
     const float scale = 1.0f / sqrtf((float)head_dim);
+    const char* v = getenv("CQS_HIP_BERT_ATTN_RESIDENT");         // read per batch: a test flips it inside one process
+    const bool resident = !(v && v[0] == '0');
+    if (resident && max_len <= 512u && (head_dim == 64u || head_dim == 32u)) {
+        if (head_dim == 64u) {
+            if (max_len <= 256u) return launch_res<64, 8, 2>(qkv, out, seq_start, seq_len, B, max_len, heads, scale, st);
+            return launch_res<64, 16, 4>(qkv, out, seq_start, seq_len, B, max_len, heads, scale, st);
+        }
+        if (max_len <= 256u) return launch_res<32, 8, 2>(qkv, out, seq_start, seq_len, B, max_len, heads, scale, st);
+        return launch_res<32, 8, 4>(qkv, out, seq_start, seq_len, B, max_len, heads, scale, st);
+    }
     if (head_dim == 64u)
         hipLaunchKernelGGL(bert_attention_kernel<64>, dim3(nblk, heads), dim3(256), 0, st, qkv, out, blk, seq_start, seq_len, heads, scale);
     else if (head_dim == 32u)

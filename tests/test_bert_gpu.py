@@ -74,6 +74,44 @@ def test_encoder_hidden_states(hip, heads):
     eng.close()
 
 
+@pytest.mark.parametrize("heads", [4, 8])            # head dim 64 and 32
+def test_resident_key_attention_at_the_block_edges(hip, monkeypatch, heads):
+    """Sequences of up to 512 tokens take the resident-key attention kernel (one workgroup per (sequence, head) or
+    per part of its queries; 128-key groups; 8 or 16 waves x 16 queries per pass): lengths around every edge it has,
+    in a batch that needs four groups and in one that needs two, with the query split forced to 1, 2, 4 and chosen by
+    the launcher - against the oracle and against the first-generation kernel (CQS_HIP_BERT_ATTN_RESIDENT=0, read per
+    batch; same products, another order of the softmax carries, bf16 row sums: close, not bit-identical)."""
+    cfg = R.BertConfig(vocab_size=500, hidden=256, layers=2, heads=heads, intermediate=512, max_pos=512)
+    eng, w = _engine(cfg, "none", seed=11)
+    for lens in ([1, 15, 16, 17, 127, 128, 129, 255, 256, 257, 300, 384, 385, 512, 33],
+                 [256, 1, 129, 255, 16, 128, 200, 31]):
+        seqs = _seqs(cfg, lens, seed=12)
+        got = eng.hidden(seqs, None)
+        assert np.array_equal(got, eng.hidden(seqs, None))     # deterministic
+        for q in ("1", "2", "4"):
+            monkeypatch.setenv("CQS_HIP_BERT_ATTN_QSPLIT", q)
+            assert np.array_equal(got, eng.hidden(seqs, None)), q      # which workgroup takes a query changes nothing
+        monkeypatch.delenv("CQS_HIP_BERT_ATTN_QSPLIT")
+        monkeypatch.setenv("CQS_HIP_BERT_ATTN_RESIDENT", "0")
+        old = eng.hidden(seqs, None)
+        monkeypatch.delenv("CQS_HIP_BERT_ATTN_RESIDENT")
+        assert not np.array_equal(got, old)                    # (the switch does select another kernel)
+        ids, mask, tt = _padded(seqs)
+        ref = R.encode(cfg, w, ids, mask, tt).numpy()
+        m = 0
+        for i, n in enumerate(lens):
+            g, o, r = got[m:m + n], old[m:m + n], ref[i, :n]
+            assert np.isfinite(g).all()
+            err = np.abs(g - r)
+            assert err.mean() / np.abs(r).mean() < 0.02 and err.max() < 0.25, (n, err.mean(), err.max())
+            assert cos(g.ravel(), r.ravel()) > 0.999, n
+            assert cos(g.ravel(), o.ravel()) > 0.9995, n
+            # no further from the oracle than the first-generation kernel (plus noise)
+            assert err.mean() <= np.abs(o - r).mean() * 1.25 + 1e-4, (n, err.mean(), np.abs(o - r).mean())
+            m += n
+    eng.close()
+
+
 def test_splade_sparse_vectors(hip):
     """`encode_batch`: activations against the oracle, and the sparse vectors the threshold leaves: every strong
     weight present with the same id, weights within bf16 noise, ascending ids, nothing at or below the threshold."""
