@@ -57,6 +57,7 @@ struct cqs_hip_embedder {
     std::vector<cqs::QueryFwdLayer> QL;   // the same pointers in the query path's layout (filled by finalize)
     bool query_path = false;              // geometry supported and not disabled by CQS_HIP_QUERY_PATH=0
     bool query_graph = true;              // CQS_HIP_QUERY_GRAPH=0: launch the query chain eagerly
+    bool query_direct = true;             // CQS_HIP_QUERY_DIRECT=0: token ids / result always through copy calls
     float *rope_global = nullptr, *rope_local = nullptr;  // [max_seq][128][2]
     std::map<std::string, bool> seen;
     bool finalized = false;
@@ -84,8 +85,16 @@ struct cqs_hip_embedder {
         bf16_t *q_qkv = nullptr, *q_attn = nullptr, *q_y = nullptr, *q_h = nullptr, *q_d1 = nullptr;
         // one captured chain per query length T = 1..64 (T is a launch parameter of every kernel: no load waits for a
         // length read from memory, no row past T is touched), captured the first time a length is seen
-        hipGraph_t q_graph[64] = {};
-        hipGraphExec_t q_exec[64] = {};
+        // [variant][T - 1]; variant 1 = "direct": the token ids are read from, and the sentence vector is written to,
+        // the context's own pinned host buffers (q_tok_pin / q_out_pin, device-visible) - no H2D / D2H copy node and no
+        // copy call around the chain.  Used when the context has no other ticket in flight (the blocking `embed_query`
+        // call); a second ticket queued on the same context would overwrite those buffers, so it takes variant 0.
+        hipGraph_t q_graph[2][64] = {};
+        hipGraphExec_t q_exec[2][64] = {};
+        int32_t* q_tok_pin = nullptr;      // pinned host, 64 ids
+        float* q_out_pin = nullptr;        // pinned host, [hidden]
+        int32_t* q_tok_pin_dev = nullptr;  // their device addresses
+        float* q_out_pin_dev = nullptr;
         uint32_t q_runs = 0;          // eager runs so far (the first sets the kernels' LDS attributes; graphs are captured after it)
         bool q_graph_failed = false;  // capture / instantiate refused once: stay eager
         unsigned long long* q_dbg = nullptr;   // CQS_HIP_QUERY_STAMPS=1: per-kernel, per-workgroup stamps of the last query
@@ -105,6 +114,7 @@ struct cqs_hip_embedder {
         hipEvent_t done = nullptr;
         uint64_t ticket = 0;       // 0 = free
         int ctx = 0;               // execution context the ticket runs on
+        bool direct = false;       // the result is in the context's q_out_pin, not in `out`
     };
     static constexpr int kSlots = 3;
     Slot slot[kSlots];
@@ -152,11 +162,15 @@ int32_t upload_f32(cqs_hip_embedder* e, float* dst, const float* src, size_t cou
 using Ctx = cqs_hip_embedder::Ctx;
 
 void free_query_scratch(Ctx& c) {
-    for (int i = 0; i < 64; ++i) {
-        if (c.q_exec[i]) (void)hipGraphExecDestroy(c.q_exec[i]);
-        if (c.q_graph[i]) (void)hipGraphDestroy(c.q_graph[i]);
-        c.q_exec[i] = nullptr; c.q_graph[i] = nullptr;
-    }
+    for (int v = 0; v < 2; ++v)
+        for (int i = 0; i < 64; ++i) {
+            if (c.q_exec[v][i]) (void)hipGraphExecDestroy(c.q_exec[v][i]);
+            if (c.q_graph[v][i]) (void)hipGraphDestroy(c.q_graph[v][i]);
+            c.q_exec[v][i] = nullptr; c.q_graph[v][i] = nullptr;
+        }
+    if (c.q_tok_pin) (void)hipHostFree(c.q_tok_pin);
+    if (c.q_out_pin) (void)hipHostFree(c.q_out_pin);
+    c.q_tok_pin = nullptr; c.q_out_pin = nullptr; c.q_tok_pin_dev = nullptr; c.q_out_pin_dev = nullptr;
     void** all[] = {(void**)&c.q_dbg, (void**)&c.q_meta, (void**)&c.q_x0, (void**)&c.q_x1, (void**)&c.q_out, (void**)&c.q_qkv, (void**)&c.q_attn,
                     (void**)&c.q_y, (void**)&c.q_h, (void**)&c.q_d1};
     for (void** p : all) { (void)hipFree(*p); *p = nullptr; }
@@ -358,6 +372,11 @@ int32_t ensure_query_scratch(cqs_hip_embedder* e, Ctx& c) {
         grab(&c.q_dbg, words);
         if (he == hipSuccess) he = hipMemsetAsync(c.q_dbg, 0, words * 8, c.stream);
     }
+    if (he == hipSuccess) he = hipHostMalloc((void**)&c.q_tok_pin, R * sizeof(int32_t), hipHostMallocDefault);
+    if (he == hipSuccess) he = hipHostMalloc((void**)&c.q_out_pin, H * sizeof(float), hipHostMallocDefault);
+    if (he == hipSuccess) he = hipHostGetDevicePointer((void**)&c.q_tok_pin_dev, c.q_tok_pin, 0);
+    if (he == hipSuccess) he = hipHostGetDevicePointer((void**)&c.q_out_pin_dev, c.q_out_pin, 0);
+    if (he == hipSuccess) memset(c.q_tok_pin, 0, R * sizeof(int32_t));
     if (he == hipSuccess) he = hipMemsetAsync(c.q_x0, 0, R * H * 4, c.stream);
     if (he == hipSuccess) he = hipMemsetAsync(c.q_x1, 0, R * H * 4, c.stream);
     if (he == hipSuccess) he = hipMemsetAsync(c.q_qkv, 0, R * nqkv(g) * 2, c.stream);
@@ -373,12 +392,14 @@ int32_t ensure_query_scratch(cqs_hip_embedder* e, Ctx& c) {
 
 // Enqueue on the context's stream: [T, tokens] H2D, the chain (graph replay once captured); leaves the sentence
 // vector (f32 [hidden], not normalised) in c.q_out.
-int32_t run_query(cqs_hip_embedder* e, Ctx& c, Slot& sl) {
+int32_t run_query(cqs_hip_embedder* e, Ctx& c, Slot& sl, bool direct) {
     const cqs::EmbedGeom& g = e->g;
     hipStream_t st = c.stream;
     int32_t rc = ensure_query_scratch(e, c);
     if (rc != CQS_HIP_OK) return rc;
-    E_TRY(e, hipMemcpyAsync(c.q_meta, sl.meta, (size_t)sl.M * sizeof(int32_t), hipMemcpyHostToDevice, st));   // slot_fill: the token ids come first
+    const int var = direct ? 1 : 0;
+    if (direct) memcpy(c.q_tok_pin, sl.meta, (size_t)sl.M * sizeof(int32_t));     // the context is idle: nobody reads it now
+    else E_TRY(e, hipMemcpyAsync(c.q_meta, sl.meta, (size_t)sl.M * sizeof(int32_t), hipMemcpyHostToDevice, st));   // slot_fill: the token ids come first
     E_TRY(e, hipEventRecord(sl.ev0, st));
     cqs::QueryFwd f{};
     f.tok = c.q_meta; f.T = sl.M; f.emb = e->emb; f.embed_scale = sqrtf((float)g.hidden); f.layer = e->QL.data(); f.layers = g.layers;
@@ -387,9 +408,10 @@ int32_t run_query(cqs_hip_embedder* e, Ctx& c, Slot& sl) {
     f.window = g.window; f.sliding_pattern = g.sliding_pattern; f.eps = g.rms_eps; f.q_scale = g.q_scale;
     f.dbg = c.q_dbg;
     f.x0 = c.q_x0; f.x1 = c.q_x1; f.qkv = c.q_qkv; f.attn = c.q_attn; f.y = c.q_y; f.h = c.q_h; f.d1 = c.q_d1; f.out = c.q_out;
+    if (direct) { f.tok = c.q_tok_pin_dev; f.out = c.q_out_pin_dev; }
     const int gi = (int)sl.M - 1;
-    if (c.q_exec[gi]) {
-        E_TRY(e, hipGraphLaunch(c.q_exec[gi], st));
+    if (c.q_exec[var][gi]) {
+        E_TRY(e, hipGraphLaunch(c.q_exec[var][gi], st));
         return CQS_HIP_OK;
     }
     if (e->query_graph && !c.q_graph_failed && c.q_runs >= 1) {
@@ -400,14 +422,14 @@ int32_t run_query(cqs_hip_embedder* e, Ctx& c, Slot& sl) {
             hipGraph_t gr = nullptr;
             he = hipStreamEndCapture(st, &gr);
             if (he == hipSuccess && le != hipSuccess) he = le;
-            if (he == hipSuccess) he = hipGraphInstantiate(&c.q_exec[gi], gr, nullptr, nullptr, 0);
+            if (he == hipSuccess) he = hipGraphInstantiate(&c.q_exec[var][gi], gr, nullptr, nullptr, 0);
             if (he == hipSuccess) {
-                c.q_graph[gi] = gr;
-                E_TRY(e, hipGraphLaunch(c.q_exec[gi], st));
+                c.q_graph[var][gi] = gr;
+                E_TRY(e, hipGraphLaunch(c.q_exec[var][gi], st));
                 return CQS_HIP_OK;
             }
             if (gr) (void)hipGraphDestroy(gr);
-            c.q_exec[gi] = nullptr;
+            c.q_exec[var][gi] = nullptr;
         }
         (void)hipGetLastError();
         c.q_graph_failed = true;        // not a device failure: the eager chain below computes the same thing
@@ -586,6 +608,8 @@ int32_t cqs_hip_embedder_finalize(cqs_hip_embedder* e) CQS_ABI_TRY {
     const char* qg = getenv("CQS_HIP_QUERY_GRAPH");
     e->query_path = cqs::query_forward_supported(e->g) && !(qp && qp[0] == '0');
     e->query_graph = !(qg && qg[0] == '0');
+    const char* qd = getenv("CQS_HIP_QUERY_DIRECT");
+    e->query_direct = !(qd && qd[0] == '0');
     e->finalized = true;
     return CQS_HIP_OK;
 } CQS_ABI_CATCH(e)
@@ -717,10 +741,11 @@ int32_t submit_locked(cqs_hip_embedder* e, uint32_t B, const std::function<int32
         E_TRY(e, hipEventRecord(sl->ev1, st));
         E_TRY(e, hipEventRecord(sl->done, st));
     } else if (slot_takes_query_path(e, *sl)) {
-        rc = run_query(e, c, *sl);
-        if (rc != CQS_HIP_OK) return rc;
+        sl->direct = e->query_direct && load[ci] == 0;          // nothing else in flight on this context
+        rc = run_query(e, c, *sl, sl->direct);
+        if (rc != CQS_HIP_OK) { sl->direct = false; return rc; }
         E_TRY(e, hipEventRecord(sl->ev1, st));
-        E_TRY(e, hipMemcpyAsync(sl->out, c.q_out, (size_t)H * sizeof(float), hipMemcpyDeviceToHost, st));
+        if (!sl->direct) E_TRY(e, hipMemcpyAsync(sl->out, c.q_out, (size_t)H * sizeof(float), hipMemcpyDeviceToHost, st));
         E_TRY(e, hipEventRecord(sl->done, st));
     } else {
         rc = run_layers(e, c, *sl);
@@ -776,7 +801,7 @@ int32_t cqs_hip_embed_collect(cqs_hip_embedder* e, uint64_t ticket, float* out) 
     if (he != hipSuccess) { sl->ticket = 0; return efail(e, CQS_HIP_ERR_DEVICE, "collect: device failure", he); }
     const uint32_t H = e->g.hidden, B = sl->B;
     if (out) {                         // out == NULL: abandon the ticket (wait, release the slot, drop the rows)
-        memcpy(out, sl->out, (size_t)B * H * sizeof(float));
+        memcpy(out, sl->direct ? e->ctx[sl->ctx].q_out_pin : sl->out, (size_t)B * H * sizeof(float));
         const int32_t* seq_len = sl->meta + (size_t)2 * sl->M + B;
         for (uint32_t b = 0; b < B; ++b)   // empty rows: exact zeros, like the reference's zero-mask pooling
             if (seq_len[b] == 0) memset(out + (size_t)b * H, 0, (size_t)H * sizeof(float));
@@ -784,6 +809,7 @@ int32_t cqs_hip_embed_collect(cqs_hip_embedder* e, uint64_t ticket, float* out) 
     float ms = -1.f;
     if (hipEventElapsedTime(&ms, sl->ev0, sl->ev1) == hipSuccess) e->last_ms = ms;
     sl->ticket = 0;
+    sl->direct = false;
     return CQS_HIP_OK;
 } CQS_ABI_CATCH(e)
 

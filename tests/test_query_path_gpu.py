@@ -71,6 +71,27 @@ def test_graph_replay_equals_eager_across_lengths(hip, monkeypatch):
     eng_g.close(); eng_e.close()
 
 
+def test_direct_host_buffers_equal_the_copy_calls(hip, monkeypatch):
+    """A query on an idle context reads its token ids from, and writes its vector to, the context's pinned host buffers
+    (no H2D / D2H copy calls); CQS_HIP_QUERY_DIRECT=0 keeps the copies.  Same kernels, same arithmetic: bit-identical -
+    also when a later query is shorter than the one before it (stale ids past T in the pinned buffer are never read),
+    and for tickets queued behind one another (the second on a context takes the copy variant)."""
+    eng_d, w = make(SMALL, seed=37)
+    monkeypatch.setenv("CQS_HIP_QUERY_DIRECT", "0")
+    eng_c, _ = make(SMALL, seed=37)
+    monkeypatch.delenv("CQS_HIP_QUERY_DIRECT")
+    for j, n in enumerate([64, 3, 17, 1, 48, 8, 8, 33]):
+        ids, mask = _one(SMALL, n, seed=500 + j)
+        a, b = eng_d.run(ids, mask), eng_c.run(ids, mask)
+        assert np.array_equal(a, b), (j, n)
+    qs = [_one(SMALL, n, seed=600 + n) for n in (12, 40, 7)]
+    want = [eng_c.run(i, m) for i, m in qs]
+    tickets = [eng_d.submit(i, m) for i, m in qs]             # contexts 0, 1, 0: the third is queued behind the first
+    for t, wv in zip(tickets, want):
+        assert np.array_equal(eng_d.collect(t, 1), wv)
+    eng_d.close(); eng_c.close()
+
+
 def test_query_path_full_geometry(hip):
     """EmbeddingGemma's real per-layer geometry (768 | 3 x 256 q, 1 kv | 1152 | Dense 3072), 4 layers incl. one
     full-attention layer, the 262 144-row vocabulary left out (a 4 096-row table): vs the fp32 oracle."""
