@@ -51,6 +51,23 @@ struct MfmaParams {
     uint32_t q_blocks;   // scan_mfma16_kernel: query blocks of QT per row tile (task = row tile * q_blocks + query block)
 };
 
+// max over each 32-lane half of the wave, in every lane: four DPP steps inside the 16-lane rows (quad_perm xor 1, xor 2,
+// row_half_mirror, row_mirror) + one v_permlane16_swap between the rows of a half - VALU only (as __shfl_xor these were
+// 5 ds_bpermute round trips through the LDS queue per maximum, 160 per wave and tile)
+template <int CTRL>
+__device__ __forceinline__ float scan_dpp(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float half_wave_max(float m) {
+    typedef unsigned pu2 __attribute__((ext_vector_type(2)));
+    m = fmaxf(m, scan_dpp<0xB1>(m));
+    m = fmaxf(m, scan_dpp<0x4E>(m));
+    m = fmaxf(m, scan_dpp<0x141>(m));
+    m = fmaxf(m, scan_dpp<0x140>(m));
+    const pu2 a = __builtin_amdgcn_permlane16_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+    return fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+}
+
 template <int QW, int WQ, int RW, int WR, bool NT>
 __global__ __launch_bounds__(64 * WQ * WR, WQ * WR / 4) void scan_mfma_kernel(const MfmaParams p) {
     constexpr int QT = 32 * QW * WQ, RT = 32 * RW * WR;
@@ -221,8 +238,7 @@ __global__ __launch_bounds__(64 * WQ * WR, WQ * WR / 4) void scan_mfma_kernel(co
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     float m = fmaxf(acc[a][2 * g][r], acc[a][2 * g + 1][r]);
-#pragma unroll
-                    for (int off = 16; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+                    m = half_wave_max(m);
                     const uint32_t qi = (uint32_t)((wq * QW + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh);
                     if (l31 == 0 && qi < p.b)
                         p.gmax[(size_t)qi * (p.n_pad / 64u) + task * gpt + (uint32_t)(wr * (RW / 2) + g)] = m;
@@ -407,8 +423,7 @@ __global__ __launch_bounds__(256, 2) void scan_mfma16_kernel(const MfmaParams p)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     float m = fmaxf(acc[a][2 * g][r], acc[a][2 * g + 1][r]);
-#pragma unroll
-                    for (int off = 16; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+                    m = half_wave_max(m);
                     const uint32_t qi = (uint32_t)((wq * QW + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh);
                     if (l31 == 0 && qi < b_live)
                         gmax[(size_t)qi * (p.n_pad / 64u) + rtile * gpt + (uint32_t)(wr * (RW / 2) + g)] = m;
