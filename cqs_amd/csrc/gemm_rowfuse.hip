@@ -89,7 +89,11 @@ __global__ __launch_bounds__(512, 2) void gemm_rowfuse_kernel(const bf16_t* __re
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {
         const uint32_t R = (uint32_t)(8 * hf) + r8;
+#if defined(CQS_RF_ABLATE_SAMEW)   // timing experiment: every wave streams wave 0's rows (1 / 8 of the distinct lines per CU)
+        voffW[hf] = (R * K + ((pc ^ ((R >> 1) & 7u)) * 8u)) * 2u;
+#else
         voffW[hf] = (((uint32_t)(96 * wid) + R) * K + ((pc ^ ((R >> 1) & 7u)) * 8u)) * 2u;
+#endif
     }
     // A: wave w covers tile rows 8 w + r8 (R = that row & 15)
     uint32_t arow = (uint32_t)(8 * wid) + r8;
