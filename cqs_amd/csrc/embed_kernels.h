@@ -159,4 +159,10 @@ hipError_t launch_query_forward(const QueryFwd& f, hipStream_t st);
 // f32 -> bf16 (round to nearest even), n elements
 hipError_t launch_f32_to_bf16(const float* in, bf16_t* out, size_t n, hipStream_t st);
 
+// C[M, N] = act(A W^T + bias) for M <= 64 rows through the search-time GEMM kernels (query_kernels.hip): N % 8 == 0,
+// K % 128 == 0, out in {BF16, BF16_GELU, F32}; hipErrorNotSupported otherwise (the caller falls back to launch_gemm_bias's
+// other kernels).  Not bit-identical to them: K is split over a workgroup's four waves.
+hipError_t launch_gemm_small_rows(const bf16_t* A, const bf16_t* W, const float* bias, void* C, uint32_t M, uint32_t N,
+                                  uint32_t K, uint32_t ldc, GemmOut out, hipStream_t st);
+
 }  // namespace cqs

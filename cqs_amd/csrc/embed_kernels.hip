@@ -1314,6 +1314,15 @@ hipError_t launch_gemm_bias(const bf16_t* A, const bf16_t* W, const float* bias,
     // Crossover measured on whole forwards (tools/bert_fewrows_sweep.py): few-rows wins up to ~900 tokens for BERT-base
     // (hidden 768), ~600 for BERT-large (1024), ~2000 for MiniLM (384) - for ALL of a layer's projections, the K = 4 x
     // hidden one included - i.e. tokens x hidden <~ 640 Ki; min(N, K) is the hidden size of every BERT projection.
+    // up to 64 rows (a SPLADE query, one short passage): the search-time kernels - K split over a workgroup's waves, 96-384
+    // workgroups - instead of 24-96 lone waves walking all of K (BERT-base FFN2 at 16 tokens: 25 us -> 3 us)
+    if (M <= 64u) {
+        const char* sr = getenv("CQS_HIP_GEMM_SMALL_ROWS");       // read per call: a test flips it inside one process
+        if (!(sr && sr[0] == '0')) {
+            const hipError_t e = launch_gemm_small_rows(A, W, bias, C, M, N, K, ldc, out, st);
+            if (e != hipErrorNotSupported) return e;
+        }
+    }
     static const uint64_t few_mh = [] { const char* f = getenv("CQS_HIP_GEMM_BIAS_FEWROWS_MH"); return f ? (uint64_t)atoll(f) : 640ull * 1024ull; }();
     if ((uint64_t)M * (N < K ? N : K) <= few_mh && N % 64u == 0) return launch_gemm_fewrows(A, W, bias, C, M, N, K, ldc, out, st);
     // just above the few-rows range the 128 x 128 kernel still beats a mostly empty round of 256-row tiles (measured:

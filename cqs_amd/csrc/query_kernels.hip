@@ -88,6 +88,22 @@ __device__ __forceinline__ float qf_gelu_tanh(float x) {      // as gelu_tanh (e
     const float u2 = 2.0f * k0 * (x + k1 * x * x * x);
     return x * __frcp_rn(1.0f + __expf(-u2));
 }
+__device__ __forceinline__ float qf_gelu_erf(float x) {       // as gelu_erf (embed_kernels.hip): Abramowitz-Stegun 7.1.26
+    const float z = __builtin_fabsf(x) * 0.70710678118654752f;
+    const float t = __frcp_rn(1.0f + 0.3275911f * z);
+    const float poly = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f) * t;
+    const float e = 1.0f - poly * __expf(-z * z);
+    return 0.5f * x * (1.0f + __builtin_copysignf(e, x));
+}
+// bias + activation of the plain / staged kernels' epilogue (columns col .. col + 3)
+__device__ __forceinline__ f4 qf_bias_act(f4 v, const float* __restrict__ bias, int32_t act, uint32_t col) {
+    if (bias) v += *(const f4*)(bias + col);
+    if (act == 1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = qf_gelu_erf(v[r]);
+    }
+    return v;
+}
 
 // Diagnostic stamps (off unless the engine was created under CQS_HIP_QUERY_STAMPS=1): workgroup b (< 256) of chain
 // kernel `slot` writes the 100 MHz realtime counter at phase i - where a 4 us kernel that moves 30 KB spends its time.
@@ -116,6 +132,8 @@ struct QfGemmParams {
     uint32_t K, ldc;
     uint32_t T;               // tokens, 1..64: a LAUNCH parameter (the engine keeps one captured graph per length)
     int32_t one_row;          // 1: the GEMM's activations are ONE row (the pooled vector)
+    const float* bias;        // plain / staged kernels: nullable, [N] f32 added before the activation (BERT projections)
+    int32_t act;              // plain / staged kernels: 1 = erf-GELU after the bias (BERT's FFN)
     unsigned long long* dbg;  // nullable (CQS_HIP_QUERY_STAMPS=1): [kernel slot][workgroup < 256][8] realtime stamps
     uint32_t dbg_slot;
 };
@@ -182,6 +200,7 @@ __global__ __launch_bounds__(256) void qf_gemm_plain_kernel(const QfGemmParams p
     const uint32_t row = 16u * (uint32_t)wid + (uint32_t)l15;
     if (row >= rows || 4 * lg >= NC) return;                       // columns 4 lg .. 4 lg + 3 of the tile: real iff < NC
     const size_t off = (size_t)row * p.ldc + blockIdx.x * (uint32_t)NC + 4u * (uint32_t)lg;
+    v = qf_bias_act(v, p.bias, p.act, blockIdx.x * (uint32_t)NC + 4u * (uint32_t)lg);
     if (EPI == QF_EPI_F32) {
         *(f4*)((float*)p.C + off) = v;
     } else {
@@ -306,6 +325,7 @@ __global__ __launch_bounds__(256) void qf_gemm_staged_kernel(const QfGemmParams 
     const uint32_t row = 16u * (uint32_t)wid + (uint32_t)l15;
     if (row >= rows || 4 * lg >= NC) return;
     const size_t off = (size_t)row * p.ldc + blockIdx.x * (uint32_t)NC + 4u * (uint32_t)lg;
+    v = qf_bias_act(v, p.bias, p.act, blockIdx.x * (uint32_t)NC + 4u * (uint32_t)lg);
     if (EPI == QF_EPI_F32) {
         *(f4*)((float*)p.C + off) = v;
     } else {
@@ -1070,6 +1090,21 @@ hipError_t qf_forward_t(const QueryFwd& f, hipStream_t st) {
 }
 
 }  // namespace
+
+// C[M, N] = act(A[M, K] W[N, K]^T + bias) for M <= 64 rows (a search-time SPLADE query, a rerank of one short passage):
+// the search-time GEMM kernels above - 8 output columns per workgroup, K split over its 4 waves, both operands staged
+// through LDS by coalesced loads where they fit - instead of one wave walking all of K per 32 x 32 tile.
+// hipErrorNotSupported: shape outside what those kernels take (the caller falls back).
+hipError_t launch_gemm_small_rows(const bf16_t* A, const bf16_t* W, const float* bias, void* C, uint32_t M, uint32_t N,
+                                  uint32_t K, uint32_t ldc, GemmOut out, hipStream_t st) {
+    if (M == 0) return hipSuccess;
+    if (M > 64u || N % 8u || K % 128u || K < 128u) return hipErrorNotSupported;
+    if (out != GEMM_OUT_BF16 && out != GEMM_OUT_BF16_GELU && out != GEMM_OUT_F32) return hipErrorNotSupported;
+    QfGemmParams p{};
+    p.T = M; p.A = A; p.K = K; p.W = W; p.C = C; p.ldc = ldc; p.bias = bias; p.act = out == GEMM_OUT_BF16_GELU ? 1 : 0;
+    if (out == GEMM_OUT_F32) return qf_launch_plain<QF_EPI_F32, 8>(p, N, st);
+    return qf_launch_plain<QF_EPI_BF16, 8>(p, N, st);
+}
 
 bool query_forward_supported(const EmbedGeom& g) {
     const uint32_t HQ = g.heads * 256u;

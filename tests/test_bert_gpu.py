@@ -143,7 +143,20 @@ def test_splade_sparse_vectors(hip):
         for tok, wt in g.items():
             assert wd[tok] > thr - 0.08                                      # nothing far below the threshold got in
         j += 1
-    assert enc.encode(seqs[0]) == got[0]
+    # `encode` = a batch of one: 40 tokens alone take the search-time GEMM kernels (another f32 association than the
+    # batch's kernels): the same vector up to bf16 noise - ids equal away from the threshold, weights within 0.01
+    one, many = dict(enc.encode(seqs[0])), dict(got[0])
+    for tok in set(one) | set(many):
+        if tok in one and tok in many:
+            assert abs(one[tok] - many[tok]) < 0.01, (tok, one[tok], many[tok])
+        else:
+            assert abs((one.get(tok) or many.get(tok)) - thr) < 0.02, (tok, one.get(tok), many.get(tok))
+    import os
+    os.environ["CQS_HIP_GEMM_SMALL_ROWS"] = "0"
+    try:
+        assert enc.encode(seqs[0]) == got[0]                                    # the same kernels: the same bits
+    finally:
+        del os.environ["CQS_HIP_GEMM_SMALL_ROWS"]
     eng.close()
 
 
@@ -172,14 +185,52 @@ def test_splade_ids_at_the_default_threshold(hip):
     eng.close()
 
 
-def test_splade_padding_free_and_batch_invariant(hip):
+def test_splade_padding_free_and_batch_invariant(hip, monkeypatch):
+    """Packed tokens: a sequence's activations do not depend on its neighbours in the batch - bit for bit as long as the
+    projections take the same kernels.  Batches of up to 64 tokens take the search-time GEMM kernels (K split over a
+    workgroup's waves: another f32 association), so a short sequence ALONE is compared bit for bit with that path
+    switched off (CQS_HIP_GEMM_SMALL_ROWS=0, read per call) and to cosine 0.9999 / 2 % of the largest activation with it."""
     cfg = R.BertConfig(vocab_size=1000, hidden=384, layers=2, heads=12, intermediate=768, max_pos=128)
     eng, _ = _engine(cfg, "mlm", seed=5)
     seqs = _seqs(cfg, [33, 100, 5], seed=6)
     full = eng.splade_dense(seqs)
+    assert np.array_equal(eng.splade_dense(seqs), full)                     # deterministic
+    assert np.array_equal(eng.splade_dense([seqs[1]])[0], full[1])          # 100 tokens alone: the same kernels
+    for i in (0, 2):
+        alone = eng.splade_dense([seqs[i]])[0]
+        assert np.array_equal(eng.splade_dense([seqs[i]])[0], alone)
+        assert cos(alone, full[i]) > 0.9999 and np.max(np.abs(alone - full[i])) < 0.02 * np.abs(full[i]).max() + 1e-3
+    monkeypatch.setenv("CQS_HIP_GEMM_SMALL_ROWS", "0")
     for i, s in enumerate(seqs):
         assert np.array_equal(eng.splade_dense([s])[0], full[i])            # packed: neighbours do not matter
-    assert np.array_equal(eng.splade_dense(seqs), full)                     # deterministic
+    monkeypatch.delenv("CQS_HIP_GEMM_SMALL_ROWS")
+    eng.close()
+
+
+@pytest.mark.parametrize("hidden,heads,inter", [(768, 12, 3072), (384, 12, 1536), (1024, 16, 4096)])
+def test_small_batches_through_the_search_time_gemms(hip, monkeypatch, hidden, heads, inter):
+    """A batch of up to 64 tokens (a SPLADE query, one short passage) runs its projections through the search-time GEMM
+    kernels (`launch_gemm_small_rows`: bias + erf-GELU epilogue; staged operands for K in {384, 768, 3072}, the gather form
+    for other K): token counts around the row-tile edges, BERT-base / MiniLM / BERT-large widths, against the oracle and
+    against the one-wave-per-tile kernels (CQS_HIP_GEMM_SMALL_ROWS=0)."""
+    cfg = R.BertConfig(vocab_size=700, hidden=hidden, layers=2, heads=heads, intermediate=inter, max_pos=128)
+    eng, w = _engine(cfg, "none", seed=21)
+    for lens in ([1], [8], [16], [17], [33], [48], [49], [64], [20, 30, 14], [3, 2]):
+        seqs = _seqs(cfg, lens, seed=22 + sum(lens))
+        got = eng.hidden(seqs, None)
+        monkeypatch.setenv("CQS_HIP_GEMM_SMALL_ROWS", "0")
+        old = eng.hidden(seqs, None)
+        monkeypatch.delenv("CQS_HIP_GEMM_SMALL_ROWS")
+        ids, mask, tt = _padded(seqs)
+        ref = R.encode(cfg, w, ids, mask, tt).numpy()
+        m = 0
+        for i, n in enumerate(lens):
+            g, o, r = got[m:m + n], old[m:m + n], ref[i, :n]
+            assert np.isfinite(g).all()
+            err = np.abs(g - r)
+            assert err.mean() / np.abs(r).mean() < 0.02 and err.max() < 0.25, (lens, i, err.mean(), err.max())
+            assert cos(g.ravel(), r.ravel()) > 0.999 and cos(g.ravel(), o.ravel()) > 0.9995, (lens, i)
+            m += n
     eng.close()
 
 
