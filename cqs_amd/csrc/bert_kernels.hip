@@ -562,29 +562,29 @@ __global__ __launch_bounds__(256) void splade_activate_kernel(float* __restrict_
 
 // Threshold filter of src/splade/mod.rs:1049-1062 on the device: row b of the [B, V] activations -> its entries
 // > threshold as (id, weight), ascending id, at most `cap` of them (count[b] reports how many there ARE: a count above
-// cap tells the caller to take the dense row instead).  One workgroup per row; 1024 columns per step, ordered by a
-// block-wide exclusive scan of the per-thread hit counts.  NaN > t is false (dropped), +Inf passes, as in the reference.
-__global__ __launch_bounds__(256) void splade_sparsify_kernel(const float* __restrict__ dense, uint32_t V, float threshold,
-                                                              uint32_t cap, uint32_t* __restrict__ out_ids,
-                                                              float* __restrict__ out_w, uint32_t* __restrict__ out_count) {
-    constexpr uint32_t PER = 16;                         // consecutive columns per thread per step (4096 per workgroup step)
-    __shared__ uint32_t wave_tot[4];
-    __shared__ uint32_t base_s;
+// cap tells the caller to take the dense row instead).  One workgroup of 16 waves per row; a thread owns 32 CONSECUTIVE
+// columns of a 32 768-column step (a BERT vocabulary is one step: every load of the row is in flight at once, one
+// block-wide exclusive scan of the per-thread hit counts orders the output; the first version - 256 threads, 4 096
+// columns and two barriers per step - took 26 us for the one row of a search-time query).  NaN > t is false (dropped),
+// +Inf passes, as in the reference.
+__global__ __launch_bounds__(1024) void splade_sparsify_kernel(const float* __restrict__ dense, uint32_t V, float threshold,
+                                                               uint32_t cap, uint32_t* __restrict__ out_ids,
+                                                               float* __restrict__ out_w, uint32_t* __restrict__ out_count) {
+    constexpr uint32_t PER = 32;
+    __shared__ uint32_t wave_tot[16];
     const uint32_t b = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
     const float* row = dense + (size_t)b * V;
-    if (tid == 0) base_s = 0;
-    __syncthreads();
-    for (uint32_t v0 = 0; v0 < V; v0 += 256u * PER) {
+    uint32_t base = 0;                                   // hits in the steps before this one (the same in every thread)
+    for (uint32_t v0 = 0; v0 < V; v0 += 1024u * PER) {
         const uint32_t v = v0 + tid * PER;
         float x[PER];
         uint32_t hit = 0;
 #pragma unroll
-        for (uint32_t j = 0; j < PER; ++j) {
-            x[j] = v + j < V ? row[v + j] : 0.f;
-            hit |= (uint32_t)(v + j < V && x[j] > threshold) << j;
-        }
+        for (uint32_t j = 0; j < PER; ++j) x[j] = v + j < V ? row[v + j] : 0.f;
+#pragma unroll
+        for (uint32_t j = 0; j < PER; ++j) hit |= (uint32_t)(v + j < V && x[j] > threshold) << j;
         const uint32_t n = (uint32_t)__builtin_popcount(hit);
-        // exclusive scan of n over the workgroup: inside the wave by shuffles, across the 4 waves through LDS
+        // exclusive scan of n over the workgroup: inside the wave by shuffles, across the 16 waves through LDS
         uint32_t inc = n;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
@@ -593,20 +593,26 @@ __global__ __launch_bounds__(256) void splade_sparsify_kernel(const float* __res
         }
         if (lane == 63u) wave_tot[wid] = inc;
         __syncthreads();
-        uint32_t before = base_s;
-        for (uint32_t w = 0; w < wid; ++w) before += wave_tot[w];
-        uint32_t pos = before + inc - n;
+        uint32_t before = base, total = 0;
 #pragma unroll
-        for (uint32_t j = 0; j < PER; ++j)
-            if ((hit >> j) & 1u) {
-                if (pos < cap) { out_ids[(size_t)b * cap + pos] = v + j; out_w[(size_t)b * cap + pos] = x[j]; }
-                ++pos;
-            }
-        __syncthreads();
-        if (tid == 0) base_s += wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
-        __syncthreads();
+        for (uint32_t w = 0; w < 16u; ++w) {
+            const uint32_t t = wave_tot[w];
+            before += w < wid ? t : 0u;
+            total += t;
+        }
+        uint32_t pos = before + inc - n;
+        if (hit) {
+#pragma unroll
+            for (uint32_t j = 0; j < PER; ++j)
+                if ((hit >> j) & 1u) {
+                    if (pos < cap) { out_ids[(size_t)b * cap + pos] = v + j; out_w[(size_t)b * cap + pos] = x[j]; }
+                    ++pos;
+                }
+        }
+        base += total;
+        __syncthreads();                                 // wave_tot is rewritten by the next step
     }
-    if (tid == 0) out_count[b] = base_s;
+    if (tid == 0) out_count[b] = base;
 }
 
 // Pooling of the BERT-family EMBEDDERS (e5-base, v9-200k, bge-large presets: src/embedder/models.rs:346-405), over the
@@ -647,7 +653,7 @@ hipError_t launch_bert_pool(const bf16_t* x, const int32_t* seq_start, const int
 hipError_t launch_splade_sparsify(const float* dense, uint32_t B, uint32_t V, float threshold, uint32_t cap, uint32_t* out_ids,
                                   float* out_w, uint32_t* out_count, hipStream_t st) {
     if (B == 0) return hipSuccess;
-    hipLaunchKernelGGL(splade_sparsify_kernel, dim3(B), dim3(256), 0, st, dense, V, threshold, cap, out_ids, out_w, out_count);
+    hipLaunchKernelGGL(splade_sparsify_kernel, dim3(B), dim3(1024), 0, st, dense, V, threshold, cap, out_ids, out_w, out_count);
     return hipGetLastError();
 }
 
