@@ -686,6 +686,51 @@ def abi_after_group_leg(a, torch, np, world, k, dim, rows_per_device=250_000, bu
     return box.get("res")
 
 
+def strong_n1_leg(a, torch, k, dim, total_rows, budget_s=120.0):
+    """Rank 0, after the process group is gone (N > 1 strong mode): the SAME corpus size on ONE GPU, one query per step -
+    the N = 1 point of the strong-scaling curve, measured in the same run (the driver's own N = 1 run is the headline
+    configs[1] workload, 1M rows: not comparable with a 10M-row strong-scaling line).  Watchdog thread, never loses the line."""
+    import threading
+    box = {}
+
+    def work():
+        try:
+            from cqs_amd import HipIndex
+            dev0 = torch.device("cuda", 0)
+            torch.cuda.set_device(0)
+            rows = make_unit_rows(torch, total_rows, dim, 0xC950021, dev0)
+            q = make_unit_rows(torch, 32, dim, 0xC950022, dev0)
+            idx = HipIndex.build_from_device(None, rows.data_ptr(), total_rows, dim, borrow=True, keepalive=rows)
+            keys = torch.zeros((1, k), dtype=torch.int64, device=dev0)
+            cnt = torch.zeros((1,), dtype=torch.int32, device=dev0)
+            st = torch.cuda.current_stream().cuda_stream
+            for i in range(8):
+                idx.search_device(q[i % 32].data_ptr(), 1, k, keys.data_ptr(), cnt.data_ptr(), stream=st)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            steps = 24
+            e0.record()
+            for i in range(steps):
+                idx.search_device(q[i % 32].data_ptr(), 1, k, keys.data_ptr(), cnt.data_ptr(), stream=st)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / steps
+            assert int(cnt.item()) == k
+            idx.close()
+            box["res"] = {"n_gpus": 1, "rows": total_rows, "value": round(1e3 / ms, 2), "unit": "queries/s", "ms_per_step": round(ms, 4),
+                          "steps": steps, "note": "the same corpus size on ONE GPU (rank 0, after the timed region): the N = 1 point of this "
+                                                  "line's strong-scaling curve"}
+        except BaseException as e:      # noqa: BLE001 - the line must survive
+            box["res"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+
+    t = threading.Thread(target=work, daemon=True)
+    t.start()
+    t.join(budget_s)
+    if t.is_alive():
+        return {"error": "strong-scaling N = 1 leg exceeded its %.0f s budget" % budget_s, "_hung": True}
+    return box.get("res")
+
+
 def main():
     a = parse()
     import numpy as np
@@ -973,6 +1018,14 @@ def main():
         other = other_configs(torch, np, HipIndex, idx, rows, queries, dim, dev, st)
 
     abi = None
+    strong_n1 = None
+    if other and isinstance(other.get("rows10M"), dict) and "queries_per_sec" in other["rows10M"]:
+        # N = 1 (headline = configs[1], 1M rows): the N = 1 point of the strong-scaling curve the N > 1 lines measure
+        # (configs[4]: ONE 10M-row corpus) is the 10M-row extra of this very run
+        strong_n1 = {"n_gpus": 1, "rows": 10_000_000, "value": other["rows10M"]["queries_per_sec"], "unit": "queries/s",
+                     "ms_per_step": other["rows10M"]["ms_per_query"],
+                     "note": "= other_configs.rows10M: the corpus of the N > 1 lines (`--mode strong`, BASELINE configs[4]) on ONE GPU; "
+                             "scale N > 1 values against THIS number, not against the headline `value` (1M rows)"}
     if rank == 0 and world == 1 and mode == "single" and a.abi_devices:
         abi = abi_sharded_leg(a, torch, np, rows, queries[W:], k, dim)
     # N > 1 under RCCL: the C ABI's single-process sharded handle (what the Rust daemon binds) gets its first
@@ -1008,6 +1061,8 @@ def main():
         dist = None
         if rank == 0:
             abi = abi_after_group_leg(a, torch, np, world, k, dim)
+            if mode == "strong" and not (abi or {}).get("_hung"):
+                strong_n1 = strong_n1_leg(a, torch, k, dim, total_rows)
     if rank == 0:
         if mode == "weak":
             total_q = K * bq * world
@@ -1048,6 +1103,7 @@ def main():
             "latency_host_api": latency,
             "other_configs": other,
             "abi_sharded": abi,
+            "strong_scaling_n1": strong_n1,
             "embed": embed,
             "e2e": e2e,
             "aux_models": aux,

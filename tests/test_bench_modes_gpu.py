@@ -53,6 +53,11 @@ def test_strong_mode_one_rank_rccl(hip):
     ab = d["abi_sharded"]
     assert ab and "error" not in ab, ab
     assert ab["devices"] == [0] and ab["checked_vs_single_device"] and ab["rows"] == 250000 and ab["queries_per_sec_host_api"] > 0
+    # ... and the N = 1 point of the line's own strong-scaling curve: the same corpus size on one GPU, measured by rank 0
+    # in the same run (the driver's N = 1 run is the headline 1M-row workload, not comparable with a 10M-row line)
+    s1 = d["strong_scaling_n1"]
+    assert s1 and "error" not in s1, s1
+    assert s1["n_gpus"] == 1 and s1["rows"] == 300000 and s1["value"] > 0 and s1["unit"] == "queries/s"
 
 
 def test_single_gpu_line_carries_the_same_keys(hip):
