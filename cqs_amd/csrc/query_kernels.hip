@@ -357,7 +357,11 @@ __global__ __launch_bounds__(64 * NW) void qf_gemm_kernel(const QfGemmParams p) 
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, lg = lane >> 4;
     QF_STAMP(p, 0);
-    const uint32_t T = p.T;
+    // blockIdx.y = row block (17-32 tokens: two blocks of 16 rows x 16-column tiles - a workgroup then pulls 16 rows of
+    // x / y through its CU's L2 port instead of all 32: the prologue is bound by exactly that); rows are
+    // local to the block from here on, `T` = how many of them are real
+    const uint32_t row0 = blockIdx.y * (uint32_t)(16 * MT);
+    const uint32_t T = p.T - row0 < (uint32_t)(16 * MT) ? p.T - row0 : (uint32_t)(16 * MT);
     constexpr uint32_t kw = H / NW;                                // this wave's K range: [wid kw, (wid + 1) kw)
     constexpr int S = H / NW / 32;                                 // k-steps of 32 per wave
     static_assert(H % (32 * NW) == 0, "the waves split K in whole 32-deep steps");
@@ -370,16 +374,18 @@ __global__ __launch_bounds__(64 * NW) void qf_gemm_kernel(const QfGemmParams p) 
     // (thread = row tid / 32 of the slice, 16-byte chunks tid % 32 + 32 j: a wave-instruction covers 2 rows x 512 B; a
     // fragment gather of 16 rows x 64 B costs ~44 clocks of address processing per instruction against ~16), lands while
     // the rows are normalised and goes through LDS: sW [NT][NC][LDA].
-    static_assert(NC == 8, "one 8-row weight slice per tile");
+    static_assert(NC == 8 || NC == 16, "an 8- or 16-row weight slice per tile");
     typedef uint32_t u4 __attribute__((ext_vector_type(4)));
-    constexpr int WL = NW == 4 ? NT : 1;                           // slices per thread (8 waves: threads 256.. take the second tile)
+    // slice row i = NC tile + r (i < NT NC) is copied by the 32-thread group i % (2 NW), pass i / (2 NW)
+    constexpr int WG32 = 2 * NW;                                   // 32-thread groups of the workgroup
+    constexpr int WL = (NT * NC + WG32 - 1) / WG32;                // slice rows per group
     const uint32_t wg = (uint32_t)tid >> 5, wl32 = (uint32_t)tid & 31u;
-    const bool wload = NW == 4 || (wg >> 3) < (uint32_t)NT;
     u4 wreg[WL][NCH];
 #pragma unroll
     for (int t = 0; t < WL; ++t) {
-        const uint32_t tile = NW == 4 ? (uint32_t)t : (wload ? wg >> 3 : 0u);
-        const bf16_t* src = p.W + (size_t)(wrow0 + 32u * tile + (wg & 7u)) * H + wl32 * 8u;
+        const uint32_t i = wg + (uint32_t)(WG32 * t);
+        const uint32_t ic = i < (uint32_t)(NT * NC) ? i : (uint32_t)(NT * NC - 1);     // (a group past the slice re-copies its last row)
+        const bf16_t* src = p.W + (size_t)(wrow0 + 32u * (ic / (uint32_t)NC) + ic % (uint32_t)NC) * H + wl32 * 8u;
 #pragma unroll
         for (int j = 0; j < NCH; ++j) wreg[t][j] = *(const u4*)(src + 256 * j);
     }
@@ -391,12 +397,12 @@ __global__ __launch_bounds__(64 * NW) void qf_gemm_kernel(const QfGemmParams p) 
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             if (PRO == QF_PRO_EMBED) {
-                const bf4 e = *(const bf4*)(p.emb + (size_t)(uint32_t)p.tok[row] * H + c * 256 + c0);
+                const bf4 e = *(const bf4*)(p.emb + (size_t)(uint32_t)p.tok[row0 + row] * H + c * 256 + c0);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) xv[c][i] = (float)e[i] * p.scale;
             } else {
-                xv[c] = *(const f4*)(p.x_in + (size_t)row * H + c * 256 + c0);
-                const bf4 yb = *(const bf4*)(p.y + (size_t)row * H + c * 256 + c0);
+                xv[c] = *(const f4*)(p.x_in + (size_t)(row0 + row) * H + c * 256 + c0);
+                const bf4 yb = *(const bf4*)(p.y + (size_t)(row0 + row) * H + c * 256 + c0);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) yv[c][i] = (float)yb[i];
             }
@@ -436,7 +442,7 @@ __global__ __launch_bounds__(64 * NW) void qf_gemm_kernel(const QfGemmParams p) 
 #pragma unroll
                 for (int i = 0; i < 4; ++i) o[i] = (bf16_t)(xv[c][i] * invx * wn1[c][i]);
                 *(bf4*)(sA + (size_t)row * LDA + c * 256 + c0) = o;
-                if (blockIdx.x == 0) *(f4*)(p.x_out + (size_t)row * H + c * 256 + c0) = xv[c];
+                if (blockIdx.x == 0) *(f4*)(p.x_out + (size_t)(row0 + row) * H + c * 256 + c0) = xv[c];
             }
         }
     };
@@ -491,13 +497,12 @@ __global__ __launch_bounds__(64 * NW) void qf_gemm_kernel(const QfGemmParams p) 
         // MFMA, and columns past the real rows are never stored)
     }
     // rows [T, 16 MT) of the tile are not initialised either, for the same reason
-    if (wload) {
 #pragma unroll
-        for (int t = 0; t < WL; ++t) {
-            const uint32_t tile = NW == 4 ? (uint32_t)t : wg >> 3;
+    for (int t = 0; t < WL; ++t) {
+        const uint32_t i = wg + (uint32_t)(WG32 * t);
+        const uint32_t ic = i < (uint32_t)(NT * NC) ? i : (uint32_t)(NT * NC - 1);
 #pragma unroll
-            for (int j = 0; j < NCH; ++j) *(u4*)(sW + (size_t)(tile * (uint32_t)NC + (wg & 7u)) * LDA + wl32 * 8u + 256 * j) = wreg[t][j];
-        }
+        for (int j = 0; j < NCH; ++j) *(u4*)(sW + (size_t)ic * LDA + wl32 * 8u + 256 * j) = wreg[t][j];
     }
     __syncthreads();
     QF_STAMP(p, 1);
@@ -539,7 +544,7 @@ __global__ __launch_bounds__(64 * NW) void qf_gemm_kernel(const QfGemmParams p) 
     const uint32_t rows = PRO == QF_PRO_POOL ? 1u : T;
     const uint32_t row = 16u * (uint32_t)wid + (uint32_t)l15;
     if (row >= rows || 4 * lg >= NC) return;                       // columns 4 lg .. 4 lg + 3 of the tile: real iff < NC
-    const size_t off = (size_t)row * p.ldc + blockIdx.x * (uint32_t)NC + 4u * (uint32_t)lg;
+    const size_t off = (size_t)(row0 + row) * p.ldc + blockIdx.x * (uint32_t)NC + 4u * (uint32_t)lg;
     bf4 o;
     if (EPI == QF_EPI_GEGLU) {
 #pragma unroll
@@ -874,17 +879,19 @@ int qf_debug_repeat() {
 }
 
 template <class Kern, class P>
-hipError_t qf_launch(Kern kern, DynLdsOnce& once, const P& p0, uint32_t grid, size_t lds, hipStream_t st, uint32_t threads = 256u) {
+hipError_t qf_launch(Kern kern, DynLdsOnce& once, const P& p0, uint32_t grid_x, size_t lds, hipStream_t st, uint32_t threads = 256u,
+                     uint32_t grid_y = 1u) {
+    const dim3 grid(grid_x, grid_y);
     const hipError_t e = once.ensure((const void*)kern, lds);
     if (e != hipSuccess) return e;
     if (qf_debug_repeat() == 2 && p0.dbg) {       // diagnostic: every kernel twice (cold vs warm operands), slots 2 s and 2 s + 1
         P q = p0;
         q.dbg_slot = 2 * p0.dbg_slot;
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, st, q);
+        hipLaunchKernelGGL(kern, grid, dim3(threads), lds, st, q);
         q.dbg_slot++;
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, st, q);
+        hipLaunchKernelGGL(kern, grid, dim3(threads), lds, st, q);
     } else {
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, st, p0);
+        hipLaunchKernelGGL(kern, grid, dim3(threads), lds, st, p0);
     }
     return hipGetLastError();
 }
@@ -916,6 +923,15 @@ hipError_t qf_launch_pro(const QfGemmParams& p, uint32_t n_out_cols, hipStream_t
         return qf_launch(qf_gemm_kernel<NCH, PRO, EPI, NC, RBV, MTV, NWV>, once, p, n_out_cols / (uint32_t)NC, lds, st,     \
                          64u * NWV);                                                                                        \
     }()
+    // 17-32 tokens: two row blocks of 16 rows x 16-column tiles (a workgroup's prologue pulls 16 rows through its CU's
+    // L2 port, not 32, and every column of the MFMA tile is a real one); not for the pooled head (one row tile anyway)
+    static const bool split_off = [] { const char* e = getenv("CQS_HIP_QUERY_ROW_SPLIT"); return e && e[0] == '0'; }();
+    if (PRO != QF_PRO_POOL && !split_off && p.T > 16u && p.T <= 32u && n_out_cols % 16u == 0) {
+        const size_t lds = (size_t)(16 + NT * 16) * (NCH * 256 + kQfPad) * sizeof(bf16_t) + (size_t)8 * NT * 64 * 16;
+        static DynLdsOnce once;
+        return qf_launch(qf_gemm_kernel<NCH, PRO == QF_PRO_POOL ? QF_PRO_ADDNORM : PRO, EPI, 16, 2, 1, 8>, once, p, n_out_cols / 16u, lds, st,
+                         512u, 2u);
+    }
     QF_BY_T(p.T, QF_CALL);
 #undef QF_CALL
 }
