@@ -589,11 +589,14 @@ struct QfAttnParams {
 
 template <int MT> constexpr int qf_vrow() { return 32 * ((MT + 1) / 2) + 8; }   // sVt row stride: keys padded to 32, + 8
 
-// Stage rows [0, T) of kv head g and q heads [h0, h0 + NH): sQ [NH][16 MT][kQfKRow], sK [16 MT][kQfKRow], sVt [256][vrow].
-template <int MT, int RB, int NH, int NW>
+// Stage rows [0, T) of kv head g and q heads [h0, h0 + NH): sQ [NH][16 MTQ][kQfKRow], sK [16 MT][kQfKRow], sVt [256][vrow].
+// MTQ < MT: only the query rows [qrow0, qrow0 + 16 MTQ) are staged (a workgroup that owns one row block of the queries
+// still needs every key / value row); a row's q heads are then neither loaded nor rotated outside that window.
+template <int MT, int RB, int NH, int NW, int MTQ = MT>
 __device__ __forceinline__ void qf_attn_stage(const QfAttnParams& p, uint32_t h0, uint32_t g, bf16_t* sQ, bf16_t* sK, bf16_t* sVt,
-                                              int wid, int lane) {
+                                              int wid, int lane, uint32_t qrow0 = 0u) {
     constexpr int VR = qf_vrow<MT>();
+    auto inq = [&](uint32_t row) { return MTQ == MT || (row >= qrow0 && row < qrow0 + (uint32_t)(16 * MTQ)); };   // (wave-uniform)
     const uint32_t T = p.T, last = T - 1u;
     const uint32_t ld = (p.heads + 2u * p.kv_heads) * (uint32_t)kQfHD;
     const bf16_t* qb = p.qkv + (size_t)h0 * kQfHD + lane * 4;
@@ -602,8 +605,10 @@ __device__ __forceinline__ void qf_attn_stage(const QfAttnParams& p, uint32_t h0
     const float* csb = p.cos_sin + (uint32_t)(lane & 31) * 8u;
     struct Row { bf4 q[NH], k, v; f4 c0, c1; };
     auto load = [&](uint32_t row, Row& r) {
+        if (inq(row)) {
 #pragma unroll
-        for (int h = 0; h < NH; ++h) r.q[h] = *(const bf4*)(qb + (size_t)row * ld + h * kQfHD);
+            for (int h = 0; h < NH; ++h) r.q[h] = *(const bf4*)(qb + (size_t)row * ld + h * kQfHD);
+        }
         r.k = *(const bf4*)(kb + (size_t)row * ld);
         r.v = *(const bf4*)(vb + (size_t)row * ld);
         r.c0 = *(const f4*)(csb + (size_t)row * 256u);
@@ -628,9 +633,11 @@ __device__ __forceinline__ void qf_attn_stage(const QfAttnParams& p, uint32_t h0
         return o;
     };
     auto put = [&](uint32_t row, const Row& r) {
+        if (inq(row)) {
 #pragma unroll
-        for (int h = 0; h < NH; ++h)
-            *(bf4*)(sQ + ((size_t)h * 16 * MT + row) * kQfKRow + lane * 4) = rot(r.q[h], wq1, r, p.q_scale);
+            for (int h = 0; h < NH; ++h)
+                *(bf4*)(sQ + ((size_t)h * 16 * MTQ + (row - qrow0)) * kQfKRow + lane * 4) = rot(r.q[h], wq1, r, p.q_scale);
+        }
         *(bf4*)(sK + (size_t)row * kQfKRow + lane * 4) = rot(r.k, wk1, r, 1.0f);
 #pragma unroll
         for (int i = 0; i < 4; ++i) sVt[(size_t)(lane * 4 + i) * VR + row] = r.v[i];
@@ -677,16 +684,17 @@ __device__ __forceinline__ void qf_attn_stage(const QfAttnParams& p, uint32_t h0
 // returns 1 / sum.  sQh = the head's Q rows.
 template <int MT, int NDT>
 __device__ __forceinline__ float qf_attn_unit(const QfAttnParams& p, const bf16_t* sQh, const bf16_t* sK, const bf16_t* sVt,
-                                              uint32_t qt, uint32_t dt0, int l15, int lg, f4 (&o)[NDT]) {
+                                              uint32_t qt, uint32_t dt0, int l15, int lg, f4 (&o)[NDT], uint32_t qrow0 = 0u) {
     constexpr int VR = qf_vrow<MT>();
     const uint32_t T = p.T;
-    const uint32_t q = 16u * qt + (uint32_t)l15;
+    const uint32_t ql = 16u * qt + (uint32_t)l15;              // row of sQh (local to the staged query window)
+    const uint32_t q = qrow0 + ql;                             // the query's position
     f4 sc[MT];
 #pragma unroll
     for (int kt = 0; kt < MT; ++kt) sc[kt] = (f4)(0.f);
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
-        const bf8 qf = *(const bf8*)(sQh + (size_t)q * kQfKRow + 32 * s + 8 * lg);
+        const bf8 qf = *(const bf8*)(sQh + (size_t)ql * kQfKRow + 32 * s + 8 * lg);
 #pragma unroll
         for (int kt = 0; kt < MT; ++kt) {
             const bf8 kf = *(const bf8*)(sK + (size_t)(16 * kt + l15) * kQfKRow + 32 * s + 8 * lg);
@@ -781,32 +789,37 @@ __global__ __launch_bounds__(256) void qf_attention_kernel(const QfAttnParams p)
 
 // Fused: attention of ALL heads (NH = heads, one kv head) in the workgroup's LDS, then y[:, NC columns] = attn Wo^T.
 // The attention output of (head, query tile) overwrites that tile's Q rows (the unit's own wave is their only reader).
-template <int MT, int RB, int NH, int NC, int NW>
+// MTQ < MT (17-32 tokens: MT = 2 key tiles, MTQ = 1): blockIdx.y = the workgroup's block of 16 MTQ query rows; it stages
+// every key / value row but only its own queries (and their cos / sin rows), runs NH MTQ attention units and multiplies
+// 16 MTQ rows of o_proj against an NC = 16 column slice - less to pull through the CU's L2 port, half the units per workgroup.
+template <int MT, int RB, int NH, int NC, int NW, int MTQ = MT>
 __global__ __launch_bounds__(64 * NW) void qf_attn_oproj_kernel(const QfAttnParams p) {
     constexpr int K = NH * kQfHD, kw = K / NW, S = kw / 32;          // o_proj's K = heads x 256; this wave's K range and k-steps
     static_assert(K % (32 * NW) == 0, "the waves split K in whole 32-deep steps");
     extern __shared__ __attribute__((aligned(16))) unsigned char qf_smem[];
-    bf16_t* const sQ = (bf16_t*)qf_smem;                               // [NH][16 MT][kQfKRow]: Q, then O
-    bf16_t* const sK = sQ + (size_t)NH * 16 * MT * kQfKRow;
+    bf16_t* const sQ = (bf16_t*)qf_smem;                               // [NH][16 MTQ][kQfKRow]: Q, then O
+    bf16_t* const sK = sQ + (size_t)NH * 16 * MTQ * kQfKRow;
     bf16_t* const sVt = sK + (size_t)16 * MT * kQfKRow;
-    float* const red = (float*)(sVt + (size_t)kQfHD * qf_vrow<MT>());  // [4 waves][MT][64 lanes] f4
+    float* const red = (float*)(sVt + (size_t)kQfHD * qf_vrow<MT>());  // [NW waves][MTQ][64 lanes] f4
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, lg = lane >> 4;
     QF_STAMP(p, 0);
+    const uint32_t qrow0 = blockIdx.y * (uint32_t)(16 * MTQ);
     // o_proj's weight slice (NC consecutive rows: one contiguous block) first, by coalesced loads (thread = row tid / 32,
     // 16-byte chunks tid % 32 + 32 j); it lands while the attention runs and goes through LDS (sW [NC][K + 8]) - except
     // at 3 row tiles, where LDS is full and the fragments are gathered from global memory as before
-    static_assert(NC == 8, "one 8-row weight slice per workgroup");
+    static_assert(NC == 8 || NC == 16, "an 8- or 16-row weight slice per workgroup");
+    static_assert(NC <= 2 * NW, "one slice row per 32-thread group");
     constexpr bool kStageW = MT < 3;
     constexpr int LDW = K + 8;
     typedef uint32_t u4 __attribute__((ext_vector_type(4)));
-    bf16_t* const sW = (bf16_t*)(red + NW * MT * 64 * 4);
+    bf16_t* const sW = (bf16_t*)(red + NW * MTQ * 64 * 4);
     const uint32_t wg = (uint32_t)tid >> 5, wl32 = (uint32_t)tid & 31u;
     u4 wreg[NH];
     bf8 wf[S];
     if (kStageW) {
-        if (wg < 8u) {
+        if (wg < (uint32_t)NC) {
             const bf16_t* src = p.wo + (size_t)(blockIdx.x * (uint32_t)NC + wg) * K + wl32 * 8u;
 #pragma unroll
             for (int j = 0; j < NH; ++j) wreg[j] = *(const u4*)(src + 256 * j);
@@ -816,14 +829,14 @@ __global__ __launch_bounds__(64 * NW) void qf_attn_oproj_kernel(const QfAttnPara
 #pragma unroll
         for (int s = 0; s < S; ++s) wf[s] = *(const bf8*)(wp + 32 * s);
     }
-    qf_attn_stage<MT, RB, NH, NW>(p, 0u, 0u, sQ, sK, sVt, wid, lane);
+    qf_attn_stage<MT, RB, NH, NW, MTQ>(p, 0u, 0u, sQ, sK, sVt, wid, lane, qrow0);
     __syncthreads();
     QF_STAMP(p, 1);
-    for (uint32_t u = (uint32_t)wid; u < (uint32_t)(NH * MT); u += (uint32_t)NW) {   // (head, query tile) units over the waves
-        const uint32_t h = u / (uint32_t)MT, qt = u % (uint32_t)MT;
-        bf16_t* sQh = sQ + (size_t)h * 16 * MT * kQfKRow;
+    for (uint32_t u = (uint32_t)wid; u < (uint32_t)(NH * MTQ); u += (uint32_t)NW) {   // (head, query tile) units over the waves
+        const uint32_t h = u / (uint32_t)MTQ, qt = u % (uint32_t)MTQ;
+        bf16_t* sQh = sQ + (size_t)h * 16 * MTQ * kQfKRow;
         f4 o[16];
-        const float rinv = qf_attn_unit<MT, 16>(p, sQh, sK, sVt, qt, 0u, l15, lg, o);
+        const float rinv = qf_attn_unit<MT, 16>(p, sQh, sK, sVt, qt, 0u, l15, lg, o, qrow0);
         bf16_t* orow = sQh + (size_t)(16u * qt + (uint32_t)l15) * kQfKRow + 4 * lg;
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
@@ -833,7 +846,7 @@ __global__ __launch_bounds__(64 * NW) void qf_attn_oproj_kernel(const QfAttnPara
             *(bf4*)(orow + 16 * j) = ob;
         }
     }
-    if (kStageW && wg < 8u) {
+    if (kStageW && wg < (uint32_t)NC) {
 #pragma unroll
         for (int j = 0; j < NH; ++j) *(u4*)(sW + (size_t)wg * LDW + wl32 * 8u + 256 * j) = wreg[j];
     }
@@ -844,27 +857,27 @@ __global__ __launch_bounds__(64 * NW) void qf_attn_oproj_kernel(const QfAttnPara
         for (int s = 0; s < S; ++s) wf[s] = *(const bf8*)(sW + (size_t)(l15 % NC) * LDW + wid * kw + 8 * lg + 32 * s);
     }
     // y tile: B operand (attention rows) from LDS: row 16 m + l15, k = wid kw + 32 s + 8 lg -> head k / 256, dim k % 256
-    f4 acc[MT];
+    f4 acc[MTQ];
 #pragma unroll
-    for (int m = 0; m < MT; ++m) acc[m] = (f4)(0.f);
+    for (int m = 0; m < MTQ; ++m) acc[m] = (f4)(0.f);
 #pragma unroll
     for (int s = 0; s < S; ++s) {
         const int k = wid * kw + 32 * s;                               // wave-uniform; a 32-wide step never straddles a head
-        const bf16_t* src = sQ + (size_t)(k / kQfHD) * 16 * MT * kQfKRow + (k % kQfHD) + 8 * lg;
+        const bf16_t* src = sQ + (size_t)(k / kQfHD) * 16 * MTQ * kQfKRow + (k % kQfHD) + 8 * lg;
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
+        for (int m = 0; m < MTQ; ++m) {
             const bf8 a = *(const bf8*)(src + (size_t)(16 * m + l15) * kQfKRow);
             acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s], a, acc[m], 0, 0, 0);
         }
     }
 #pragma unroll
-    for (int m = 0; m < MT; ++m) *(f4*)(red + ((size_t)(wid * MT + m) * 64 + lane) * 4) = acc[m];
+    for (int m = 0; m < MTQ; ++m) *(f4*)(red + ((size_t)(wid * MTQ + m) * 64 + lane) * 4) = acc[m];
     __syncthreads();
-    if (wid >= MT) return;
+    if (wid >= MTQ) return;
     f4 v = *(const f4*)(red + ((size_t)wid * 64 + lane) * 4);
 #pragma unroll
-    for (int w = 1; w < NW; ++w) v += *(const f4*)(red + ((size_t)(w * MT + wid) * 64 + lane) * 4);
-    const uint32_t row = 16u * (uint32_t)wid + (uint32_t)l15;
+    for (int w = 1; w < NW; ++w) v += *(const f4*)(red + ((size_t)(w * MTQ + wid) * 64 + lane) * 4);
+    const uint32_t row = qrow0 + 16u * (uint32_t)wid + (uint32_t)l15;
     if (row >= p.T || 4 * lg >= NC) return;
     bf4 ob;
 #pragma unroll
@@ -1024,6 +1037,13 @@ hipError_t qf_launch_attn_oproj_h(const QfAttnParams& a, hipStream_t st) {
     if (a.T <= 4u) return QF_AO(1, 1, 4);
     if (a.T <= 8u) return QF_AO(2, 1, 4);
     if (a.T <= 16u) return QF_AO(2, 1, 8);
+    static const bool split_off = [] { const char* e = getenv("CQS_HIP_QUERY_ROW_SPLIT"); return e && e[0] == '0'; }();
+    if (a.T <= 32u && !split_off && a.H % 16u == 0) {               // two query blocks of 16 rows x 16-column o_proj tiles
+        static DynLdsOnce once;
+        const size_t lds = ((size_t)(NH * 16 + 32) * kQfKRow + (size_t)kQfHD * qf_vrow<2>()) * sizeof(bf16_t) + (size_t)8 * 64 * 16 +
+                           (size_t)16 * (NH * kQfHD + 8) * sizeof(bf16_t);
+        return qf_launch(qf_attn_oproj_kernel<2, 4, NH, 16, 8, 1>, once, a, a.H / 16u, lds, st, 512u, 2u);
+    }
     if (a.T <= 32u) return QF_AO(4, 2, 8);
     if (a.T <= 48u) return QF_AO(4, 3, 8);
     return hipErrorNotSupported;
