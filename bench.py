@@ -312,7 +312,7 @@ def embed_leg(a, rank, world, dist, torch, np, dev, all_reduce_max):
             assert rc == 0 and np.array_equal(out, eng.run(ids, mask))
             qlat["by_tokens"][str(n)] = {"ms": round(dt * 1e3, 4), "abi_ms": round(dt_abi * 1e3, 4), "device_ms": round(dms / reps, 4),
                                          "mean_ms": round(float(np.mean(walls)) * 1e3, 4), "max_ms": round(float(np.max(walls)) * 1e3, 4),
-                                         "path": ("search-time kernels (%d launches / layer, hipGraph)" % (4 if n <= 48 else 5)) if n <= 64 else "batch chain",
+                                         "path": "search-time kernels (4 launches / layer, hipGraph)" if n <= 64 else "batch chain",
                                          "weight_stream_frac_of_hbm_peak": round(wbytes / (dms / reps / 1e3) / 1e9 / HBM_PEAK_GBS, 4)}
     cpu = None
     if rank == 0 and world == 1 and a.cpu_seconds > 0:

@@ -230,7 +230,10 @@ __global__ __launch_bounds__(256) void qf_gemm_staged_kernel(const QfGemmParams 
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, lg = lane >> 4;
     QF_STAMP(p, 0);
-    const uint32_t rows = ONE ? 1u : p.T;
+    // blockIdx.y = block of 16 MT rows (33-64 tokens run as two blocks of 32: 64 rows of K = 1152 do not fit LDS beside the
+    // weight slice, and the gather kernel they used to take pays ~44 clocks of address processing per fragment load)
+    const uint32_t row0 = ONE ? 0u : blockIdx.y * (uint32_t)(16 * MT);
+    const uint32_t rows = ONE ? 1u : (p.T - row0 < (uint32_t)(16 * MT) ? p.T - row0 : (uint32_t)(16 * MT));
     const uint32_t K = p.K, kc = K / 8u, kw = K / 4u, nb = kw / (32u * (uint32_t)CH);
     const uint32_t ldk = K + 8u;                                   // LDS row stride (elements)
     bf16_t* const sW = (bf16_t*)qf_smem;                           // [NC][ldk]
@@ -258,7 +261,7 @@ __global__ __launch_bounds__(256) void qf_gemm_staged_kernel(const QfGemmParams 
 #pragma unroll
         for (int i = 0; i < AI; ++i) {
             const uint32_t r = 8u * (uint32_t)i + rg;
-            const bf16_t* asrc = p.A + (size_t)(r < rows ? r : rows - 1u) * K;
+            const bf16_t* asrc = p.A + (size_t)(row0 + (r < rows ? r : rows - 1u)) * K;
 #pragma unroll
             for (int j = 0; j < KC32; ++j) {
                 const uint32_t c = l32 + 32u * (uint32_t)j < kc ? l32 + 32u * (uint32_t)j : kc - 1u;
@@ -324,7 +327,7 @@ __global__ __launch_bounds__(256) void qf_gemm_staged_kernel(const QfGemmParams 
     for (int w = 1; w < 4; ++w) v += *(const f4*)(red + ((size_t)(w * MT + wid) * 64 + lane) * 4);
     const uint32_t row = 16u * (uint32_t)wid + (uint32_t)l15;
     if (row >= rows || 4 * lg >= NC) return;
-    const size_t off = (size_t)row * p.ldc + blockIdx.x * (uint32_t)NC + 4u * (uint32_t)lg;
+    const size_t off = (size_t)(row0 + row) * p.ldc + blockIdx.x * (uint32_t)NC + 4u * (uint32_t)lg;
     v = qf_bias_act(v, p.bias, p.act, blockIdx.x * (uint32_t)NC + 4u * (uint32_t)lg);
     if (EPI == QF_EPI_F32) {
         *(f4*)((float*)p.C + off) = v;
@@ -811,7 +814,7 @@ __global__ __launch_bounds__(64 * NW) void qf_attn_oproj_kernel(const QfAttnPara
     // at 3 row tiles, where LDS is full and the fragments are gathered from global memory as before
     static_assert(NC == 8 || NC == 16, "an 8- or 16-row weight slice per workgroup");
     static_assert(NC <= 2 * NW, "one slice row per 32-thread group");
-    constexpr bool kStageW = MT < 3;
+    constexpr bool kStageW = MT < 3 || MTQ < MT;                     // (a block of the queries leaves LDS room at any key count)
     constexpr int LDW = K + 8;
     typedef uint32_t u4 __attribute__((ext_vector_type(4)));
     bf16_t* const sW = (bf16_t*)(red + NW * MTQ * 64 * 4);
@@ -936,14 +939,14 @@ hipError_t qf_launch_pro(const QfGemmParams& p, uint32_t n_out_cols, hipStream_t
         return qf_launch(qf_gemm_kernel<NCH, PRO, EPI, NC, RBV, MTV, NWV>, once, p, n_out_cols / (uint32_t)NC, lds, st,     \
                          64u * NWV);                                                                                        \
     }()
-    // 17-32 tokens: two row blocks of 16 rows x 16-column tiles (a workgroup's prologue pulls 16 rows through its CU's
-    // L2 port, not 32, and every column of the MFMA tile is a real one); not for the pooled head (one row tile anyway)
+    // over 16 tokens: row blocks of 16 rows x 16-column tiles (a workgroup's prologue pulls 16 rows through its CU's L2
+    // port, not all of them, and every column of the MFMA tile is a real one); not for the pooled head (one row tile anyway)
     static const bool split_off = [] { const char* e = getenv("CQS_HIP_QUERY_ROW_SPLIT"); return e && e[0] == '0'; }();
-    if (PRO != QF_PRO_POOL && !split_off && p.T > 16u && p.T <= 32u && n_out_cols % 16u == 0) {
+    if (PRO != QF_PRO_POOL && !split_off && p.T > 16u && n_out_cols % 16u == 0) {
         const size_t lds = (size_t)(16 + NT * 16) * (NCH * 256 + kQfPad) * sizeof(bf16_t) + (size_t)8 * NT * 64 * 16;
         static DynLdsOnce once;
         return qf_launch(qf_gemm_kernel<NCH, PRO == QF_PRO_POOL ? QF_PRO_ADDNORM : PRO, EPI, 16, 2, 1, 8>, once, p, n_out_cols / 16u, lds, st,
-                         512u, 2u);
+                         512u, (p.T + 15u) / 16u);
     }
     QF_BY_T(p.T, QF_CALL);
 #undef QF_CALL
@@ -970,7 +973,7 @@ hipError_t qf_launch_plain_ch(const QfGemmParams& p, uint32_t n_out_cols, hipStr
 // K classes of the staged kernel: (k-steps per batch, chunk iterations per row).  Unknown K, 49-64 rows (LDS) or the
 // experiment switch CQS_HIP_QUERY_STAGED=0: the gather kernel.
 template <int MT, int EPI, int NC, int ONE>
-hipError_t qf_launch_staged(const QfGemmParams& p, uint32_t n_out_cols, hipStream_t st) {
+hipError_t qf_launch_staged(const QfGemmParams& p, uint32_t n_out_cols, hipStream_t st, uint32_t row_blocks = 1u) {
     static const bool off = [] { const char* e = getenv("CQS_HIP_QUERY_STAGED"); return e && e[0] == '0'; }();
     if (off || NC != 8) return hipErrorNotSupported;
     const size_t lds = (size_t)(NC + (ONE ? 1 : 16 * MT)) * (p.K + 8u) * sizeof(bf16_t) + (size_t)4 * MT * 64 * 16;
@@ -978,7 +981,7 @@ hipError_t qf_launch_staged(const QfGemmParams& p, uint32_t n_out_cols, hipStrea
 #define QF_ST(CHV, KCV)                                                                                                  \
     do {                                                                                                                 \
         static DynLdsOnce once;                                                                                          \
-        return qf_launch(qf_gemm_staged_kernel<MT, CHV, KCV, EPI, NC, ONE>, once, p, n_out_cols / (uint32_t)NC, lds, st); \
+        return qf_launch(qf_gemm_staged_kernel<MT, CHV, KCV, EPI, NC, ONE>, once, p, n_out_cols / (uint32_t)NC, lds, st, 256u, row_blocks); \
     } while (0)
     switch (p.K) {
         case 768: QF_ST(6, 3);
@@ -1001,6 +1004,7 @@ hipError_t qf_launch_plain(const QfGemmParams& p, uint32_t n_out_cols, hipStream
         else if (rows <= 16u) e = qf_launch_staged<1, EPI, NC, 0>(p, n_out_cols, st);
         else if (rows <= 32u) e = qf_launch_staged<2, EPI, NC, 0>(p, n_out_cols, st);
         else if (rows <= 48u) e = qf_launch_staged<3, EPI, NC, 0>(p, n_out_cols, st);
+        if (e == hipErrorNotSupported && rows > 32u) e = qf_launch_staged<2, EPI, NC, 0>(p, n_out_cols, st, (rows + 31u) / 32u);   // two blocks of 32 rows
         if (e != hipErrorNotSupported) return e;
     }
     if (rows <= 16u) return qf_launch_plain_ch<1, EPI, NC>(p, n_out_cols, st);
@@ -1038,11 +1042,18 @@ hipError_t qf_launch_attn_oproj_h(const QfAttnParams& a, hipStream_t st) {
     if (a.T <= 8u) return QF_AO(2, 1, 4);
     if (a.T <= 16u) return QF_AO(2, 1, 8);
     static const bool split_off = [] { const char* e = getenv("CQS_HIP_QUERY_ROW_SPLIT"); return e && e[0] == '0'; }();
-    if (a.T <= 32u && !split_off && a.H % 16u == 0) {               // two query blocks of 16 rows x 16-column o_proj tiles
-        static DynLdsOnce once;
-        const size_t lds = ((size_t)(NH * 16 + 32) * kQfKRow + (size_t)kQfHD * qf_vrow<2>()) * sizeof(bf16_t) + (size_t)8 * 64 * 16 +
-                           (size_t)16 * (NH * kQfHD + 8) * sizeof(bf16_t);
-        return qf_launch(qf_attn_oproj_kernel<2, 4, NH, 16, 8, 1>, once, a, a.H / 16u, lds, st, 512u, 2u);
+    if (!split_off && a.H % 16u == 0) {                             // query blocks of 16 rows x 16-column o_proj tiles
+#define QF_AOS(MTV)                                                                                                          \
+    [&]() {                                                                                                                 \
+        static DynLdsOnce once;                                                                                             \
+        const size_t lds = ((size_t)(NH * 16 + 16 * MTV) * kQfKRow + (size_t)kQfHD * qf_vrow<MTV>()) * sizeof(bf16_t) +     \
+                           (size_t)8 * 64 * 16 + (size_t)16 * (NH * kQfHD + 8) * sizeof(bf16_t);                            \
+        return qf_launch(qf_attn_oproj_kernel<MTV, 4, NH, 16, 8, 1>, once, a, a.H / 16u, lds, st, 512u, (a.T + 15u) / 16u); \
+    }()
+        if (a.T <= 32u) return QF_AOS(2);
+        if (a.T <= 48u) return QF_AOS(3);
+        return QF_AOS(4);
+#undef QF_AOS
     }
     if (a.T <= 32u) return QF_AO(4, 2, 8);
     if (a.T <= 48u) return QF_AO(4, 3, 8);
