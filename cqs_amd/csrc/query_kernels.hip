@@ -344,7 +344,7 @@ __global__ __launch_bounds__(256) void qf_gemm_staged_kernel(const QfGemmParams 
 // NCH = H / 256, K = H.  Rows: one WAVE per row, wave w takes rows w, w + 4, ... in batches of RB rows (RB = 1, 2, 4
 // by T for T <= 16: one batch; longer queries loop over batches of 4, the next batch's loads issued before the current
 // one is reduced).  A batch slot past T re-does row T - 1.
-template <int NCH, int PRO, int EPI, int NC, int RB, int MT, int NW>
+template <int NCH, int PRO, int EPI, int NC, int RB, int MT, int NW, int BR = 16 * MT>
 __global__ __launch_bounds__(64 * NW) void qf_gemm_kernel(const QfGemmParams p) {
     constexpr int H = NCH * 256;
     constexpr int NT = EPI == QF_EPI_GEGLU ? 2 : 1;               // weight tiles per workgroup
@@ -363,8 +363,11 @@ __global__ __launch_bounds__(64 * NW) void qf_gemm_kernel(const QfGemmParams p) 
     // blockIdx.y = row block (17-32 tokens: two blocks of 16 rows x 16-column tiles - a workgroup then pulls 16 rows of
     // x / y through its CU's L2 port instead of all 32: the prologue is bound by exactly that); rows are
     // local to the block from here on, `T` = how many of them are real
-    const uint32_t row0 = blockIdx.y * (uint32_t)(16 * MT);
-    const uint32_t T = p.T - row0 < (uint32_t)(16 * MT) ? p.T - row0 : (uint32_t)(16 * MT);
+    // (BR < 16: 9-16 tokens as two blocks of 8 rows - half the MFMA tile's rows idle, but 8 rows less to pull and one row
+    // per wave in the prologue)
+    static_assert(BR <= 16 * MT, "a row block fits the workgroup's row tiles");
+    const uint32_t row0 = blockIdx.y * (uint32_t)BR;
+    const uint32_t T = p.T - row0 < (uint32_t)BR ? p.T - row0 : (uint32_t)BR;
     constexpr uint32_t kw = H / NW;                                // this wave's K range: [wid kw, (wid + 1) kw)
     constexpr int S = H / NW / 32;                                 // k-steps of 32 per wave
     static_assert(H % (32 * NW) == 0, "the waves split K in whole 32-deep steps");
@@ -595,11 +598,11 @@ template <int MT> constexpr int qf_vrow() { return 32 * ((MT + 1) / 2) + 8; }   
 // Stage rows [0, T) of kv head g and q heads [h0, h0 + NH): sQ [NH][16 MTQ][kQfKRow], sK [16 MT][kQfKRow], sVt [256][vrow].
 // MTQ < MT: only the query rows [qrow0, qrow0 + 16 MTQ) are staged (a workgroup that owns one row block of the queries
 // still needs every key / value row); a row's q heads are then neither loaded nor rotated outside that window.
-template <int MT, int RB, int NH, int NW, int MTQ = MT>
+template <int MT, int RB, int NH, int NW, int MTQ = MT, int QB = 16 * MTQ>
 __device__ __forceinline__ void qf_attn_stage(const QfAttnParams& p, uint32_t h0, uint32_t g, bf16_t* sQ, bf16_t* sK, bf16_t* sVt,
                                               int wid, int lane, uint32_t qrow0 = 0u) {
     constexpr int VR = qf_vrow<MT>();
-    auto inq = [&](uint32_t row) { return MTQ == MT || (row >= qrow0 && row < qrow0 + (uint32_t)(16 * MTQ)); };   // (wave-uniform)
+    auto inq = [&](uint32_t row) { return (MTQ == MT && QB == 16 * MTQ) || (row >= qrow0 && row < qrow0 + (uint32_t)QB); };   // (wave-uniform)
     const uint32_t T = p.T, last = T - 1u;
     const uint32_t ld = (p.heads + 2u * p.kv_heads) * (uint32_t)kQfHD;
     const bf16_t* qb = p.qkv + (size_t)h0 * kQfHD + lane * 4;
@@ -795,7 +798,7 @@ __global__ __launch_bounds__(256) void qf_attention_kernel(const QfAttnParams p)
 // MTQ < MT (17-32 tokens: MT = 2 key tiles, MTQ = 1): blockIdx.y = the workgroup's block of 16 MTQ query rows; it stages
 // every key / value row but only its own queries (and their cos / sin rows), runs NH MTQ attention units and multiplies
 // 16 MTQ rows of o_proj against an NC = 16 column slice - less to pull through the CU's L2 port, half the units per workgroup.
-template <int MT, int RB, int NH, int NC, int NW, int MTQ = MT>
+template <int MT, int RB, int NH, int NC, int NW, int MTQ = MT, int QB = 16 * MTQ>
 __global__ __launch_bounds__(64 * NW) void qf_attn_oproj_kernel(const QfAttnParams p) {
     constexpr int K = NH * kQfHD, kw = K / NW, S = kw / 32;          // o_proj's K = heads x 256; this wave's K range and k-steps
     static_assert(K % (32 * NW) == 0, "the waves split K in whole 32-deep steps");
@@ -808,7 +811,8 @@ __global__ __launch_bounds__(64 * NW) void qf_attn_oproj_kernel(const QfAttnPara
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, lg = lane >> 4;
     QF_STAMP(p, 0);
-    const uint32_t qrow0 = blockIdx.y * (uint32_t)(16 * MTQ);
+    static_assert(QB <= 16 * MTQ, "a query block fits the staged query tiles");
+    const uint32_t qrow0 = blockIdx.y * (uint32_t)QB;               // (QB < 16: 9-16 tokens as two blocks of 8 queries)
     // o_proj's weight slice (NC consecutive rows: one contiguous block) first, by coalesced loads (thread = row tid / 32,
     // 16-byte chunks tid % 32 + 32 j); it lands while the attention runs and goes through LDS (sW [NC][K + 8]) - except
     // at 3 row tiles, where LDS is full and the fragments are gathered from global memory as before
@@ -832,7 +836,7 @@ __global__ __launch_bounds__(64 * NW) void qf_attn_oproj_kernel(const QfAttnPara
 #pragma unroll
         for (int s = 0; s < S; ++s) wf[s] = *(const bf8*)(wp + 32 * s);
     }
-    qf_attn_stage<MT, RB, NH, NW, MTQ>(p, 0u, 0u, sQ, sK, sVt, wid, lane, qrow0);
+    qf_attn_stage<MT, RB, NH, NW, MTQ, QB>(p, 0u, 0u, sQ, sK, sVt, wid, lane, qrow0);
     __syncthreads();
     QF_STAMP(p, 1);
     for (uint32_t u = (uint32_t)wid; u < (uint32_t)(NH * MTQ); u += (uint32_t)NW) {   // (head, query tile) units over the waves
@@ -880,8 +884,8 @@ __global__ __launch_bounds__(64 * NW) void qf_attn_oproj_kernel(const QfAttnPara
     f4 v = *(const f4*)(red + ((size_t)wid * 64 + lane) * 4);
 #pragma unroll
     for (int w = 1; w < NW; ++w) v += *(const f4*)(red + ((size_t)(w * MTQ + wid) * 64 + lane) * 4);
-    const uint32_t row = qrow0 + 16u * (uint32_t)wid + (uint32_t)l15;
-    if (row >= p.T || 4 * lg >= NC) return;
+    const uint32_t lrow = 16u * (uint32_t)wid + (uint32_t)l15, row = qrow0 + lrow;
+    if (lrow >= (uint32_t)QB || row >= p.T || 4 * lg >= NC) return;
     bf4 ob;
 #pragma unroll
     for (int r = 0; r < 4; ++r) ob[r] = (bf16_t)v[r];
@@ -942,6 +946,12 @@ hipError_t qf_launch_pro(const QfGemmParams& p, uint32_t n_out_cols, hipStream_t
     // over 16 tokens: row blocks of 16 rows x 16-column tiles (a workgroup's prologue pulls 16 rows through its CU's L2
     // port, not all of them, and every column of the MFMA tile is a real one); not for the pooled head (one row tile anyway)
     static const bool split_off = [] { const char* e = getenv("CQS_HIP_QUERY_ROW_SPLIT"); return e && e[0] == '0'; }();
+    if (PRO != QF_PRO_POOL && !split_off && p.T > 4u && p.T <= 16u && n_out_cols % 16u == 0) {      // blocks of 8 rows (5-8 tokens: one)
+        const size_t lds = (size_t)(16 + NT * 16) * (NCH * 256 + kQfPad) * sizeof(bf16_t) + (size_t)8 * NT * 64 * 16;
+        static DynLdsOnce once;
+        return qf_launch(qf_gemm_kernel<NCH, PRO == QF_PRO_POOL ? QF_PRO_ADDNORM : PRO, EPI, 16, 1, 1, 8, 8>, once, p, n_out_cols / 16u, lds, st,
+                         512u, (p.T + 7u) / 8u);
+    }
     if (PRO != QF_PRO_POOL && !split_off && p.T > 16u && n_out_cols % 16u == 0) {
         const size_t lds = (size_t)(16 + NT * 16) * (NCH * 256 + kQfPad) * sizeof(bf16_t) + (size_t)8 * NT * 64 * 16;
         static DynLdsOnce once;
@@ -1040,21 +1050,23 @@ hipError_t qf_launch_attn_oproj_h(const QfAttnParams& a, hipStream_t st) {
     }()
     if (a.T <= 4u) return QF_AO(1, 1, 4);
     if (a.T <= 8u) return QF_AO(2, 1, 4);
-    if (a.T <= 16u) return QF_AO(2, 1, 8);
     static const bool split_off = [] { const char* e = getenv("CQS_HIP_QUERY_ROW_SPLIT"); return e && e[0] == '0'; }();
-    if (!split_off && a.H % 16u == 0) {                             // query blocks of 16 rows x 16-column o_proj tiles
-#define QF_AOS(MTV)                                                                                                          \
+    if (!split_off && a.H % 16u == 0) {                             // blocks of 8 / 16 queries x 16-column o_proj tiles
+#define QF_AOS(MTV, RBV, QBV)                                                                                                \
     [&]() {                                                                                                                 \
         static DynLdsOnce once;                                                                                             \
         const size_t lds = ((size_t)(NH * 16 + 16 * MTV) * kQfKRow + (size_t)kQfHD * qf_vrow<MTV>()) * sizeof(bf16_t) +     \
                            (size_t)8 * 64 * 16 + (size_t)16 * (NH * kQfHD + 8) * sizeof(bf16_t);                            \
-        return qf_launch(qf_attn_oproj_kernel<MTV, 4, NH, 16, 8, 1>, once, a, a.H / 16u, lds, st, 512u, (a.T + 15u) / 16u); \
+        return qf_launch(qf_attn_oproj_kernel<MTV, RBV, NH, 16, 8, 1, QBV>, once, a, a.H / 16u, lds, st, 512u,              \
+                         (a.T + (uint32_t)QBV - 1u) / (uint32_t)QBV);                                                       \
     }()
-        if (a.T <= 32u) return QF_AOS(2);
-        if (a.T <= 48u) return QF_AOS(3);
-        return QF_AOS(4);
+        if (a.T <= 16u) return QF_AOS(1, 2, 8);                     // 9-16 tokens: two blocks of 8 queries
+        if (a.T <= 32u) return QF_AOS(2, 4, 16);
+        if (a.T <= 48u) return QF_AOS(3, 4, 16);
+        return QF_AOS(4, 4, 16);
 #undef QF_AOS
     }
+    if (a.T <= 16u) return QF_AO(2, 1, 8);
     if (a.T <= 32u) return QF_AO(4, 2, 8);
     if (a.T <= 48u) return QF_AO(4, 3, 8);
     return hipErrorNotSupported;
