@@ -173,11 +173,19 @@ __global__ __launch_bounds__(512, 2) void gemm_rowfuse_kernel(const bf16_t* __re
 #pragma unroll
                 for (int sb = 0; sb < 2; ++sb) wn[sb] = *(const bf8*)(sw + (uint32_t)((j + 1) * kRfSlot) + foff[sb]);
             }
+#if defined(CQS_RF_ABLATE_HALFDMA)   // timing experiments (wrong results): half the W refills / no MFMAs
+            if ((j & 1) == 0)
+#endif
             fill_w(kn, j);                                // slot j is in registers: refill it
+#if defined(CQS_RF_ABLATE_NOMFMA)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[j][t][0] += (float)wf[0][t] * (float)af[t][1][0];
+#else
 #pragma unroll
             for (int sb = 0; sb < 2; ++sb)
 #pragma unroll
                 for (int t = 0; t < 4; ++t) acc[j][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[sb], af[t][sb], acc[j][t], 0, 0, 0);
+#endif
             if (j < 5) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 wf[0] = wn[0]; wf[1] = wn[1];
