@@ -351,7 +351,7 @@ int32_t run_layers(cqs_hip_embedder* e, Ctx& c, Slot& sl) {
 }
 
 // ---- the search-time path: ONE sequence of <= 64 tokens (`embed_query`, src/embedder/core.rs:768-856) ---------------
-// 122 launches (5 per layer + 2) of query_kernels.hip instead of the batch chain's ~230, replayed from a hipGraph
+// 98 launches (4 per layer + 2) of query_kernels.hip instead of the batch chain's ~230, replayed from a hipGraph
 // captured on the context's second query (eager launches of 2-3 us kernels are host-bound: ~3.5 us of host time each).
 bool slot_takes_query_path(const cqs_hip_embedder* e, const Slot& sl) {
     return e->query_path && sl.B == 1 && sl.M >= 1 && sl.M <= cqs::kQueryFwdMaxTokens;

@@ -8,29 +8,30 @@
 // 1.3 ms.  What bounds a kernel here is LATENCY: a launch boundary (~1.3 us, MI355X_MICROARCH.md price list
 // "boundary"), one round trip to L2 / MALL for the activations the previous kernel wrote, one for the weights.  So:
 //
-//   * 5 launches per layer, the minimum the data flow allows with every projection's N range spread over the chip (a
+//   * 4 launches per layer, the minimum the data flow allows with every projection's N range spread over the chip (a
 //     row norm needs the whole row = all N-slices of the producing GEMM, so every GEMM output is a grid-wide seam; a
 //     grid barrier inside one launch costs 4-5 us on this chip, 3x a launch boundary - not a persistent kernel):
 //         QKV      [ x += norm(down_prev)(1+w) ; xn = norm(x)(1+w) ]  -> qkv = xn Wqkv^T
-//         attention[ k norm + rope, q norm + rope + scale ]           -> softmax(q k^T) v         (one workgroup per q head)
-//         o_proj                                                        -> y = attn Wo^T
+//         attention[ k norm + rope, q norm + rope + scale ] + o_proj  -> y = softmax(q k^T) v Wo^T   (every o_proj workgroup
+//                                                                        redoes the attention of all heads in its own LDS)
 //         GeGLU    [ x += norm(y)(1+w) ; xn = norm(x)(1+w) ]          -> h = gelu(xn Wg^T) * (xn Wu^T)
 //         down                                                          -> y = h Wd^T
 //     the row-wise add + RMSNorm pairs live in the PROLOGUE of the GEMM that consumes them: every workgroup recomputes
-//     them for all <= 64 rows (<= 150 KB of L2 reads, ~0.3 us of VALU) instead of a launch + a round trip each; workgroup 0
-//     also writes the new residual stream to the other of two x buffers (everybody reads the old one: no race);
-//   * a GEMM workgroup = 16 output columns x all rows, its 4 waves split K: N / 16 workgroups (48-144) stream one
-//     16 x K weight slice each (24-37 KB), every weight fragment requested BEFORE the prologue so that the weight
-//     latency hides under the activation round trip + norm; v_mfma_f32_16x16x32_bf16 with the weight rows as the A
-//     operand (a lane ends with 4 consecutive output columns of one token row), partial tiles summed through LDS;
-//   * the head (final add + norm, mean pool, Dense 768 -> 3072 -> 768) is two more launches of the same kernel;
-//   * measured (in-kernel stamps, tools/query_stamps.py): a workgroup's memory pipeline retires ~28 KB per microsecond
-//     in this regime (12 dwordx4 loads per lane of 4 waves take 0.9 us to ISSUE and 0.8 us more to return), a launch
-//     boundary costs 1.3 us - so a kernel's time is its bytes PER WORKGROUP: weight tiles are 4-8 rows wide (the MFMA's
-//     other rows are zeros: 200-300 workgroups instead of 48-80), no row past the query's length is loaded (T is a
-//     launch parameter; the engine keeps one captured hipGraph per length), reductions are DPP + readlane;
-// K order differs from the batch kernels (4-way K split) -> results agree with the batch path to bf16 rounding noise
-// (cosine >= 0.9999, tests/test_query_path_gpu.py), not bit for bit.
+//     them for its rows instead of a launch + a round trip each; the workgroup of column tile 0 also writes the new residual
+//     stream to the other of two x buffers (everybody reads the old one: no race);
+//   * a GEMM workgroup = 8 or 16 output columns x a block of rows, its 4 or 8 waves split K (partial tiles summed through
+//     LDS); weight slice and activation rows arrive by COALESCED loads and go through LDS (a fragment gather of 16 rows x
+//     64 B costs ~44 clocks of address processing per wave-instruction against ~16 for a contiguous 1 KB);
+//     v_mfma_f32_16x16x32_bf16 with the weight rows as the A operand (a lane ends with 4 consecutive output columns of
+//     one token row);
+//   * what a kernel costs is (a) its executed instruction count (one wave per SIMD: template parameters instead of guards,
+//     DPP + readlane reductions) and (b) the bytes ONE workgroup pulls through its CU's L2 port (~70 GB/s for lines every
+//     workgroup shares): from 5 tokens on the rows are cut into blocks of 8 (<= 16 tokens) or 16 rows (blockIdx.y) x
+//     16-column tiles, so a workgroup normalises only its block;
+//   * the head (final add + norm, mean pool, Dense 768 -> 3072 -> 768) is two more launches of the same kernels;
+//   * T is a launch parameter (no row past the query's length is loaded; the engine keeps one captured hipGraph per length).
+// K order differs from the batch kernels (K split over a workgroup's waves) -> results agree with the batch path to bf16
+// rounding noise (cosine >= 0.9999, tests/test_query_path_gpu.py), not bit for bit.  Numbers: DESIGN.md 3.8.
 #include "embed_kernels.h"
 #include "launch_util.h"
 

@@ -1,4 +1,4 @@
-"""The search-time forward (cqs_amd/csrc/query_kernels.hip): ONE sequence of <= 64 tokens runs 5 launches per layer +
+"""The search-time forward (cqs_amd/csrc/query_kernels.hip): ONE sequence of <= 64 tokens runs 4 launches per layer +
 2 for the head, replayed from a hipGraph - what `Embedder::embed_query` (src/embedder/core.rs:768-856) costs on every
 search.  Checked: (1) against the fp32 oracle (oracle/gemma3_ref.py) at lengths {1, 8, 33, 64}, tiny and full
 geometry - the reference holds no golden vector for the forward, so numerics stay "parity unpinned" as everywhere on
