@@ -948,6 +948,12 @@ hipError_t qf_launch_pro(const QfGemmParams& p, uint32_t n_out_cols, hipStream_t
     // port, not all of them, and every column of the MFMA tile is a real one); not for the pooled head (one row tile anyway)
     static const bool split_off = [] { const char* e = getenv("CQS_HIP_QUERY_ROW_SPLIT"); return e && e[0] == '0'; }();
     if (PRO != QF_PRO_POOL && !split_off && p.T > 4u && p.T <= 16u && n_out_cols % 16u == 0) {      // blocks of 8 rows (5-8 tokens: one)
+        if (p.T <= 8u) {                     // one block: 8-column tiles (160 / 144 workgroups of 49 / 62 KB beat 80 / 72 of 62 / 86)
+            const size_t lds = (size_t)(16 + NT * 8) * (NCH * 256 + kQfPad) * sizeof(bf16_t) + (size_t)8 * NT * 64 * 16;
+            static DynLdsOnce once8;
+            return qf_launch(qf_gemm_kernel<NCH, PRO == QF_PRO_POOL ? QF_PRO_ADDNORM : PRO, EPI, 8, 1, 1, 8, 8>, once8, p, n_out_cols / 8u, lds, st,
+                             512u, (p.T + 7u) / 8u);
+        }
         const size_t lds = (size_t)(16 + NT * 16) * (NCH * 256 + kQfPad) * sizeof(bf16_t) + (size_t)8 * NT * 64 * 16;
         static DynLdsOnce once;
         return qf_launch(qf_gemm_kernel<NCH, PRO == QF_PRO_POOL ? QF_PRO_ADDNORM : PRO, EPI, 16, 1, 1, 8, 8>, once, p, n_out_cols / 16u, lds, st,
