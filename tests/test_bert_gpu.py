@@ -112,6 +112,38 @@ def test_resident_key_attention_at_the_block_edges(hip, monkeypatch, heads):
     eng.close()
 
 
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_resident_key_attention_random_batches(hip, monkeypatch, seed):
+    """Random ragged batches (empty sequences, lengths to 512, 1-12 sequences, head dims 64 and 32): the resident-key
+    attention kernel against the first-generation one on the same engine - finite, deterministic, cosine >= 0.9995 per
+    sequence, and equally close to each other whatever the query split."""
+    rng = np.random.default_rng(1000 + seed)
+    heads = int(rng.choice([4, 8]))
+    cfg = R.BertConfig(vocab_size=400, hidden=256, layers=1, heads=heads, intermediate=256, max_pos=512)
+    eng, _ = _engine(cfg, "none", seed=50 + seed)
+    for _ in range(4):
+        nseq = int(rng.integers(1, 13))
+        top = int(rng.choice([40, 130, 256, 300, 512]))
+        lens = [int(x) for x in rng.integers(0, top + 1, size=nseq)]
+        if sum(lens) == 0:
+            lens[0] = 3
+        seqs = _seqs(cfg, lens, seed=int(rng.integers(1, 10_000)))
+        got = eng.hidden(seqs, None)
+        assert np.isfinite(got).all() and np.array_equal(got, eng.hidden(seqs, None))
+        monkeypatch.setenv("CQS_HIP_BERT_ATTN_QSPLIT", str(int(rng.choice([1, 2, 4]))))
+        assert np.array_equal(got, eng.hidden(seqs, None))
+        monkeypatch.delenv("CQS_HIP_BERT_ATTN_QSPLIT")
+        monkeypatch.setenv("CQS_HIP_BERT_ATTN_RESIDENT", "0")
+        old = eng.hidden(seqs, None)
+        monkeypatch.delenv("CQS_HIP_BERT_ATTN_RESIDENT")
+        m = 0
+        for n in lens:
+            if n:
+                assert cos(got[m:m + n].ravel(), old[m:m + n].ravel()) > 0.9995, (heads, lens, n)
+            m += n
+    eng.close()
+
+
 def test_splade_sparse_vectors(hip):
     """`encode_batch`: activations against the oracle, and the sparse vectors the threshold leaves: every strong
     weight present with the same id, weights within bf16 noise, ascending ids, nothing at or below the threshold."""
