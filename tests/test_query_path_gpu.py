@@ -27,7 +27,7 @@ def test_query_path_matches_the_oracle_and_the_batch_path(hip, monkeypatch):
     monkeypatch.setenv("CQS_HIP_QUERY_PATH", "0")
     eng_b, _ = make(SMALL, seed=31)                      # the same weights through the batch chain only
     monkeypatch.delenv("CQS_HIP_QUERY_PATH")
-    for n in LENS + [2, 15, 16, 17, 48, 63]:
+    for n in LENS + [2, 4, 5, 9, 15, 16, 17, 24, 25, 31, 32, 40, 48, 49, 56, 63]:      # every row-block edge (blocks of 8 / 16 rows)
         ids, mask = _one(SMALL, n, seed=100 + n)
         got = eng_q.run(ids, mask)[0]
         ref = G.forward(SMALL, w, ids, mask)[0]
