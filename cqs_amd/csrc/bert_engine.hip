@@ -68,7 +68,7 @@ struct cqs_hip_bert {
     struct Ctx {
         hipStream_t stream = nullptr;
         uint32_t tok_cap = 0, seq_cap = 0, blk_cap = 0;
-        bf16_t *x = nullptr, *y = nullptr, *qkv = nullptr, *att = nullptr, *h = nullptr, *pooled = nullptr;
+        bf16_t *x = nullptr, *x2 = nullptr, *y = nullptr, *qkv = nullptr, *att = nullptr, *h = nullptr, *pooled = nullptr;   // x2: the other residual buffer of the fused small-batch chain
         float *dense = nullptr, *cls = nullptr;
         uint32_t *sp_ids = nullptr, *sp_cnt = nullptr;  // device-side threshold filter: [sp_rows * sp_cap] ids / weights, [sp_rows] counts
         float* sp_w = nullptr;
@@ -145,7 +145,7 @@ using BCtx = cqs_hip_bert::Ctx;
 using BSlot = cqs_hip_bert::Slot;
 
 void free_scratch(BCtx& c) {
-    void** all[] = {(void**)&c.x, (void**)&c.y, (void**)&c.qkv, (void**)&c.att, (void**)&c.h,
+    void** all[] = {(void**)&c.x, (void**)&c.x2, (void**)&c.y, (void**)&c.qkv, (void**)&c.att, (void**)&c.h,
                     (void**)&c.pooled, (void**)&c.dense, (void**)&c.cls, (void**)&c.d_meta};
     for (void** p : all) { (void)hipFree(*p); *p = nullptr; }
     (void)hipFree(c.sp_ids); (void)hipFree(c.sp_w); (void)hipFree(c.sp_cnt);
@@ -161,6 +161,7 @@ int32_t ensure_scratch(cqs_hip_bert* e, BCtx& c, uint32_t M, uint32_t B, uint32_
     const cqs_hip_bert_config& cf = e->cfg;
     const size_t H = cf.hidden;
     B_TRY(e, hipMalloc((void**)&c.x, (size_t)Mc * H * 2));
+    B_TRY(e, hipMalloc((void**)&c.x2, (size_t)std::min<uint32_t>(Mc, 64u) * H * 2));
     B_TRY(e, hipMalloc((void**)&c.y, (size_t)Mc * H * 2));
     B_TRY(e, hipMalloc((void**)&c.qkv, (size_t)Mc * 3 * H * 2));
     B_TRY(e, hipMalloc((void**)&c.att, (size_t)Mc * H * 2));
@@ -229,6 +230,37 @@ int32_t run_encoder(cqs_hip_bert* e, BCtx& c, BSlot& sl, const int32_t* tokens, 
                   *d_blk = d_len + B;
     const uint32_t H = cf.hidden, I = cf.intermediate;
     B_TRY(e, cqs::launch_bert_embed_ln(d_tok, d_pos, d_tt, e->word, e->posw, e->typew, e->emb_g, e->emb_b, cf.ln_eps, c.x, M, H, st));
+    // Up to 64 tokens (a search-time query): 5 launches per layer instead of 7 - each residual add + LayerNorm runs in the
+    // prologue of the projection that consumes it (launch_gemm_small_rows_addln: every workgroup normalises the rows it
+    // multiplies; the stream alternates between two buffers because everybody reads the old one)
+    {
+        const char* sr = getenv("CQS_HIP_GEMM_SMALL_ROWS");       // (the switch of the small-rows kernels covers this chain too)
+        const bool fused = M <= 64u && !(sr && sr[0] == '0') && (H == 768u || H == 1024u || H == 256u) && H % 16u == 0 && I % 16u == 0;
+        if (fused) {
+            bf16_t* cur = c.x;
+            bf16_t* oth = c.x2;
+            for (uint32_t l = 0; l < cf.layers; ++l) {
+                const BertLayer& w = e->L[l];
+                if (l == 0) {
+                    B_TRY(e, cqs::launch_gemm_bias(cur, w.wqkv, w.bqkv, c.qkv, M, 3u * H, H, 3u * H, cqs::GEMM_OUT_BF16, st));
+                } else {
+                    const BertLayer& pv = e->L[l - 1];
+                    B_TRY(e, cqs::launch_gemm_small_rows_addln(cur, c.y, pv.ln2_g, pv.ln2_b, cf.ln_eps, oth, w.wqkv, w.bqkv, c.qkv, M, 3u * H, H,
+                                                               3u * H, cqs::GEMM_OUT_BF16, st));
+                    std::swap(cur, oth);
+                }
+                B_TRY(e, cqs::launch_bert_attention(c.qkv, c.att, d_blk, nblk, d_start, d_len, B, max_len, cf.heads, H / cf.heads, st));
+                B_TRY(e, cqs::launch_gemm_bias(c.att, w.wo, w.bo, c.y, M, H, H, H, cqs::GEMM_OUT_BF16, st));
+                B_TRY(e, cqs::launch_gemm_small_rows_addln(cur, c.y, w.ln1_g, w.ln1_b, cf.ln_eps, oth, w.w1, w.b1, c.h, M, I, H, I,
+                                                           cqs::GEMM_OUT_BF16_GELU, st));
+                std::swap(cur, oth);
+                B_TRY(e, cqs::launch_gemm_bias(c.h, w.w2, w.b2, c.y, M, H, I, H, cqs::GEMM_OUT_BF16, st));
+            }
+            const BertLayer& lw = e->L[cf.layers - 1u];
+            B_TRY(e, cqs::launch_bert_add_ln(cur, c.y, lw.ln2_g, lw.ln2_b, cf.ln_eps, c.x, M, H, st));     // the final hidden states, in c.x
+            return CQS_HIP_OK;
+        }
+    }
     for (uint32_t l = 0; l < cf.layers; ++l) {
         const BertLayer& w = e->L[l];
         B_TRY(e, cqs::launch_gemm_bias(c.x, w.wqkv, w.bqkv, c.qkv, M, 3u * H, H, 3u * H, cqs::GEMM_OUT_BF16, st));

@@ -165,4 +165,10 @@ hipError_t launch_f32_to_bf16(const float* in, bf16_t* out, size_t n, hipStream_
 hipError_t launch_gemm_small_rows(const bf16_t* A, const bf16_t* W, const float* bias, void* C, uint32_t M, uint32_t N,
                                   uint32_t K, uint32_t ldc, GemmOut out, hipStream_t st);
 
+// launch_gemm_small_rows with the producer's residual add + LayerNorm in the prologue (BERT post-LN layers, M <= 64):
+// x_out = bf16(LayerNorm(x + y) gamma + beta); C = act(x_out W^T + bias).  H in {256, 768, 1024}, N % 16 == 0, x_out != x.
+hipError_t launch_gemm_small_rows_addln(const bf16_t* x, const bf16_t* y, const float* gamma, const float* beta, float eps,
+                                        bf16_t* x_out, const bf16_t* W, const float* bias, void* C, uint32_t M, uint32_t N,
+                                        uint32_t H, uint32_t ldc, GemmOut out, hipStream_t st);
+
 }  // namespace cqs

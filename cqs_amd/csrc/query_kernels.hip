@@ -114,7 +114,8 @@ __device__ __forceinline__ f4 qf_bias_act(f4 v, const float* __restrict__ bias, 
             (P).dbg[((size_t)(P).dbg_slot * 256u + blockIdx.x) * 8u + (i)] = __builtin_amdgcn_s_memrealtime(); \
     } while (0)
 
-enum { QF_PRO_NONE = 0, QF_PRO_EMBED = 1, QF_PRO_ADDNORM = 2, QF_PRO_POOL = 3 };
+enum { QF_PRO_NONE = 0, QF_PRO_EMBED = 1, QF_PRO_ADDNORM = 2, QF_PRO_POOL = 3,
+       QF_PRO_ADDLN = 4 /* BERT: x = LayerNorm(xb_in + y) gamma + beta (bf16 stream), the GEMM's activations = x */ };
 enum { QF_EPI_BF16 = 0, QF_EPI_GEGLU = 1, QF_EPI_F32 = 2 };
 
 struct QfGemmParams {
@@ -133,8 +134,10 @@ struct QfGemmParams {
     uint32_t K, ldc;
     uint32_t T;               // tokens, 1..64: a LAUNCH parameter (the engine keeps one captured graph per length)
     int32_t one_row;          // 1: the GEMM's activations are ONE row (the pooled vector)
-    const float* bias;        // plain / staged kernels: nullable, [N] f32 added before the activation (BERT projections)
-    int32_t act;              // plain / staged kernels: 1 = erf-GELU after the bias (BERT's FFN)
+    const float* bias;        // nullable, [N] f32 added before the activation (BERT projections; not with GEGLU)
+    int32_t act;              // 1 = erf-GELU after the bias (BERT's FFN)
+    const bf16_t* xb_in;      // ADDLN: the bf16 residual stream [rows, H]; w_post = gamma, w_next = beta, eps
+    bf16_t* xb_out;           // ADDLN: the new stream (written by the workgroups of column tile 0; != xb_in)
     unsigned long long* dbg;  // nullable (CQS_HIP_QUERY_STAMPS=1): [kernel slot][workgroup < 256][8] realtime stamps
     uint32_t dbg_slot;
 };
@@ -407,6 +410,11 @@ __global__ __launch_bounds__(64 * NW) void qf_gemm_kernel(const QfGemmParams p) 
                 const bf4 e = *(const bf4*)(p.emb + (size_t)(uint32_t)p.tok[row0 + row] * H + c * 256 + c0);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) xv[c][i] = (float)e[i] * p.scale;
+            } else if (PRO == QF_PRO_ADDLN) {
+                const bf4 xb = *(const bf4*)(p.xb_in + (size_t)(row0 + row) * H + c * 256 + c0);
+                const bf4 yb = *(const bf4*)(p.y + (size_t)(row0 + row) * H + c * 256 + c0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) xv[c][i] = (float)xb[i] + (float)yb[i];
             } else {
                 xv[c] = *(const f4*)(p.x_in + (size_t)(row0 + row) * H + c * 256 + c0);
                 const bf4 yb = *(const bf4*)(p.y + (size_t)(row0 + row) * H + c * 256 + c0);
@@ -419,6 +427,31 @@ __global__ __launch_bounds__(64 * NW) void qf_gemm_kernel(const QfGemmParams p) 
 #pragma unroll
     for (int c = 0; c < NCH; ++c) psum[c] = (f4)(0.f);
     auto finish_row = [&](uint32_t row, bool count, f4 (&xv)[NCH], f4 (&yv)[NCH]) {
+        if (PRO == QF_PRO_ADDLN) {
+            // LayerNorm of v = x + y (bert_add_ln_kernel's arithmetic: mean, then the biased variance around it, two passes
+            // over the registers); wp1 = gamma, wn1 = beta
+            float sm = 0.f;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) sm += xv[c][i];
+            const float mean = qf_wave_sum(sm) / (float)H;
+            float q = 0.f;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { const float a = xv[c][i] - mean; q += a * a; }
+            const float inv = rsqrtf(qf_wave_sum(q) / (float)H + p.eps);
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                bf4 o;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i] = (bf16_t)((xv[c][i] - mean) * inv * wp1[c][i] + wn1[c][i]);
+                *(bf4*)(sA + (size_t)row * LDA + c * 256 + c0) = o;
+                if (blockIdx.x == 0) *(bf4*)(p.xb_out + (size_t)(row0 + row) * H + c * 256 + c0) = o;
+            }
+            return;
+        }
         if (PRO != QF_PRO_EMBED) {                                   // x += norm(y) (1 + w_post)   (add_norm_kernel's arithmetic)
             float ss = 0.f;
 #pragma unroll
@@ -463,6 +496,11 @@ __global__ __launch_bounds__(64 * NW) void qf_gemm_kernel(const QfGemmParams p) 
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         const f4 a = *(const f4*)(p.w_next + c * 256 + c0);
+        if (PRO == QF_PRO_ADDLN) {                                   // beta, gamma as they are
+            wn1[c] = a;
+            wp1[c] = *(const f4*)(p.w_post + c * 256 + c0);
+            continue;
+        }
         wn1[c] = a + 1.0f;
         if (PRO != QF_PRO_EMBED) wp1[c] = *(const f4*)(p.w_post + c * 256 + c0) + 1.0f;
     }
@@ -557,6 +595,7 @@ __global__ __launch_bounds__(64 * NW) void qf_gemm_kernel(const QfGemmParams p) 
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[r] = (bf16_t)(qf_gelu_tanh(v[0][r]) * v[NT - 1][r]);
     } else {
+        if (PRO == QF_PRO_ADDLN) v[0] = qf_bias_act(v[0], p.bias, p.act, blockIdx.x * (uint32_t)NC + 4u * (uint32_t)lg);
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[r] = (bf16_t)v[0][r];
     }
@@ -1170,6 +1209,23 @@ hipError_t launch_gemm_small_rows(const bf16_t* A, const bf16_t* W, const float*
     p.T = M; p.A = A; p.K = K; p.W = W; p.C = C; p.ldc = ldc; p.bias = bias; p.act = out == GEMM_OUT_BF16_GELU ? 1 : 0;
     if (out == GEMM_OUT_F32) return qf_launch_plain<QF_EPI_F32, 8>(p, N, st);
     return qf_launch_plain<QF_EPI_BF16, 8>(p, N, st);
+}
+
+// The same with the producer's residual add + LayerNorm in the prologue (BERT's post-LN layers):
+//   x_out = bf16(LayerNorm(x + y) gamma + beta);  C = act(x_out W^T + bias)
+// for M <= 64 rows, K = H in {256, 768, 1024}; x_out != x (every workgroup reads x, column tile 0 writes x_out).
+hipError_t launch_gemm_small_rows_addln(const bf16_t* x, const bf16_t* y, const float* gamma, const float* beta, float eps,
+                                        bf16_t* x_out, const bf16_t* W, const float* bias, void* C, uint32_t M, uint32_t N,
+                                        uint32_t H, uint32_t ldc, GemmOut out, hipStream_t st) {
+    if (M == 0) return hipSuccess;
+    if (M > 64u || N % 16u || x == x_out || (out != GEMM_OUT_BF16 && out != GEMM_OUT_BF16_GELU)) return hipErrorNotSupported;
+    QfGemmParams p{};
+    p.T = M; p.xb_in = x; p.y = y; p.w_post = gamma; p.w_next = beta; p.eps = eps; p.xb_out = x_out;
+    p.W = W; p.C = C; p.ldc = ldc; p.bias = bias; p.act = out == GEMM_OUT_BF16_GELU ? 1 : 0;
+    if (H == 768u) return qf_launch_pro<3, QF_PRO_ADDLN, QF_EPI_BF16, 8>(p, N, st);
+    if (H == 1024u) return qf_launch_pro<4, QF_PRO_ADDLN, QF_EPI_BF16, 8>(p, N, st);
+    if (H == 256u) return qf_launch_pro<1, QF_PRO_ADDLN, QF_EPI_BF16, 8>(p, N, st);
+    return hipErrorNotSupported;
 }
 
 bool query_forward_supported(const EmbedGeom& g) {
