@@ -58,6 +58,7 @@ struct cqs_hip_embedder {
     bool query_path = false;              // geometry supported and not disabled by CQS_HIP_QUERY_PATH=0
     bool query_graph = true;              // CQS_HIP_QUERY_GRAPH=0: launch the query chain eagerly
     bool query_direct = true;             // CQS_HIP_QUERY_DIRECT=0: token ids / result always through copy calls
+    bool single_ctx = false;              // CQS_HIP_EMBED_CONTEXTS=1: one execution context (A/B hook for the two-chain overlap)
     float *rope_global = nullptr, *rope_local = nullptr;  // [max_seq][128][2]
     std::map<std::string, bool> seen;
     bool finalized = false;
@@ -610,6 +611,8 @@ int32_t cqs_hip_embedder_finalize(cqs_hip_embedder* e) CQS_ABI_TRY {
     e->query_graph = !(qg && qg[0] == '0');
     const char* qd = getenv("CQS_HIP_QUERY_DIRECT");
     e->query_direct = !(qd && qd[0] == '0');
+    const char* ec = getenv("CQS_HIP_EMBED_CONTEXTS");
+    e->single_ctx = ec && ec[0] == '1';
     e->finalized = true;
     return CQS_HIP_OK;
 } CQS_ABI_CATCH(e)
@@ -728,7 +731,8 @@ int32_t submit_locked(cqs_hip_embedder* e, uint32_t B, const std::function<int32
     int load[cqs_hip_embedder::kCtx] = {0, 0};
     for (const cqs_hip_embedder::Slot& s2 : e->slot)
         if (s2.ticket != 0) load[s2.ctx]++;
-    const int ci = load[0] == load[1] ? (load[0] == 0 ? 0 : 1 - e->last_ctx) : (load[0] < load[1] ? 0 : 1);
+    int ci = load[0] == load[1] ? (load[0] == 0 ? 0 : 1 - e->last_ctx) : (load[0] < load[1] ? 0 : 1);
+    if (e->single_ctx) ci = 0;            // CQS_HIP_EMBED_CONTEXTS=1: every ticket on one stream (tickets still overlap host packing / copies)
     e->last_ctx = ci;
     sl->ctx = ci;
     Ctx& c = e->ctx[ci];
