@@ -511,7 +511,7 @@ def test_fused_projection_addnorm_is_bit_identical_to_the_two_launch_chain(hip, 
         monkeypatch.setenv("CQS_HIP_GEMM_FUSE_NORM", "0")
         plain = eng.run(ids, mask)
         monkeypatch.setenv("CQS_HIP_GEMM_FUSE_NORM", "1")
-        monkeypatch.setenv("CQS_HIP_GEMM_FUSE_NORM_MIN_ROWS", "256")     # (default 4096: the test batches are smaller)
+        monkeypatch.setenv("CQS_HIP_GEMM_FUSE_NORM_MIN_ROWS", "256")     # (default 12288: the test batches are smaller)
         fused = eng.run(ids, mask)
         monkeypatch.delenv("CQS_HIP_GEMM_FUSE_NORM_MIN_ROWS")
         assert np.array_equal(fused, plain), float(np.max(np.abs(fused - plain)))
