@@ -1409,7 +1409,7 @@ hipError_t launch_v_transpose(const bf16_t* qkv, bf16_t* vt, const int32_t* blk,
 }
 
 // Which attention kernel a batch gets.  With several q-heads per kv head: head-sharing workgroups on the 64-key LDS-DMA
-// kernel (row-major V, no V^T), at EVERY batch size - rounds 1-2 kept one q-head per workgroup on the register-staged
+// kernel (row-major V, no V^T), from ~1.5k tokens on - rounds 1-2 kept one q-head per workgroup on the register-staged
 // kernel (which reads V^T) below one head-sharing workgroup per CU ("more, thinner workgroups fill the chip better": +6 %
 // against round 1's head-sharing kernel); against the LDS-DMA kernel that rule lost 2-7 % of the whole forward at 4-48
 // ragged sequences (tools/embed_att_layout_sweep.sh, round 3).  CQS_HIP_ATT_KERNEL=reg keeps the register-staged kernel,
@@ -1424,8 +1424,8 @@ static AttPlan att_plan(uint32_t nblk, uint32_t heads, uint32_t kv_heads) {
             n_cu = 256;
     }
     const uint32_t ratio = kv_heads ? heads / kv_heads : 0u;
-    bool share = ratio > 1u;
-    (void)nblk; (void)n_cu;
+    bool share = ratio > 1u && nblk * 2u * kv_heads >= 24u;      // (under ~1.5k tokens - one sequence - the thin workgroups are as fast or faster)
+    (void)n_cu;
     if (const char* f = getenv("CQS_HIP_ATT_LAYOUT")) {
         if (f[0] == 's') share = ratio > 1u;
         else if (f[0] == 'p') share = false;
