@@ -135,6 +135,71 @@ __global__ __launch_bounds__(256) void bert_add_ln_kernel(const bf16_t* __restri
     ln_row_store<VEC>(v, nc, H, gamma, beta, eps, out + (size_t)m * H, lane);
 }
 
+// The same for the hidden sizes of the models at hand (768, 1024, 256; 384 with 4-byte lanes), TWO tokens per wave with every load of both
+// in flight before the first reduction, chunk count at compile time, gamma / beta as 16-byte loads: the kernel is a pure
+// HBM stream (75 MB at 64 x 256 tokens x 768) and ran at 65 % of the rate add_norm_kernel reaches.  Same per-lane order of
+// additions and the same reductions as bert_add_ln_kernel<4>: bit-identical.
+template <int VEC, int NC>
+__global__ __launch_bounds__(256) void bert_add_ln2_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ r,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           float eps, bf16_t* __restrict__ out, uint32_t M) {
+    typedef __bf16 bfv __attribute__((ext_vector_type(VEC)));
+    typedef float fv __attribute__((ext_vector_type(VEC)));
+    constexpr uint32_t H = 64u * VEC * NC;
+    const int lane = threadIdx.x & 63;
+    const uint32_t m0 = (blockIdx.x * 4u + (threadIdx.x >> 6)) * 2u;
+    if (m0 >= M) return;
+    const bool two = m0 + 1u < M;
+    const uint32_t m1 = two ? m0 + 1u : m0;
+    float v[2][NC][VEC];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const size_t row = (size_t)(t ? m1 : m0) * H;
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            const uint32_t col = (uint32_t)((64 * i + lane) * VEC);
+            const bfv x = *(const bfv*)(a + row + col);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) v[t][i][e] = (float)x[e];
+            if (r) {
+                const bfv y = *(const bfv*)(r + row + col);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) v[t][i][e] += (float)y[e];
+            }
+        }
+    }
+    fv g[NC], b[NC];
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        g[i] = *(const fv*)(gamma + (64 * i + lane) * VEC);
+        b[i] = *(const fv*)(beta + (64 * i + lane) * VEC);
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        float sm = 0.f;
+#pragma unroll
+        for (int i = 0; i < NC; ++i)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) sm += v[t][i][e];
+        const float mean = wave_sum64(sm) / (float)H;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NC; ++i)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) { const float d = v[t][i][e] - mean; q += d * d; }
+        const float inv = rsqrtf(wave_sum64(q) / (float)H + eps);
+        if (t == 1 && !two) break;
+        bf16_t* o = out + (size_t)(t ? m1 : m0) * H;
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            bfv w;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) w[e] = (bf16_t)((v[t][i][e] - mean) * inv * g[i][e] + b[i][e]);
+            *(bfv*)(o + (64 * i + lane) * VEC) = w;
+        }
+    }
+}
+
 // ---- multi-head attention, head dim HD = 32 or 64, bidirectional over one packed sequence -----------------------
 // One workgroup = 4 waves = 64 consecutive queries of ONE head of one sequence, 16 queries per wave.  Same product
 // layout as attention_dma_kernel (embed_kernels.hip): S^T = K Q^T with keys on MFMA rows (softmax is lane-local), the
@@ -675,7 +740,12 @@ hipError_t launch_bert_add_ln(const bf16_t* a, const bf16_t* r, const float* gam
                               bf16_t* out, uint32_t M, uint32_t H, hipStream_t st) {
     if (M == 0) return hipSuccess;
     if (H % 128u || H > 1024u) return hipErrorInvalidValue;
-    if (H % 256u == 0) hipLaunchKernelGGL(bert_add_ln_kernel<4>, dim3((M + 3u) / 4u), dim3(256), 0, st, a, r, gamma, beta, eps, out, M, H);
+    const uint32_t g2 = (M + 7u) / 8u;                     // 4 waves x 2 tokens per workgroup
+    if (H == 768u) hipLaunchKernelGGL((bert_add_ln2_kernel<4, 3>), dim3(g2), dim3(256), 0, st, a, r, gamma, beta, eps, out, M);
+    else if (H == 1024u) hipLaunchKernelGGL((bert_add_ln2_kernel<4, 4>), dim3(g2), dim3(256), 0, st, a, r, gamma, beta, eps, out, M);
+    else if (H == 256u) hipLaunchKernelGGL((bert_add_ln2_kernel<4, 1>), dim3(g2), dim3(256), 0, st, a, r, gamma, beta, eps, out, M);
+    else if (H == 384u) hipLaunchKernelGGL((bert_add_ln2_kernel<2, 3>), dim3(g2), dim3(256), 0, st, a, r, gamma, beta, eps, out, M);
+    else if (H % 256u == 0) hipLaunchKernelGGL(bert_add_ln_kernel<4>, dim3((M + 3u) / 4u), dim3(256), 0, st, a, r, gamma, beta, eps, out, M, H);
     else hipLaunchKernelGGL(bert_add_ln_kernel<2>, dim3((M + 3u) / 4u), dim3(256), 0, st, a, r, gamma, beta, eps, out, M, H);
     return hipGetLastError();
 }
