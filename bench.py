@@ -51,8 +51,9 @@ def parse():
     ap.add_argument("--e2e-chunks", type=int, default=100_000, help="configs[3]: chunks embedded + indexed end to end (0 = skip)")
     ap.add_argument("--abi-after", type=int, default=1, help="N>1 (RCCL) only: after the timed region rank 0 also runs the "
                     "single-process sharded handle over devices 0..N-1 into `abi_sharded` (0 = skip)")
-    ap.add_argument("--abi-devices", type=str, default="", help="N=1 only: also run the single-process sharded index "
-                    "(cqs_hip_index_create_sharded) over this comma-separated device list, e.g. 0,1,2,3 (or 0,0 on one GPU)")
+    ap.add_argument("--abi-devices", type=str, default="0,0,0,0", help="N=1 only: also run the single-process sharded index "
+                    "(cqs_hip_index_create_sharded) over this comma-separated device list, e.g. 0,1,2,3; the default names "
+                    "device 0 four times (the one-GPU form: four 250k-row shards, per-shard scan, gather, host merge); '' = skip")
     return ap.parse_args()
 
 
@@ -88,6 +89,32 @@ def check_topk(torch, np, rows, q, keys_u64, count, k, row_base=0, exhaustive=Tr
     return r, s
 
 
+def file_sha256(path):
+    import hashlib
+    try:
+        return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
+    except OSError:
+        return None
+
+
+def physical_cores():
+    """One logical CPU per physical core among the CPUs this process may run on (sysfs thread_siblings_list)."""
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        allowed = list(range(os.cpu_count() or 1))
+    seen, out = set(), []
+    for c in allowed:
+        try:
+            sib = open("/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list" % c).read().strip()
+        except OSError:
+            sib = str(c)
+        if sib not in seen:
+            seen.add(sib)
+            out.append(c)
+    return out
+
+
 def cpu_baseline(rows_host, queries_host, k, seconds):
     """The oracle (C restatement of the reference CPU scan, search/query.rs:453-482 minus SQLite) timed on this
     host with the dot body simsimd's run-time dispatch would take here (AVX-512 / AVX2+FMA / scalar - the ISA
@@ -105,19 +132,31 @@ def cpu_baseline(rows_host, queries_host, k, seconds):
         if el >= seconds and done >= 2:
             break
     out["value"] = round(done / el, 3)
+    # multi-thread leg: one worker per PHYSICAL core this process may use (SMT siblings share the core's load ports; the
+    # scan is memory-bound), at most 64; worker t is pinned to its core, and the corpus copy it scans was FIRST TOUCHED
+    # shard by shard by those same pinned workers, so every worker streams from its own NUMA node.  (Round 3 scanned an
+    # array one thread had touched: 64 workers read one node's memory, 83 GB/s on a 256-core host.)
     cores = os.cpu_count() or 1
-    threads = min(cores, 64)
+    cpus = physical_cores()
+    threads = max(1, min(len(cpus), 64))
+    oracle.set_worker_cpus(cpus[:threads])
+    local = oracle.first_touch_copy(rows_host, threads)
     t0 = time.perf_counter()
     done_mt = 0
     while True:
-        oracle.brute_force_mt(rows_host, queries_host[done_mt % len(queries_host)], k, 0.0, threads, oracle.DOT_NATIVE)
+        oracle.brute_force_mt(local, queries_host[done_mt % len(queries_host)], k, 0.0, threads, oracle.DOT_NATIVE)
         done_mt += 1
         el = time.perf_counter() - t0
         if el >= seconds and done_mt >= 2:
             break
+    oracle.set_worker_cpus([])
+    del local
     out["mt_value"] = round(done_mt / el, 3)
     out["mt_cores"] = threads
+    out["mt_gb_per_s"] = round(done_mt * n * rows_host.shape[1] * 4 / el / 1e9, 1)
+    out["mt_placement"] = "one pinned worker per physical core, corpus shard first-touched by its own worker"
     out["host_cores"] = cores
+    out["host_physical_cores_usable"] = len(cpus)
     out["sample"] = (f"{done} single-thread + {done_mt} {threads}-thread queries, each a full scan of the same "
                      f"{n}x{rows_host.shape[1]} fp32 corpus held in RAM, k={k}, threshold 0.0 (oracle: simsimd "
                      f"dot restated, body that ran: {out['isa']}; + clamp + BoundedScoreHeap)")
@@ -286,12 +325,13 @@ def embed_leg(a, rank, world, dist, torch, np, dev, all_reduce_max):
                         "(`HipEmbedEngine.run`), abi_ms = the C call alone on prepared buffers, both the MEDIAN of 40 calls (mean_ms / max_ms: the same "
                         "calls through the mirror); device_ms = HIP events around the chain, mean",
                 "weight_bytes_streamed": wbytes, "by_tokens": {}}
-        for n in (8, 16, 32, 64, 65):
+        for n in (8, 16, 32, 64, 65, 128):
             ids = rng.integers(1, V, size=(1, n)).astype(np.int64)
             mask = np.ones((1, n), np.int64)
             for _ in range(6):
                 eng.run(ids, mask)                   # (both contexts: eager run, capture, replays)
             reps = 40
+            gs0 = eng.query_graph_stats()
             dms, walls = 0.0, []
             for _ in range(reps):
                 t0 = time.perf_counter()
@@ -310,10 +350,54 @@ def embed_leg(a, rank, world, dist, torch, np, dev, all_reduce_max):
                 abi.append(time.perf_counter() - t0)
             dt_abi = float(np.median(abi))
             assert rc == 0 and np.array_equal(out, eng.run(ids, mask))
+            gs1 = eng.query_graph_stats()
+            calls = 2 * reps + 1
+            replays, eager = gs1["replays"] - gs0["replays"], gs1["eager"] - gs0["eager"]
+            path = ("search-time kernels, hipGraph replay" if replays == calls else
+                    "search-time kernels, EAGER launches (%d of %d calls)" % (eager, calls) if eager else "batch chain")
             qlat["by_tokens"][str(n)] = {"ms": round(dt * 1e3, 4), "abi_ms": round(dt_abi * 1e3, 4), "device_ms": round(dms / reps, 4),
                                          "mean_ms": round(float(np.mean(walls)) * 1e3, 4), "max_ms": round(float(np.max(walls)) * 1e3, 4),
-                                         "path": "search-time kernels (4 launches / layer, hipGraph)" if n <= 64 else "batch chain",
+                                         "path": path,          # observed (cqs_hip_embedder_query_graph_stats), not assumed
                                          "weight_stream_frac_of_hbm_peak": round(wbytes / (dms / reps / 1e3) / 1e9 / HBM_PEAK_GBS, 4)}
+        # first-call cost: a length the engine has never seen pays an eager chain, then capture +
+        # instantiate; `cqs_hip_embedder_warm` moves that to start-up.  Measured on lengths no call above has used.
+        import ctypes as C
+
+        def abi_call(n, seed):
+            ids = np.random.default_rng(seed).integers(1, V, size=(1, n)).astype(np.int64)
+            mask = np.ones((1, n), np.int64)
+            out = np.zeros((1, eng.dim()), np.float32)
+            t0 = time.perf_counter()
+            rc = eng._lib.cqs_hip_embed(eng._h, ids.ctypes.data_as(C.c_void_p), mask.ctypes.data_as(C.c_void_p), 1, n, out.ctypes.data_as(C.c_void_p))
+            dt = time.perf_counter() - t0
+            assert rc == 0 and np.all(np.isfinite(out))
+            return dt * 1e3
+
+        cold = {}
+        for n in (11, 23, 47, 90):
+            calls = [abi_call(n, 900 + n + j) for j in range(8)]
+            cold[str(n)] = {"first_ms": round(calls[0], 4), "second_ms": round(calls[1], 4), "third_ms": round(calls[2], 4),
+                            "steady_ms": round(float(np.median(calls[4:])), 4)}
+        t0 = time.perf_counter()
+        eng.warm(128)
+        warm_s = time.perf_counter() - t0
+        gsw = eng.query_graph_stats()
+        warmed = {}
+        for n in (12, 24, 48, 96):
+            calls = [abi_call(n, 950 + n + j) for j in range(12)]
+            warmed[str(n)] = {"first_ms": round(calls[0], 4), "steady_ms": round(float(np.median(calls[2:])), 4),
+                              "first_over_steady": round(calls[0] / float(np.median(calls[2:])), 3)}
+        lens = np.random.default_rng(0xC950041).integers(1, 129, size=240)
+        walls = np.array([abi_call(int(n), 1000 + j) for j, n in enumerate(lens)])
+        gsr = eng.query_graph_stats()
+        qlat["first_call_ms"] = {"no_warm": cold, "after_warm": warmed, "warm_seconds": round(warm_s, 3),
+                                 "graphs_after_warm": gsw["captured"], "capture_failures": gsw["failed"],
+                                 "what": "abi_ms of the FIRST blocking cqs_hip_embed at a token count the engine has not served: "
+                                         "no_warm = cold for that length (eager chain; the second call captures + instantiates); "
+                                         "after_warm = after cqs_hip_embedder_warm(128)"}
+        qlat["random_lengths"] = {"calls": int(len(walls)), "lengths": "uniform 1..128", "p50_ms": round(float(np.percentile(walls, 50)), 4),
+                                  "p99_ms": round(float(np.percentile(walls, 99)), 4), "max_ms": round(float(walls.max()), 4),
+                                  "eager_chains_during": gsr["eager"] - gsw["eager"], "captures_during": gsr["captured"] - gsw["captured"]}
     cpu = None
     if rank == 0 and world == 1 and a.cpu_seconds > 0:
         cpu = embed_cpu_baseline(np, cfg, weights, a.cpu_seconds, a.embed_len)
@@ -627,6 +711,64 @@ def aux_models_leg(a, np):
     return out
 
 
+def concurrent_clients_leg(np, idx, qh, k, dim):
+    """What N daemon client threads see (src/cli/watch/daemon.rs:273: one thread per client, all calling `search` on one
+    Arc<dyn VectorIndex>): N threads, each one blocking `cqs_hip_index_search` call at a time, one query per call, on the
+    headline corpus.  `native`: the threads are std::threads inside the library calling the public entry point (a Rust
+    daemon has no interpreter lock); `python`: Python threads through ctypes (GIL released during the call, taken between
+    calls).  Every answer is compared bit for bit with the same query asked alone."""
+    import ctypes as C
+    import threading
+    lib = idx._lib
+    storm = lib.cqs_hip_debug_client_storm
+    storm.restype = C.c_double
+    storm.argtypes = [C.c_void_p, C.c_void_p] + [C.c_uint32] * 5 + [C.c_void_p] * 3
+    nq = 48                                               # a multiple of every thread count below
+    q = np.ascontiguousarray(qh[:nq], dtype=np.float32)
+    assert q.shape[0] == nq
+    want = [idx.search_batch(q[i], k) for i in range(nq)]
+    want_r = np.stack([w[0][0] for w in want])
+    want_s = np.stack([w[1][0] for w in want])
+    out = {"what": "N threads, each one blocking cqs_hip_index_search(b = 1) at a time on the headline corpus; queries/s over all "
+                   "threads; every answer bit-identical to the lone call's (checked)", "k": k, "native_threads": {}, "python_threads": {}}
+    for T in (1, 2, 4, 8, 16):
+        per = max(60, 1920 // T)
+        rows = np.zeros((nq, k), np.uint64)
+        scores = np.zeros((nq, k), np.float32)
+        counts = np.zeros((nq,), np.uint32)
+        storm(idx._h, q.ctypes.data, nq, dim, k, T, 24, rows.ctypes.data, scores.ctypes.data, counts.ctypes.data)   # warm
+        p0, q0 = idx.combine_stats()
+        el = storm(idx._h, q.ctypes.data, nq, dim, k, T, per, rows.ctypes.data, scores.ctypes.data, counts.ctypes.data)
+        p1, q1 = idx.combine_stats()
+        assert el > 0, "a client call failed"
+        assert np.all(counts == k) and np.array_equal(rows, want_r) and np.array_equal(scores, want_s), "combined answers differ from the lone call's"
+        out["native_threads"][str(T)] = {"queries_per_sec": round(T * per / el, 1), "ms_per_call": round(el / per * 1e3, 4),
+                                          "mean_callers_per_pass": round((q1 - q0) / max(p1 - p0, 1), 2), "checked": True}
+    for T in (1, 8):
+        per = max(60, 960 // T)
+        bufs = [(np.zeros((1, k), np.uint64), np.zeros((1, k), np.float32), np.zeros((1,), np.uint32)) for _ in range(T)]
+        bad = []
+
+        def work(t):
+            r, s_, c = bufs[t]
+            qi = t % nq
+            for _ in range(per):
+                rc = lib.cqs_hip_index_search(idx._h, q[qi].ctypes.data, 1, dim, k, None, 0, 0.0, r.ctypes.data, s_.ctypes.data, c.ctypes.data)
+                if rc != 0 or not (np.array_equal(r[0], want_r[qi]) and np.array_equal(s_[0], want_s[qi])):
+                    bad.append((t, qi, rc))
+                    return
+                qi = (qi + T) % nq
+
+        th = [threading.Thread(target=work, args=(t,)) for t in range(T)]
+        t0 = time.perf_counter()
+        [x.start() for x in th]
+        [x.join() for x in th]
+        el = time.perf_counter() - t0
+        assert not bad, bad
+        out["python_threads"][str(T)] = {"queries_per_sec": round(T * per / el, 1), "ms_per_call": round(el / per * 1e3, 4), "checked": True}
+    return out
+
+
 def abi_sharded_leg(a, torch, np, rows, queries, k, dim):
     """Single-process multi-GPU path behind the C ABI (cqs_hip_index_create_sharded): synchronous host-API queries
     on the same corpus, checked against the single-device answer."""
@@ -644,8 +786,13 @@ def abi_sharded_leg(a, torch, np, rows, queries, k, dim):
     res = [sh.search_batch(qh[i], k) for i in range(nq)]
     el = time.perf_counter() - t0
     single = HipIndex.build_from_device(None, rows.data_ptr(), rows.shape[0], dim, borrow=True, keepalive=rows)
-    for i in (0, nq // 2, nq - 1):
-        r1, s1, c1 = single.search_batch(qh[i], k)
+    for i in range(min(10, nq)):
+        single.search_batch(qh[i], k)
+    t0 = time.perf_counter()
+    ref = [single.search_batch(qh[i], k) for i in range(nq)]
+    el1 = time.perf_counter() - t0
+    for i in range(nq):                                 # EVERY timed query against the single-device answer
+        r1, s1, c1 = ref[i]
         assert c1[0] == res[i][2][0] and np.max(np.abs(s1 - res[i][1])) <= 2e-6
         if np.all(np.abs(np.diff(s1[0])) > 4e-6):
             assert np.array_equal(r1, res[i][0])
@@ -654,7 +801,11 @@ def abi_sharded_leg(a, torch, np, rows, queries, k, dim):
     sh.close()
     return {"devices": devs, "shards": [{"device": d, "rows": r, "rccl": rc} for d, _f, r, rc in info],
             "queries_per_sec_host_api": round(nq / el, 1), "ms_per_query": round(el / nq * 1e3, 4),
-            "build_s": round(t_build, 2), "checked_vs_single_device": True}
+            "single_device_same_queries": {"queries_per_sec_host_api": round(nq / el1, 1), "ms_per_query": round(el1 / nq * 1e3, 4)},
+            "vs_single_device": round(el1 / el, 4), "queries": nq,
+            "build_s": round(t_build, 2), "checked_vs_single_device": True, "checked": True,
+            "what": "cqs_hip_index_create_sharded -> per-shard scan + select -> gather -> host merge, blocking host API, "
+                    "one query per call; a device named more than once gathers without RCCL (one-GPU form)"}
 
 
 def abi_after_group_leg(a, torch, np, world, k, dim, rows_per_device=250_000, budget_s=150.0):
@@ -987,7 +1138,14 @@ def main():
             try:
                 tj = json.load(open(tpath))
                 if tj.get("alg_bytes_per_launch") == alg_bytes and nq_scan == 1:
-                    traffic, traffic_src = tj.get("hbm_bytes_per_launch"), tj.get("source")
+                    # NOT measured in this run: the committed PMC summary, with the commit it was measured at and the
+                    # kernel instantiation it measured - a scan-kernel change after that commit invalidates it
+                    traffic = tj.get("hbm_bytes_per_launch")
+                    traffic_src = {"file": "profiles/scan_traffic.json", "how": tj.get("source"),
+                                   "measured_at_commit": tj.get("commit"), "kernel": tj.get("kernel"),
+                                   "scan_kernels_hip_sha256_then": tj.get("scan_kernels_sha256"),
+                                   "scan_kernels_hip_sha256_now": file_sha256(os.path.join(ROOT, "cqs_amd", "csrc", "scan_kernels.hip")),
+                                   "measured_in_this_run": False}
             except Exception:
                 traffic = None
         roofline = {"bound": "hbm", "kernel": "scan_gemv_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
@@ -1007,6 +1165,11 @@ def main():
         el = time.perf_counter() - t1
         latency = {"queries_per_sec": round(len(qh) / el, 1), "ms_per_query": round(el / len(qh) * 1e3, 4),
                    "what": "cqs_hip_index_search, host query in / host results out, one call at a time"}
+
+    clients = None
+    if rank == 0 and world == 1 and mode == "single" and a.extras:
+        qc = make_unit_rows(torch, 48, dim, 0xC950031, dev).cpu().numpy()
+        clients = concurrent_clients_leg(np, idx, qc, k, dim)
 
     cpu = None
     if rank == 0 and world == 1 and a.cpu_seconds > 0:
@@ -1101,6 +1264,7 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
             "latency_host_api": latency,
+            "concurrent_clients": clients,
             "other_configs": other,
             "abi_sharded": abi,
             "strong_scaling_n1": strong_n1,

@@ -64,6 +64,7 @@ SIGNATURES = [
     ("cqs_hip_index_search_device", C.c_int32,
      [_c_idx, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_float,
       C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("cqs_hip_index_combine_stats", None, [_c_idx, _pp(C.c_uint64), _pp(C.c_uint64)]),
     ("cqs_hip_index_neighbors", C.c_int32, [_c_idx, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, _pp(C.c_uint32)]),
     ("cqs_hip_unpack_keys", None, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     ("cqs_hip_merge_keys", C.c_size_t,
@@ -82,6 +83,8 @@ SIGNATURES = [
     ("cqs_hip_embed_submit", C.c_int32, [_c_idx, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, _pp(C.c_uint64)]),
     ("cqs_hip_embed_submit_ragged", C.c_int32, [_c_idx, C.c_void_p, C.c_void_p, C.c_uint32, _pp(C.c_uint64)]),
     ("cqs_hip_embed_collect", C.c_int32, [_c_idx, C.c_uint64, C.c_void_p]),
+    ("cqs_hip_embedder_warm", C.c_int32, [_c_idx, C.c_uint32]),
+    ("cqs_hip_embedder_query_graph_stats", None, [_c_idx, _pp(C.c_uint64), _pp(C.c_uint64), _pp(C.c_uint64), _pp(C.c_uint64)]),
     ("cqs_hip_normalize_l2_rows", None, [C.c_void_p, C.c_uint64, C.c_uint32]),
     ("cqs_hip_embed_hidden", C.c_int32, [_c_idx, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
     ("cqs_hip_embedder_last_ms", C.c_float, [_c_idx]),

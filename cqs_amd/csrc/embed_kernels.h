@@ -45,7 +45,7 @@ hipError_t launch_add_norm(float* x, const bf16_t* y, const float* w_post, const
 
 // launch_gemm_bf16(A, W, y, GEMM_OUT_BF16) + launch_add_norm(x, y, ...) in ONE launch (gemm_rowfuse.hip): a workgroup owns
 // 64 whole rows x all H = 768 columns, so y never leaves the CU.  Same bits as the two-launch chain.  H must be 768.
-bool gemm_addnorm_supported(uint32_t M, uint32_t H, uint32_t K);     // shape + CQS_HIP_GEMM_FUSE_NORM / _MIN_ROWS
+bool gemm_addnorm_supported(uint32_t M, uint32_t H, uint32_t K);     // shape only (the engine decides by batch size: embedder.hip)
 hipError_t launch_gemm_addnorm(const bf16_t* A, const bf16_t* W, float* x, const float* w_post, const float* w_next,
                                float eps, bf16_t* xn, float* out, int final, uint32_t M, uint32_t H, uint32_t K,
                                hipStream_t st);

@@ -59,6 +59,11 @@ struct cqs_hip_embedder {
     bool query_graph = true;              // CQS_HIP_QUERY_GRAPH=0: launch the query chain eagerly
     bool query_direct = true;             // CQS_HIP_QUERY_DIRECT=0: token ids / result always through copy calls
     bool single_ctx = false;              // CQS_HIP_EMBED_CONTEXTS=1: one execution context (A/B hook for the two-chain overlap)
+    // o_proj / down fused with the residual add + both norms (gemm_rowfuse.hip).  Read ONCE, at finalize
+    // (CQS_HIP_GEMM_FUSE_NORM / _MIN_ROWS); tests flip it through cqs_hip_debug_embedder_set_fuse_norm.
+    bool fuse_norm = true;
+    uint32_t fuse_min_rows = 12288;       // below ~12.7k tokens the two-launch chain wins (a 64-row tile per CU streams the
+                                          // whole W panel whatever the row count: measured 3.89 vs 3.46 ms at 5k tokens)
     float *rope_global = nullptr, *rope_local = nullptr;  // [max_seq][128][2]
     std::map<std::string, bool> seen;
     bool finalized = false;
@@ -90,18 +95,22 @@ struct cqs_hip_embedder {
         // the context's own pinned host buffers (q_tok_pin / q_out_pin, device-visible) - no H2D / D2H copy node and no
         // copy call around the chain.  Used when the context has no other ticket in flight (the blocking `embed_query`
         // call); a second ticket queued on the same context would overwrite those buffers, so it takes variant 0.
-        hipGraph_t q_graph[2][64] = {};
-        hipGraphExec_t q_exec[2][64] = {};
+        hipGraph_t q_graph[2][cqs::kQueryFwdMaxTokens] = {};
+        hipGraphExec_t q_exec[2][cqs::kQueryFwdMaxTokens] = {};
+        bool q_capture_failed[2][cqs::kQueryFwdMaxTokens] = {};   // capture / instantiate refused for THIS (variant, length): it stays eager
         int32_t* q_tok_pin = nullptr;      // pinned host, 64 ids
         float* q_out_pin = nullptr;        // pinned host, [hidden]
         int32_t* q_tok_pin_dev = nullptr;  // their device addresses
         float* q_out_pin_dev = nullptr;
-        uint32_t q_runs = 0;          // eager runs so far (the first sets the kernels' LDS attributes; graphs are captured after it)
-        bool q_graph_failed = false;  // capture / instantiate refused once: stay eager
         unsigned long long* q_dbg = nullptr;   // CQS_HIP_QUERY_STAMPS=1: per-kernel, per-workgroup stamps of the last query
     };
     static constexpr int kCtx = 2;
     Ctx ctx[kCtx];
+    // Search-time chain bookkeeping (cqs_hip_embedder_query_graph_stats).  A length's kernels differ by length class
+    // (row-block variants), and their dynamic-LDS attributes are set on first launch - which must not happen inside a
+    // stream capture: the first query of every length runs eagerly, the second is captured.
+    bool q_len_ran[cqs::kQueryFwdMaxTokens] = {};   // this length's kernels have been launched once (attributes set)
+    uint64_t q_captured = 0, q_capture_failures = 0, q_replays = 0, q_eager = 0;
 
     // Submission slots (pinned host staging + events): batch i+1 is packed and enqueued while batch i computes;
     // results come back through the slot's pinned `out` (cqs_hip_embed_submit / _collect).
@@ -164,7 +173,7 @@ using Ctx = cqs_hip_embedder::Ctx;
 
 void free_query_scratch(Ctx& c) {
     for (int v = 0; v < 2; ++v)
-        for (int i = 0; i < 64; ++i) {
+        for (uint32_t i = 0; i < cqs::kQueryFwdMaxTokens; ++i) {
             if (c.q_exec[v][i]) (void)hipGraphExecDestroy(c.q_exec[v][i]);
             if (c.q_graph[v][i]) (void)hipGraphDestroy(c.q_graph[v][i]);
             c.q_exec[v][i] = nullptr; c.q_graph[v][i] = nullptr;
@@ -331,7 +340,8 @@ int32_t run_layers(cqs_hip_embedder* e, Ctx& c, Slot& sl) {
                                        c.d_vt_start, c.vt_ld, g.heads, g.kv_heads, full ? 0u : g.window, w.n_q, rope,
                                        g.rms_eps, g.q_scale, st));
         // o_proj, then x += norm(y)(1 + w); xn = norm(x)(1 + w'): one launch where a workgroup can own whole rows
-        if (cqs::gemm_addnorm_supported(M, H, g.heads * g.head_dim)) {
+        const bool fuse = e->fuse_norm && M >= e->fuse_min_rows;
+        if (fuse && cqs::gemm_addnorm_supported(M, H, g.heads * g.head_dim)) {
             E_TRY(e, cqs::launch_gemm_addnorm(c.attn, w.wo, c.x, w.n_post_attn, w.n_pre_ffw, g.rms_eps, c.xn, nullptr, 0, M, H,
                                               g.heads * g.head_dim, st));
         } else {
@@ -341,7 +351,7 @@ int32_t run_layers(cqs_hip_embedder* e, Ctx& c, Slot& sl) {
         E_TRY(e, cqs::launch_gemm_bf16(c.xn, w.wgu, c.h, M, 2u * g.inter, H, g.inter, cqs::GEMM_OUT_GEGLU, st));
         const bool last = (l + 1u == g.layers);
         const float* w_next = last ? e->n_final : e->L[l + 1].n_in;
-        if (cqs::gemm_addnorm_supported(M, H, g.inter)) {
+        if (fuse && cqs::gemm_addnorm_supported(M, H, g.inter)) {
             E_TRY(e, cqs::launch_gemm_addnorm(c.h, w.wd, c.x, w.n_post_ffw, w_next, g.rms_eps, c.xn, c.hidden, last ? 1 : 0, M, H, g.inter, st));
         } else {
             E_TRY(e, cqs::launch_gemm_bf16(c.h, w.wd, c.y, M, H, g.inter, H, cqs::GEMM_OUT_BF16, st));
@@ -413,30 +423,41 @@ int32_t run_query(cqs_hip_embedder* e, Ctx& c, Slot& sl, bool direct) {
     const int gi = (int)sl.M - 1;
     if (c.q_exec[var][gi]) {
         E_TRY(e, hipGraphLaunch(c.q_exec[var][gi], st));
+        e->q_replays++;
         return CQS_HIP_OK;
     }
-    if (e->query_graph && !c.q_graph_failed && c.q_runs >= 1) {
+    if (e->query_graph && !c.q_capture_failed[var][gi] && e->q_len_ran[gi]) {
         // capture the chain (kernel launches only; every argument is a fixed device address), instantiate, replay
+        const char* stage = "hipStreamBeginCapture";
         hipError_t he = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
         if (he == hipSuccess) {
             const hipError_t le = cqs::launch_query_forward(f, st);
             hipGraph_t gr = nullptr;
             he = hipStreamEndCapture(st, &gr);
-            if (he == hipSuccess && le != hipSuccess) he = le;
-            if (he == hipSuccess) he = hipGraphInstantiate(&c.q_exec[var][gi], gr, nullptr, nullptr, 0);
+            stage = "hipStreamEndCapture";
+            if (he == hipSuccess && le != hipSuccess) { he = le; stage = "a launch inside the capture"; }
+            if (he == hipSuccess) { he = hipGraphInstantiate(&c.q_exec[var][gi], gr, nullptr, nullptr, 0); stage = "hipGraphInstantiate"; }
             if (he == hipSuccess) {
                 c.q_graph[var][gi] = gr;
+                e->q_captured++;
                 E_TRY(e, hipGraphLaunch(c.q_exec[var][gi], st));
+                e->q_replays++;
                 return CQS_HIP_OK;
             }
             if (gr) (void)hipGraphDestroy(gr);
             c.q_exec[var][gi] = nullptr;
         }
         (void)hipGetLastError();
-        c.q_graph_failed = true;        // not a device failure: the eager chain below computes the same thing
+        // not a device failure (the eager chain below computes the same thing), but never silent: counted, latched for
+        // this (variant, length) only, and the cause is left in last_error
+        c.q_capture_failed[var][gi] = true;
+        e->q_capture_failures++;
+        e->last_error = std::string("query graph capture failed at ") + stage + " (" + std::to_string(sl.M) + " tokens, variant " +
+                        std::to_string(var) + "): " + hipGetErrorString(he) + "; this length runs eagerly";
     }
     E_TRY(e, cqs::launch_query_forward(f, st));
-    c.q_runs++;
+    e->q_len_ran[gi] = true;
+    e->q_eager++;
     return CQS_HIP_OK;
 }
 
@@ -613,6 +634,8 @@ int32_t cqs_hip_embedder_finalize(cqs_hip_embedder* e) CQS_ABI_TRY {
     e->query_direct = !(qd && qd[0] == '0');
     const char* ec = getenv("CQS_HIP_EMBED_CONTEXTS");
     e->single_ctx = ec && ec[0] == '1';
+    if (const char* fn = getenv("CQS_HIP_GEMM_FUSE_NORM")) e->fuse_norm = fn[0] != '0';
+    if (const char* fr = getenv("CQS_HIP_GEMM_FUSE_NORM_MIN_ROWS")) e->fuse_min_rows = (uint32_t)atoi(fr);
     e->finalized = true;
     return CQS_HIP_OK;
 } CQS_ABI_CATCH(e)
@@ -829,6 +852,58 @@ int32_t cqs_hip_embed(cqs_hip_embedder* e, const int64_t* ids, const int64_t* ma
     return cqs_hip_embed_collect(e, t, out);
 } CQS_ABI_CATCH(e)
 
+// `Embedder::warm()` (src/embedder/core.rs:933-957: pay first-call cost before the first real query).  The search-time
+// chain keeps one captured hipGraph per (query length, execution context, variant); without this call each is built
+// the first time its length is seen (an eager chain + capture + instantiate + first replay on that query's clock).
+// Runs every length 1..max_tokens once eagerly (sets the kernels' launch attributes), then captures, instantiates and
+// replays each graph once, on both contexts, with token id 0.  Needs a free submission slot; nothing may be in flight.
+int32_t cqs_hip_embedder_warm(cqs_hip_embedder* e, uint32_t max_tokens) CQS_ABI_TRY {
+    if (!e) return CQS_HIP_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (e->poisoned.load(std::memory_order_acquire)) return CQS_HIP_ERR_POISONED;
+    if (!e->finalized) return efail(e, CQS_HIP_ERR_INVALID, "warm: weights not finalized");
+    if (!e->query_path || max_tokens == 0) return CQS_HIP_OK;
+    for (const cqs_hip_embedder::Slot& s2 : e->slot)
+        if (s2.ticket != 0) return efail(e, CQS_HIP_ERR_INVALID, "warm: tickets are in flight (collect them first)");
+    cqs_hip_embedder::Slot& sl = e->slot[0];
+    E_TRY(e, hipSetDevice(e->device));
+    const uint32_t Tmax = std::min(max_tokens, std::min(cqs::kQueryFwdMaxTokens, e->g.max_seq));
+    int32_t rc = slot_reserve(e, sl, 1, Tmax, 1);
+    if (rc != CQS_HIP_OK) return rc;
+    memset(sl.meta, 0, sl.meta_cap * sizeof(int32_t));          // token id 0 at every position
+    const int n_ctx = e->single_ctx ? 1 : cqs_hip_embedder::kCtx;
+    for (uint32_t T = 1; T <= Tmax; ++T) {
+        sl.B = 1; sl.M = T; sl.nblk = 1;
+        for (int ci = 0; ci < n_ctx; ++ci) {
+            Ctx& c = e->ctx[ci];
+            for (int var = 1; var >= 0; --var) {
+                if (var == 1 && !e->query_direct) continue;
+                for (int tries = 0; tries < 3; ++tries) {
+                    if ((rc = run_query(e, c, sl, var == 1)) != CQS_HIP_OK) return rc;
+                    if (c.q_exec[var][T - 1] || c.q_capture_failed[var][T - 1] || !e->query_graph) break;
+                }
+            }
+            E_TRY(e, hipStreamSynchronize(c.stream));
+        }
+    }
+    return CQS_HIP_OK;
+} CQS_ABI_CATCH(e)
+
+// Search-time chain counters since the engine was made: graphs captured, captures that failed (those lengths run
+// eagerly; the cause is in last_error), graph replays, eager chain runs.  Any pointer may be NULL.
+void cqs_hip_embedder_query_graph_stats(const cqs_hip_embedder* e, uint64_t* captured, uint64_t* failed, uint64_t* replays,
+                                        uint64_t* eager) CQS_ABI_TRY {
+    uint64_t v[4] = {0, 0, 0, 0};
+    if (e) {
+        std::lock_guard<std::mutex> lk(e->mu);
+        v[0] = e->q_captured; v[1] = e->q_capture_failures; v[2] = e->q_replays; v[3] = e->q_eager;
+    }
+    if (captured) *captured = v[0];
+    if (failed) *failed = v[1];
+    if (replays) *replays = v[2];
+    if (eager) *eager = v[3];
+} CQS_ABI_CATCH_VOID
+
 // Diagnostic twin (synchronous): final-norm hidden states [B, L, hidden], zeros at padded positions.
 int32_t cqs_hip_embed_hidden(cqs_hip_embedder* e, const int64_t* ids, const int64_t* mask, uint32_t B, uint32_t L, float* out) CQS_ABI_TRY {
     if (!e) return CQS_HIP_ERR_INVALID;
@@ -878,6 +953,15 @@ void cqs_hip_normalize_l2_rows(float* rows, uint64_t n, uint32_t dim) CQS_ABI_TR
             for (uint32_t i = 0; i < dim; ++i) v[i] *= inv;
         }
     }
+} CQS_ABI_CATCH_VOID
+
+// Test hook (not part of the public header): the fused projection + add + norms kernel on / off and the token count it
+// starts at, for THIS engine (the environment is read once, at finalize).  min_rows = 0 keeps the current threshold.
+void cqs_hip_debug_embedder_set_fuse_norm(cqs_hip_embedder* e, int32_t on, uint32_t min_rows) CQS_ABI_TRY {
+    if (!e) return;
+    std::lock_guard<std::mutex> lk(e->mu);
+    e->fuse_norm = on != 0;
+    if (min_rows) e->fuse_min_rows = min_rows;
 } CQS_ABI_CATCH_VOID
 
 // Diagnostic (not part of the public header; CQS_HIP_QUERY_STAMPS=1 at engine creation): the stamps the query chain's

@@ -28,7 +28,6 @@
 #include "embed_kernels.h"
 #include "launch_util.h"
 
-#include <cstdlib>
 #include <type_traits>
 
 namespace cqs {
@@ -264,14 +263,8 @@ __global__ __launch_bounds__(512, 2) void gemm_rowfuse_kernel(const bf16_t* __re
 
 }  // namespace
 
-bool gemm_addnorm_supported(uint32_t M, uint32_t H, uint32_t K) {
-    const char* e0 = getenv("CQS_HIP_GEMM_FUSE_NORM");                  // (read per call: tests flip it inside one process)
-    const char* e1 = getenv("CQS_HIP_GEMM_FUSE_NORM_MIN_ROWS");
-    const bool off = e0 && e0[0] == '0';
-    const uint32_t min_rows = e1 ? (uint32_t)atoi(e1) : 12288u;          // (below ~12.7k tokens the two-launch chain wins: a 64-row tile per CU
-                                                                         // streams the whole W panel whatever the row count: measured 3.89 vs 3.46 ms at 5k tokens)
-    return !off && H == (uint32_t)kRfH && K % 64u == 0 && K >= 64u && M >= min_rows && (uint64_t)M * K < (1ull << 31) &&
-           (uint64_t)H * K < (1ull << 31);
+bool gemm_addnorm_supported(uint32_t M, uint32_t H, uint32_t K) {   // shape only; whether the forward uses it is the engine's setting
+    return M > 0 && H == (uint32_t)kRfH && K % 64u == 0 && K >= 64u && (uint64_t)M * K < (1ull << 31) && (uint64_t)H * K < (1ull << 31);
 }
 
 hipError_t launch_gemm_addnorm(const bf16_t* A, const bf16_t* W, float* x, const float* w_post, const float* w_next,

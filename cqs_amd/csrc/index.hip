@@ -11,12 +11,14 @@
 #include <atomic>
 #include <cmath>
 #include <cerrno>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include <fcntl.h>
@@ -56,6 +58,7 @@ void free_scratch(cqs_hip_index* x) {
     x->d_q = x->d_scores = nullptr; x->d_gmax = nullptr;
     x->d_out_keys = nullptr; x->d_out_counts = nullptr;
     x->h_q = nullptr; x->h_out_keys = nullptr; x->h_out_counts = nullptr;
+    x->h_out_keys_dev = nullptr; x->h_out_counts_dev = nullptr;
     x->q_cap = 0; x->k_cap = 0; x->scr_n_pad = 0;
 }
 
@@ -79,6 +82,13 @@ int32_t ensure_scratch(cqs_hip_index* x, uint32_t b, uint32_t k) {
     HIP_TRY(x, hipHostMalloc(&x->h_q, (size_t)qc * x->dim * sizeof(float), hipHostMallocDefault));
     HIP_TRY(x, hipHostMalloc(&x->h_out_keys, (size_t)qc * kc * sizeof(uint64_t), hipHostMallocDefault));
     HIP_TRY(x, hipHostMalloc(&x->h_out_counts, (size_t)qc * sizeof(uint32_t), hipHostMallocDefault));
+    // device-visible addresses of the two result buffers (small blocks: the select kernel writes them directly);
+    // a runtime that cannot map them leaves the pointers null and every block takes the copy path
+    if (hipHostGetDevicePointer((void**)&x->h_out_keys_dev, x->h_out_keys, 0) != hipSuccess ||
+        hipHostGetDevicePointer((void**)&x->h_out_counts_dev, x->h_out_counts, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        x->h_out_keys_dev = nullptr; x->h_out_counts_dev = nullptr;
+    }
     x->q_cap = qc; x->k_cap = kc; x->scr_n_pad = n_pad;
     return CQS_HIP_OK;
 }
@@ -96,10 +106,10 @@ uint32_t max_query_block(const cqs_hip_index* x) {
 
 // Enqueue scan + select for queries already on the device.  Caller holds mu.
 int32_t enqueue_search(cqs_hip_index* x, const float* d_q, uint32_t b, uint32_t k, const uint32_t* d_keep,
-                       uint32_t mode, float thr, uint64_t* d_out_keys, uint32_t* d_out_counts, hipStream_t st) {
+                       uint32_t mode, float thr, uint64_t* d_out_keys, uint32_t* d_out_counts, hipStream_t st, bool gemv_only) {
     // the previous search may still be running on another stream and owns the same scratch
     if (x->done_valid && x->done_stream != st) HIP_TRY(x, hipStreamWaitEvent(st, x->done, 0));
-    if (cqs::use_mfma(b, x->dim)) {
+    if (!gemv_only && cqs::use_mfma(b, x->dim)) {
         // the matrix-core path reads whole query tiles: stage the block in d_q with a zero tail
         const size_t qbytes = (size_t)b * x->dim * sizeof(float);
         if (d_q != x->d_q) HIP_TRY(x, hipMemcpyAsync(x->d_q, d_q, qbytes, hipMemcpyDeviceToDevice, st));
@@ -124,7 +134,8 @@ int32_t enqueue_search(cqs_hip_index* x, const float* d_q, uint32_t b, uint32_t 
     a.work = x->d_work;
     a.n_cu = x->n_cu;
     a.dbg = x->d_dbg;
-    a.tiers = cqs::plan_tiers(a.n_pad, x->n_cu, cqs::uniform_groups(b, x->dim));
+    a.gemv_only = gemv_only;
+    a.tiers = cqs::plan_tiers(a.n_pad, x->n_cu, !gemv_only && cqs::uniform_groups(b, x->dim));
     const bool timed = x->timing && x->ev_used + 2 <= kMaxTimingEvents;
     if (timed) {
         while (x->ev.size() < x->ev_used + 2) {
@@ -185,6 +196,8 @@ int32_t create_common(uint64_t n, uint32_t dim, uint32_t metric, int32_t device,
         delete x;
         return CQS_HIP_ERR_DEVICE;
     }
+    if (const char* ce = getenv("CQS_HIP_COMBINE")) x->combine = ce[0] != '0';          // read once per handle
+    if (const char* cw = getenv("CQS_HIP_COMBINE_WAIT_US")) x->combine_wait_us = (uint32_t)atoi(cw);
     if (getenv("CQS_HIP_DEBUG_STAMPS")) {
         const size_t bytes = (16 + 2 * cqs::kDbgWaves) * sizeof(unsigned long long);
         if (hipMalloc(&x->d_dbg, bytes) == hipSuccess) (void)hipMemset(x->d_dbg, 0, bytes);
@@ -633,26 +646,53 @@ int32_t cqs_hip_index_search_device(cqs_hip_index* x, const float* d_queries, ui
     return enqueue_search(x, d_queries, b, k, d_keep_bitset, mode, threshold, d_out_keys, d_out_counts, st);
 } CQS_ABI_CATCH(x)
 
-int32_t cqs_hip_index_search(cqs_hip_index* x, const float* queries, uint32_t b, uint32_t query_dim, uint32_t k,
-                             const uint32_t* keep_bitset, uint32_t mode, float threshold, uint64_t* out_rows,
-                             float* out_scores, uint32_t* out_counts) CQS_ABI_TRY {
-    CQS_ROCTX_RANGE("cqs_hip_index_search");
-    if (!x) return CQS_HIP_ERR_INVALID;
-    if (x->sh) return cqs_sharded::search(x, queries, b, query_dim, k, keep_bitset, mode, threshold, out_rows, out_scores, out_counts);
-    std::lock_guard<std::mutex> g(x->mu);
-    if (x->poisoned.load(std::memory_order_acquire)) return CQS_HIP_ERR_POISONED;  // src/cagra.rs:486-490
-    if (b == 0) return CQS_HIP_OK;
-    if (!queries || !out_counts) return fail(x, CQS_HIP_ERR_INVALID, "search: null buffer");
-    for (uint32_t i = 0; i < b; ++i) out_counts[i] = 0;
-    if (x->n == 0 || k == 0) return CQS_HIP_OK;               // src/cagra.rs:445-447
-    if (query_dim != x->dim) {                                  // src/cagra.rs:449-456
-        x->last_error = "search: query dimension mismatch (empty result)";
-        return CQS_HIP_OK;
-    }
-    if (k > kMaxK) return fail(x, CQS_HIP_ERR_INVALID, "search: k > max_k");
-    if (mode > CQS_HIP_MODE_PIPELINE) return fail(x, CQS_HIP_ERR_INVALID, "search: bad mode");
-    if (!out_rows || !out_scores) return fail(x, CQS_HIP_ERR_INVALID, "search: null output buffer");
+}  // extern "C"
 
+namespace cqs_idx {
+
+// Debug print of the kernels' stamps (CQS_HIP_DEBUG_STAMPS=1).  Caller holds mu; the stream is idle.
+static void print_debug_stamps(cqs_hip_index* x) {
+    unsigned long long h[16];   // 100 MHz realtime counter: 10 ns ticks
+    if (hipMemcpy(h, x->d_dbg, sizeof h, hipMemcpyDeviceToHost) == hipSuccess)
+        fprintf(stderr, "[cqs_hip] select_finish us: zero %.2f hist %.2f decide %.2f groups %.2f scores %.2f sort %.2f emit %.2f | groups=%llu cand=%llu\n",
+                0.0, (h[1] - h[0]) / 100.0, (h[2] - h[1]) / 100.0, (h[3] - h[2]) / 100.0, (h[4] - h[3]) / 100.0,
+                (h[5] - h[4]) / 100.0, (h[6] - h[5]) / 100.0, h[8], h[9]);
+    // scan waves: spread of start and end times relative to the first wave's start
+    std::vector<unsigned long long> w(2 * cqs::kDbgWaves);
+    if (hipMemcpy(w.data(), x->d_dbg + 16, w.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return;
+    std::vector<double> st, en;
+    unsigned long long t0 = ~0ull;
+    for (uint32_t i = 0; i < cqs::kDbgWaves; ++i) if (w[2 * i] && w[2 * i] < t0) t0 = w[2 * i];
+    for (uint32_t i = 0; i < cqs::kDbgWaves; ++i)
+        if (w[2 * i] && w[2 * i + 1]) { st.push_back((w[2 * i] - t0) / 100.0); en.push_back((w[2 * i + 1] - t0) / 100.0); }
+    if (!st.empty()) {
+        std::sort(st.begin(), st.end());
+        std::sort(en.begin(), en.end());
+        auto pc = [](const std::vector<double>& v, double f) { return v[(size_t)(f * (v.size() - 1))]; };
+        fprintf(stderr, "[cqs_hip] scan waves=%zu start us p0 %.1f p50 %.1f p90 %.1f p100 %.1f | end us p0 %.1f p10 %.1f p50 %.1f p90 %.1f p100 %.1f | select ends %.1f\n",
+                st.size(), pc(st, 0), pc(st, .5), pc(st, .9), pc(st, 1), pc(en, 0), pc(en, .1), pc(en, .5), pc(en, .9), pc(en, 1),
+                (h[6] - t0) / 100.0);
+    }
+    (void)hipMemset(x->d_dbg + 16, 0, w.size() * sizeof(unsigned long long));
+}
+
+// One host query of a block and where its answer goes.
+struct HostQuery {
+    const float* q;          // [dim]
+    uint64_t* out_rows;      // [k]
+    float* out_scores;       // [k]
+    uint32_t* out_count;
+};
+
+// The host-buffer search proper: `b` queries with one (k, mode, threshold, bitset), scanned in blocks the scratch
+// budget allows.  Caller holds mu, has checked the arguments and zeroed the counts.  `gemv_only`: every block goes
+// through the HBM-streaming passes of <= 8 queries, whose scores do not depend on how many queries share a pass (same
+// per-lane FMA chain, same butterfly) - what the combining queue needs to hand each caller the bits it would have got alone.
+static int32_t search_host_locked(cqs_hip_index* x, const HostQuery* qs, uint32_t b, uint32_t k, const uint32_t* keep_bitset,
+                                  uint32_t mode, float threshold, bool gemv_only) {
+    if (x->inject_fail.exchange(0, std::memory_order_acq_rel) != 0)
+        return fail(x, CQS_HIP_ERR_DEVICE, "search: injected device failure (test hook)");
+    if (x->n == 0 || k == 0) return CQS_HIP_OK;               // src/cagra.rs:445-447
     HIP_TRY(x, hipSetDevice(x->device));
     // a device-API search on a caller stream may still use the shared scratch this call is about to overwrite
     if (x->done_valid && x->done_stream != x->stream) HIP_TRY(x, hipStreamWaitEvent(x->stream, x->done, 0));
@@ -684,7 +724,7 @@ int32_t cqs_hip_index_search(cqs_hip_index* x, const float* queries, uint32_t b,
         if (rc != CQS_HIP_OK) return rc;
         // stage queries; a non-finite query yields an empty result (src/cagra.rs:464-470)
         for (uint32_t i = 0; i < nb; ++i) {
-            const float* src = queries + (size_t)(done + i) * x->dim;
+            const float* src = qs[done + i].q;
             float* dst = x->h_q + (size_t)i * x->dim;
             bool ok = true;
             for (uint32_t d = 0; d < x->dim; ++d) ok &= std::isfinite(src[d]);
@@ -693,48 +733,191 @@ int32_t cqs_hip_index_search(cqs_hip_index* x, const float* queries, uint32_t b,
             else memset(dst, 0, (size_t)x->dim * sizeof(float));
         }
         HIP_TRY(x, hipMemcpyAsync(x->d_q, x->h_q, (size_t)nb * x->dim * sizeof(float), hipMemcpyHostToDevice, x->stream));
-        rc = enqueue_search(x, x->d_q, nb, k_eff, d_keep, mode, threshold, x->d_out_keys, x->d_out_counts, x->stream);
+        // Small blocks: the select kernel writes keys and counts straight into the pinned host buffers (device-visible
+        // addresses): no copy calls behind the kernels, one wait.  Large blocks keep the device buffers + two copies
+        // (hundreds of KB of scattered 8-byte stores over PCIe would cost more than the copies).
+        const bool direct = x->h_out_keys_dev && x->h_out_counts_dev && (size_t)nb * k_eff <= kDirectOutKeys;
+        rc = enqueue_search(x, x->d_q, nb, k_eff, d_keep, mode, threshold, direct ? x->h_out_keys_dev : x->d_out_keys,
+                            direct ? x->h_out_counts_dev : x->d_out_counts, x->stream, gemv_only);
         if (rc != CQS_HIP_OK) return rc;
-        HIP_TRY(x, hipMemcpyAsync(x->h_out_keys, x->d_out_keys, (size_t)nb * k_eff * sizeof(uint64_t), hipMemcpyDeviceToHost, x->stream));
-        HIP_TRY(x, hipMemcpyAsync(x->h_out_counts, x->d_out_counts, (size_t)nb * sizeof(uint32_t), hipMemcpyDeviceToHost, x->stream));
-        HIP_TRY(x, hipStreamSynchronize(x->stream));
-        if (x->d_dbg) {  // 100 MHz realtime counter: 10 ns ticks
-            unsigned long long h[16];
-            if (hipMemcpy(h, x->d_dbg, sizeof h, hipMemcpyDeviceToHost) == hipSuccess)
-                fprintf(stderr, "[cqs_hip] select_finish us: zero %.2f hist %.2f decide %.2f groups %.2f scores %.2f sort %.2f emit %.2f | groups=%llu cand=%llu\n",
-                        0.0, (h[1] - h[0]) / 100.0, (h[2] - h[1]) / 100.0, (h[3] - h[2]) / 100.0, (h[4] - h[3]) / 100.0,
-                        (h[5] - h[4]) / 100.0, (h[6] - h[5]) / 100.0, h[8], h[9]);
-            // scan waves: spread of start and end times relative to the first wave's start
-            std::vector<unsigned long long> w(2 * cqs::kDbgWaves);
-            if (hipMemcpy(w.data(), x->d_dbg + 16, w.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess) {
-                std::vector<double> st, en;
-                unsigned long long t0 = ~0ull;
-                for (uint32_t i = 0; i < cqs::kDbgWaves; ++i) if (w[2 * i] && w[2 * i] < t0) t0 = w[2 * i];
-                for (uint32_t i = 0; i < cqs::kDbgWaves; ++i)
-                    if (w[2 * i] && w[2 * i + 1]) { st.push_back((w[2 * i] - t0) / 100.0); en.push_back((w[2 * i + 1] - t0) / 100.0); }
-                if (!st.empty()) {
-                    std::sort(st.begin(), st.end());
-                    std::sort(en.begin(), en.end());
-                    auto pc = [](const std::vector<double>& v, double f) { return v[(size_t)(f * (v.size() - 1))]; };
-                    fprintf(stderr, "[cqs_hip] scan waves=%zu start us p0 %.1f p50 %.1f p90 %.1f p100 %.1f | end us p0 %.1f p10 %.1f p50 %.1f p90 %.1f p100 %.1f | select ends %.1f\n",
-                            st.size(), pc(st, 0), pc(st, .5), pc(st, .9), pc(st, 1), pc(en, 0), pc(en, .1), pc(en, .5), pc(en, .9), pc(en, 1),
-                            (h[6] - t0) / 100.0);
-                }
-                (void)hipMemset(x->d_dbg + 16, 0, w.size() * sizeof(unsigned long long));
-            }
+        if (!direct) {
+            HIP_TRY(x, hipMemcpyAsync(x->h_out_keys, x->d_out_keys, (size_t)nb * k_eff * sizeof(uint64_t), hipMemcpyDeviceToHost, x->stream));
+            HIP_TRY(x, hipMemcpyAsync(x->h_out_counts, x->d_out_counts, (size_t)nb * sizeof(uint32_t), hipMemcpyDeviceToHost, x->stream));
         }
+        HIP_TRY(x, hipStreamSynchronize(x->stream));
+        if (x->d_dbg) print_debug_stamps(x);
         for (uint32_t i = 0; i < nb; ++i) {
             const uint32_t qi = done + i;
             if (bad[qi]) continue;
             uint32_t c = x->h_out_counts[i];
             if (c > k_eff) c = k_eff;
-            cqs_hip_unpack_keys(x->h_out_keys + (size_t)i * k_eff, c, out_rows + (size_t)qi * k, out_scores + (size_t)qi * k);
-            out_counts[qi] = c;
+            cqs_hip_unpack_keys(x->h_out_keys + (size_t)i * k_eff, c, qs[qi].out_rows, qs[qi].out_scores);
+            *qs[qi].out_count = c;
         }
         done += nb;
     }
     return CQS_HIP_OK;
+}
+
+// ---- the combining queue --------------------------------------------------------------------------------------------
+// Concurrent single-query callers of cqs_hip_index_search (the daemon's client threads, src/cli/watch/daemon.rs:273,
+// on one Arc<dyn VectorIndex>) used to queue on the handle mutex for one 0.5 ms pass EACH, although one pass scans up to
+// 8 queries for 0.50-0.54 ms.  Now a caller parks its query; whoever leads next takes the device, gathers
+// the parked queries with the same (k, mode, threshold) and runs them as ONE block of gemv passes; every caller gets
+// exactly the bits a lone call would have produced (search_host_locked, gemv_only).  Bitsets, multi-query blocks and
+// sharded handles keep the serial path.
+constexpr uint32_t kCombineCap = 32;     // queries per combined block (4 passes of 8)
+
+static bool same_params(const cqs_combine_req* a, const cqs_combine_req* b) {
+    return a->k == b->k && a->mode == b->mode && memcmp(&a->thr, &b->thr, sizeof(float)) == 0;
+}
+static uint32_t count_like_front(const cqs_hip_index* x) {
+    uint32_t n = 0;
+    for (const cqs_combine_req* r : x->pending) n += same_params(r, x->pending.front()) ? 1u : 0u;
+    return n;
+}
+
+// Lead one pass.  `lk` holds cmu on entry and on exit; x->leader is set by the caller.
+static void combine_lead(cqs_hip_index* x, std::unique_lock<std::mutex>& lk) {
+    lk.unlock();
+    std::unique_lock<std::mutex> dev(x->mu);       // the device is ours: the previous pass (or any other entry point) is over
+    lk.lock();
+    // Stragglers: if recent passes carried more callers than are parked now, their threads are on their way back (a
+    // caller needs some tens of microseconds between getting its answer and asking again).  Waiting for them costs up to
+    // combine_wait_us once; scanning without them costs them a whole pass.  A lone caller never waits: expect is 1.
+    const uint32_t target = x->expect < kCombineCap ? x->expect : kCombineCap;
+    if (x->combine_wait_us && count_like_front(x) < target) {
+        const auto t_end = std::chrono::steady_clock::now() + std::chrono::microseconds(x->combine_wait_us);
+        for (;;) {
+            lk.unlock();
+            for (int i = 0; i < 64; ++i) __builtin_ia32_pause();
+            lk.lock();
+            if (count_like_front(x) >= target || std::chrono::steady_clock::now() >= t_end) break;
+        }
+    }
+    // seal the block: the oldest request and everything parked with its parameters, oldest first
+    cqs_combine_req* batch[kCombineCap];
+    uint32_t nb = 0, left_like = 0;
+    {
+        const cqs_combine_req head = *x->pending.front();
+        std::deque<cqs_combine_req*> keep;
+        for (cqs_combine_req* r : x->pending) {
+            if (same_params(r, &head)) {
+                if (nb < kCombineCap) { batch[nb++] = r; continue; }
+                ++left_like;
+            }
+            keep.push_back(r);
+        }
+        x->pending.swap(keep);
+        x->n_pending.store((uint32_t)x->pending.size(), std::memory_order_relaxed);
+    }
+    x->expect = nb + left_like;                    // what this pass saw (>= 1)
+    lk.unlock();
+
+    int32_t rc = CQS_HIP_OK;
+    bool poisoned = x->poisoned.load(std::memory_order_acquire);
+    if (poisoned) rc = CQS_HIP_ERR_POISONED;
+    else {
+        try {
+            HostQuery hq[kCombineCap];
+            for (uint32_t i = 0; i < nb; ++i) hq[i] = HostQuery{batch[i]->q, batch[i]->out_rows, batch[i]->out_scores, batch[i]->out_count};
+            rc = search_host_locked(x, hq, nb, batch[0]->k, nullptr, batch[0]->mode, batch[0]->thr, /*gemv_only=*/true);
+        } catch (const std::bad_alloc&) {
+            rc = fail(x, CQS_HIP_ERR_NOMEM, "search: out of host memory");
+        } catch (...) {
+            rc = fail(x, CQS_HIP_ERR_INVALID, "search: unexpected C++ exception");
+        }
+        x->stat_passes.fetch_add(1, std::memory_order_relaxed);
+        x->stat_queries.fetch_add(nb, std::memory_order_relaxed);
+        poisoned = x->poisoned.load(std::memory_order_acquire);
+    }
+    dev.unlock();
+
+    lk.lock();
+    for (uint32_t i = 0; i < nb; ++i) {
+        // the call that met the failure reports it; whoever rode along on a handle that is now poisoned gets what
+        // any later call gets (src/cagra.rs:486-490)
+        batch[i]->rc = (rc != CQS_HIP_OK && i > 0 && poisoned) ? CQS_HIP_ERR_POISONED : rc;
+        batch[i]->done = true;
+    }
+    if (poisoned) {                                // nobody stays parked on a dead handle
+        for (cqs_combine_req* r : x->pending) { r->rc = CQS_HIP_ERR_POISONED; r->done = true; }
+        x->pending.clear();
+        x->n_pending.store(0, std::memory_order_relaxed);
+    } else if (!x->pending.empty()) {
+        // callers that arrived during this pass with the same parameters could have ridden along: tell the next leader
+        uint32_t like = 0;
+        for (const cqs_combine_req* r : x->pending) like += same_params(r, batch[0]) ? 1u : 0u;
+        if (nb + like > x->expect) x->expect = nb + like;
+    }
+}
+
+static int32_t combine_search(cqs_hip_index* x, cqs_combine_req& r) {
+    std::unique_lock<std::mutex> lk(x->cmu);
+    x->pending.push_back(&r);
+    x->n_pending.store((uint32_t)x->pending.size(), std::memory_order_relaxed);
+    while (!r.done) {
+        if (!x->leader) {
+            x->leader = true;
+            struct Reset {                             // whatever happens in there, the next caller can lead
+                cqs_hip_index* x; std::unique_lock<std::mutex>& lk;
+                ~Reset() { if (!lk.owns_lock()) lk.lock(); x->leader = false; x->ccv.notify_all(); }
+            } reset{x, lk};
+            combine_lead(x, lk);
+        } else {
+            x->ccv.wait(lk);
+        }
+    }
+    return r.rc;
+}
+
+}  // namespace cqs_idx
+
+extern "C" {
+
+int32_t cqs_hip_index_search(cqs_hip_index* x, const float* queries, uint32_t b, uint32_t query_dim, uint32_t k,
+                             const uint32_t* keep_bitset, uint32_t mode, float threshold, uint64_t* out_rows,
+                             float* out_scores, uint32_t* out_counts) CQS_ABI_TRY {
+    CQS_ROCTX_RANGE("cqs_hip_index_search");
+    if (!x) return CQS_HIP_ERR_INVALID;
+    if (x->sh) return cqs_sharded::search(x, queries, b, query_dim, k, keep_bitset, mode, threshold, out_rows, out_scores, out_counts);
+    // One query, no filter, arguments in order: the combining queue (dim is immutable; everything else the locked
+    // path would check is checked here or inside the pass).
+    if (x->combine && b == 1 && !keep_bitset && queries && out_counts && out_rows && out_scores && query_dim == x->dim &&
+        k >= 1 && k <= kMaxK && mode <= CQS_HIP_MODE_PIPELINE) {
+        if (x->poisoned.load(std::memory_order_acquire)) return CQS_HIP_ERR_POISONED;  // src/cagra.rs:486-490
+        out_counts[0] = 0;
+        bool finite = true;
+        for (uint32_t d = 0; d < query_dim; ++d) finite &= std::isfinite(queries[d]);
+        if (!finite) return CQS_HIP_OK;                                                // src/cagra.rs:464-470
+        cqs_combine_req r{queries, k, mode, threshold, out_rows, out_scores, out_counts};
+        return combine_search(x, r);
+    }
+    std::lock_guard<std::mutex> g(x->mu);
+    if (x->poisoned.load(std::memory_order_acquire)) return CQS_HIP_ERR_POISONED;  // src/cagra.rs:486-490
+    if (b == 0) return CQS_HIP_OK;
+    if (!queries || !out_counts) return fail(x, CQS_HIP_ERR_INVALID, "search: null buffer");
+    for (uint32_t i = 0; i < b; ++i) out_counts[i] = 0;
+    if (x->n == 0 || k == 0) return CQS_HIP_OK;               // src/cagra.rs:445-447
+    if (query_dim != x->dim) {                                  // src/cagra.rs:449-456
+        x->last_error = "search: query dimension mismatch (empty result)";
+        return CQS_HIP_OK;
+    }
+    if (k > kMaxK) return fail(x, CQS_HIP_ERR_INVALID, "search: k > max_k");
+    if (mode > CQS_HIP_MODE_PIPELINE) return fail(x, CQS_HIP_ERR_INVALID, "search: bad mode");
+    if (!out_rows || !out_scores) return fail(x, CQS_HIP_ERR_INVALID, "search: null output buffer");
+    std::vector<HostQuery> hq(b);
+    for (uint32_t i = 0; i < b; ++i)
+        hq[i] = HostQuery{queries + (size_t)i * x->dim, out_rows + (size_t)i * k, out_scores + (size_t)i * k, out_counts + i};
+    return search_host_locked(x, hq.data(), b, k, keep_bitset, mode, threshold, /*gemv_only=*/false);
 } CQS_ABI_CATCH(x)
+
+// Combining-queue counters since the handle was made: passes run by the queue and the queries they carried (bench /
+// tests; not in the Rust trait).  Either pointer may be NULL.
+void cqs_hip_index_combine_stats(const cqs_hip_index* x, uint64_t* passes, uint64_t* queries) CQS_ABI_TRY {
+    if (passes) *passes = x ? x->stat_passes.load(std::memory_order_relaxed) : 0;
+    if (queries) *queries = x ? x->stat_queries.load(std::memory_order_relaxed) : 0;
+} CQS_ABI_CATCH_VOID
 
 // `find_neighbors` (src/cli/commands/search/neighbors.rs:86-132) for a row of this index: the query is the
 // target row where it already lies in HBM (no H2D), the scan asks for limit + 1 and the target itself is
@@ -804,5 +987,46 @@ int32_t cqs_hip_index_scan_time(cqs_hip_index* x, uint32_t* launches, double* to
     x->ev_used = 0;
     return CQS_HIP_OK;
 } CQS_ABI_CATCH(x)
+
+
+// Test hook (not part of the public header): the next host search on this handle fails as a device error would
+// (the handle ends up poisoned) - how tests/test_threads_gpu.py reaches the combining queue's failure path.
+void cqs_hip_debug_index_fail_next(cqs_hip_index* x) CQS_ABI_TRY {
+    if (x) x->inject_fail.store(1, std::memory_order_release);
+} CQS_ABI_CATCH_VOID
+
+// Bench aid (not part of the public header): `n_threads` native threads, each calling the PUBLIC blocking entry point
+// cqs_hip_index_search `per_thread` times with one query at a time (thread t asks queries t, t + n_threads, ... of the
+// `n_queries` host rows, round and round) - what the reference's daemon does with one thread per client
+// (src/cli/watch/daemon.rs:273), without a Python interpreter lock between the callers.  out_rows / out_scores /
+// out_counts [n_queries, k] / [n_queries] receive each query's last answer.  Returns wall seconds, < 0 on a failed call.
+double cqs_hip_debug_client_storm(cqs_hip_index* x, const float* queries, uint32_t n_queries, uint32_t dim, uint32_t k,
+                                  uint32_t n_threads, uint32_t per_thread, uint64_t* out_rows, float* out_scores,
+                                  uint32_t* out_counts) CQS_ABI_TRY {
+    if (!x || !queries || !n_queries || !n_threads || !out_rows || !out_scores || !out_counts) return -1.0;
+    std::atomic<int32_t> bad{0};
+    std::atomic<uint32_t> ready{0};
+    std::atomic<bool> go{false};
+    std::vector<std::thread> th;
+    th.reserve(n_threads);
+    for (uint32_t t = 0; t < n_threads; ++t)
+        th.emplace_back([&, t]() {
+            ready.fetch_add(1);
+            while (!go.load(std::memory_order_acquire)) std::this_thread::yield();
+            uint32_t qi = t % n_queries;
+            for (uint32_t i = 0; i < per_thread; ++i) {
+                const int32_t rc = cqs_hip_index_search(x, queries + (size_t)qi * dim, 1, dim, k, nullptr, CQS_HIP_MODE_RAW, 0.f,
+                                                        out_rows + (size_t)qi * k, out_scores + (size_t)qi * k, out_counts + qi);
+                if (rc != CQS_HIP_OK) { bad.store(rc); break; }
+                qi = (qi + n_threads) % n_queries;
+            }
+        });
+    while (ready.load() < n_threads) std::this_thread::yield();
+    const auto t0 = std::chrono::steady_clock::now();
+    go.store(true, std::memory_order_release);
+    for (std::thread& t : th) t.join();
+    const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return bad.load() ? -1.0 : el;
+} CQS_ABI_CATCH_VAL(-1.0)
 
 }  // extern "C"

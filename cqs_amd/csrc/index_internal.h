@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <condition_variable>
+#include <deque>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -12,6 +14,19 @@
 #include "scan_kernels.h"
 
 namespace cqs_sharded { struct ShardSet; }
+
+// One single-query host search waiting for a pass over the corpus (the combining queue of cqs_hip_index_search).
+// Lives on its caller's stack; the pointers are the caller's own output buffers.
+struct cqs_combine_req {
+    const float* q;          // [dim] host, validated (finite)
+    uint32_t k, mode;
+    float thr;
+    uint64_t* out_rows;
+    float* out_scores;
+    uint32_t* out_count;
+    int32_t rc = 0;
+    bool done = false;
+};
 
 struct cqs_hip_index {
     int device = 0;
@@ -42,6 +57,8 @@ struct cqs_hip_index {
     float* h_q = nullptr;
     uint64_t* h_out_keys = nullptr;
     uint32_t* h_out_counts = nullptr;
+    uint64_t* h_out_keys_dev = nullptr;     // device-visible addresses of the two buffers above (null: not mappable)
+    uint32_t* h_out_counts_dev = nullptr;
 
     // Searches share one scratch (d_scores, d_gmax, d_work, d_q): the handle orders them across streams.
     // Every enqueue records `done` on its stream; an enqueue on a DIFFERENT stream first waits on it.
@@ -60,12 +77,29 @@ struct cqs_hip_index {
     mutable std::mutex mu;
     std::atomic<bool> poisoned{false};
     std::string last_error;
+
+    // Combining queue (index.hip, cqs_hip_index_search): concurrent single-query callers park here and ride ONE pass
+    // over the corpus (up to kMaxGemvQ queries share the HBM stream in registers).  `cmu` orders the queue only; the
+    // device work itself still runs under `mu`.  The reference serialises its callers behind Mutex<GpuState>
+    // (src/cagra.rs:263) one search at a time; the daemon calls `search` from one thread per client
+    // (src/cli/watch/daemon.rs:273).
+    std::mutex cmu;
+    std::condition_variable ccv;
+    std::deque<cqs_combine_req*> pending;
+    std::atomic<uint32_t> n_pending{0};   // = pending.size(), readable without cmu (the leader's short wait for stragglers)
+    bool leader = false;                  // somebody is collecting / running a combined pass
+    uint32_t expect = 1;                  // callers the next pass should expect (what recent passes saw); guarded by cmu
+    bool combine = true;                  // CQS_HIP_COMBINE=0: every caller takes the serial path
+    uint32_t combine_wait_us = 100;       // CQS_HIP_COMBINE_WAIT_US: longest a leader waits for expected stragglers
+    std::atomic<uint64_t> stat_passes{0}, stat_queries{0};   // combined passes run / queries they carried
+    std::atomic<int32_t> inject_fail{0};  // test hook (cqs_hip_debug_index_fail_next): the next host search fails as a device error
 };
 
 namespace cqs_idx {
 
 constexpr size_t kMaxTimingEvents = 8192;
 constexpr uint64_t kNtBytes = 200ull << 20;  // corpus larger than this streams past L2/MALL
+constexpr size_t kDirectOutKeys = 8192;      // host searches of up to this many result keys have them written straight to pinned host memory
 
 uint64_t pad_rows(uint64_t n);
 int32_t fail(cqs_hip_index* idx, int32_t code, const char* what, hipError_t e = hipSuccess);
@@ -74,7 +108,8 @@ int32_t ensure_scratch(cqs_hip_index* x, uint32_t b, uint32_t k);
 uint32_t max_query_block(const cqs_hip_index* x);
 // Enqueue scan + select for queries already on the device.  Caller holds mu.
 int32_t enqueue_search(cqs_hip_index* x, const float* d_q, uint32_t b, uint32_t k, const uint32_t* d_keep,
-                       uint32_t mode, float thr, uint64_t* d_out_keys, uint32_t* d_out_counts, hipStream_t st);
+                       uint32_t mode, float thr, uint64_t* d_out_keys, uint32_t* d_out_counts, hipStream_t st,
+                       bool gemv_only = false);
 hipError_t quiesce(cqs_hip_index* x);
 int32_t stage_keep(cqs_hip_index* x, const uint32_t* host_words, uint64_t words);
 int32_t create_common(uint64_t n, uint32_t dim, uint32_t metric, int32_t device, uint64_t row_base,

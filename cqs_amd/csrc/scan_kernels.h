@@ -51,6 +51,8 @@ struct ScanArgs {
     TaskTiers tiers;        // plan_tiers(n_pad, n_cu, uniform_groups(b, dim))
     uint32_t* work;         // [kWorkWords] work-queue heads (zero on entry)
     uint32_t n_cu;          // compute units of the device
+    bool gemv_only = false; // never the matrix-core kernel, whatever b: blocks of > 8 queries run as passes of <= 8
+                            // (the scores of a gemv pass do not depend on how many queries share it)
     void* dbg;              // nullable: (16 + 2 * kDbgWaves) x u64: select_finish phase stamps, then the scan's
                             // per-wave start/end stamps (CQS_HIP_DEBUG_STAMPS=1)
 };

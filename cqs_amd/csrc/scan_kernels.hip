@@ -605,7 +605,10 @@ __global__ __launch_bounds__(1024) void select_finish_kernel(const float* __rest
 }
 
 // ---- launchers -------------------------------------------------------------
-bool scan_dim_supported(uint32_t dim) { return dim >= 4 && dim % 4 == 0 && dim <= 2048; }
+// dim <= 2048: up to 8 chunks per row, 1..8 queries per pass.  2052..4096 (the reference's presets reach 2560 and 4096,
+// src/embedder/models.rs:515,572): 9..16 chunks per row - a row is 9..16 KiB, so ONE row per batch already keeps as many
+// bytes in flight as eight 768-d rows; one query per pass (16 chunks x 4 registers of query + two row buffers = 192 VGPRs).
+bool scan_dim_supported(uint32_t dim) { return dim >= 4 && dim % 4 == 0 && dim <= 4096; }
 
 #ifndef CQS_SCAN_PIPE
 #define CQS_SCAN_PIPE 1
@@ -719,9 +722,11 @@ static hipError_t launch_gemv_groups(const ScanArgs& a, hipStream_t st) {
             else if (left >= 4) { g = 4; e = launch_gemv<NCH, 4, 4>(a, done, g, slot, st); }
             else if (left >= 2) { g = 2; e = launch_gemv<NCH, 2, 4>(a, done, g, slot, st); }
             else { g = 1; e = launch_gemv<NCH, 1, CQS_SCAN_RI1>(a, done, g, slot, st); }
-        } else {
+        } else if constexpr (NCH <= 8) {
             if (left >= 2) { g = 2; e = launch_gemv<NCH, 2, 2>(a, done, g, slot, st); }
             else { g = 1; e = launch_gemv<NCH, 1, 2>(a, done, g, slot, st); }
+        } else {
+            g = 1; e = launch_gemv<NCH, 1, 1>(a, done, g, slot, st);
         }
         if (e != hipSuccess) return e;
         done += g;
@@ -736,7 +741,7 @@ static hipError_t launch_gemv_groups(const ScanArgs& a, hipStream_t st) {
 
 hipError_t launch_scan(const ScanArgs& a, hipStream_t st) {
     if (a.b == 0 || a.n == 0) return hipSuccess;
-    if (use_mfma(a.b, a.dim)) {
+    if (!a.gemv_only && use_mfma(a.b, a.dim)) {
         uint32_t slot = 0;
         for (uint32_t q0 = 0; q0 < a.b; q0 += 256u) {
             const uint32_t nq = (a.b - q0) < 256u ? (a.b - q0) : 256u;
@@ -760,6 +765,14 @@ hipError_t launch_scan(const ScanArgs& a, hipStream_t st) {
         case 6: return launch_gemv_groups<6>(a, st);
         case 7: return launch_gemv_groups<7>(a, st);
         case 8: return launch_gemv_groups<8>(a, st);
+        case 9: return launch_gemv_groups<9>(a, st);
+        case 10: return launch_gemv_groups<10>(a, st);
+        case 11: return launch_gemv_groups<11>(a, st);
+        case 12: return launch_gemv_groups<12>(a, st);
+        case 13: return launch_gemv_groups<13>(a, st);
+        case 14: return launch_gemv_groups<14>(a, st);
+        case 15: return launch_gemv_groups<15>(a, st);
+        case 16: return launch_gemv_groups<16>(a, st);
         default: return hipErrorInvalidValue;
     }
 }

@@ -82,6 +82,10 @@ struct ShardSet {
     size_t gather_cap = 0;               // keys per shard slot (>= b * k of the current block)
     std::vector<hipEvent_t> ev;          // copy path: "shard s finished its select"
     uint64_t* h_gather = nullptr;        // pinned [n_shards][gather_cap]
+    std::vector<uint64_t*> h_gather_dev; // copy path: h_gather's address as shard s's device sees it (null: not mappable)
+    uint32_t* h_counts = nullptr;        // pinned [n_shards][count_cap]: the shards' per-query counts (copy path; unused by the merge)
+    std::vector<uint32_t*> h_counts_dev;
+    size_t count_cap = 0;
     float* h_q = nullptr;                // pinned query block
     size_t hq_cap = 0;                   // floats
     uint32_t searches = 0, gathers_rccl = 0;
@@ -119,6 +123,7 @@ void free_gather(ShardSet* ss) {
         ss->d_gather[s] = nullptr;
     }
     if (ss->h_gather) { (void)hipHostFree(ss->h_gather); ss->h_gather = nullptr; }
+    ss->h_gather_dev.clear();
     ss->gather_cap = 0;
 }
 
@@ -134,7 +139,44 @@ int32_t ensure_gather(cqs_hip_index* p, size_t keys) {
         P_TRY(p, hipMalloc(&ss->d_gather[s], G * keys * sizeof(uint64_t)));
     }
     P_TRY(p, hipHostMalloc((void**)&ss->h_gather, G * keys * sizeof(uint64_t), hipHostMallocPortable));
+    // copy path (a device named twice): every shard's select kernel writes its keys straight into its slot of the
+    // pinned gather buffer - no device-side gather buffer, no copy calls; any device that cannot map it keeps the copies
+    ss->h_gather_dev.assign(G, nullptr);
+    if (!ss->use_rccl) {
+        for (size_t s = 0; s < G; ++s) {
+            uint64_t* dp = nullptr;
+            if (hipSetDevice(ss->shard[s]->device) != hipSuccess || hipHostGetDevicePointer((void**)&dp, ss->h_gather, 0) != hipSuccess) {
+                (void)hipGetLastError();
+                ss->h_gather_dev.assign(G, nullptr);
+                break;
+            }
+            ss->h_gather_dev[s] = dp;
+        }
+    }
     ss->gather_cap = keys;
+    return CQS_HIP_OK;
+}
+
+// pinned per-shard count rows for the direct-output copy path (the merge counts non-zero keys itself)
+int32_t ensure_counts(cqs_hip_index* p, size_t nb) {
+    ShardSet* ss = p->sh;
+    const size_t G = ss->shard.size();
+    if (nb <= ss->count_cap) return CQS_HIP_OK;
+    for (cqs_hip_index* c : ss->shard) { P_TRY(p, hipSetDevice(c->device)); P_TRY(p, quiesce(c)); }
+    if (ss->h_counts) (void)hipHostFree(ss->h_counts);
+    ss->h_counts = nullptr; ss->count_cap = 0;
+    ss->h_counts_dev.assign(G, nullptr);
+    P_TRY(p, hipHostMalloc((void**)&ss->h_counts, G * nb * sizeof(uint32_t), hipHostMallocPortable));
+    for (size_t s = 0; s < G; ++s) {
+        uint32_t* dp = nullptr;
+        if (hipSetDevice(ss->shard[s]->device) != hipSuccess || hipHostGetDevicePointer((void**)&dp, ss->h_counts, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            ss->h_counts_dev.assign(G, nullptr);
+            break;
+        }
+        ss->h_counts_dev[s] = dp;
+    }
+    ss->count_cap = nb;
     return CQS_HIP_OK;
 }
 
@@ -157,6 +199,10 @@ int32_t search_block(cqs_hip_index* p, uint32_t nb, uint32_t k_eff, const uint32
     const size_t keys = (size_t)nb * k_eff;
     int32_t rc = ensure_gather(p, keys);
     if (rc != CQS_HIP_OK) return rc;
+    if (!ss->use_rccl && (rc = ensure_counts(p, nb)) != CQS_HIP_OK) return rc;
+    // copy path, small blocks: the select kernels write into the pinned gather buffer themselves (slot s = [s * keys, + keys))
+    const bool direct = !ss->use_rccl && keys <= kDirectOutKeys && !ss->h_gather_dev.empty() && ss->h_gather_dev[0] &&
+                        !ss->h_counts_dev.empty() && ss->h_counts_dev[0];
     const size_t qbytes = (size_t)nb * p->dim * sizeof(float);
     // 1. every device: query block H2D, scan + select into its own d_out_keys ([nb][k_eff], zero padded)
     for (size_t s = 0; s < G; ++s) {
@@ -176,11 +222,13 @@ int32_t search_block(cqs_hip_index* p, uint32_t nb, uint32_t k_eff, const uint32
                 d_keep = c->d_keep;
             }
         }
+        uint64_t* const keys_out = direct ? ss->h_gather_dev[s] + s * keys : c->d_out_keys;
+        uint32_t* const counts_out = direct ? ss->h_counts_dev[s] + s * nb : c->d_out_counts;
         if (skip) {
-            P_TRY(p, hipMemsetAsync(c->d_out_keys, 0, keys * sizeof(uint64_t), c->stream));
+            P_TRY(p, hipMemsetAsync(keys_out, 0, keys * sizeof(uint64_t), c->stream));
         } else {
             P_TRY(p, hipMemcpyAsync(c->d_q, ss->h_q, qbytes, hipMemcpyHostToDevice, c->stream));   // the query broadcast
-            if ((rc = enqueue_search(c, c->d_q, nb, k_eff, d_keep, mode, thr, c->d_out_keys, c->d_out_counts, c->stream)) != CQS_HIP_OK)
+            if ((rc = enqueue_search(c, c->d_q, nb, k_eff, d_keep, mode, thr, keys_out, counts_out, c->stream)) != CQS_HIP_OK)
                 return child_fail(p, s, rc);
         }
     }
@@ -210,7 +258,8 @@ int32_t search_block(cqs_hip_index* p, uint32_t nb, uint32_t k_eff, const uint32
             } else {
                 P_TRY(p, hipSetDevice(c0->device));
             }
-            P_TRY(p, hipMemcpyAsync(ss->d_gather[0] + s * keys, c->d_out_keys, keys * sizeof(uint64_t), hipMemcpyDefault, c0->stream));
+            if (!direct)
+                P_TRY(p, hipMemcpyAsync(ss->d_gather[0] + s * keys, c->d_out_keys, keys * sizeof(uint64_t), hipMemcpyDefault, c0->stream));
         }
     }
     // 3. one D2H from the first device and ONE host wait, on that device's stream: its copy of the gathered lists is
@@ -222,8 +271,9 @@ int32_t search_block(cqs_hip_index* p, uint32_t nb, uint32_t k_eff, const uint32
     {
         cqs_hip_index* c0 = ss->shard[0];
         P_TRY(p, hipSetDevice(c0->device));
-        P_TRY(p, hipMemcpyAsync(ss->h_gather, ss->d_gather[0], G * keys * sizeof(uint64_t), hipMemcpyDeviceToHost, c0->stream));
-        P_TRY(p, hipStreamSynchronize(c0->stream));
+        if (!direct)
+            P_TRY(p, hipMemcpyAsync(ss->h_gather, ss->d_gather[0], G * keys * sizeof(uint64_t), hipMemcpyDeviceToHost, c0->stream));
+        P_TRY(p, hipStreamSynchronize(c0->stream));   // (direct: the stream has waited on every shard's event above)
     }
     // 4. host k-way merge per query (lists of query q: h_gather + s * keys + q * k_eff, zero padded)
     std::vector<uint32_t> counts(G);
@@ -257,6 +307,7 @@ void destroy(cqs_hip_index* p) {
     for (size_t s = 0; s < ss->ev.size(); ++s)
         if (ss->ev[s]) { (void)hipSetDevice(ss->shard[s]->device); (void)hipEventDestroy(ss->ev[s]); }
     if (ss->h_q) (void)hipHostFree(ss->h_q);
+    if (ss->h_counts) (void)hipHostFree(ss->h_counts);
     for (cqs_hip_index* c : ss->shard) cqs_hip_index_destroy(c);
     delete ss;
     p->sh = nullptr;

@@ -121,6 +121,18 @@ class HipEmbedEngine:
     def last_ms(self) -> float:
         return float(self._lib.cqs_hip_embedder_last_ms(self._h))
 
+    def warm(self, max_tokens: int = 128) -> None:
+        """`cqs_hip_embedder_warm`: build and replay the search-time chain's graphs for every length 1..max_tokens."""
+        rc = self._lib.cqs_hip_embedder_warm(self._h, int(max_tokens))
+        if rc != _lib.OK:
+            raise HipError(rc, self.last_error())
+
+    def query_graph_stats(self) -> dict:
+        """`cqs_hip_embedder_query_graph_stats`: {captured, failed, replays, eager} of the search-time chain."""
+        v = [C.c_uint64() for _ in range(4)]
+        self._lib.cqs_hip_embedder_query_graph_stats(self._h, *[C.byref(x) for x in v])
+        return dict(zip(("captured", "failed", "replays", "eager"), (int(x.value) for x in v)))
+
     def run(self, input_ids: np.ndarray, attention_mask: np.ndarray) -> np.ndarray:
         """`session.run`: i64 [B, L] x2 -> f32 [B, dim] (`sentence_embedding`, not normalised)."""
         ids = np.ascontiguousarray(input_ids, dtype=np.int64)
@@ -258,5 +270,8 @@ class Embedder:
             self._cache.popitem(last=False)
         return v
 
-    def warm(self) -> None:  # core.rs:933-957
+    def warm(self, max_tokens: int = 128) -> None:  # core.rs:933-957
+        """One dummy inference like the reference - plus the search-time chain's graphs for every query length up to
+        `max_tokens`, which would otherwise be built on the first query of each length."""
+        self.engine.warm(max_tokens)
         self.embed_query("warmup")

@@ -446,6 +446,12 @@ class HipIndex(VectorIndex):
         if rc != _lib.OK:
             raise HipError(rc, self.last_error())
 
+    def combine_stats(self) -> Tuple[int, int]:
+        """(passes, queries) the handle's combining queue has run since it was made (`cqs_hip_index_combine_stats`)."""
+        p, q = C.c_uint64(), C.c_uint64()
+        self._lib.cqs_hip_index_combine_stats(self._h, C.byref(p), C.byref(q))
+        return int(p.value), int(q.value)
+
     def set_timing(self, on: bool) -> None:
         self._lib.cqs_hip_index_set_timing(self._h, 1 if on else 0)
 

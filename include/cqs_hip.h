@@ -78,7 +78,7 @@ int32_t cqs_hip_device_mem(int32_t device, uint64_t* free_bytes, uint64_t* total
  * `prepare_index_data` (src/hnsw/mod.rs:688-746) so len() and row->id agree.
  * `row_base` is added to every emitted row id (0 for a whole corpus; the shard
  * offset when the corpus is row-sharded over several GPUs/processes).
- * dim must be a multiple of 4 and <= 2048. */
+ * dim must be a multiple of 4 and <= 4096 (the reference's presets reach 4096, src/embedder/models.rs:572). */
 int32_t cqs_hip_index_create(const float* rows, uint64_t n, uint32_t dim, uint32_t metric,
                              int32_t device, uint64_t row_base, cqs_hip_index** out);
 /* Same, from rows already resident in `device`'s HBM.  borrow != 0: the index
@@ -161,7 +161,19 @@ size_t cqs_hip_index_last_error(const cqs_hip_index* idx, char* buf, size_t cap)
  * and out_scores likewise, ordered by (score desc under f32 total order, row
  * asc) — the reference's order (candidate.rs:327, neighbors.rs:131) with
  * integer ids.  Non-finite scores are never emitted (src/cagra.rs:649-651).
- * Slots past out_counts[q] are untouched. */
+ * Slots past out_counts[q] are untouched.
+ *
+ * Concurrent callers (the daemon calls `search` from one thread per client on a shared
+ * Arc<dyn VectorIndex>, src/cli/watch/daemon.rs:273; CAGRA serialises them behind
+ * Mutex<GpuState>, src/cagra.rs:263): calls with b == 1 and no bitset that meet on one
+ * handle are COMBINED - a caller that finds the device busy parks its query, and whoever
+ * takes the device next scans every parked query with the same (k, mode, threshold) in one
+ * pass over the corpus (up to 8 queries share the HBM stream; more run as consecutive
+ * passes inside the same hold of the device).  Each caller receives exactly the bytes a
+ * lone call would have produced.  A lone caller pays two uncontended mutex operations.
+ * Calls with a bitset, b > 1, or on a sharded handle run one after the other as before.
+ * If a pass fails, the call that led it returns the device error and every parked caller
+ * returns CQS_HIP_ERR_POISONED.  CQS_HIP_COMBINE=0 (read at create) turns the queue off. */
 int32_t cqs_hip_index_search(cqs_hip_index* idx, const float* queries, uint32_t b, uint32_t query_dim,
                              uint32_t k, const uint32_t* keep_bitset, uint32_t mode, float threshold,
                              uint64_t* out_rows, float* out_scores, uint32_t* out_counts);
@@ -205,6 +217,11 @@ void cqs_hip_unpack_keys(const uint64_t* keys, size_t count, uint64_t* rows, flo
  * min(k, total) keys, sorted descending; returns that count. */
 size_t cqs_hip_merge_keys(const uint64_t* lists, const uint32_t* counts, size_t n_lists, size_t stride,
                           size_t k, uint64_t* out_keys);
+
+/* Combining-queue counters of a handle since it was made: passes the queue ran and the
+ * queries they carried (queries / passes = mean callers per pass).  Either pointer may be
+ * NULL.  Diagnostic; not part of the VectorIndex trait. */
+void cqs_hip_index_combine_stats(const cqs_hip_index* idx, uint64_t* passes, uint64_t* queries);
 
 /* ---- profiling aid ---------------------------------------------------------
  * With timing enabled every search brackets its dominant scan kernel launch(es)
@@ -297,6 +314,18 @@ int32_t cqs_hip_embed_submit(cqs_hip_embedder* e, const int64_t* input_ids, cons
 int32_t cqs_hip_embed_submit_ragged(cqs_hip_embedder* e, const int32_t* tokens, const uint32_t* lens, uint32_t batch,
                                     uint64_t* ticket);
 int32_t cqs_hip_embed_collect(cqs_hip_embedder* e, uint64_t ticket, float* out);
+/* `Embedder::warm()` (src/embedder/core.rs:933-957): pay the first-call cost of the search-time forward before the
+ * first real query.  One sequence of up to 128 tokens (`embed_query`) runs a kernel chain of its own, replayed from a
+ * hipGraph kept per (token count, execution context); a graph is otherwise built the first time its length is seen
+ * (eager chain + capture + instantiate on that query's clock).  warm builds and replays the graphs of every length
+ * 1..max_tokens (clamped to what the search-time path serves).  Call it with no ticket in flight
+ * (CQS_HIP_ERR_INVALID otherwise); it takes about a second for max_tokens = 128. */
+int32_t cqs_hip_embedder_warm(cqs_hip_embedder* e, uint32_t max_tokens);
+/* Search-time chain counters since the engine was made: graphs captured, captures that FAILED (that length runs its
+ * chain eagerly from then on; the cause is in cqs_hip_embedder_last_error), graph replays, eager chain runs.  Any
+ * pointer may be NULL.  Diagnostic: lets a caller (and the bench) see which path a query really took. */
+void cqs_hip_embedder_query_graph_stats(const cqs_hip_embedder* e, uint64_t* captured, uint64_t* failed,
+                                        uint64_t* replays, uint64_t* eager);
 /* `normalize_l2` (src/embedder/pooling.rs:60-67) applied to each row of a host [n, dim] matrix, in place: f32
  * left-to-right sum of squares, scale by 1/sqrt when > 0, zero rows stay zero.  Host code (no device work). */
 void cqs_hip_normalize_l2_rows(float* rows, uint64_t n, uint32_t dim);

@@ -8,10 +8,14 @@
  * Every function cites the reference file:line (relative to the cqs repo
  * root, v1.51.0) whose behaviour it restates.
  */
+#ifndef _GNU_SOURCE
+#define _GNU_SOURCE   /* pthread_setaffinity_np */
+#endif
 #include "cqs_oracle.h"
 
 #include <math.h>
 #include <pthread.h>
+#include <sched.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -543,10 +547,55 @@ void cqs_oracle_last_token_pool(const float* hidden, const int64_t* mask, size_t
 /* ---- multi-threaded baseline --------------------------------------------- */
 typedef struct {
     const float* rows; size_t lo, hi, dim; const float* query; size_t limit; float threshold; int dot_kind;
-    uint64_t* ids; float* scores; size_t count;
+    uint64_t* ids; float* scores; size_t count; int t;
 } mt_job;
+/* Worker placement for the multi-thread baseline (bench.py's cpu_baseline): with pinning on, worker t of T runs on the
+ * t-th CPU of the caller's list and stays there, so that a corpus whose shard t was FIRST TOUCHED by worker t
+ * (cqs_oracle_first_touch_copy) is read from that worker's own NUMA node.  Off (the default): the OS places the threads. */
+static int g_pin_count = 0;
+static int g_pin_cpus[1024];
+void cqs_oracle_set_worker_cpus(const int* cpus, int count) {
+    if (!cpus || count < 0) count = 0;
+    if (count > 1024) count = 1024;
+    for (int i = 0; i < count; ++i) g_pin_cpus[i] = cpus[i];
+    g_pin_count = count;
+}
+static void pin_worker(int t) {
+    if (g_pin_count <= 0) return;
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    CPU_SET(g_pin_cpus[t % g_pin_count], &set);
+    (void)pthread_setaffinity_np(pthread_self(), sizeof set, &set);
+}
+typedef struct { float* dst; const float* src; size_t lo, hi, dim; int t; } ft_job;
+static void* ft_worker(void* p) {
+    ft_job* j = (ft_job*)p;
+    pin_worker(j->t);
+    if (j->hi > j->lo) memcpy(j->dst + j->lo * j->dim, j->src + j->lo * j->dim, (j->hi - j->lo) * j->dim * sizeof(float));
+    return NULL;
+}
+/* dst (untouched pages, e.g. a fresh numpy.empty) <- src, shard t of `threads` copied by worker t: the same row
+ * partition cqs_oracle_brute_force_mt uses, so each scan worker later reads pages its own node holds. */
+void cqs_oracle_first_touch_copy(float* dst, const float* src, size_t n, size_t dim, int threads) {
+    if (threads < 1) threads = 1;
+    ft_job* jobs = (ft_job*)calloc((size_t)threads, sizeof(ft_job));
+    pthread_t* th = (pthread_t*)calloc((size_t)threads, sizeof(pthread_t));
+    size_t per = (n + (size_t)threads - 1) / (size_t)threads;
+    for (int t = 0; t < threads; ++t) {
+        size_t lo = per * (size_t)t, hi = lo + per;
+        if (lo > n) lo = n;
+        if (hi > n) hi = n;
+        jobs[t] = (ft_job){dst, src, lo, hi, dim, t};
+        pthread_create(&th[t], NULL, ft_worker, &jobs[t]);
+    }
+    for (int t = 0; t < threads; ++t) pthread_join(th[t], NULL);
+    free(jobs);
+    free(th);
+}
+
 static void* mt_worker(void* p) {
     mt_job* j = (mt_job*)p;
+    pin_worker(j->t);
     cqs_oracle_heap* h = cqs_oracle_heap_new(j->limit);
     for (size_t r = j->lo; r < j->hi; ++r) {
         float base, score;
@@ -571,7 +620,7 @@ size_t cqs_oracle_brute_force_mt(const float* rows, size_t n, size_t dim, const 
         if (hi > n) hi = n;
         jobs[t] = (mt_job){rows, lo, hi, dim, query, limit, threshold, dot_kind,
                            (uint64_t*)malloc(sizeof(uint64_t) * (limit ? limit : 1)),
-                           (float*)malloc(sizeof(float) * (limit ? limit : 1)), 0};
+                           (float*)malloc(sizeof(float) * (limit ? limit : 1)), 0, t};
         pthread_create(&th[t], NULL, mt_worker, &jobs[t]);
     }
     cqs_oracle_heap* h = cqs_oracle_heap_new(limit);

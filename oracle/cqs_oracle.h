@@ -128,6 +128,10 @@ void cqs_oracle_last_token_pool(const float* hidden, const int64_t* mask, size_t
  * Same as cqs_oracle_brute_force but over `threads` contiguous row shards with
  * a final merge by the same comparator (the reference itself is single-
  * threaded per query, search/query.rs:362).  Uses pthreads. */
+/* Baseline placement (bench.py cpu_baseline): pin worker t to cpus[t % count] (count 0 = let the OS place threads), and
+ * copy src into untouched dst pages with the same per-worker row partition, so each worker scans node-local memory. */
+void cqs_oracle_set_worker_cpus(const int* cpus, int count);
+void cqs_oracle_first_touch_copy(float* dst, const float* src, size_t n, size_t dim, int threads);
 size_t cqs_oracle_brute_force_mt(const float* rows, size_t n, size_t dim, const float* query,
                                  size_t limit, float threshold, int threads, int dot_kind,
                                  uint64_t* ids_out, float* scores_out);

@@ -62,6 +62,8 @@ def lib() -> C.CDLL:
             "cqs_oracle_cls_pool": (None, [vp, sz, sz, sz, vp]),
             "cqs_oracle_last_token_pool": (None, [vp, vp, sz, sz, sz, vp]),
             "cqs_oracle_brute_force_mt": (sz, [vp, sz, sz, vp, sz, f, i, i, vp, vp]),
+            "cqs_oracle_set_worker_cpus": (None, [vp, i]),
+            "cqs_oracle_first_touch_copy": (None, [vp, vp, sz, sz, i]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(L, name)
@@ -170,6 +172,21 @@ def brute_force_mt(rows, query, limit, threshold, threads, kind=DOT_SIMSIMD):
     sc = np.zeros((max(limit, 1),), dtype=np.float32)
     c = lib().cqs_oracle_brute_force_mt(_p(rows), n, dim, _p(query), limit, threshold, threads, kind, _p(ids), _p(sc))
     return ids[:c], sc[:c]
+
+
+def set_worker_cpus(cpus) -> None:
+    """Pin worker t of the multi-thread scan / first-touch copy to cpus[t % len(cpus)]; [] = the OS places threads."""
+    arr = np.ascontiguousarray(list(cpus), dtype=np.int32)
+    lib().cqs_oracle_set_worker_cpus(_p(arr) if len(arr) else None, len(arr))
+
+
+def first_touch_copy(src, threads):
+    """A copy of `src` whose shard t (the row partition of brute_force_mt with `threads` workers) was first touched by
+    worker t - with pinned workers each shard then sits on its scanner's NUMA node."""
+    src = _f32(src)
+    dst = np.empty_like(src)                       # fresh mapping: pages are placed when the workers write them
+    lib().cqs_oracle_first_touch_copy(_p(dst), _p(src), src.shape[0], src.shape[1], threads)
+    return dst
 
 
 def dot_isa(native: bool = False) -> str:

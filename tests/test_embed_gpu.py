@@ -498,7 +498,16 @@ def test_fewrows_gemm_is_bit_identical_to_the_tiled_kernel(hip, monkeypatch):
                 assert float((a - ref).abs().max()) < 2e-2
 
 
-def test_fused_projection_addnorm_is_bit_identical_to_the_two_launch_chain(hip, monkeypatch):
+def set_fuse_norm(eng, on, min_rows=0):
+    """The engine reads CQS_HIP_GEMM_FUSE_NORM* once, at finalize; tests switch the fused kernels through the debug hook."""
+    import ctypes as C
+    f = eng._lib.cqs_hip_debug_embedder_set_fuse_norm
+    f.restype = None
+    f.argtypes = [C.c_void_p, C.c_int32, C.c_uint32]
+    f(eng._h, 1 if on else 0, min_rows)
+
+
+def test_fused_projection_addnorm_is_bit_identical_to_the_two_launch_chain(hip):
     """gemm_rowfuse.hip: o_proj / down + residual add + both RMSNorms in one launch (a workgroup owns 64 whole rows x
     768 columns).  Same MFMA and k order as the 256-row GEMM, the row phase is add_norm_kernel's arithmetic -> the
     embeddings must equal the two-launch chain's BIT FOR BIT; ragged token counts (last tile partly filled), both the
@@ -508,15 +517,13 @@ def test_fused_projection_addnorm_is_bit_identical_to_the_two_launch_chain(hip, 
     eng, w = make(cfg, seed=41)
     for lens in ([700, 650, 33, 517], [64] * 20, [1000, 3]):             # 1900, 1280 and 1003 tokens
         ids, mask = batch(cfg, lens, seed=sum(lens))
-        monkeypatch.setenv("CQS_HIP_GEMM_FUSE_NORM", "0")
+        set_fuse_norm(eng, False)
         plain = eng.run(ids, mask)
-        monkeypatch.setenv("CQS_HIP_GEMM_FUSE_NORM", "1")
-        monkeypatch.setenv("CQS_HIP_GEMM_FUSE_NORM_MIN_ROWS", "256")     # (default 12288: the test batches are smaller)
+        set_fuse_norm(eng, True, 256)                                    # (default 12288: the test batches are smaller)
         fused = eng.run(ids, mask)
-        monkeypatch.delenv("CQS_HIP_GEMM_FUSE_NORM_MIN_ROWS")
         assert np.array_equal(fused, plain), float(np.max(np.abs(fused - plain)))
     ids, mask = batch(cfg, [300, 41], seed=5)
-    monkeypatch.setenv("CQS_HIP_GEMM_FUSE_NORM_MIN_ROWS", "64")
+    set_fuse_norm(eng, True, 64)
     got = eng.run(ids, mask)
     ref = G.forward(cfg, w, ids, mask)
     for i in range(2):

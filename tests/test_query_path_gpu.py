@@ -45,18 +45,26 @@ def test_query_path_matches_the_oracle_and_the_batch_path(hip, monkeypatch):
 
 
 def test_graph_replay_equals_eager_across_lengths(hip, monkeypatch):
-    """One graph per execution context, captured on the context's second query; T is read from device memory, so the
-    same graph must serve every length.  Tickets alternate contexts: 12 queries = 6 per context (1 eager, 1 capture +
-    replay, 4 replays).  Eager engine (CQS_HIP_QUERY_GRAPH=0) = the reference answer, bit for bit."""
+    """One graph per (query length, execution context, variant): the first query of a length runs the chain eagerly (its
+    kernels' launch attributes are set outside any capture), the second is captured, later ones replay.  The eager
+    engine (CQS_HIP_QUERY_GRAPH=0) = the reference answer, bit for bit.  The counters must show that graphs really were
+    captured and replayed and that no capture failed - an engine that silently fell back to eager launches would pass the
+    comparison vacuously."""
     eng_g, w = make(SMALL, seed=33)
     monkeypatch.setenv("CQS_HIP_QUERY_GRAPH", "0")
     eng_e, _ = make(SMALL, seed=33)
     monkeypatch.delenv("CQS_HIP_QUERY_GRAPH")
-    order = [8, 64, 1, 33, 5, 17, 64, 2, 40, 16, 1, 50]
+    order = [8, 64, 1, 33, 5, 17, 64, 2, 40, 16, 1, 50, 8, 64, 1, 8, 64, 1]
     for j, n in enumerate(order):
         ids, mask = _one(SMALL, n, seed=200 + j)
         a, b = eng_g.run(ids, mask), eng_e.run(ids, mask)
         assert np.array_equal(a, b), (j, n, float(np.max(np.abs(a - b))))
+    st = eng_g.query_graph_stats()
+    assert st["failed"] == 0, (st, eng_g.last_error())
+    assert st["captured"] >= 3 and st["replays"] >= 5, st         # 8 / 64 / 1 came three times each: eager, capture + replay, replay
+    assert st["eager"] == len(set(order)), st                      # one eager chain per distinct length, no more
+    se = eng_e.query_graph_stats()
+    assert se["captured"] == 0 and se["replays"] == 0 and se["eager"] == len(order), se
     # a long row in between (batch chain on the same stream / scratch), then the graph again
     ids, mask = _one(SMALL, 200, seed=7)
     assert np.array_equal(eng_g.run(ids, mask), eng_e.run(ids, mask))
@@ -69,6 +77,29 @@ def test_graph_replay_equals_eager_across_lengths(hip, monkeypatch):
     for t, wv in zip(reversed(tickets), reversed(want)):
         assert np.array_equal(eng_g.collect(t, 1), wv)
     eng_g.close(); eng_e.close()
+
+
+def test_warm_builds_every_graph_and_the_first_query_replays(hip):
+    """`cqs_hip_embedder_warm` (`Embedder::warm`, src/embedder/core.rs:933-957): after it, the FIRST query of any length
+    is a graph replay - no eager chain, no capture on the query's clock - and answers what a cold engine answers."""
+    eng_w, w = make(SMALL, seed=39)
+    eng_c, _ = make(SMALL, seed=39)
+    eng_w.warm(64)
+    st0 = eng_w.query_graph_stats()
+    assert st0["failed"] == 0, (st0, eng_w.last_error())
+    assert st0["captured"] >= 2 * 64, st0                            # every length, at least the blocking call's variant on both contexts
+    for j, n in enumerate([37, 5, 64, 1, 22]):
+        ids, mask = _one(SMALL, n, seed=700 + j)
+        a = eng_w.run(ids, mask)
+        st = eng_w.query_graph_stats()
+        assert st["eager"] == st0["eager"] and st["captured"] == st0["captured"], (n, st0, st)   # nothing built on the query's clock
+        assert st["replays"] == st0["replays"] + j + 1
+        assert np.array_equal(a, eng_c.run(ids, mask)), n
+    t = eng_w.submit(*_one(SMALL, 9, seed=720))
+    with pytest.raises(Exception):
+        eng_w.warm(8)                                                # a ticket is in flight
+    eng_w.collect(t, 1)
+    eng_w.close(); eng_c.close()
 
 
 def test_direct_host_buffers_equal_the_copy_calls(hip, monkeypatch):

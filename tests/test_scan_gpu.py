@@ -283,6 +283,29 @@ def test_other_dims(hip, oracle, dim):
     idx.close()
 
 
+@pytest.mark.parametrize("dim", [2052, 2560, 3000, 4096])
+def test_wide_dims_single_and_batched(hip, oracle, dim):
+    """The reference's presets reach 2560 and 4096 dimensions (src/embedder/models.rs:515,572) and its index traits are
+    dimension-generic: rows of 9-16 KiB take the one-row-per-batch gemv variants (one query per pass), query blocks of
+    >= 9 the matrix-core kernel (any dim % 32 == 0).  A corpus large enough for 64-row tasks, the keep bitset and the
+    PIPELINE mode ride along; 4100 is refused at create."""
+    rows = synth.gaussian_unit(9000, dim, seed=133)
+    qs = synth.gaussian_unit(12, dim, seed=134)
+    idx = HipIndex.build_from_flat(None, rows)
+    check(oracle, idx, rows, qs[0], 20)
+    check(oracle, idx, rows, qs[:3], 10)                        # three passes of one query
+    check(oracle, idx, rows, qs, 20)                            # 12 queries: matrix cores when dim % 32 == 0
+    keep = np.random.default_rng(135).integers(0, 2**32, size=(9000 + 31) // 32, dtype=np.uint64).astype(np.uint32)
+    check(oracle, idx, rows, qs[1], 20, keep=keep)
+    check(oracle, idx, rows, qs[2], 20, mode=1, thr=0.02)
+    idx.close()
+    small = HipIndex.build_from_flat(None, rows[:700])          # 16-row tasks
+    check(oracle, small, rows[:700], qs[3], 10)
+    small.close()
+    with pytest.raises(Exception):
+        HipIndex.build_from_flat(None, np.zeros((10, 4100), np.float32))
+
+
 def test_dot_metric_unnormalised(hip, oracle):
     rng = np.random.default_rng(7)
     rows = (rng.standard_normal((4000, 768)) * rng.uniform(0.1, 30, (4000, 1))).astype(np.float32)

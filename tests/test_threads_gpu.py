@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 from cqs_amd import HipIndex, synth
+from cqs_amd.index import HipError
 
 pytestmark = pytest.mark.gpu
 
@@ -42,6 +43,97 @@ def test_index_search_from_three_threads(hip):
             assert np.array_equal(r, want_blk[0]) and np.array_equal(s, want_blk[1])
 
     _run_threads(work, 3)
+    idx.close()
+
+
+def test_combining_queue_hands_every_caller_its_lone_answer(hip):
+    """concurrent single-query callers share passes over the corpus (include/cqs_hip.h, search: "Concurrent
+    callers").  8 and 16 threads, one query per call; every answer must equal, bit for bit, what the same call returns
+    alone - and the queue must really have combined (more queries than passes)."""
+    rows = synth.gaussian_unit(300_000, seed=15)
+    qs = synth.gaussian_unit(64, seed=16)
+    idx = HipIndex.build_from_flat(None, rows)
+    want = [idx.search_batch(qs[i], 20) for i in range(len(qs))]
+    p0, q0 = idx.combine_stats()
+    assert p0 == q0 == len(qs)                 # a lone caller: one query per pass
+
+    for n_threads in (8, 16):
+        def work(t):
+            for rep in range(12):
+                for i in range(t, len(qs), n_threads):
+                    r, s, c = idx.search_batch(qs[i], 20)
+                    assert np.array_equal(r, want[i][0]) and np.array_equal(s, want[i][1]) and np.array_equal(c, want[i][2]), (t, rep, i)
+        _run_threads(work, n_threads)
+    p1, q1 = idx.combine_stats()
+    assert q1 - q0 == 2 * 12 * len(qs)
+    assert (q1 - q0) > 1.5 * (p1 - p0), f"the queue did not combine: {q1 - q0} queries in {p1 - p0} passes"
+    idx.close()
+
+
+def test_combining_queue_mixed_callers(hip):
+    """Callers with different k, PIPELINE mode, a bitset, a multi-query block and a non-finite query all at once: each
+    group rides its own passes (or the serial path) and gets the answer it gets alone."""
+    from cqs_amd import _lib
+    rows = synth.gaussian_unit(120_000, seed=25)
+    qs = synth.gaussian_unit(32, seed=26)
+    idx = HipIndex.build_from_flat(None, rows)
+    keep = np.random.default_rng(27).integers(0, 2**32, size=(len(rows) + 31) // 32, dtype=np.uint64).astype(np.uint32)
+    kinds = [dict(k=20), dict(k=50), dict(k=20, mode=_lib.MODE_PIPELINE, threshold=0.05), dict(k=10, keep_bitset=keep)]
+    want = {(j, i): idx.search_batch(qs[i], **kw) for j, kw in enumerate(kinds) for i in range(len(qs))}
+    want_blk = idx.search_batch(qs[:12], 20)
+    nanq = qs[0].copy()
+    nanq[5] = np.nan
+
+    def work(t):
+        j = t % len(kinds)
+        for rep in range(6):
+            for i in range(t % 8, len(qs), 8):
+                r, s, c = idx.search_batch(qs[i], **kinds[j])
+                w = want[(j, i)]
+                assert np.array_equal(r, w[0]) and np.array_equal(s, w[1]) and np.array_equal(c, w[2]), (t, rep, i)
+            if t == 0:
+                r, s, c = idx.search_batch(qs[:12], 20)
+                assert np.array_equal(r, want_blk[0]) and np.array_equal(s, want_blk[1])
+            if t == 1:
+                assert int(idx.search_batch(nanq, 20)[2][0]) == 0
+
+    _run_threads(work, 12)
+    idx.close()
+
+
+def test_poisoned_handle_wakes_every_parked_caller(hip):
+    """A pass that fails poisons the handle (src/cagra.rs:472-489): the call that led it reports the device error, every
+    caller parked behind it - and every later call - returns CQS_HIP_ERR_POISONED; nobody hangs."""
+    import ctypes as C
+    from cqs_amd import _lib
+    rows = synth.gaussian_unit(200_000, seed=35)
+    qs = synth.gaussian_unit(16, seed=36)
+    idx = HipIndex.build_from_flat(None, rows)
+    lib = _lib.load()
+    lib.cqs_hip_debug_index_fail_next.argtypes = [C.c_void_p]
+    lib.cqs_hip_debug_index_fail_next.restype = None
+    codes = []
+    lock = threading.Lock()
+    start = threading.Barrier(9)
+
+    def work(t):
+        start.wait()
+        for rep in range(40):
+            try:
+                idx.search_batch(qs[(t + rep) % len(qs)], 20)
+            except HipError as e:
+                with lock:
+                    codes.append(e.code)
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(8)]
+    [x.start() for x in th]
+    start.wait()
+    lib.cqs_hip_debug_index_fail_next(idx._h)
+    [x.join(timeout=60) for x in th]
+    assert not any(x.is_alive() for x in th), "a caller is still parked on a poisoned handle"
+    assert idx.is_poisoned()
+    assert codes.count(_lib.ERR_DEVICE) == 1, codes
+    assert codes.count(_lib.ERR_POISONED) == len(codes) - 1 and len(codes) >= 8, codes
     idx.close()
 
 

@@ -3,7 +3,7 @@
 with kernel names truncated, for committing under profiles/.
 
   summarize_prof.py DIR [DIR ...]                       text summary on stdout
-  summarize_prof.py --scan-traffic FETCH_DIR WRITE_DIR ALG_BYTES OUT.json
+  summarize_prof.py --scan-traffic FETCH_DIR WRITE_DIR ALG_BYTES OUT.json [COMMIT]
         per-launch HBM bytes of scan_gemv_kernel from the two PMC passes, corrected as MI355X_MICROARCH.md prescribes
         (FETCH_SIZE is in KiB and counts wide reads at half size on gfx950: x 1024 x 2; WRITE_SIZE: x 1024)"""
 import csv
@@ -59,7 +59,14 @@ def counters(d):
             print(f"{k:72s} {c:28s} dispatches={cnt:5d} mean={tot/cnt:16.3f}")
 
 
-def scan_traffic(fetch_dir, write_dir, alg_bytes, out):
+def scan_traffic(fetch_dir, write_dir, alg_bytes, out, commit=None):
+    import hashlib
+    import os
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    try:
+        sha = hashlib.sha256(open(os.path.join(here, "cqs_amd", "csrc", "scan_kernels.hip"), "rb").read()).hexdigest()[:16]
+    except OSError:
+        sha = None
     fm, wm = counter_means(fetch_dir), counter_means(write_dir)
     f = [(k, v) for k, v in fm.items() if k[1] == "FETCH_SIZE" and "scan_gemv_kernel" in k[0]]
     w = [(k, v) for k, v in wm.items() if k[1] == "WRITE_SIZE" and "scan_gemv_kernel" in k[0]]
@@ -71,6 +78,7 @@ def scan_traffic(fetch_dir, write_dir, alg_bytes, out):
     wr = wt / wc * 1024.0
     json.dump({"kernel": fk[0], "alg_bytes_per_launch": int(alg_bytes), "hbm_bytes_per_launch": round(rd + wr),
                "read_bytes": round(rd), "write_bytes": round(wr), "dispatches": fc,
+               "commit": commit, "scan_kernels_sha256": sha,     # what the counters were measured on (bench.py quotes both)
                "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `bench.py --steps 50`, "
                          "FETCH_SIZE KiB x 1024 x 2 (gfx950 wide-read correction), WRITE_SIZE KiB x 1024; "
                          "see profiles/ for the summary of the same run"}, open(out, "w"), indent=1)
@@ -80,7 +88,7 @@ def scan_traffic(fetch_dir, write_dir, alg_bytes, out):
 
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "--scan-traffic":
-        scan_traffic(*sys.argv[2:6])
+        scan_traffic(*sys.argv[2:7])
     else:
         for d in sys.argv[1:]:
             kernel_stats(d)
