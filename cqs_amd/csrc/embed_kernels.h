@@ -50,6 +50,17 @@ hipError_t launch_gemm_addnorm(const bf16_t* A, const bf16_t* W, float* x, const
                                float eps, bf16_t* xn, float* out, int final, uint32_t M, uint32_t H, uint32_t K,
                                hipStream_t st);
 
+// The same fused projection, second generation: a PAIR of workgroups owns 128 rows, each one 384-column half; row sums
+// are exchanged between the partners inside the launch (gemm_rowfuse.hip).  xch: gemm_addnorm_pair_scratch_bytes(M) of
+// device memory private to the stream; tag: differs from every earlier launch on that buffer, never 0; *err is set to 1
+// if an exchange timed out (the results of that launch are then garbage; the launch itself always ends).
+// Wp: the projection's weights [H][K] re-ordered once by launch_pack_rowfuse_w into the 2 KB blocks the kernel streams.
+size_t gemm_addnorm_pair_scratch_bytes(uint32_t M);
+hipError_t launch_pack_rowfuse_w(const bf16_t* src, bf16_t* dst, uint32_t N, uint32_t K, hipStream_t st);
+hipError_t launch_gemm_addnorm_pair(const bf16_t* A, const bf16_t* Wp, float* x, const float* w_post, const float* w_next,
+                                    float eps, bf16_t* xn, float* out, int final, uint32_t M, uint32_t H, uint32_t K,
+                                    void* xch, uint32_t tag, unsigned* err, hipStream_t st);
+
 // C[M,N] = A[M,K] (bf16, row-major) x W[N,K]^T (bf16, row-major), f32 accumulate on the matrix cores.
 //   GEMM_OUT_BF16 : C bf16 [M, ldc]
 //   GEMM_OUT_F32  : C f32  [M, ldc]
@@ -57,7 +68,27 @@ hipError_t launch_gemm_addnorm(const bf16_t* A, const bf16_t* W, float* x, const
 //                   channels; C bf16 [M, ldc] gets N/2 columns = gelu_tanh(gate) * up
 // Requires N % 128 == 0, K % 64 == 0.
 enum GemmOut { GEMM_OUT_BF16 = 0, GEMM_OUT_F32 = 1, GEMM_OUT_GEGLU = 2, GEMM_OUT_BF16_GELU = 3 /* bf16(gelu_erf(x + bias)): launch_gemm_p8 / _bias only */,
-               GEMM_OUT_ROWMAX = 4 /* launch_gemm_rowmax only */ };
+               GEMM_OUT_ROWMAX = 4 /* launch_gemm_rowmax only */, GEMM_OUT_QKV = 5 /* launch_gemm_qkv_rope only */ };
+
+// What the QKV projection's fused epilogue needs (GEMM_OUT_QKV): per-head RMSNorm (1 + w), RoPE and the q scale applied
+// to the tile before it is stored - the work of kv_prep_kernel (k heads) and of the attention kernels' Q prologue.
+struct QkvEpilogue {
+    const int32_t* pos;       // [M] position of each packed token in its sequence
+    const float* wq;          // [256] q-head norm weight
+    const float* wk;          // [256] k-head norm weight
+    const float* cos_sin;     // [max_seq][128][2] of the layer type
+    float eps, q_scale;
+    uint32_t heads, kv_heads; // heads == 3 * kv_heads
+};
+// qkv[M, (heads + 2 kv) * 256] = norm / rope / scale (A Wf^T): ONE launch of 256 x 320 tiles, each tile = one whole q or k
+// head (256 columns: normalised, rotated, q scaled) + a 64-column slice of v (stored as is).  Wf = the projection's rows in
+// tile order (launch_permute_qkv_rows).  Replaces GEMM + kv_prep + the attention kernel's own Q norm (attention then runs
+// with q_norm_w = NULL).  gemm_qkv_rope_supported: geometry fits AND the planner would run 256 x 320 tiles over the whole
+// projection anyway (a full round at this M) - otherwise the three-launch chain is the faster one.
+bool gemm_qkv_rope_supported(uint32_t M, uint32_t hidden, uint32_t heads, uint32_t kv_heads, uint32_t head_dim);
+hipError_t launch_permute_qkv_rows(const bf16_t* wqkv, bf16_t* wf, uint32_t heads, uint32_t kv_heads, uint32_t K, hipStream_t st);
+hipError_t launch_gemm_qkv_rope(const bf16_t* A, const bf16_t* Wf, bf16_t* qkv, uint32_t M, uint32_t K, const QkvEpilogue& epi,
+                                hipStream_t st);
 hipError_t launch_gemm_bf16(const bf16_t* A, const bf16_t* W, void* C, uint32_t M, uint32_t N, uint32_t K,
                             uint32_t ldc, GemmOut out, hipStream_t st, const float* bias = nullptr /*[N] f32; not with GEGLU*/);
 

@@ -66,6 +66,20 @@ __global__ __launch_bounds__(256) void embed_norm_kernel(const int32_t* __restri
     }
 }
 
+// Row sums are taken HALF BY HALF: lane L owns, in half h = L >> 5, the columns (H / 2) h + 128 c + 4 (L & 31) + {0..3},
+// c = 0..NCH-1; a half's partial is summed over its 32 lanes (butterfly 16, 8, 4, 2, 1) and the row's sum of squares is
+// left + right.  That is the order in which the pair-split fused kernel (gemm_rowfuse.hip: two workgroups own the two
+// column halves of a row block and exchange their partials) can also sum - so the two stay bit-identical.
+__device__ __forceinline__ float half_row_sum(float v) {      // over the 32 lanes of this lane's half-wave; same bits in all of them
+#pragma unroll
+    for (int off = 16; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ float row_sum_of_halves(float v, int lane) {
+    v = half_row_sum(v);
+    const float o = __shfl_xor(v, 32, 64);
+    return lane < 32 ? v + o : o + v;                          // left + right on both sides
+}
 template <int NCH, int FINAL>
 __global__ __launch_bounds__(256) void add_norm_kernel(float* __restrict__ x, const bf16_t* __restrict__ y,
                                                        const float* __restrict__ w_post,
@@ -75,11 +89,12 @@ __global__ __launch_bounds__(256) void add_norm_kernel(float* __restrict__ x, co
     const int lane = threadIdx.x & 63;
     const uint32_t row = blockIdx.x * 4u + (threadIdx.x >> 6);
     if (row >= M) return;
+    const uint32_t col0 = (uint32_t)(lane >> 5) * (H / 2u) + (uint32_t)(lane & 31) * 4u;
     f4 yv[NCH], xv[NCH];
     float ss = 0.f;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-        const uint32_t col = (uint32_t)c * 256u + (uint32_t)lane * 4u;
+        const uint32_t col = col0 + (uint32_t)c * 128u;
         const bf4 yb = *(const bf4*)(y + (size_t)row * H + col);
 #pragma unroll
         for (int i = 0; i < 4; ++i) yv[c][i] = (float)yb[i];
@@ -87,11 +102,11 @@ __global__ __launch_bounds__(256) void add_norm_kernel(float* __restrict__ x, co
 #pragma unroll
         for (int i = 0; i < 4; ++i) ss += yv[c][i] * yv[c][i];
     }
-    const float invy = rsqrtf(wave_sum(ss) / (float)H + eps);
+    const float invy = rsqrtf(row_sum_of_halves(ss, lane) / (float)H + eps);
     float sx = 0.f;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-        const uint32_t col = (uint32_t)c * 256u + (uint32_t)lane * 4u;
+        const uint32_t col = col0 + (uint32_t)c * 128u;
         const f4 w = *(const f4*)(w_post + col);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -100,10 +115,10 @@ __global__ __launch_bounds__(256) void add_norm_kernel(float* __restrict__ x, co
         }
         *(f4*)(x + (size_t)row * H + col) = xv[c];
     }
-    const float invx = rsqrtf(wave_sum(sx) / (float)H + eps);
+    const float invx = rsqrtf(row_sum_of_halves(sx, lane) / (float)H + eps);
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-        const uint32_t col = (uint32_t)c * 256u + (uint32_t)lane * 4u;
+        const uint32_t col = col0 + (uint32_t)c * 128u;
         const f4 w = *(const f4*)(w_next + col);
         if (FINAL) {
             f4 o;
@@ -1235,10 +1250,10 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const bf16_t* __restri
     }
 }
 
-hipError_t launch_gemm_bf16(const bf16_t* A, const bf16_t* W, void* C, uint32_t M, uint32_t N, uint32_t K,
-                            uint32_t ldc, GemmOut out, hipStream_t st, const float* bias) {
-    if (M == 0) return hipSuccess;
-    if (N % 128u || K % 64u || (bias && out == GEMM_OUT_GEGLU)) return hipErrorInvalidValue;
+// Kernel plan of one [M, N, K] projection: n1 columns with tile kind tn1 (0 = the 128 x 128 kernel, 3..5 = 256 x 64 tn),
+// the remaining N - n1 columns (if any) with tn2.
+struct GemmPlan { uint32_t n1; int tn1, tn2; };
+static GemmPlan plan_gemm(uint32_t M, uint32_t N, uint32_t K, GemmOut out) {
     static int n_cu = 0;
     if (n_cu == 0) {
         int dev = 0;
@@ -1255,8 +1270,8 @@ hipError_t launch_gemm_bf16(const bf16_t* A, const bf16_t* W, void* C, uint32_t 
     // 256 columns = one round of 128 x 128: 62 us instead of 73).
     const float kscale = (float)K / 768.f;
     const float geglu = out == GEMM_OUT_GEGLU ? 1.f : 0.f;
-    uint32_t cu = (uint32_t)n_cu;
-    if (const char* f = getenv("CQS_HIP_GEMM_CUS")) { const int v = atoi(f); if (v > 0) cu = (uint32_t)v; }   // experiment hook: plan for part of the chip
+    static const uint32_t cu_env = [] { const char* f = getenv("CQS_HIP_GEMM_CUS"); const int v = f ? atoi(f) : 0; return v > 0 ? (uint32_t)v : 0u; }();
+    const uint32_t cu = cu_env ? cu_env : (uint32_t)n_cu;      // (experiment hook: plan for part of the chip; read once)
     const bool fits = (uint64_t)M * K < (1ull << 31) && (uint64_t)N * K < (1ull << 31);
     const float cost[6] = {0.f, 0.f, 0.f, 24.f, 25.5f, 32.5f};
     auto one = [&](uint32_t n, int t) -> float {              // cost of n columns with one kernel; < 0: not applicable
@@ -1285,7 +1300,7 @@ hipError_t launch_gemm_bf16(const bf16_t* A, const bf16_t* W, void* C, uint32_t 
             if (c < best) { best = c; n1 = c1; tn1 = t; tn2 = t2; }
         }
     }
-    if (const char* f = getenv("CQS_HIP_GEMM_TILE")) {  // test hook: "small" / "pp:<tn>" force one kernel
+    if (const char* f = getenv("CQS_HIP_GEMM_TILE")) {  // test hook: "small" / "pp:<tn>" force one kernel (read per call: tests flip it)
         n1 = N;
         if (f[0] == 's') tn1 = 0;
         else if (f[0] == 'p') {
@@ -1293,10 +1308,28 @@ hipError_t launch_gemm_bf16(const bf16_t* A, const bf16_t* W, void* C, uint32_t 
             tn1 = (t >= 3 && t <= 5 && fits && N % (64u * (uint32_t)t) == 0) ? t : 0;
         }
     }
+    return {n1, tn1, tn2};
+}
+
+bool gemm_qkv_rope_supported(uint32_t M, uint32_t hidden, uint32_t heads, uint32_t kv_heads, uint32_t head_dim) {
+    if (head_dim != 256u || kv_heads == 0u || heads != 3u * kv_heads || hidden % 64u) return false;
+    const uint32_t N = (heads + 2u * kv_heads) * head_dim;
+    const GemmPlan p = plan_gemm(M, N, hidden, GEMM_OUT_BF16);
+    return p.n1 == N && p.tn1 == 5;                      // the plain projection would be one launch of 256 x 320 tiles too
+}
+
+hipError_t launch_gemm_bf16(const bf16_t* A, const bf16_t* W, void* C, uint32_t M, uint32_t N, uint32_t K,
+                            uint32_t ldc, GemmOut out, hipStream_t st, const float* bias) {
+    if (M == 0) return hipSuccess;
+    if (N % 128u || K % 64u || (bias && out == GEMM_OUT_GEGLU)) return hipErrorInvalidValue;
+    const GemmPlan pl = plan_gemm(M, N, K, out);
+    const uint32_t n1 = pl.n1;
+    const int tn1 = pl.tn1, tn2 = pl.tn2;
     if (n1 == N) return launch_gemm_one(A, W, C, M, N, K, ldc, out, tn1, st, bias);
     const size_t coff = out == GEMM_OUT_GEGLU ? n1 / 2u : n1;    // output columns of the first part
     void* c2 = out == GEMM_OUT_F32 ? (void*)((float*)C + coff) : (void*)((bf16_t*)C + coff);
-    if (tn1 >= 3 && tn2 >= 3 && tn1 != tn2 && !bias && out != GEMM_OUT_BF16_GELU && !getenv("CQS_HIP_GEMM_NO_DUAL")) {   // both parts in one launch
+    static const bool no_dual = getenv("CQS_HIP_GEMM_NO_DUAL") != nullptr;                       // (read once)
+    if (tn1 >= 3 && tn2 >= 3 && tn1 != tn2 && !bias && out != GEMM_OUT_BF16_GELU && !no_dual) {   // both parts in one launch
         const hipError_t d = launch_gemm_p8_dual(A, W, C, n1, tn1, W + (size_t)n1 * K, c2, N - n1, tn2, M, K, ldc, out, st);
         if (d != hipErrorNotSupported) return d;
     }

@@ -39,6 +39,8 @@ uint16_t f32_to_bf16_bits(float f) {
 }
 struct LayerW {
     bf16_t *wqkv = nullptr, *wo = nullptr, *wgu = nullptr, *wd = nullptr;
+    bf16_t *wo_p = nullptr, *wd_p = nullptr;      // wo / wd in the block order of the pair-split fused kernel (made at finalize)
+    bf16_t* wqkv_f = nullptr;                     // wqkv rows in tile order for the fused norm + RoPE epilogue (made at finalize)
     float *n_in = nullptr, *n_post_attn = nullptr, *n_pre_ffw = nullptr, *n_post_ffw = nullptr, *n_q = nullptr, *n_k = nullptr;
 };
 
@@ -61,9 +63,12 @@ struct cqs_hip_embedder {
     bool single_ctx = false;              // CQS_HIP_EMBED_CONTEXTS=1: one execution context (A/B hook for the two-chain overlap)
     // o_proj / down fused with the residual add + both norms (gemm_rowfuse.hip).  Read ONCE, at finalize
     // (CQS_HIP_GEMM_FUSE_NORM / _MIN_ROWS); tests flip it through cqs_hip_debug_embedder_set_fuse_norm.
-    bool fuse_norm = true;
-    uint32_t fuse_min_rows = 12288;       // below ~12.7k tokens the two-launch chain wins (a 64-row tile per CU streams the
-                                          // whole W panel whatever the row count: measured 3.89 vs 3.46 ms at 5k tokens)
+    int fuse_norm = 2;                    // 0 = two launches, 1 = the 64-row kernel of round 3, 2 = the pair-split kernel (128 rows x 384 columns)
+    uint32_t fuse_min_rows = 12288;       // below ~12.7k tokens the two-launch chain beat the 64-row kernel (a 64-row tile per CU
+                                          // streams the whole W panel whatever the row count: 3.89 vs 3.46 ms at 5k tokens)
+    bool fuse_qkv = true;                 // CQS_HIP_QKV_FUSE=0: QKV GEMM + kv_prep + the attention kernel's own Q norm instead of the fused epilogue
+    unsigned* fuse_err = nullptr;         // pinned host word (device-visible at fuse_err_dev): set by the pair kernel if an exchange timed out
+    unsigned* fuse_err_dev = nullptr;
     float *rope_global = nullptr, *rope_local = nullptr;  // [max_seq][128][2]
     std::map<std::string, bool> seen;
     bool finalized = false;
@@ -82,6 +87,8 @@ struct cqs_hip_embedder {
         // [tok M][pos M][seq_start B][seq_len B][vt_start B][blk 2 nblk]; the pointers are carved per batch
         int32_t* d_meta = nullptr;
         size_t meta_cap = 0;   // int32 elements
+        void* xch = nullptr;   // pair-split fused projection: the partners' row-sum granules (gemm_addnorm_pair_scratch_bytes(tok_cap))
+        uint32_t xch_tag = 0;  // sequence number of the last launch that used xch (the granules' tag; never 0)
         int32_t *d_tok = nullptr, *d_pos = nullptr, *d_seq_start = nullptr, *d_seq_len = nullptr,
                 *d_vt_start = nullptr, *d_blk = nullptr;
         // search-time path (query_kernels.hip): fixed 64-row scratch, allocated once and never moved, so that the
@@ -188,7 +195,7 @@ void free_query_scratch(Ctx& c) {
 
 void free_scratch(Ctx& c) {
     void** all[] = {(void**)&c.x, (void**)&c.y, (void**)&c.hidden, (void**)&c.out, (void**)&c.xn, (void**)&c.qkv,
-                    (void**)&c.vt, (void**)&c.attn, (void**)&c.h, (void**)&c.pooled, (void**)&c.d1, (void**)&c.d_meta};
+                    (void**)&c.vt, (void**)&c.attn, (void**)&c.h, (void**)&c.pooled, (void**)&c.d1, (void**)&c.d_meta, &c.xch};
     for (void** p : all) { (void)hipFree(*p); *p = nullptr; }
     c.d_tok = c.d_pos = c.d_seq_start = c.d_seq_len = c.d_vt_start = c.d_blk = nullptr;
     c.tok_cap = c.seq_cap = c.vt_ld = c.blk_cap = 0;
@@ -217,6 +224,9 @@ int32_t ensure_scratch(cqs_hip_embedder* e, Ctx& c, uint32_t M, uint32_t B, uint
     E_TRY(e, dmalloc(&c.d1, (size_t)Bc * g.dense_hidden));
     c.meta_cap = (size_t)2 * Mc + (size_t)3 * Bc + (size_t)2 * bc;
     E_TRY(e, dmalloc(&c.d_meta, c.meta_cap));
+    E_TRY(e, hipMalloc(&c.xch, cqs::gemm_addnorm_pair_scratch_bytes(Mc)));
+    E_TRY(e, hipMemset(c.xch, 0, cqs::gemm_addnorm_pair_scratch_bytes(Mc)));     // tag 0 = never written
+    c.xch_tag = 0;
     c.tok_cap = Mc; c.seq_cap = Bc; c.vt_ld = vc; c.blk_cap = bc;
     return CQS_HIP_OK;
 }
@@ -327,36 +337,45 @@ int32_t run_layers(cqs_hip_embedder* e, Ctx& c, Slot& sl) {
     E_TRY(e, hipEventRecord(sl.ev0, st));
     const uint32_t nblk = sl.nblk;
     const bool need_vt = cqs::attention_reads_vt(nblk, g.heads, g.kv_heads);
+    const bool qkv_fused = e->fuse_qkv && !need_vt && e->L[0].wqkv_f && cqs::gemm_qkv_rope_supported(M, H, g.heads, g.kv_heads, g.head_dim);
     E_TRY(e, cqs::launch_embed_norm(c.d_tok, e->emb, sqrtf((float)H), e->L[0].n_in, g.rms_eps, c.x, c.xn, M, H, st));
     for (uint32_t l = 0; l < g.layers; ++l) {
         const LayerW& w = e->L[l];
         const bool full = ((l + 1u) % g.sliding_pattern) == 0u;
-        E_TRY(e, cqs::launch_gemm_bf16(c.xn, w.wqkv, c.qkv, M, nqkv(g), H, nqkv(g), cqs::GEMM_OUT_BF16, st));
-        // k heads + V^T here; the attention kernel normalises / rotates its own Q fragments (q is 3/4 of the rope's bytes)
         const float* rope = full ? e->rope_global : e->rope_local;
-        E_TRY(e, cqs::launch_kv_prep(c.qkv, c.vt, c.d_pos, w.n_q, w.n_k, rope, g.rms_eps, g.q_scale, M, g.heads, g.kv_heads,
-                                     c.d_blk, nblk, c.d_seq_start, c.d_seq_len, c.d_vt_start, c.vt_ld, need_vt ? 1 : 0, st));
-        E_TRY(e, cqs::launch_attention(c.qkv, c.vt, c.attn, c.d_blk, nblk, c.d_seq_start, c.d_seq_len,
-                                       c.d_vt_start, c.vt_ld, g.heads, g.kv_heads, full ? 0u : g.window, w.n_q, rope,
-                                       g.rms_eps, g.q_scale, st));
-        // o_proj, then x += norm(y)(1 + w); xn = norm(x)(1 + w'): one launch where a workgroup can own whole rows
-        const bool fuse = e->fuse_norm && M >= e->fuse_min_rows;
-        if (fuse && cqs::gemm_addnorm_supported(M, H, g.heads * g.head_dim)) {
-            E_TRY(e, cqs::launch_gemm_addnorm(c.attn, w.wo, c.x, w.n_post_attn, w.n_pre_ffw, g.rms_eps, c.xn, nullptr, 0, M, H,
-                                              g.heads * g.head_dim, st));
+        // QKV projection.  Full rounds of 256 x 320 tiles: each tile = one q / k head + a slice of v, and the GEMM's epilogue
+        // does the head's RMSNorm + RoPE (+ q scale) itself - no kv_prep launch, no Q prologue in the attention kernel
+        if (qkv_fused) {
+            cqs::QkvEpilogue ep{c.d_pos, w.n_q, w.n_k, rope, g.rms_eps, g.q_scale, g.heads, g.kv_heads};
+            E_TRY(e, cqs::launch_gemm_qkv_rope(c.xn, w.wqkv_f, c.qkv, M, H, ep, st));
         } else {
-            E_TRY(e, cqs::launch_gemm_bf16(c.attn, w.wo, c.y, M, H, g.heads * g.head_dim, H, cqs::GEMM_OUT_BF16, st));
-            E_TRY(e, cqs::launch_add_norm(c.x, c.y, w.n_post_attn, w.n_pre_ffw, g.rms_eps, c.xn, nullptr, 0, M, H, st));
+            E_TRY(e, cqs::launch_gemm_bf16(c.xn, w.wqkv, c.qkv, M, nqkv(g), H, nqkv(g), cqs::GEMM_OUT_BF16, st));
+            // k heads + V^T here; the attention kernel normalises / rotates its own Q fragments (q is 3/4 of the rope's bytes)
+            E_TRY(e, cqs::launch_kv_prep(c.qkv, c.vt, c.d_pos, w.n_q, w.n_k, rope, g.rms_eps, g.q_scale, M, g.heads, g.kv_heads,
+                                         c.d_blk, nblk, c.d_seq_start, c.d_seq_len, c.d_vt_start, c.vt_ld, need_vt ? 1 : 0, st));
         }
+        E_TRY(e, cqs::launch_attention(c.qkv, c.vt, c.attn, c.d_blk, nblk, c.d_seq_start, c.d_seq_len,
+                                       c.d_vt_start, c.vt_ld, g.heads, g.kv_heads, full ? 0u : g.window, qkv_fused ? nullptr : w.n_q, rope,
+                                       g.rms_eps, g.q_scale, st));
+        const int fuse = (e->fuse_norm && M >= e->fuse_min_rows && e->fuse_err_dev) ? e->fuse_norm : 0;
+        auto proj_norm = [&](const bf16_t* Ain, const bf16_t* Wp, const bf16_t* Wpk, uint32_t Kp, const float* wpost, const float* wnext, float* outp, int fin) -> int32_t {
+            if (fuse == 2 && Wpk && cqs::gemm_addnorm_supported(M, H, Kp)) {
+                if (++c.xch_tag == 0u) c.xch_tag = 1u;
+                E_TRY(e, cqs::launch_gemm_addnorm_pair(Ain, Wpk, c.x, wpost, wnext, g.rms_eps, c.xn, outp, fin, M, H, Kp, c.xch, c.xch_tag, e->fuse_err_dev, st));
+            } else if (fuse == 1 && cqs::gemm_addnorm_supported(M, H, Kp)) {
+                E_TRY(e, cqs::launch_gemm_addnorm(Ain, Wp, c.x, wpost, wnext, g.rms_eps, c.xn, outp, fin, M, H, Kp, st));
+            } else {
+                E_TRY(e, cqs::launch_gemm_bf16(Ain, Wp, c.y, M, H, Kp, H, cqs::GEMM_OUT_BF16, st));
+                E_TRY(e, cqs::launch_add_norm(c.x, c.y, wpost, wnext, g.rms_eps, c.xn, outp, fin, M, H, st));
+            }
+            return CQS_HIP_OK;
+        };
+        // o_proj, then x += norm(y)(1 + w); xn = norm(x)(1 + w'): one launch where workgroups can own whole rows
+        if ((rc = proj_norm(c.attn, w.wo, w.wo_p, g.heads * g.head_dim, w.n_post_attn, w.n_pre_ffw, nullptr, 0)) != CQS_HIP_OK) return rc;
         E_TRY(e, cqs::launch_gemm_bf16(c.xn, w.wgu, c.h, M, 2u * g.inter, H, g.inter, cqs::GEMM_OUT_GEGLU, st));
         const bool last = (l + 1u == g.layers);
         const float* w_next = last ? e->n_final : e->L[l + 1].n_in;
-        if (fuse && cqs::gemm_addnorm_supported(M, H, g.inter)) {
-            E_TRY(e, cqs::launch_gemm_addnorm(c.h, w.wd, c.x, w.n_post_ffw, w_next, g.rms_eps, c.xn, c.hidden, last ? 1 : 0, M, H, g.inter, st));
-        } else {
-            E_TRY(e, cqs::launch_gemm_bf16(c.h, w.wd, c.y, M, H, g.inter, H, cqs::GEMM_OUT_BF16, st));
-            E_TRY(e, cqs::launch_add_norm(c.x, c.y, w.n_post_ffw, w_next, g.rms_eps, c.xn, c.hidden, last ? 1 : 0, M, H, st));
-        }
+        if ((rc = proj_norm(c.h, w.wd, w.wd_p, g.inter, w.n_post_ffw, w_next, c.hidden, last ? 1 : 0)) != CQS_HIP_OK) return rc;
     }
     return CQS_HIP_OK;
 }
@@ -532,6 +551,10 @@ int32_t cqs_hip_embedder_create(const cqs_hip_embed_config* c, int32_t device, c
     g.q_scale = 1.0f / sqrtf(c->query_pre_attn_scalar);
     bool ok = hipSetDevice(device) == hipSuccess;
     for (cqs_hip_embedder::Ctx& c : e->ctx) ok = ok && hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking) == hipSuccess;
+    if (ok && hipHostMalloc((void**)&e->fuse_err, 64, hipHostMallocDefault) == hipSuccess) {
+        *e->fuse_err = 0u;
+        if (hipHostGetDevicePointer((void**)&e->fuse_err_dev, e->fuse_err, 0) != hipSuccess) { (void)hipGetLastError(); e->fuse_err_dev = nullptr; }
+    } else (void)hipGetLastError();                        // (no mappable word: the engine keeps the two-launch chain)
     const size_t H = g.hidden, D = g.head_dim;
     e->L.resize(g.layers);
     ok = ok && dmalloc(&e->emb, (size_t)g.vocab * H) == hipSuccess && dmalloc(&e->n_final, H) == hipSuccess &&
@@ -621,6 +644,27 @@ int32_t cqs_hip_embedder_finalize(cqs_hip_embedder* e) CQS_ABI_TRY {
         for (const char* t : kLayerTensors) need.push_back("layers." + std::to_string(l) + "." + t);
     for (const std::string& n : need)
         if (!e->seen.count(n)) return efail(e, CQS_HIP_ERR_INVALID, "finalize: missing tensor " + n);
+    // the pair-split fused projection kernel streams its weights in 2 KB blocks: re-order wo / wd once (hidden 768 only)
+    if (e->g.hidden == 768u && (e->g.heads * e->g.head_dim) % 64u == 0u && e->g.inter % 64u == 0u) {
+        if (hipSetDevice(e->device) != hipSuccess) return efail(e, CQS_HIP_ERR_DEVICE, "hipSetDevice");
+        const uint32_t H = e->g.hidden, Ko = e->g.heads * e->g.head_dim, Kd = e->g.inter;
+        for (LayerW& w : e->L) {
+            if (!w.wo_p) E_TRY(e, dmalloc(&w.wo_p, (size_t)H * Ko));
+            if (!w.wd_p) E_TRY(e, dmalloc(&w.wd_p, (size_t)H * Kd));
+            E_TRY(e, cqs::launch_pack_rowfuse_w(w.wo, w.wo_p, H, Ko, nullptr));
+            E_TRY(e, cqs::launch_pack_rowfuse_w(w.wd, w.wd_p, H, Kd, nullptr));
+        }
+        E_TRY(e, hipDeviceSynchronize());
+    }
+    if (e->g.heads == 3u * e->g.kv_heads && e->g.head_dim == 256u) {     // QKV rows in tile order for the fused norm + RoPE epilogue
+        if (hipSetDevice(e->device) != hipSuccess) return efail(e, CQS_HIP_ERR_DEVICE, "hipSetDevice");
+        for (LayerW& w : e->L) {
+            if (!w.wqkv_f) E_TRY(e, dmalloc(&w.wqkv_f, (size_t)(e->g.heads + e->g.kv_heads) * 320u * e->g.hidden));
+            E_TRY(e, cqs::launch_permute_qkv_rows(w.wqkv, w.wqkv_f, e->g.heads, e->g.kv_heads, e->g.hidden, nullptr));
+        }
+        E_TRY(e, hipDeviceSynchronize());
+    }
+    if (const char* fq = getenv("CQS_HIP_QKV_FUSE")) e->fuse_qkv = fq[0] != '0';
     e->QL.resize(e->L.size());
     for (size_t l = 0; l < e->L.size(); ++l) {
         const LayerW& w = e->L[l];
@@ -634,7 +678,7 @@ int32_t cqs_hip_embedder_finalize(cqs_hip_embedder* e) CQS_ABI_TRY {
     e->query_direct = !(qd && qd[0] == '0');
     const char* ec = getenv("CQS_HIP_EMBED_CONTEXTS");
     e->single_ctx = ec && ec[0] == '1';
-    if (const char* fn = getenv("CQS_HIP_GEMM_FUSE_NORM")) e->fuse_norm = fn[0] != '0';
+    if (const char* fn = getenv("CQS_HIP_GEMM_FUSE_NORM")) e->fuse_norm = fn[0] == '0' ? 0 : (fn[0] == '1' ? 1 : 2);
     if (const char* fr = getenv("CQS_HIP_GEMM_FUSE_NORM_MIN_ROWS")) e->fuse_min_rows = (uint32_t)atoi(fr);
     e->finalized = true;
     return CQS_HIP_OK;
@@ -696,6 +740,7 @@ void cqs_hip_embedder_destroy(cqs_hip_embedder* e) CQS_ABI_TRY {
         if (c.stream) (void)hipStreamSynchronize(c.stream);
     void* g[] = {e->emb, e->n_final, e->dense1, e->dense2, e->rope_global, e->rope_local};
     for (void* p : g) (void)hipFree(p);
+    if (e->fuse_err) (void)hipHostFree(e->fuse_err);
     for (Ctx& c : e->ctx) { free_scratch(c); free_query_scratch(c); }
     for (cqs_hip_embedder::Slot& sl : e->slot) {
         if (sl.meta) (void)hipHostFree(sl.meta);
@@ -705,7 +750,7 @@ void cqs_hip_embedder_destroy(cqs_hip_embedder* e) CQS_ABI_TRY {
         if (sl.done) (void)hipEventDestroy(sl.done);
     }
     for (LayerW& w : e->L) {
-        void* ws[] = {w.wqkv, w.wo, w.wgu, w.wd, w.n_in, w.n_post_attn, w.n_pre_ffw, w.n_post_ffw, w.n_q, w.n_k};
+        void* ws[] = {w.wqkv_f, w.wo_p, w.wd_p, w.wqkv, w.wo, w.wgu, w.wd, w.n_in, w.n_post_attn, w.n_pre_ffw, w.n_post_ffw, w.n_q, w.n_k};
         for (void* p : ws) (void)hipFree(p);
     }
     for (Ctx& c : e->ctx)
@@ -826,6 +871,10 @@ int32_t cqs_hip_embed_collect(cqs_hip_embedder* e, uint64_t ticket, float* out) 
     const hipError_t he = hipEventSynchronize(sl->done);
     std::lock_guard<std::mutex> lk(e->mu);
     if (he != hipSuccess) { sl->ticket = 0; return efail(e, CQS_HIP_ERR_DEVICE, "collect: device failure", he); }
+    if (e->fuse_err && *(volatile unsigned*)e->fuse_err != 0u) {   // a pair of the fused projection kernel never met: the rows are garbage
+        sl->ticket = 0;
+        return efail(e, CQS_HIP_ERR_DEVICE, "collect: fused projection pair exchange timed out");
+    }
     const uint32_t H = e->g.hidden, B = sl->B;
     if (out) {                         // out == NULL: abandon the ticket (wait, release the slot, drop the rows)
         memcpy(out, sl->direct ? e->ctx[sl->ctx].q_out_pin : sl->out, (size_t)B * H * sizeof(float));
@@ -960,8 +1009,15 @@ void cqs_hip_normalize_l2_rows(float* rows, uint64_t n, uint32_t dim) CQS_ABI_TR
 void cqs_hip_debug_embedder_set_fuse_norm(cqs_hip_embedder* e, int32_t on, uint32_t min_rows) CQS_ABI_TRY {
     if (!e) return;
     std::lock_guard<std::mutex> lk(e->mu);
-    e->fuse_norm = on != 0;
+    e->fuse_norm = on < 0 ? 0 : (on > 2 ? 2 : on);     // 0 = two launches, 1 = the 64-row kernel, 2 = the pair-split kernel
     if (min_rows) e->fuse_min_rows = min_rows;
+} CQS_ABI_CATCH_VOID
+
+// Test hook (not part of the public header): the QKV projection's fused norm + RoPE epilogue on / off for THIS engine.
+void cqs_hip_debug_embedder_set_fuse_qkv(cqs_hip_embedder* e, int32_t on) CQS_ABI_TRY {
+    if (!e) return;
+    std::lock_guard<std::mutex> lk(e->mu);
+    e->fuse_qkv = on != 0;
 } CQS_ABI_CATCH_VOID
 
 // Diagnostic (not part of the public header; CQS_HIP_QUERY_STAMPS=1 at engine creation): the stamps the query chain's

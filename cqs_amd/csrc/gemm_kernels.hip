@@ -81,7 +81,8 @@ __device__ __forceinline__ void gemm_pp_body(const bf16_t* __restrict__ A, const
                                              const uint32_t bid /*workgroup index among this problem's*/,
                                              const float* __restrict__ bias = nullptr /*[N] added before the activation*/,
                                              const int32_t* __restrict__ row_seq = nullptr /*ROWMAX: sequence of each row*/,
-                                             uint32_t n_valid = 0 /*ROWMAX: columns >= n_valid are padding*/) {
+                                             uint32_t n_valid = 0 /*ROWMAX: columns >= n_valid are padding*/,
+                                             const QkvEpilogue* __restrict__ epi = nullptr /*QKV (kernel argument memory)*/) {
     constexpr int BN = 64 * TN;
     constexpr int kBuf = (kP8M + BN) * 64;                      // elements per LDS buffer
     constexpr int PA = 2, PB = TN;                              // DMA instructions per wave: an A half / the B tile
@@ -313,6 +314,97 @@ __device__ __forceinline__ void gemm_pp_body(const bf16_t* __restrict__ A, const
         }
         return;
     }
+    if constexpr (OUT == GEMM_OUT_QKV) {
+        // The tile = [one whole q or k head: 256 columns | 64 columns of v] (weights in tile order, launch_permute_qkv_rows):
+        // head tile t goes to qkv columns [256 t, + 256) after RMSNorm (1 + w), RoPE and (q heads) the attention scale, the
+        // v slice to columns [256 (heads + kv) + 64 t, + 64) as it is.  Arithmetic = qk_norm_rope_block / load_q_fragments
+        // (embed_kernels.hip) on the bf16-rounded projection, so the attention kernels read what they used to compute.
+        // Two passes of 128 rows through the bf16 stage; then wave w takes stage rows 16 w .. 16 w + 15 two at a time: lanes
+        // 0-31 one row, lanes 32-63 the next; lane (l = lane & 31) owns dims 4 l + {0..3} and their rotation partners 128 + ...
+        static_assert(TN == 5, "QKV epilogue: 256 + 64 columns per tile");
+        const uint32_t tcol = n0 / (uint32_t)BN;
+        const uint32_t nh = epi->heads + epi->kv_heads;
+        const bool is_q = tcol < epi->heads;
+        const float* const wnorm = is_q ? epi->wq : epi->wk;
+        const float qs = is_q ? epi->q_scale : 1.0f;
+        const float eps = epi->eps;
+        const int hw = lane >> 5, l31 = lane & 31;
+        f4 w1lo = *(const f4*)(wnorm + 4 * l31), w1hi = *(const f4*)(wnorm + 128 + 4 * l31);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { w1lo[e] = 1.0f + w1lo[e]; w1hi[e] = 1.0f + w1hi[e]; }
+        constexpr int kStride = BN + 4;                             // elements (8-byte aligned rows, bank shift of 2 dwords)
+        bf16_t* const stage = p8smem;                               // 128 x kStride elements = 81 KiB
+        bf16_t* const Cq = (bf16_t*)Cv;
+        const uint32_t vcol0 = nh * 256u + tcol * 64u;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            // this pass's rows of the wave: positions + cos / sin rows requested before the stage is written
+            uint32_t grow[8];
+            f4 cs0[8], cs1[8];
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const uint32_t sr = (uint32_t)(16 * wid + 2 * it + hw);
+                grow[it] = m0 + (sr >> 6) * 128u + (uint32_t)(64 * p) + (sr & 63u);
+                const uint32_t gr = grow[it] < M ? grow[it] : M - 1u;
+                const float* cs = epi->cos_sin + ((size_t)(uint32_t)epi->pos[gr] * 128u + (uint32_t)l31 * 4u) * 2u;
+                cs0[it] = *(const f4*)cs;
+                cs1[it] = *(const f4*)(cs + 4);
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                bf16_t* rowp = stage + (size_t)(wm * 64 + t * 16 + l15) * kStride;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    bf4 o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = (bf16_t)acc[4 * p + t][j][r];
+                    *(bf4*)(rowp + wn * 16 * TN + j * 16 + 4 * lg) = o;
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const uint32_t sr = (uint32_t)(16 * wid + 2 * it + hw);
+                const bf4 lo = *(const bf4*)(stage + (size_t)sr * kStride + 4 * l31);
+                const bf4 hi = *(const bf4*)(stage + (size_t)sr * kStride + 128 + 4 * l31);
+                float vlo[4], vhi[4], ss = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { vlo[e] = (float)lo[e]; vhi[e] = (float)hi[e]; }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ss += vlo[e] * vlo[e];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ss += vhi[e] * vhi[e];
+#pragma unroll
+                for (int off = 16; off >= 1; off >>= 1) ss += __shfl_xor(ss, off, 64);   // over the row's 32 lanes
+                const float inv = rsqrtf(ss / 256.0f + eps);
+                const float c4[4] = {cs0[it][0], cs0[it][2], cs1[it][0], cs1[it][2]};
+                const float s4[4] = {cs0[it][1], cs0[it][3], cs1[it][1], cs1[it][3]};
+                bf4 olo, ohi;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float nlo = vlo[e] * inv * w1lo[e];
+                    const float nhi = vhi[e] * inv * w1hi[e];
+                    olo[e] = (bf16_t)((nlo * c4[e] - nhi * s4[e]) * qs);     // d < 128: n cos - x[d + 128] sin
+                    ohi[e] = (bf16_t)((nhi * c4[e] + nlo * s4[e]) * qs);     // d >= 128: n cos + x[d - 128] sin
+                }
+                if (grow[it] < M) {
+                    bf16_t* dst = Cq + (size_t)grow[it] * ldc + tcol * 256u + 4u * (uint32_t)l31;
+                    *(bf4*)dst = olo;
+                    *(bf4*)(dst + 128) = ohi;
+                }
+            }
+            // the v slice: 128 rows x 64 columns = 2048 8-byte pieces, 16 lanes per row (one 128-byte line)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t c = (uint32_t)tid + 512u * (uint32_t)u;
+                const uint32_t sr = c >> 4, ch = c & 15u;
+                const uint32_t row = m0 + (sr >> 6) * 128u + (uint32_t)(64 * p) + (sr & 63u);
+                if (row < M) *(bf4*)(Cq + (size_t)row * ldc + vcol0 + ch * 4u) = *(const bf4*)(stage + (size_t)sr * kStride + 256u + ch * 4u);
+            }
+            if (p == 0) __syncthreads();
+        }
+        return;
+    }
     if (OUT == GEMM_OUT_BF16 || OUT == GEMM_OUT_BF16_GELU) {
         f4 bv[TN];                                                  // this lane's 4 columns of each n-tile
 #pragma unroll
@@ -397,6 +489,24 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16_t* __restric
     gemm_pp_body<TN, OUT>(A, W, Cv, M, N, K, ldc, blockIdx.x, bias, row_seq, n_valid);
 }
 
+// The QKV projection with its fused epilogue: the same body, the epilogue's inputs by value in kernel-argument memory.
+__global__ __launch_bounds__(512, 2) void gemm_pp_qkv_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
+                                                             bf16_t* __restrict__ qkv, uint32_t M, uint32_t N, uint32_t K,
+                                                             uint32_t ldc, const QkvEpilogue epi) {
+    gemm_pp_body<5, GEMM_OUT_QKV>(A, W, qkv, M, N, K, ldc, blockIdx.x, nullptr, nullptr, 0u, &epi);
+}
+
+// Wf rows in tile order: tile t (t < heads + kv) = [the 256 rows of head slot t | v rows 64 t .. 64 t + 63]; one thread per 16 bytes.
+__global__ __launch_bounds__(256) void permute_qkv_rows_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst,
+                                                               uint32_t nh, uint32_t K) {
+    const uint32_t chunk = blockIdx.x * 256u + threadIdx.x, cpr = K / 8u;
+    if (chunk >= nh * 320u * cpr) return;
+    const uint32_t drow = chunk / cpr, c = chunk % cpr;
+    const uint32_t t = drow / 320u, r = drow % 320u;
+    const uint32_t srow = r < 256u ? t * 256u + r : nh * 256u + t * 64u + (r - 256u);
+    *(bf8*)(dst + (size_t)drow * K + (size_t)c * 8u) = *(const bf8*)(src + (size_t)srow * K + (size_t)c * 8u);
+}
+
 // Two problems that share A, M and K (the two column ranges launch_gemm_bf16 cuts a GEMM into: whole rounds of one
 // tile width + the rest with another) in ONE launch: workgroups [0, n_first) run the first, the rest the second, so
 // the second part's workgroups start as CUs come free instead of after a kernel boundary.
@@ -444,6 +554,31 @@ hipError_t launch_p8(const bf16_t* A, const bf16_t* W, void* C, uint32_t M, uint
 }
 
 }  // namespace
+
+hipError_t launch_permute_qkv_rows(const bf16_t* wqkv, bf16_t* wf, uint32_t heads, uint32_t kv_heads, uint32_t K, hipStream_t st) {
+    if (!wqkv || !wf || heads != 3u * kv_heads || K % 8u) return hipErrorInvalidValue;
+    const uint32_t nh = heads + kv_heads;
+    hipLaunchKernelGGL(permute_qkv_rows_kernel, dim3((nh * 320u * (K / 8u) + 255u) / 256u), dim3(256), 0, st, wqkv, wf, nh, K);
+    return hipGetLastError();
+}
+
+hipError_t launch_gemm_qkv_rope(const bf16_t* A, const bf16_t* Wf, bf16_t* qkv, uint32_t M, uint32_t K, const QkvEpilogue& epi,
+                                hipStream_t st) {
+    if (M == 0) return hipSuccess;
+    const uint32_t nh = epi.heads + epi.kv_heads, N = nh * 320u;
+    if (epi.heads != 3u * epi.kv_heads || K % 64u || K < 64u || (uint64_t)M * K >= (1ull << 31) || (uint64_t)N * K >= (1ull << 31) ||
+        !epi.pos || !epi.wq || !epi.wk || !epi.cos_sin)
+        return hipErrorInvalidValue;
+    const dim3 grid(nh * ((M + kP8M - 1) / kP8M));
+    const size_t lds = (size_t)2 * (kP8M + 320) * 64 * sizeof(bf16_t);
+    static std::atomic<uint64_t> attr_devices{0};
+    {
+        const hipError_t e = set_max_dynamic_lds((const void*)gemm_pp_qkv_kernel, lds, attr_devices);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(gemm_pp_qkv_kernel, grid, dim3(512), lds, st, A, Wf, qkv, M, N, K, N, epi);
+    return hipGetLastError();
+}
 
 // tn: n-tiles per wave (tile width 64 tn: 192 / 256 / 320); N % (64 tn) == 0, K % 64 == 0, M * K < 2^31 elements.
 hipError_t launch_gemm_p8(const bf16_t* A, const bf16_t* W, void* C, uint32_t M, uint32_t N, uint32_t K, uint32_t ldc,

@@ -261,6 +261,320 @@ __global__ __launch_bounds__(512, 2) void gemm_rowfuse_kernel(const bf16_t* __re
     }
 }
 
+
+// =====================================================================================================================
+// Second generation (round 4): a PAIR of workgroups owns 128 token rows; each computes one 384-column HALF of all 768.
+//
+// Why: the 64-row tile above streams the whole W panel (96 KB per 64-deep k-step) through every CU, and that stream -
+// not the matrix cores, not HBM - bounds its main loop (§3.5b of DESIGN.md: ~30 B/clk per CU whatever instruction
+// carries the bytes).  A workgroup that owns 128 rows x 384 columns needs W's half panel (48 KB) + a 128-row A tile
+// (16 KB) per k-step for the SAME 12.6 MFLOP: 64 KB instead of 104 KB.  The price: a row's sum of squares is now split
+// over two workgroups, twice per launch (y rows, then the new x rows) - exchanged as 8-byte {tag, value} granules
+// (one sc1 store per granule, polled with sc1 loads: cdna_hip_programming.md Guideline 16, form R2; tag = the launch's
+// sequence number, so nothing has to be zeroed between launches; every spin is bounded and a timeout raises *err).
+// Partners are workgroups b and b ^ 8: under the round-robin placement they share an XCD, so the pair's A rows are
+// read from HBM once (speed only; nothing depends on placement).  Partners sit within 16 consecutive workgroups, so at
+// most 8 workgroups of a launch can be waiting for a partner that is not resident yet.
+//   * 8 waves; wave w owns columns [48 w, 48 w + 48) of its half = 3 n-tiles, all 128 rows = 8 m-tiles: 96 accumulators;
+//   * W: the wave's own 48 rows through 6 private slots = 3 n-tiles x 2 k-steps (slot (kt & 1, j) is refilled with
+//     k-step kt + 2 as soon as its fragments are in registers): ~10 KB per wave always in flight, no barrier;
+//   * A: the shared 128 x 64 tile of a k-step, THREE buffers, requested two k-steps ahead, one barrier per k-step;
+//   * every counted wait is vmcnt(14): between a DMA and its use the wave issues exactly 14 more (see kstep);
+//   * row sums half by half, left + right: the order add_norm_kernel uses too (embed_kernels.hip) -> same bits as the
+//     two-launch chain.
+constexpr int kR2Rows = 128;                              // token rows per workgroup pair
+constexpr int kR2Half = 384;                              // columns per workgroup
+constexpr int kR2Slot = 16 * 128;                         // one W slot: 16 rows x 64 k = 2 KB
+constexpr int kR2WRing = 8 * 6 * kR2Slot;                 // 8 waves x (3 n-tiles x 2 k-steps) = 96 KB
+constexpr int kR2ATile = kR2Rows * 128;                   // 16 KB
+constexpr int kR2Lds = kR2WRing + 3 * kR2ATile;           // 144 KB
+constexpr int kR2Ldy = kR2Half + 8;                       // epilogue row stride (elements): 128 x 392 x 2 B = 98 KB
+constexpr uint32_t kR2SpinMax = 1u << 21;
+
+typedef __attribute__((address_space(1))) unsigned long long r2_gu64;
+typedef __attribute__((address_space(1))) unsigned r2_gu32;
+
+// dst = the weights [N][K] in the order gemm_rowfuse2_kernel streams them: block (n / 16, k / 64) of 2 KB = 16 rows x 64 k,
+// row r at byte r * 128, its 16-byte chunk c stored at chunk c ^ ((r >> 1) & 7) (the LDS swizzle, applied once here).
+__global__ __launch_bounds__(256) void pack_rowfuse_w_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, uint32_t N, uint32_t K) {
+    const uint32_t nk = K / 64u;
+    const uint32_t chunk = blockIdx.x * 256u + threadIdx.x;           // one 16-byte chunk per thread
+    if (chunk >= N * (K / 8u)) return;
+    const uint32_t n = chunk / (K / 8u), kc = chunk % (K / 8u);       // row, chunk of 8 k
+    const uint32_t kt = kc / 8u, c = kc % 8u, r = n % 16u, jt = n / 16u;
+    const bf8 v = *(const bf8*)(src + (size_t)n * K + (size_t)kc * 8u);
+    *(bf8*)(dst + ((size_t)(jt * nk + kt) * 16u + r) * 64u + ((c ^ ((r >> 1) & 7u)) * 8u)) = v;
+}
+
+template <int FINAL>
+__global__ __launch_bounds__(512, 2) void gemm_rowfuse2_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W /*packed: pack_rowfuse_w_kernel*/,
+                                                               float* __restrict__ x, const float* __restrict__ w_post,
+                                                               const float* __restrict__ w_next, float eps,
+                                                               bf16_t* __restrict__ xn, float* __restrict__ out,
+                                                               uint32_t M, uint32_t K, unsigned long long* xch /*[2][2][Mpad] granules*/,
+                                                               uint32_t Mpad, uint32_t tag, unsigned* err) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char rf_smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, lg = lane >> 4;
+    // workgroups 16 g + i and 16 g + 8 + i (i < 8) form pair 8 g + i; the half is bit 3 of the index
+    const uint32_t bid = blockIdx.x;
+    const uint32_t half = (bid >> 3) & 1u;
+    const uint32_t pair = (bid >> 4) * 8u + (bid & 7u);
+    const uint32_t m0 = pair * (uint32_t)kR2Rows;
+    if (m0 >= M) return;                                  // (an odd tail group: both partners leave together)
+    const uint32_t rows_left = M - m0;                    // >= 1
+    const uint32_t nk = K / 64u;
+    const uint32_t n0 = half * (uint32_t)kR2Half;
+
+    const uint32_t r8 = (uint32_t)lane >> 3;
+    const uint32_t pc = (uint32_t)lane & 7u;
+    // W comes PACKED (pack_rowfuse_w_kernel): the 2 KB LDS image of (n-tile, k-step) - 16 rows x 128 B, swizzle applied - is
+    // one contiguous 2 KB block at ((n-tile * nk + k-step) * 2 KB), so a DMA instruction reads 1 KB in one piece instead
+    // of eight 128-byte segments of eight rows (the texture addresser works per segment).
+    const uint32_t voffW = (uint32_t)lane * 16u;
+    // A: instruction i of 16 covers tile rows 8 i .. 8 i + 7; wave w issues i = w and i = w + 8
+    uint32_t voffA[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        uint32_t arow = (uint32_t)(8 * wid + 64 * u) + r8;
+        const uint32_t aR = arow & 15u;
+        if (arow >= rows_left) arow = rows_left - 1u;     // rows past M: any real row (their outputs are never stored)
+        voffA[u] = (arow * K + ((pc ^ ((aR >> 1) & 7u)) * 8u)) * 2u;
+    }
+    const char* const gA = (const char*)(A + (size_t)m0 * K);
+    const char* const gW = (const char*)W;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)rf_smem;
+    auto dma = [&](const char* sbase, uint32_t voff, uint32_t lds_byte) {
+        const uint32_t m0v = lds0 + lds_byte;
+        asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                     :: "s"(m0v), "v"(voff), "s"(sbase) : "memory");   // (hipcc rejects an "m0" clobber: "reserved register"; M0 is set and consumed inside this one statement)
+    };
+    const uint32_t wring = (uint32_t)(wid * 6 * kR2Slot);
+    const uint32_t ntile0 = half * 24u + (uint32_t)(3 * wid);   // first of this wave's three 16-column tiles
+    auto fill_w = [&](uint32_t kt, uint32_t par, int j) {  // slot (par, j) <- k-step kt
+        const char* src = gW + ((ntile0 + (uint32_t)j) * nk + kt) * (uint32_t)kR2Slot;   // (32-bit: a 64-bit multiply would leave the scalar unit)
+        const uint32_t lb = wring + (par * 3u + (uint32_t)j) * (uint32_t)kR2Slot;
+        dma(src, voffW, lb);
+        dma(src + 1024, voffW, lb + 1024u);
+    };
+    auto fill_a = [&](uint32_t kt, uint32_t buf) {         // this wave's two pieces of A tile kt into buffer buf
+        const uint32_t lb = (uint32_t)kR2WRing + buf * (uint32_t)kR2ATile;
+        dma(gA + (size_t)kt * 128u, voffA[0], lb + (uint32_t)(wid * 1024));
+        dma(gA + (size_t)kt * 128u, voffA[1], lb + (uint32_t)(8192 + wid * 1024));
+    };
+    const uint32_t swr = ((uint32_t)l15 >> 1) & 7u;
+    uint32_t foff[2];
+#pragma unroll
+    for (int sb = 0; sb < 2; ++sb) foff[sb] = (uint32_t)l15 * 128u + ((((uint32_t)(4 * sb + lg)) ^ swr) * 16u);
+
+    f4 acc[3][8];
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int t = 0; t < 8; ++t) acc[j][t] = (f4)(0.f);
+
+    const uint32_t klast = nk - 1u;
+    // One k-step.  DMA issue order of a wave, step after step: A (kt + 2) x 2, then W (kt + 2, j) x 2 behind the fragment
+    // reads of slot (kt, j), j = 0, 1, 2 - eight instructions per step.  They complete in issue order, so:
+    //   A (kt), issued at the top of step kt - 2: behind it W (kt, 0..2) = 6 and step kt - 1's 8          -> vmcnt(14)
+    //   W (kt, j), issued in step kt - 2: behind it W (kt, j+1..2) = 2 (2 - j), step kt - 1's 8, and this step's
+    //   A (kt + 2) + W (kt + 2, 0..j-1) = 2 + 2 j                                                         -> vmcnt(14)
+    // The last two steps keep issuing (harmless) requests of the last k-step so that the counts never change.
+    auto kstep = [&](uint32_t kt, uint32_t abuf /*kt % 3*/) {
+        RF_WAIT_VM(14);                                   // this wave's pieces of A (kt)
+        asm volatile("s_barrier" ::: "memory");          // ... and everybody's; everybody is done reading A (kt - 1)
+        const uint32_t kn = kt + 2u <= klast ? kt + 2u : klast;
+        fill_a(kn, abuf == 0u ? 2u : abuf - 1u);          // buffer (kt + 2) % 3 = (kt - 1) % 3
+        const unsigned char* sa = rf_smem + kR2WRing + abuf * (uint32_t)kR2ATile;
+        const uint32_t par = kt & 1u;
+        const unsigned char* sw = rf_smem + wring + par * (uint32_t)(3 * kR2Slot);
+        bf8 af[8][2], wf[2], wn[2];
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+#pragma unroll
+            for (int sb = 0; sb < 2; ++sb) af[t][sb] = *(const bf8*)(sa + (uint32_t)(t * 2048) + foff[sb]);
+        RF_WAIT_VM(14);                                   // slot (kt, 0)
+#pragma unroll
+        for (int sb = 0; sb < 2; ++sb) wf[sb] = *(const bf8*)(sw + foff[sb]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            fill_w(kn, par, j);                           // slot (kt, j) is in registers: refill it with k-step kt + 2
+            if (j < 2) {
+                RF_WAIT_VM(14);                           // slot (kt, j + 1)
+#pragma unroll
+                for (int sb = 0; sb < 2; ++sb) wn[sb] = *(const bf8*)(sw + (uint32_t)((j + 1) * kR2Slot) + foff[sb]);
+            }
+#if defined(CQS_R2_ABLATE_NOMFMA)   // timing experiment (wrong results)
+#pragma unroll
+            for (int t = 0; t < 8; ++t) acc[j][t][0] += (float)wf[0][t] * (float)af[t][1][0] + (float)wf[1][t & 3] * (float)af[t][0][1];
+#else
+#pragma unroll
+            for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+                for (int t = 0; t < 8; ++t) acc[j][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[sb], af[t][sb], acc[j][t], 0, 0, 0);
+#endif
+            if (j < 2) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                wf[0] = wn[0]; wf[1] = wn[1];
+            }
+        }
+    };
+    // prologue = the issue pattern of steps -2 and -1
+    fill_a(0u, 0u);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) fill_w(0u, 0u, j);
+    {
+        const uint32_t k1 = klast >= 1u ? 1u : 0u;
+        fill_a(k1, 1u);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) fill_w(k1, 1u, j);
+    }
+    {
+        uint32_t abuf = 0u;
+        for (uint32_t kt = 0; kt <= klast; ++kt) {
+            kstep(kt, abuf);
+            abuf = abuf == 2u ? 0u : abuf + 1u;
+        }
+    }
+    RF_WAIT_VM(0);                                        // the tail's surplus requests are done before LDS is reused
+#if defined(CQS_R2_ABLATE_NOEPI)    // timing experiment (wrong results): the main loop alone
+    if (acc[0][0][0] != 12345.678f || acc[1][3][1] != 1.f || acc[2][7][2] != 2.f) return;
+#endif
+
+    // ---- epilogue ----
+    __syncthreads();                                      // every wave is out of the ring
+    bf16_t* const sY = (bf16_t*)rf_smem;                  // [128][kR2Ldy]
+    // acc[j][t][r] = y[token 16 t + l15][column n0 + 48 wid + 16 j + 4 lg + r]
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            bf4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = (bf16_t)acc[j][t][r];
+            *(bf4*)(sY + (size_t)(16 * t + l15) * kR2Ldy + 48 * wid + 16 * j + 4 * lg) = o;
+        }
+    // wave w: rows 16 w .. 16 w + 15, two at a time: lanes 0-31 row 2 i, lanes 32-63 row 2 i + 1; lane (l = lane & 31) owns
+    // columns n0 + 128 c + 4 l + {0..3}, c = 0, 1, 2.
+    const int hw = lane >> 5, l31 = lane & 31;
+    const uint32_t cbase = n0 + (uint32_t)l31 * 4u;
+    __syncthreads();
+    // the x rows are requested here: their latency hides under phase 1 (LDS only) and the first exchange
+    f4 xv[8][3];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const uint32_t r = (uint32_t)(16 * wid + 2 * i + hw);
+        const uint32_t row = m0 + (r < rows_left ? r : rows_left - 1u);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) xv[i][c] = *(const f4*)(x + (size_t)row * kRfH + cbase + c * 128);
+    }
+    f4 wpo[3], wne[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        wpo[c] = *(const f4*)(w_post + cbase + c * 128);
+        wne[c] = *(const f4*)(w_next + cbase + c * 128);
+    }
+
+    // granules of this wave's 16 rows: lanes with l31 < 8 hold row 2 l31 + hw (= the row of iteration i = l31 in its half-wave)
+    r2_gu64* const gx = (r2_gu64*)xch;
+    const uint32_t grow = m0 + (uint32_t)(16 * wid + 2 * l31 + hw);               // (< Mpad for l31 < 8)
+    auto exchange = [&](uint32_t phase, float mine) -> float {                     // returns the partner's value of the same row
+        float theirs = 0.f;
+        if (l31 < 8) {
+            r2_gu64* const mine_p = gx + ((size_t)(phase * 2u + half) * Mpad + grow);
+            r2_gu64* const their_p = gx + ((size_t)(phase * 2u + (half ^ 1u)) * Mpad + grow);
+            __hip_atomic_store(mine_p, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(mine),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            uint32_t spins = 0;
+#if defined(CQS_R2_ABLATE_NOEXCH)   // timing experiment (wrong results): nobody waits for the partner
+            theirs = mine;
+            if (tag == 0u)
+#endif
+            for (;;) {
+                const unsigned long long g = __hip_atomic_load(their_p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((uint32_t)(g >> 32) == tag) { theirs = __uint_as_float((uint32_t)g); break; }
+                if (++spins > kR2SpinMax) {               // the partner never came: never hang, say so
+                    __hip_atomic_store((r2_gu32*)err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+        }
+        return theirs;
+    };
+    auto half_sum = [&](float v) -> float {               // over the 32 lanes of the half-wave (same bits in all of them)
+#pragma unroll
+        for (int off = 16; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+        return v;
+    };
+
+    // phase 1: this half's sum of squares of every y row
+    float mine1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const uint32_t r = (uint32_t)(16 * wid + 2 * i + hw);
+        float ss = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const bf4 yb = *(const bf4*)(sY + (size_t)r * kR2Ldy + c * 128 + l31 * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float v = (float)yb[e]; ss += v * v; }
+        }
+        ss = half_sum(ss);
+        mine1 = (l31 == i) ? ss : mine1;
+    }
+    const float theirs1 = exchange(0u, mine1);
+    // phase 2: x += rmsnorm(y) (1 + w_post); this half's sum of squares of the new x rows
+    float mine2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const uint32_t r = (uint32_t)(16 * wid + 2 * i + hw);
+        const float a = __shfl(mine1, (lane & 32) + i, 64), b = __shfl(theirs1, (lane & 32) + i, 64);
+        const float tot = half == 0u ? a + b : b + a;     // left + right
+        const float invy = rsqrtf(tot / (float)kRfH + eps);
+        float sx = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const bf4 yb = *(const bf4*)(sY + (size_t)r * kR2Ldy + c * 128 + l31 * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                xv[i][c][e] += (float)yb[e] * invy * (1.0f + wpo[c][e]);
+                sx += xv[i][c][e] * xv[i][c][e];
+            }
+            if (r < rows_left) *(f4*)(x + (size_t)(m0 + r) * kRfH + cbase + c * 128) = xv[i][c];
+        }
+        sx = half_sum(sx);
+        mine2 = (l31 == i) ? sx : mine2;
+    }
+    const float theirs2 = exchange(1u, mine2);
+    // phase 3: the next pre-norm of the new x
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const uint32_t r = (uint32_t)(16 * wid + 2 * i + hw);
+        const float a = __shfl(mine2, (lane & 32) + i, 64), b = __shfl(theirs2, (lane & 32) + i, 64);
+        const float tot = half == 0u ? a + b : b + a;
+        const float invx = rsqrtf(tot / (float)kRfH + eps);
+        if (r >= rows_left) continue;
+        const size_t row = (size_t)(m0 + r);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            if (FINAL) {
+                f4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = xv[i][c][e] * invx * (1.0f + wne[c][e]);
+                *(f4*)(out + row * kRfH + cbase + c * 128) = o;
+            } else {
+                bf4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (bf16_t)(xv[i][c][e] * invx * (1.0f + wne[c][e]));
+                *(bf4*)(xn + row * kRfH + cbase + c * 128) = o;
+            }
+        }
+    }
+}
+
 }  // namespace
 
 bool gemm_addnorm_supported(uint32_t M, uint32_t H, uint32_t K) {   // shape only; whether the forward uses it is the engine's setting
@@ -282,6 +596,41 @@ hipError_t launch_gemm_addnorm(const bf16_t* A, const bf16_t* W, float* x, const
         const hipError_t e = once[0].ensure((const void*)gemm_rowfuse_kernel<0>, (size_t)kRfLds);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(gemm_rowfuse_kernel<0>, grid, dim3(512), (size_t)kRfLds, st, A, W, x, w_post, w_next, eps, xn, out, M, K);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_pack_rowfuse_w(const bf16_t* src, bf16_t* dst, uint32_t N, uint32_t K, hipStream_t st) {
+    if (N % 16u || K % 64u || !src || !dst) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(pack_rowfuse_w_kernel, dim3((N * (K / 8u) + 255u) / 256u), dim3(256), 0, st, src, dst, N, K);
+    return hipGetLastError();
+}
+
+// The pair-split kernel (gemm_rowfuse2_kernel).  Wp = the weights packed by launch_pack_rowfuse_w.  xch: device buffer of 4 * Mpad u64 granules, Mpad = M rounded up to
+// 128, private to the calling stream (launches that share it must be stream-ordered); tag: a number that differs from
+// every earlier launch on that buffer (never 0); err: a word the kernel sets to 1 if a pair exchange timed out.
+size_t gemm_addnorm_pair_scratch_bytes(uint32_t M) { return (size_t)4 * ((M + 127u) / 128u * 128u) * sizeof(unsigned long long); }
+
+hipError_t launch_gemm_addnorm_pair(const bf16_t* A, const bf16_t* Wp, float* x, const float* w_post, const float* w_next,
+                                    float eps, bf16_t* xn, float* out, int final, uint32_t M, uint32_t H, uint32_t K,
+                                    void* xch, uint32_t tag, unsigned* err, hipStream_t st) {
+    if (M == 0) return hipSuccess;
+    if (H != (uint32_t)kRfH || K % 64u || K < 64u || (uint64_t)M * K >= (1ull << 31) || !xch || !err || tag == 0u) return hipErrorInvalidValue;
+    const uint32_t pairs = (M + (uint32_t)kR2Rows - 1u) / (uint32_t)kR2Rows;
+    const uint32_t Mpad = pairs * (uint32_t)kR2Rows;
+    // workgroup index = 16 (pair / 8) + 8 half + pair % 8: groups of 16 hold 8 whole pairs; a tail group is sized as a whole
+    const dim3 grid((pairs + 7u) / 8u * 16u);
+    static DynLdsOnce once[2];
+    if (final) {
+        const hipError_t e = once[1].ensure((const void*)gemm_rowfuse2_kernel<1>, (size_t)kR2Lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(gemm_rowfuse2_kernel<1>, grid, dim3(512), (size_t)kR2Lds, st, A, Wp, x, w_post, w_next, eps, xn, out, M, K,
+                           (unsigned long long*)xch, Mpad, tag, err);
+    } else {
+        const hipError_t e = once[0].ensure((const void*)gemm_rowfuse2_kernel<0>, (size_t)kR2Lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(gemm_rowfuse2_kernel<0>, grid, dim3(512), (size_t)kR2Lds, st, A, Wp, x, w_post, w_next, eps, xn, out, M, K,
+                           (unsigned long long*)xch, Mpad, tag, err);
     }
     return hipGetLastError();
 }

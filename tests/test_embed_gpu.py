@@ -504,28 +504,85 @@ def set_fuse_norm(eng, on, min_rows=0):
     f = eng._lib.cqs_hip_debug_embedder_set_fuse_norm
     f.restype = None
     f.argtypes = [C.c_void_p, C.c_int32, C.c_uint32]
-    f(eng._h, 1 if on else 0, min_rows)
+    f(eng._h, int(on), min_rows)                # 0 = two launches, 1 = round 3's 64-row kernel, 2 = the pair-split kernel
 
 
 def test_fused_projection_addnorm_is_bit_identical_to_the_two_launch_chain(hip):
-    """gemm_rowfuse.hip: o_proj / down + residual add + both RMSNorms in one launch (a workgroup owns 64 whole rows x
-    768 columns).  Same MFMA and k order as the 256-row GEMM, the row phase is add_norm_kernel's arithmetic -> the
-    embeddings must equal the two-launch chain's BIT FOR BIT; ragged token counts (last tile partly filled), both the
-    xn and the final-norm output forms (4 layers: the last `down` runs FINAL).  Also against the fp32 oracle."""
+    """gemm_rowfuse.hip: o_proj / down + residual add + both RMSNorms in one launch.  Round 4's kernel gives 128 token rows
+    to a PAIR of workgroups, each computing one 384-column half; the partners exchange their halves of every row's sum of
+    squares inside the launch (twice).  Same MFMA and k order as the 256-row GEMM, and the row sums are taken half by
+    half, left + right - the order add_norm_kernel uses too - so the embeddings must equal the two-launch chain's BIT FOR
+    BIT: ragged token counts (last row block partly filled, odd pair counts, a tail group of fewer than 8 pairs), both the
+    xn and the final-norm output forms (4 layers: the last `down` runs FINAL), twice in a row on the same engine (the
+    granules' launch tags must tell a fresh value from the previous launch's).  Also against the fp32 oracle."""
     cfg = G.GemmaConfig(vocab_size=4096, hidden=768, layers=4, heads=3, kv_heads=1, head_dim=256, intermediate=1152,
                         dense_hidden=3072, sliding_window=512, sliding_pattern=2, max_seq=2048)
     eng, w = make(cfg, seed=41)
-    for lens in ([700, 650, 33, 517], [64] * 20, [1000, 3]):             # 1900, 1280 and 1003 tokens
+    for lens in ([700, 650, 33, 517], [64] * 20, [1000, 3], [128], [129], [2047, 2048, 1, 300]):   # 1900, 1280, 1003, 128, 129, 4396 tokens
         ids, mask = batch(cfg, lens, seed=sum(lens))
-        set_fuse_norm(eng, False)
+        set_fuse_norm(eng, 0)
         plain = eng.run(ids, mask)
-        set_fuse_norm(eng, True, 256)                                    # (default 12288: the test batches are smaller)
+        set_fuse_norm(eng, 2, 64)                                        # (default threshold: the test batches are smaller)
         fused = eng.run(ids, mask)
-        assert np.array_equal(fused, plain), float(np.max(np.abs(fused - plain)))
+        assert np.array_equal(fused, plain), (lens, float(np.max(np.abs(fused - plain))))
+        assert np.array_equal(eng.run(ids, mask), plain), lens            # again: stale granules of the launch before
+        t = [eng.submit(ids, mask) for _ in range(3)]                     # both execution contexts, three tickets in flight
+        for tk in t:
+            assert np.array_equal(eng.collect(tk, len(lens)), plain), lens
     ids, mask = batch(cfg, [300, 41], seed=5)
-    set_fuse_norm(eng, True, 64)
     got = eng.run(ids, mask)
     ref = G.forward(cfg, w, ids, mask)
     for i in range(2):
         assert cos(got[i], ref[i]) > 0.999
+    # round 3's 64-row kernel (kept for A/B): its row sums run over whole rows, so it agrees to rounding, not bit for bit
+    set_fuse_norm(eng, 1, 64)
+    old = eng.run(ids, mask)
+    set_fuse_norm(eng, 0)
+    plain = eng.run(ids, mask)
+    for i in range(2):
+        assert cos(old[i], plain[i]) > 0.99999
+    eng.close()
+
+
+def set_fuse_qkv(eng, on):
+    import ctypes as C
+    f = eng._lib.cqs_hip_debug_embedder_set_fuse_qkv
+    f.restype = None
+    f.argtypes = [C.c_void_p, C.c_int32]
+    f(eng._h, 1 if on else 0)
+
+
+def test_fused_qkv_epilogue_matches_the_three_launch_chain_and_the_oracle(hip, monkeypatch):
+    """Round 4: the QKV projection's 256 x 320 tiles each hold one whole q / k head + a 64-column slice of v (weights in tile
+    order), and the GEMM's epilogue applies the head's RMSNorm (1 + w), RoPE and the q scale itself - `kv_prep_kernel` and
+    the attention kernel's own Q norm disappear (5 launches per layer).  Same formulas on the same bf16-rounded projection;
+    only the order in which a head's 256 squares are summed differs, so the embeddings agree to rounding (cosine >= 0.99999),
+    not bit for bit - and the path must really be a different one (not equal bitwise).  The planner takes the fused kernel
+    by itself only where 256 x 320 tiles make full rounds (32 x 512 tokens); CQS_HIP_GEMM_TILE=pp:5 forces it on a batch small
+    enough for the fp32 oracle.  Full and sliding-window layers, ragged lengths, a partly filled last row tile."""
+    cfg = G.GemmaConfig(vocab_size=4096, hidden=768, layers=4, heads=3, kv_heads=1, head_dim=256, intermediate=1152,
+                        dense_hidden=3072, sliding_window=512, sliding_pattern=2, max_seq=2048)
+    eng, w = make(cfg, seed=43)
+    lens = [512, 400, 300, 200, 150, 128, 100, 64, 33, 1, 700]
+    ids, mask = batch(cfg, lens, seed=77)
+    monkeypatch.setenv("CQS_HIP_GEMM_TILE", "pp:5")
+    set_fuse_qkv(eng, False)
+    plain = eng.run(ids, mask)
+    set_fuse_qkv(eng, True)
+    fused = eng.run(ids, mask)
+    assert not np.array_equal(fused, plain), "the fused epilogue did not run (bitwise equal to the three-launch chain)"
+    ref = G.forward(cfg, w, ids, mask)
+    for i in range(len(lens)):
+        assert cos(fused[i], plain[i]) > 0.99999, (i, cos(fused[i], plain[i]))
+        assert np.max(np.abs(fused[i] - plain[i])) < 2e-2 * np.abs(plain[i]).max(), i
+        assert cos(fused[i], ref[i]) > 0.999, (i, cos(fused[i], ref[i]))
+    monkeypatch.delenv("CQS_HIP_GEMM_TILE")
+    ids, mask = batch(cfg, [512] * 32, seed=78)             # the planner's own choice: one full round of 256 x 320 tiles
+    set_fuse_qkv(eng, False)
+    plain = eng.run(ids, mask)
+    set_fuse_qkv(eng, True)
+    fused = eng.run(ids, mask)
+    assert not np.array_equal(fused, plain)
+    for i in range(32):
+        assert cos(fused[i], plain[i]) > 0.99999, (i, cos(fused[i], plain[i]))
     eng.close()
