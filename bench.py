@@ -45,7 +45,8 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of each cpu_baseline leg (0 = skip)")
     ap.add_argument("--extras", type=int, default=1, help="N=1 only: also time + check the other BASELINE configs "
                     "(k=500, 17.5k rows, 256-query blocks, 10M rows) into `other_configs` (0 = skip)")
-    ap.add_argument("--embed-steps", type=int, default=8, help="timed embedding batches per rank (0 = skip the embed leg)")
+    ap.add_argument("--embed-steps", type=int, default=24, help="timed embedding batches per rank (0 = skip the embed leg); "
+                    "the 4 x batch leg runs a quarter of them (round 3 timed 8 / 2: mostly pipeline fill and drain)")
     ap.add_argument("--embed-batch", type=int, default=32, help="sequences per embedding batch (reference: embed_batch_size() = 32)")
     ap.add_argument("--embed-len", type=int, default=512, help="tokens per sequence of the fixed-length embed leg")
     ap.add_argument("--e2e-chunks", type=int, default=100_000, help="configs[3]: chunks embedded + indexed end to end (0 = skip)")

@@ -80,14 +80,15 @@ struct QkvEpilogue {
     float eps, q_scale;
     uint32_t heads, kv_heads; // heads == 3 * kv_heads
 };
-// qkv[M, (heads + 2 kv) * 256] = norm / rope / scale (A Wf^T): ONE launch of 256 x 320 tiles, each tile = one whole q or k
-// head (256 columns: normalised, rotated, q scaled) + a 64-column slice of v (stored as is).  Wf = the projection's rows in
-// tile order (launch_permute_qkv_rows).  Replaces GEMM + kv_prep + the attention kernel's own Q norm (attention then runs
-// with q_norm_w = NULL).  gemm_qkv_rope_supported: geometry fits AND the planner would run 256 x 320 tiles over the whole
-// projection anyway (a full round at this M) - otherwise the three-launch chain is the faster one.
-bool gemm_qkv_rope_supported(uint32_t M, uint32_t hidden, uint32_t heads, uint32_t kv_heads, uint32_t head_dim);
+// qkv[M, (heads + 2 kv) * 256] = norm / rope / scale (A W^T) in ONE launch.  tn = 5: 256 x 320 tiles, each = one whole q or k
+// head (256 columns: normalised, rotated, q scaled) + a 64-column slice of v (stored as is), W = the projection's rows in
+// tile order (launch_permute_qkv_rows); tn = 4: 256 x 256 tiles = one head or 256 columns of v each, W in natural order.
+// Replaces GEMM + kv_prep + the attention kernel's own Q norm (attention then runs with q_norm_w = NULL).
+// gemm_qkv_rope_tile: 5 / 4 when the geometry fits AND the planner would run that tile over the whole projection anyway
+// (full rounds at this M), else 0 - the three-launch chain on smaller kernels is then the faster one.
+int gemm_qkv_rope_tile(uint32_t M, uint32_t hidden, uint32_t heads, uint32_t kv_heads, uint32_t head_dim);
 hipError_t launch_permute_qkv_rows(const bf16_t* wqkv, bf16_t* wf, uint32_t heads, uint32_t kv_heads, uint32_t K, hipStream_t st);
-hipError_t launch_gemm_qkv_rope(const bf16_t* A, const bf16_t* Wf, bf16_t* qkv, uint32_t M, uint32_t K, const QkvEpilogue& epi,
+hipError_t launch_gemm_qkv_rope(const bf16_t* A, const bf16_t* W, bf16_t* qkv, uint32_t M, uint32_t K, int tn, const QkvEpilogue& epi,
                                 hipStream_t st);
 hipError_t launch_gemm_bf16(const bf16_t* A, const bf16_t* W, void* C, uint32_t M, uint32_t N, uint32_t K,
                             uint32_t ldc, GemmOut out, hipStream_t st, const float* bias = nullptr /*[N] f32; not with GEGLU*/);

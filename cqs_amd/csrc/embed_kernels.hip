@@ -1311,11 +1311,14 @@ static GemmPlan plan_gemm(uint32_t M, uint32_t N, uint32_t K, GemmOut out) {
     return {n1, tn1, tn2};
 }
 
-bool gemm_qkv_rope_supported(uint32_t M, uint32_t hidden, uint32_t heads, uint32_t kv_heads, uint32_t head_dim) {
-    if (head_dim != 256u || kv_heads == 0u || heads != 3u * kv_heads || hidden % 64u) return false;
+int gemm_qkv_rope_tile(uint32_t M, uint32_t hidden, uint32_t heads, uint32_t kv_heads, uint32_t head_dim) {
+    if (head_dim != 256u || kv_heads == 0u || hidden % 64u) return 0;
     const uint32_t N = (heads + 2u * kv_heads) * head_dim;
     const GemmPlan p = plan_gemm(M, N, hidden, GEMM_OUT_BF16);
-    return p.n1 == N && p.tn1 == 5;                      // the plain projection would be one launch of 256 x 320 tiles too
+    if (p.n1 != N) return 0;                              // the plain projection would be one launch of that tile too
+    if (p.tn1 == 5 && heads == 3u * kv_heads) return 5;
+    if (p.tn1 == 4) return 4;
+    return 0;
 }
 
 hipError_t launch_gemm_bf16(const bf16_t* A, const bf16_t* W, void* C, uint32_t M, uint32_t N, uint32_t K,

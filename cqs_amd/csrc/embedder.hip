@@ -64,8 +64,8 @@ struct cqs_hip_embedder {
     // o_proj / down fused with the residual add + both norms (gemm_rowfuse.hip).  Read ONCE, at finalize
     // (CQS_HIP_GEMM_FUSE_NORM / _MIN_ROWS); tests flip it through cqs_hip_debug_embedder_set_fuse_norm.
     int fuse_norm = 2;                    // 0 = two launches, 1 = the 64-row kernel of round 3, 2 = the pair-split kernel (128 rows x 384 columns)
-    uint32_t fuse_min_rows = 12288;       // below ~12.7k tokens the two-launch chain beat the 64-row kernel (a 64-row tile per CU
-                                          // streams the whole W panel whatever the row count: 3.89 vs 3.46 ms at 5k tokens)
+    uint32_t fuse_min_rows = 4096;        // token count from which the fused kernel runs (pair-split kernel, ragged 10k-token batches, tickets in
+                                          // flight: 9.6 k chunks/s at 1024-4096, 9.4 k at 2048 / 8192, 8.3 k at 12288; round 3's 64-row kernel needed 12288)
     bool fuse_qkv = true;                 // CQS_HIP_QKV_FUSE=0: QKV GEMM + kv_prep + the attention kernel's own Q norm instead of the fused epilogue
     unsigned* fuse_err = nullptr;         // pinned host word (device-visible at fuse_err_dev): set by the pair kernel if an exchange timed out
     unsigned* fuse_err_dev = nullptr;
@@ -337,7 +337,9 @@ int32_t run_layers(cqs_hip_embedder* e, Ctx& c, Slot& sl) {
     E_TRY(e, hipEventRecord(sl.ev0, st));
     const uint32_t nblk = sl.nblk;
     const bool need_vt = cqs::attention_reads_vt(nblk, g.heads, g.kv_heads);
-    const bool qkv_fused = e->fuse_qkv && !need_vt && e->L[0].wqkv_f && cqs::gemm_qkv_rope_supported(M, H, g.heads, g.kv_heads, g.head_dim);
+    int qkv_tn = (e->fuse_qkv && !need_vt) ? cqs::gemm_qkv_rope_tile(M, H, g.heads, g.kv_heads, g.head_dim) : 0;
+    if (qkv_tn == 5 && !e->L[0].wqkv_f) qkv_tn = 0;
+    const bool qkv_fused = qkv_tn != 0;
     E_TRY(e, cqs::launch_embed_norm(c.d_tok, e->emb, sqrtf((float)H), e->L[0].n_in, g.rms_eps, c.x, c.xn, M, H, st));
     for (uint32_t l = 0; l < g.layers; ++l) {
         const LayerW& w = e->L[l];
@@ -347,7 +349,7 @@ int32_t run_layers(cqs_hip_embedder* e, Ctx& c, Slot& sl) {
         // does the head's RMSNorm + RoPE (+ q scale) itself - no kv_prep launch, no Q prologue in the attention kernel
         if (qkv_fused) {
             cqs::QkvEpilogue ep{c.d_pos, w.n_q, w.n_k, rope, g.rms_eps, g.q_scale, g.heads, g.kv_heads};
-            E_TRY(e, cqs::launch_gemm_qkv_rope(c.xn, w.wqkv_f, c.qkv, M, H, ep, st));
+            E_TRY(e, cqs::launch_gemm_qkv_rope(c.xn, qkv_tn == 5 ? w.wqkv_f : w.wqkv, c.qkv, M, H, qkv_tn, ep, st));
         } else {
             E_TRY(e, cqs::launch_gemm_bf16(c.xn, w.wqkv, c.qkv, M, nqkv(g), H, nqkv(g), cqs::GEMM_OUT_BF16, st));
             // k heads + V^T here; the attention kernel normalises / rotates its own Q fragments (q is 3/4 of the rope's bytes)
@@ -801,6 +803,8 @@ int32_t submit_locked(cqs_hip_embedder* e, uint32_t B, const std::function<int32
         if (s2.ticket != 0) load[s2.ctx]++;
     int ci = load[0] == load[1] ? (load[0] == 0 ? 0 : 1 - e->last_ctx) : (load[0] < load[1] ? 0 : 1);
     if (e->single_ctx) ci = 0;            // CQS_HIP_EMBED_CONTEXTS=1: every ticket on one stream (tickets still overlap host packing / copies)
+    // (Tried in round 4 and dropped: batches of >= 32 768 tokens all on context 0 - "stop alternating contexts" - measured
+    // 5 600 chunks/s against 5 650 for blocking calls and 5 660-5 745 for alternating contexts at 128 x 512 tokens.)
     e->last_ctx = ci;
     sl->ctx = ci;
     Ctx& c = e->ctx[ci];

@@ -321,10 +321,13 @@ __device__ __forceinline__ void gemm_pp_body(const bf16_t* __restrict__ A, const
         // (embed_kernels.hip) on the bf16-rounded projection, so the attention kernels read what they used to compute.
         // Two passes of 128 rows through the bf16 stage; then wave w takes stage rows 16 w .. 16 w + 15 two at a time: lanes
         // 0-31 one row, lanes 32-63 the next; lane (l = lane & 31) owns dims 4 l + {0..3} and their rotation partners 128 + ...
-        static_assert(TN == 5, "QKV epilogue: 256 + 64 columns per tile");
+        // TN = 4 (256-column tiles, the projection's rows in their natural order: partly filled rounds, M <~ 13k): a tile is
+        // exactly one head - or 256 columns of v, copied as they are.
+        static_assert(TN == 5 || TN == 4, "QKV epilogue: 256 (+ 64) columns per tile");
         const uint32_t tcol = n0 / (uint32_t)BN;
         const uint32_t nh = epi->heads + epi->kv_heads;
         const bool is_q = tcol < epi->heads;
+        const bool is_head = TN == 5 || tcol < nh;                  // (workgroup-uniform)
         const float* const wnorm = is_q ? epi->wq : epi->wk;
         const float qs = is_q ? epi->q_scale : 1.0f;
         const float eps = epi->eps;
@@ -335,7 +338,7 @@ __device__ __forceinline__ void gemm_pp_body(const bf16_t* __restrict__ A, const
         constexpr int kStride = BN + 4;                             // elements (8-byte aligned rows, bank shift of 2 dwords)
         bf16_t* const stage = p8smem;                               // 128 x kStride elements = 81 KiB
         bf16_t* const Cq = (bf16_t*)Cv;
-        const uint32_t vcol0 = nh * 256u + tcol * 64u;
+        const uint32_t vcol0 = TN == 5 ? nh * 256u + tcol * 64u : n0;
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             // this pass's rows of the wave: positions + cos / sin rows requested before the stage is written
@@ -346,7 +349,7 @@ __device__ __forceinline__ void gemm_pp_body(const bf16_t* __restrict__ A, const
                 const uint32_t sr = (uint32_t)(16 * wid + 2 * it + hw);
                 grow[it] = m0 + (sr >> 6) * 128u + (uint32_t)(64 * p) + (sr & 63u);
                 const uint32_t gr = grow[it] < M ? grow[it] : M - 1u;
-                const float* cs = epi->cos_sin + ((size_t)(uint32_t)epi->pos[gr] * 128u + (uint32_t)l31 * 4u) * 2u;
+                const float* cs = epi->cos_sin + ((size_t)(is_head ? (uint32_t)epi->pos[gr] : 0u) * 128u + (uint32_t)l31 * 4u) * 2u;
                 cs0[it] = *(const f4*)cs;
                 cs1[it] = *(const f4*)(cs + 4);
             }
@@ -362,6 +365,7 @@ __device__ __forceinline__ void gemm_pp_body(const bf16_t* __restrict__ A, const
                 }
             }
             __syncthreads();
+            if (is_head)
 #pragma unroll
             for (int it = 0; it < 8; ++it) {
                 const uint32_t sr = (uint32_t)(16 * wid + 2 * it + hw);
@@ -393,13 +397,24 @@ __device__ __forceinline__ void gemm_pp_body(const bf16_t* __restrict__ A, const
                     *(bf4*)(dst + 128) = ohi;
                 }
             }
-            // the v slice: 128 rows x 64 columns = 2048 8-byte pieces, 16 lanes per row (one 128-byte line)
+            if constexpr (TN == 5) {
+                // the v slice: 128 rows x 64 columns = 2048 8-byte pieces, 16 lanes per row (one 128-byte line)
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const uint32_t c = (uint32_t)tid + 512u * (uint32_t)u;
-                const uint32_t sr = c >> 4, ch = c & 15u;
-                const uint32_t row = m0 + (sr >> 6) * 128u + (uint32_t)(64 * p) + (sr & 63u);
-                if (row < M) *(bf4*)(Cq + (size_t)row * ldc + vcol0 + ch * 4u) = *(const bf4*)(stage + (size_t)sr * kStride + 256u + ch * 4u);
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t c = (uint32_t)tid + 512u * (uint32_t)u;
+                    const uint32_t sr = c >> 4, ch = c & 15u;
+                    const uint32_t row = m0 + (sr >> 6) * 128u + (uint32_t)(64 * p) + (sr & 63u);
+                    if (row < M) *(bf4*)(Cq + (size_t)row * ldc + vcol0 + ch * 4u) = *(const bf4*)(stage + (size_t)sr * kStride + 256u + ch * 4u);
+                }
+            } else if (!is_head) {
+                // a whole tile of v: 128 rows x 256 columns = 8192 8-byte pieces, a wave per row (512 bytes)
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const uint32_t c = (uint32_t)tid + 512u * (uint32_t)u;
+                    const uint32_t sr = c >> 6, ch = c & 63u;
+                    const uint32_t row = m0 + (sr >> 6) * 128u + (uint32_t)(64 * p) + (sr & 63u);
+                    if (row < M) *(bf4*)(Cq + (size_t)row * ldc + vcol0 + ch * 4u) = *(const bf4*)(stage + (size_t)sr * kStride + ch * 4u);
+                }
             }
             if (p == 0) __syncthreads();
         }
@@ -490,10 +505,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16_t* __restric
 }
 
 // The QKV projection with its fused epilogue: the same body, the epilogue's inputs by value in kernel-argument memory.
+template <int TN>
 __global__ __launch_bounds__(512, 2) void gemm_pp_qkv_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
                                                              bf16_t* __restrict__ qkv, uint32_t M, uint32_t N, uint32_t K,
                                                              uint32_t ldc, const QkvEpilogue epi) {
-    gemm_pp_body<5, GEMM_OUT_QKV>(A, W, qkv, M, N, K, ldc, blockIdx.x, nullptr, nullptr, 0u, &epi);
+    gemm_pp_body<TN, GEMM_OUT_QKV>(A, W, qkv, M, N, K, ldc, blockIdx.x, nullptr, nullptr, 0u, &epi);
 }
 
 // Wf rows in tile order: tile t (t < heads + kv) = [the 256 rows of head slot t | v rows 64 t .. 64 t + 63]; one thread per 16 bytes.
@@ -562,21 +578,27 @@ hipError_t launch_permute_qkv_rows(const bf16_t* wqkv, bf16_t* wf, uint32_t head
     return hipGetLastError();
 }
 
-hipError_t launch_gemm_qkv_rope(const bf16_t* A, const bf16_t* Wf, bf16_t* qkv, uint32_t M, uint32_t K, const QkvEpilogue& epi,
+hipError_t launch_gemm_qkv_rope(const bf16_t* A, const bf16_t* W, bf16_t* qkv, uint32_t M, uint32_t K, int tn, const QkvEpilogue& epi,
                                 hipStream_t st) {
     if (M == 0) return hipSuccess;
-    const uint32_t nh = epi.heads + epi.kv_heads, N = nh * 320u;
-    if (epi.heads != 3u * epi.kv_heads || K % 64u || K < 64u || (uint64_t)M * K >= (1ull << 31) || (uint64_t)N * K >= (1ull << 31) ||
-        !epi.pos || !epi.wq || !epi.wk || !epi.cos_sin)
+    const uint32_t nh = epi.heads + epi.kv_heads, N = (epi.heads + 2u * epi.kv_heads) * 256u;
+    if ((tn != 4 && tn != 5) || (tn == 5 && epi.heads != 3u * epi.kv_heads) || K % 64u || K < 64u || (uint64_t)M * K >= (1ull << 31) ||
+        (uint64_t)N * K >= (1ull << 31) || !epi.pos || !epi.wq || !epi.wk || !epi.cos_sin)
         return hipErrorInvalidValue;
-    const dim3 grid(nh * ((M + kP8M - 1) / kP8M));
-    const size_t lds = (size_t)2 * (kP8M + 320) * 64 * sizeof(bf16_t);
-    static std::atomic<uint64_t> attr_devices{0};
-    {
-        const hipError_t e = set_max_dynamic_lds((const void*)gemm_pp_qkv_kernel, lds, attr_devices);
+    const uint32_t mt = (M + kP8M - 1) / kP8M;
+    if (tn == 5) {
+        const size_t lds = (size_t)2 * (kP8M + 320) * 64 * sizeof(bf16_t);
+        static std::atomic<uint64_t> attr_devices{0};
+        const hipError_t e = set_max_dynamic_lds((const void*)gemm_pp_qkv_kernel<5>, lds, attr_devices);
         if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(gemm_pp_qkv_kernel<5>, dim3(nh * mt), dim3(512), lds, st, A, W, qkv, M, N, K, N, epi);
+    } else {
+        const size_t lds = (size_t)2 * (kP8M + 256) * 64 * sizeof(bf16_t);
+        static std::atomic<uint64_t> attr_devices{0};
+        const hipError_t e = set_max_dynamic_lds((const void*)gemm_pp_qkv_kernel<4>, lds, attr_devices);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(gemm_pp_qkv_kernel<4>, dim3((N / 256u) * mt), dim3(512), lds, st, A, W, qkv, M, N, K, N, epi);
     }
-    hipLaunchKernelGGL(gemm_pp_qkv_kernel, grid, dim3(512), lds, st, A, Wf, qkv, M, N, K, N, epi);
     return hipGetLastError();
 }
 

@@ -576,6 +576,15 @@ def test_fused_qkv_epilogue_matches_the_three_launch_chain_and_the_oracle(hip, m
         assert cos(fused[i], plain[i]) > 0.99999, (i, cos(fused[i], plain[i]))
         assert np.max(np.abs(fused[i] - plain[i])) < 2e-2 * np.abs(plain[i]).max(), i
         assert cos(fused[i], ref[i]) > 0.999, (i, cos(fused[i], ref[i]))
+    # 256 x 256 tiles (partly filled rounds: ragged batches of up to ~13k tokens): a tile = one head, or 256 columns of v
+    monkeypatch.setenv("CQS_HIP_GEMM_TILE", "pp:4")
+    fused4 = eng.run(ids, mask)
+    set_fuse_qkv(eng, False)
+    plain4 = eng.run(ids, mask)
+    set_fuse_qkv(eng, True)
+    assert not np.array_equal(fused4, plain4)
+    for i in range(len(lens)):
+        assert cos(fused4[i], plain4[i]) > 0.99999 and cos(fused4[i], ref[i]) > 0.999, i
     monkeypatch.delenv("CQS_HIP_GEMM_TILE")
     ids, mask = batch(cfg, [512] * 32, seed=78)             # the planner's own choice: one full round of 256 x 320 tiles
     set_fuse_qkv(eng, False)
