@@ -167,7 +167,8 @@ struct QueryFwdLayer {
 };
 struct QueryFwd {
     const int32_t* tok;               // device: token ids [T]
-    uint32_t T;                       // tokens, 1..64: a launch parameter (the engine keeps one captured hipGraph per length)
+    const int32_t* pos;               // device: [kQueryFwdMaxTokens] = 0, 1, 2, ... (queries over 64 tokens: positions of the q / k rotation launch)
+    uint32_t T;                       // tokens, 1..128: a launch parameter (the engine keeps one captured hipGraph per length)
     const bf16_t* emb;
     float embed_scale;
     const QueryFwdLayer* layer;       // host array [layers]
@@ -177,15 +178,16 @@ struct QueryFwd {
     const float *rope_global, *rope_local;
     uint32_t hidden, heads, kv_heads, inter, dense_hidden, window, sliding_pattern;
     float eps, q_scale;
-    // scratch, all for 64 rows: x0 / x1 [64, hidden] f32 (the residual stream alternates), qkv [64, (heads + 2 kv) 256],
+    // scratch, all for kQueryFwdMaxTokens rows: x0 / x1 [rows, hidden] f32 (the residual stream alternates), qkv [64, (heads + 2 kv) 256],
     // attn [64, heads 256], y [64, hidden], h [64, inter] bf16, d1 [dense_hidden] bf16, out [hidden] f32
     float *x0, *x1;
     bf16_t *qkv, *attn, *y, *h, *d1;
     float* out;
     unsigned long long* dbg;          // nullable: [5 layers + 2 kernel slots][256 workgroups][8] diagnostic stamps (query_kernels.hip)
 };
-constexpr uint32_t kQueryFwdMaxTokens = 64;
+constexpr uint32_t kQueryFwdMaxTokens = 128;
 bool query_forward_supported(const EmbedGeom& g);
+uint32_t query_forward_max_tokens(const EmbedGeom& g);            // 128 or 64: the longest sequence the chain serves for this geometry
 hipError_t launch_query_forward(const QueryFwd& f, hipStream_t st);
 
 // f32 -> bf16 (round to nearest even), n elements

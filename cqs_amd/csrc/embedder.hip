@@ -58,6 +58,7 @@ struct cqs_hip_embedder {
     std::vector<LayerW> L;
     std::vector<cqs::QueryFwdLayer> QL;   // the same pointers in the query path's layout (filled by finalize)
     bool query_path = false;              // geometry supported and not disabled by CQS_HIP_QUERY_PATH=0
+    uint32_t query_max_tokens = 64;       // longest single sequence the search-time chain serves (cqs::query_forward_max_tokens)
     bool query_graph = true;              // CQS_HIP_QUERY_GRAPH=0: launch the query chain eagerly
     bool query_direct = true;             // CQS_HIP_QUERY_DIRECT=0: token ids / result always through copy calls
     bool single_ctx = false;              // CQS_HIP_EMBED_CONTEXTS=1: one execution context (A/B hook for the two-chain overlap)
@@ -94,6 +95,7 @@ struct cqs_hip_embedder {
         // search-time path (query_kernels.hip): fixed 64-row scratch, allocated once and never moved, so that the
         // captured graphs' kernel arguments stay valid; the token ids arrive in q_meta by one H2D per query
         int32_t* q_meta = nullptr;
+        int32_t* q_pos = nullptr;          // [kQueryFwdMaxTokens] = 0, 1, 2, ...
         float *q_x0 = nullptr, *q_x1 = nullptr, *q_out = nullptr;
         bf16_t *q_qkv = nullptr, *q_attn = nullptr, *q_y = nullptr, *q_h = nullptr, *q_d1 = nullptr;
         // one captured chain per query length T = 1..64 (T is a launch parameter of every kernel: no load waits for a
@@ -188,7 +190,7 @@ void free_query_scratch(Ctx& c) {
     if (c.q_tok_pin) (void)hipHostFree(c.q_tok_pin);
     if (c.q_out_pin) (void)hipHostFree(c.q_out_pin);
     c.q_tok_pin = nullptr; c.q_out_pin = nullptr; c.q_tok_pin_dev = nullptr; c.q_out_pin_dev = nullptr;
-    void** all[] = {(void**)&c.q_dbg, (void**)&c.q_meta, (void**)&c.q_x0, (void**)&c.q_x1, (void**)&c.q_out, (void**)&c.q_qkv, (void**)&c.q_attn,
+    void** all[] = {(void**)&c.q_dbg, (void**)&c.q_pos, (void**)&c.q_meta, (void**)&c.q_x0, (void**)&c.q_x1, (void**)&c.q_out, (void**)&c.q_qkv, (void**)&c.q_attn,
                     (void**)&c.q_y, (void**)&c.q_h, (void**)&c.q_d1};
     for (void** p : all) { (void)hipFree(*p); *p = nullptr; }
 }
@@ -386,7 +388,7 @@ int32_t run_layers(cqs_hip_embedder* e, Ctx& c, Slot& sl) {
 // 98 launches (4 per layer + 2) of query_kernels.hip instead of the batch chain's ~230, replayed from a hipGraph
 // captured on the context's second query (eager launches of 2-3 us kernels are host-bound: ~3.5 us of host time each).
 bool slot_takes_query_path(const cqs_hip_embedder* e, const Slot& sl) {
-    return e->query_path && sl.B == 1 && sl.M >= 1 && sl.M <= cqs::kQueryFwdMaxTokens;
+    return e->query_path && sl.B == 1 && sl.M >= 1 && sl.M <= e->query_max_tokens;
 }
 
 int32_t ensure_query_scratch(cqs_hip_embedder* e, Ctx& c) {
@@ -395,7 +397,7 @@ int32_t ensure_query_scratch(cqs_hip_embedder* e, Ctx& c) {
     const size_t R = cqs::kQueryFwdMaxTokens, H = g.hidden;
     hipError_t he = hipSuccess;
     auto grab = [&](auto** p, size_t count) { if (he == hipSuccess) he = dmalloc(p, count); };
-    grab(&c.q_meta, R + 1); grab(&c.q_x0, R * H); grab(&c.q_x1, R * H); grab(&c.q_out, H);
+    grab(&c.q_meta, R + 1); grab(&c.q_pos, R); grab(&c.q_x0, R * H); grab(&c.q_x1, R * H); grab(&c.q_out, H);
     grab(&c.q_qkv, R * nqkv(g)); grab(&c.q_attn, R * g.heads * g.head_dim); grab(&c.q_y, R * H); grab(&c.q_h, R * g.inter);
     grab(&c.q_d1, (size_t)g.dense_hidden);
     // rows past a query's length are read (never used): keep them finite from the start
@@ -409,6 +411,11 @@ int32_t ensure_query_scratch(cqs_hip_embedder* e, Ctx& c) {
     if (he == hipSuccess) he = hipHostGetDevicePointer((void**)&c.q_tok_pin_dev, c.q_tok_pin, 0);
     if (he == hipSuccess) he = hipHostGetDevicePointer((void**)&c.q_out_pin_dev, c.q_out_pin, 0);
     if (he == hipSuccess) memset(c.q_tok_pin, 0, R * sizeof(int32_t));
+    if (he == hipSuccess) {
+        std::vector<int32_t> iota(R);
+        for (size_t i = 0; i < R; ++i) iota[i] = (int32_t)i;
+        he = hipMemcpy(c.q_pos, iota.data(), R * sizeof(int32_t), hipMemcpyHostToDevice);
+    }
     if (he == hipSuccess) he = hipMemsetAsync(c.q_x0, 0, R * H * 4, c.stream);
     if (he == hipSuccess) he = hipMemsetAsync(c.q_x1, 0, R * H * 4, c.stream);
     if (he == hipSuccess) he = hipMemsetAsync(c.q_qkv, 0, R * nqkv(g) * 2, c.stream);
@@ -434,7 +441,7 @@ int32_t run_query(cqs_hip_embedder* e, Ctx& c, Slot& sl, bool direct) {
     else E_TRY(e, hipMemcpyAsync(c.q_meta, sl.meta, (size_t)sl.M * sizeof(int32_t), hipMemcpyHostToDevice, st));   // slot_fill: the token ids come first
     E_TRY(e, hipEventRecord(sl.ev0, st));
     cqs::QueryFwd f{};
-    f.tok = c.q_meta; f.T = sl.M; f.emb = e->emb; f.embed_scale = sqrtf((float)g.hidden); f.layer = e->QL.data(); f.layers = g.layers;
+    f.tok = c.q_meta; f.pos = c.q_pos; f.T = sl.M; f.emb = e->emb; f.embed_scale = sqrtf((float)g.hidden); f.layer = e->QL.data(); f.layers = g.layers;
     f.n_final = e->n_final; f.dense1 = e->dense1; f.dense2 = e->dense2; f.rope_global = e->rope_global; f.rope_local = e->rope_local;
     f.hidden = g.hidden; f.heads = g.heads; f.kv_heads = g.kv_heads; f.inter = g.inter; f.dense_hidden = g.dense_hidden;
     f.window = g.window; f.sliding_pattern = g.sliding_pattern; f.eps = g.rms_eps; f.q_scale = g.q_scale;
@@ -676,6 +683,7 @@ int32_t cqs_hip_embedder_finalize(cqs_hip_embedder* e) CQS_ABI_TRY {
     const char* qg = getenv("CQS_HIP_QUERY_GRAPH");
     e->query_path = cqs::query_forward_supported(e->g) && !(qp && qp[0] == '0');
     e->query_graph = !(qg && qg[0] == '0');
+    e->query_max_tokens = cqs::query_forward_max_tokens(e->g);
     const char* qd = getenv("CQS_HIP_QUERY_DIRECT");
     e->query_direct = !(qd && qd[0] == '0');
     const char* ec = getenv("CQS_HIP_EMBED_CONTEXTS");
@@ -920,7 +928,7 @@ int32_t cqs_hip_embedder_warm(cqs_hip_embedder* e, uint32_t max_tokens) CQS_ABI_
         if (s2.ticket != 0) return efail(e, CQS_HIP_ERR_INVALID, "warm: tickets are in flight (collect them first)");
     cqs_hip_embedder::Slot& sl = e->slot[0];
     E_TRY(e, hipSetDevice(e->device));
-    const uint32_t Tmax = std::min(max_tokens, std::min(cqs::kQueryFwdMaxTokens, e->g.max_seq));
+    const uint32_t Tmax = std::min(max_tokens, std::min(e->query_max_tokens, e->g.max_seq));
     int32_t rc = slot_reserve(e, sl, 1, Tmax, 1);
     if (rc != CQS_HIP_OK) return rc;
     memset(sl.meta, 0, sl.meta_cap * sizeof(int32_t));          // token id 0 at every position

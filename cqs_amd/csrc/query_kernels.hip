@@ -348,7 +348,9 @@ __global__ __launch_bounds__(256) void qf_gemm_staged_kernel(const QfGemmParams 
 // NCH = H / 256, K = H.  Rows: one WAVE per row, wave w takes rows w, w + 4, ... in batches of RB rows (RB = 1, 2, 4
 // by T for T <= 16: one batch; longer queries loop over batches of 4, the next batch's loads issued before the current
 // one is reduced).  A batch slot past T re-does row T - 1.
-template <int NCH, int PRO, int EPI, int NC, int RB, int MT, int NW, int BR = 16 * MT>
+// RO: the K-split reduction buffer `red` OVERLAYS the activation tile (one more barrier between the fragment reads and the
+// partial sums) - 48-row blocks with two weight tiles then fit LDS.
+template <int NCH, int PRO, int EPI, int NC, int RB, int MT, int NW, int BR = 16 * MT, bool RO = false>
 __global__ __launch_bounds__(64 * NW) void qf_gemm_kernel(const QfGemmParams p) {
     constexpr int H = NCH * 256;
     constexpr int NT = EPI == QF_EPI_GEGLU ? 2 : 1;               // weight tiles per workgroup
@@ -356,8 +358,9 @@ __global__ __launch_bounds__(64 * NW) void qf_gemm_kernel(const QfGemmParams p) 
     constexpr int GT = PRO == QF_PRO_POOL ? 1 : MT;                // row tiles of the GEMM (POOL: the one pooled row)
     extern __shared__ __attribute__((aligned(16))) unsigned char qf_smem[];
     bf16_t* const sA = (bf16_t*)qf_smem;                           // [16 GT][LDA]
-    float* const red = (float*)(qf_smem + (size_t)16 * GT * LDA * sizeof(bf16_t));   // [4 waves][NT][GT][64 lanes] f4
-    float* const pool = red + NW * NT * GT * 64 * 4;               // POOL: [NW waves][H] column sums
+    static_assert(!RO || (size_t)NW * NT * GT * 64 * 16 <= (size_t)16 * GT * LDA * sizeof(bf16_t), "red fits inside the activation tile");
+    float* const red = RO ? (float*)qf_smem : (float*)(qf_smem + (size_t)16 * GT * LDA * sizeof(bf16_t));   // [NW waves][NT][GT][64 lanes] f4
+    float* const pool = (float*)(qf_smem + (size_t)16 * GT * LDA * sizeof(bf16_t)) + (RO ? 0 : NW * NT * GT * 64 * 4);   // POOL: [NW waves][H] column sums
     bf16_t* const sW = (bf16_t*)(pool + (PRO == QF_PRO_POOL ? NW * H : 0));   // [NT][NC][LDA] weight slice
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -572,6 +575,7 @@ __global__ __launch_bounds__(64 * NW) void qf_gemm_kernel(const QfGemmParams p) 
             for (int t = 0; t < NT; ++t) acc[t][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t][s], a, acc[t][m], 0, 0, 0);
         }
     // ---- sum the four K-quarters through LDS; wave w finishes m-tile w.  acc[t][m][r] = C[row 16 m + l15][col 4 lg + r] ----
+    if (RO) __syncthreads();                                        // everybody's fragment reads of the tile `red` overlays are done
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -625,6 +629,7 @@ struct QfAttnParams {
     uint32_t heads, kv_heads;
     uint32_t window;          // 0 = full attention; else |q - k| < window
     uint32_t T;               // launch parameter (see QfGemmParams)
+    const int32_t* pos;       // 65-128 tokens: [128] = 0, 1, 2, ... (the positions qk_norm_rope_kernel rotates by)
     // qf_attn_oproj_kernel only: y = attn Wo^T
     const bf16_t* wo;         // [H, heads 256] bf16
     bf16_t* y;                // [64, H] bf16
@@ -933,6 +938,218 @@ __global__ __launch_bounds__(64 * NW) void qf_attn_oproj_kernel(const QfAttnPara
     if (p.dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); QF_STAMP(p, 3); }
 }
 
+// ---- attention + o_proj for 65-128 tokens: the keys in TWO halves ----------------------------------------------------------
+// At > 64 keys the one-shot layout above does not fit LDS (K rows + V^T + Q of three heads + the o_proj slice: 195 KB at 128
+// keys), and 48 column tiles x 8 query blocks = 384 workgroups of > 80 KB are two rounds on 256 CUs.  Here:
+//   * q and k heads are normalised / rotated ONCE per layer by a launch of their own (qk_norm_rope_kernel, in place on the
+//     qkv rows: 128 rows x 4 heads) instead of by every workgroup (each pulled 128 KB of cos / sin rows for that, as much as
+//     K and V together); the workgroups below only copy rows;
+//   * a workgroup = 16 queries x a 32-column o_proj tile (24 x 8 = 192 workgroups: one round), 8 waves; it stages the keys
+//     in two halves of 16 MT rows and runs an online softmax across them (running maximum m, per-lane partial sum l, O
+//     rescaled by exp(m_old - m_new) between the halves): LDS = what 16 MT keys need (154 KB at MT = 4);
+//   * one (head, query tile) unit per wave (waves 0 .. NH - 1); its O accumulators live in registers across the second staging.
+template <int MT, int NH, int NW>
+__global__ __launch_bounds__(64 * NW) void qf_attn_oproj_long_kernel(const QfAttnParams p) {
+    constexpr int NC = 32;                                            // o_proj columns per workgroup = two 16-row weight tiles
+    constexpr int K = NH * kQfHD, kw = K / NW, S = kw / 32;
+    constexpr int VR = qf_vrow<MT>();
+    constexpr int LDW = K + 8;
+    static_assert(K % (32 * NW) == 0 && NH <= NW && NC == 4 * NW, "two o_proj weight rows per 32-thread group");
+    extern __shared__ __attribute__((aligned(16))) unsigned char qf_smem[];
+    bf16_t* const sQ = (bf16_t*)qf_smem;                               // [NH][16][kQfKRow]: Q, then O
+    bf16_t* const sK = sQ + (size_t)NH * 16 * kQfKRow;                 // [16 MT][kQfKRow]
+    bf16_t* const sVt = sK + (size_t)16 * MT * kQfKRow;                // [256][VR]
+    float* const red = (float*)(sVt + (size_t)kQfHD * VR);            // [NW][2][64] f4
+    bf16_t* const sW = (bf16_t*)(red + NW * 2 * 64 * 4);               // [NC][LDW]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, lg = lane >> 4;
+    QF_STAMP(p, 0);
+    const uint32_t T = p.T, last = T - 1u;
+    const uint32_t qrow0 = blockIdx.y * 16u;
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    const uint32_t wg = (uint32_t)tid >> 5, wl32 = (uint32_t)tid & 31u;   // 16 groups of 32 threads: slice rows wg and wg + 16
+    u4 wreg[2][NH];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const bf16_t* src = p.wo + (size_t)(blockIdx.x * (uint32_t)NC + wg + 16u * (uint32_t)t) * K + wl32 * 8u;
+#pragma unroll
+        for (int j = 0; j < NH; ++j) wreg[t][j] = *(const u4*)(src + 256 * j);
+    }
+    const uint32_t ld = (p.heads + 2u * p.kv_heads) * (uint32_t)kQfHD;
+    // ---- Q of the workgroup's 16 queries (already normalised, rotated, scaled): row lr = tid / 32, 16-byte chunks tid % 32 ----
+    {
+        const uint32_t lr = wg;
+        const uint32_t row = qrow0 + lr < T ? qrow0 + lr : last;
+        u4 q[NH];
+#pragma unroll
+        for (int h = 0; h < NH; ++h) q[h] = *(const u4*)(p.qkv + (size_t)row * ld + (size_t)h * kQfHD + wl32 * 8u);
+#pragma unroll
+        for (int h = 0; h < NH; ++h) *(u4*)(sQ + ((size_t)h * 16 + lr) * kQfKRow + wl32 * 8u) = q[h];
+    }
+    // ---- the two key halves ----
+    f4 o[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) o[j] = (f4)(0.f);
+    float m_run = -INFINITY, l_run = 0.f;
+    const uint32_t ql = (uint32_t)l15, qpos = qrow0 + ql;             // this lane's query (row of the staged window / position)
+    const bf16_t* const kb = p.qkv + (size_t)p.heads * kQfHD;                          // (one kv head)
+    const bf16_t* const vb = p.qkv + (size_t)(p.heads + p.kv_heads) * kQfHD + lane * 4;
+    // K rows: plain copies, 16 rows per pass (thread = row tid / 32, chunk tid % 32); V rows: one wave per row, written
+    // transposed.  The second half's rows are requested BEFORE the first half's units run (32 registers): their latency
+    // hides behind the units instead of following the barrier.
+    constexpr int KP = MT;                                            // passes of 16 rows
+    constexpr int VP = 16 * MT / NW;                                  // V rows per wave
+    u4 kk[KP];
+    bf4 vv[VP];
+    auto fetch = [&](uint32_t key0, uint32_t kend) {
+#pragma unroll
+        for (int b = 0; b < KP; ++b) {
+            const uint32_t r = key0 + wg + 16u * (uint32_t)b;
+            kk[b] = *(const u4*)(kb + (size_t)(r < kend ? r : kend - 1u) * ld + wl32 * 8u);   // a slot past the half re-does its last row
+        }
+#pragma unroll
+        for (int b = 0; b < VP; ++b) {
+            const uint32_t r = key0 + (uint32_t)wid + (uint32_t)NW * (uint32_t)b;
+            vv[b] = *(const bf4*)(vb + (size_t)(r < kend ? r : kend - 1u) * ld);
+        }
+    };
+    fetch(0u, T < (uint32_t)(16 * MT) ? T : (uint32_t)(16 * MT));
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const uint32_t key0 = (uint32_t)(half * 16 * MT);
+        const uint32_t kend = T < key0 + (uint32_t)(16 * MT) ? T : key0 + (uint32_t)(16 * MT);   // keys [key0, kend) (T > key0 by the launcher)
+        if (half) __syncthreads();                                    // every unit is done with the first half's K / V^T
+#pragma unroll
+        for (int b = 0; b < KP; ++b) {
+            const uint32_t r = key0 + wg + 16u * (uint32_t)b;
+            *(u4*)(sK + (size_t)((r < kend ? r : kend - 1u) - key0) * kQfKRow + wl32 * 8u) = kk[b];
+        }
+#pragma unroll
+        for (int b = 0; b < VP; ++b) {
+            const uint32_t r = key0 + (uint32_t)wid + (uint32_t)NW * (uint32_t)b;
+            const uint32_t lrow = (r < kend ? r : kend - 1u) - key0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sVt[(size_t)(lane * 4 + i) * VR + lrow] = vv[b][i];
+        }
+        if (half == 0) fetch((uint32_t)(16 * MT), T < (uint32_t)(32 * MT) ? T : (uint32_t)(32 * MT));
+        // V^T columns past the half's last key multiply P = 0: zeros (K rows past it hold anything: their scores are replaced)
+        if (threadIdx.x < (uint32_t)kQfHD) {
+            bf16_t* vz = sVt + (size_t)threadIdx.x * VR;
+            for (uint32_t key = kend - key0; key < 32u * ((MT + 1) / 2); ++key) vz[key] = (bf16_t)0.f;
+        }
+        __syncthreads();
+        if (wid < NH) {                                               // unit = head `wid`, the workgroup's one query tile
+            const bf16_t* sQh = sQ + (size_t)wid * 16 * kQfKRow;
+            f4 sc[MT];
+#pragma unroll
+            for (int kt = 0; kt < MT; ++kt) sc[kt] = (f4)(0.f);
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const bf8 qf = *(const bf8*)(sQh + (size_t)ql * kQfKRow + 32 * s + 8 * lg);
+#pragma unroll
+                for (int kt = 0; kt < MT; ++kt) {
+                    const bf8 kf = *(const bf8*)(sK + (size_t)(16 * kt + l15) * kQfKRow + 32 * s + 8 * lg);
+                    sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, sc[kt], 0, 0, 0);
+                }
+            }
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < MT; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const uint32_t key = key0 + (uint32_t)(16 * kt + 4 * lg + r);
+                    const uint32_t dist = key > qpos ? key - qpos : qpos - key;
+                    const bool ok = key < T && (p.window == 0u || dist < p.window);
+                    sc[kt][r] = ok ? sc[kt][r] : -INFINITY;
+                    mx = fmaxf(mx, sc[kt][r]);
+                }
+            mx = qf_xor32_max(qf_xor16_max(mx));
+            const float m_new = fmaxf(m_run, mx);
+            const float mb = m_new == -INFINITY ? 0.f : m_new;        // no attendable key so far: every weight is exp(-inf) = 0
+            if (half) {                                               // O and the row sum of the first half shrink by exp(m_old - m_new)
+                const float a = m_run == -INFINITY ? 0.f : __expf(m_run - mb);
+                l_run *= a;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) o[j] *= a;
+            }
+            m_run = m_new;
+            constexpr int KT2 = 2 * ((MT + 1) / 2);
+            bf4 pb[KT2];
+#pragma unroll
+            for (int kt = 0; kt < KT2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = kt < MT ? __expf(sc[kt < MT ? kt : 0][r] - mb) : 0.f;
+                    pb[kt][r] = (bf16_t)e;
+                    l_run += (float)pb[kt][r];                        // the rounded weights are what multiplies V
+                }
+#pragma unroll
+            for (int kbk = 0; kbk < (MT + 1) / 2; ++kbk) {
+                bf8 pf;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { pf[r] = pb[2 * kbk][r]; pf[4 + r] = pb[2 * kbk + 1][r]; }
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const bf16_t* vr = sVt + (size_t)(16u * (uint32_t)j + (uint32_t)l15) * VR + 32 * kbk + 4 * lg;
+                    const bf4 v0 = *(const bf4*)vr, v1 = *(const bf4*)(vr + 16);
+                    bf8 vf;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { vf[r] = v0[r]; vf[4 + r] = v1[r]; }
+                    o[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[j], 0, 0, 0);
+                }
+            }
+        }
+    }
+    QF_STAMP(p, 1);
+    if (wid < NH) {                                                   // O / sum over the head's Q rows (this wave is their only reader)
+        const float sum = qf_xor32_sum(qf_xor16_sum(l_run));
+        const float rinv = 1.0f / sum;                                // (a live query sees itself: sum > 0; rows past T are never stored)
+        bf16_t* orow = sQ + ((size_t)wid * 16 + (uint32_t)l15) * kQfKRow + 4 * lg;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            bf4 ob;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ob[r] = (bf16_t)(o[j][r] * rinv);
+            *(bf4*)(orow + 16 * j) = ob;
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int j = 0; j < NH; ++j) *(u4*)(sW + (size_t)(wg + 16u * (uint32_t)t) * LDW + wl32 * 8u + 256 * j) = wreg[t][j];
+    __syncthreads();
+    QF_STAMP(p, 2);
+    // ---- y tile = attention rows x the 32-column o_proj slice (two weight tiles); the waves split K ----
+    f4 acc[2];
+    acc[0] = (f4)(0.f); acc[1] = (f4)(0.f);
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const int k = wid * kw + 32 * s;                              // wave-uniform; a 32-wide step never straddles a head
+        const bf16_t* src = sQ + (size_t)(k / kQfHD) * 16 * kQfKRow + (k % kQfHD) + 8 * lg;
+        const bf8 a = *(const bf8*)(src + (size_t)l15 * kQfKRow);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const bf8 wf = *(const bf8*)(sW + (size_t)(16 * t + l15) * LDW + k + 8 * lg);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, a, acc[t], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) *(f4*)(red + ((size_t)(wid * 2 + t) * 64 + lane) * 4) = acc[t];
+    __syncthreads();
+    if (wid >= 2) return;                                             // wave t finishes weight tile t
+    f4 v = *(const f4*)(red + ((size_t)wid * 64 + lane) * 4);
+#pragma unroll
+    for (int w = 1; w < NW; ++w) v += *(const f4*)(red + ((size_t)(w * 2 + wid) * 64 + lane) * 4);
+    const uint32_t row = qrow0 + (uint32_t)l15;
+    if (row >= T) return;
+    bf4 ob;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ob[r] = (bf16_t)v[r];
+    *(bf4*)(p.y + (size_t)row * p.H + blockIdx.x * (uint32_t)NC + 16u * (uint32_t)wid + 4u * (uint32_t)lg) = ob;
+    if (p.dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); QF_STAMP(p, 3); }
+}
+
 int qf_debug_repeat() {
     static const int r = [] { const char* e = getenv("CQS_HIP_QUERY_DEBUG_REPEAT"); return e && e[0] == '2' ? 2 : 1; }();
     return r;
@@ -965,7 +1182,8 @@ hipError_t qf_launch(Kern kern, DynLdsOnce& once, const P& p0, uint32_t grid_x, 
         if ((T) <= 16u) return CALL(2, 1, 8);             \
         if ((T) <= 32u) return CALL(4, 2, 8);             \
         if ((T) <= 48u) return CALL(4, 3, 8);             \
-        return CALL(4, 4, 8);                             \
+        if ((T) <= 64u) return CALL(4, 4, 8);             \
+        return CALL(4, 8, 8);                             \
     } while (0)
 
 template <int NCH, int PRO, int EPI, int NC>
@@ -998,12 +1216,31 @@ hipError_t qf_launch_pro(const QfGemmParams& p, uint32_t n_out_cols, hipStream_t
         return qf_launch(qf_gemm_kernel<NCH, PRO == QF_PRO_POOL ? QF_PRO_ADDNORM : PRO, EPI, 16, 1, 1, 8, 8>, once, p, n_out_cols / 16u, lds, st,
                          512u, (p.T + 7u) / 8u);
     }
+    if (PRO != QF_PRO_POOL && !split_off && p.T > 96u && NT == 2 && n_out_cols % 16u == 0) {
+        // GeGLU at 97-128 tokens: row blocks of 48 (72 column tiles x 3 = 216 workgroups: ONE round on 256 CUs; blocks of 32 rows
+        // made 288: 12.4 -> 10.7 us).  The QKV projection keeps blocks of 16 rows (48-row blocks: 8.2 -> 9.9 us - its time is the
+        // rows a wave normalises, not the rounds).
+        constexpr bool RO = NT == 2 && NCH >= 3;                    // (two weight tiles of hidden 768+: `red` overlays the activation tile)
+        const size_t lds = (size_t)(48 + NT * 16) * (NCH * 256 + kQfPad) * sizeof(bf16_t) + (RO ? 0 : (size_t)8 * NT * 3 * 64 * 16);
+        static DynLdsOnce once48;
+        return qf_launch(qf_gemm_kernel<NCH, PRO == QF_PRO_POOL ? QF_PRO_ADDNORM : PRO, EPI, 16, 4, 3, 8, 48, RO>, once48, p, n_out_cols / 16u, lds, st,
+                         512u, (p.T + 47u) / 48u);
+    }
+    if (PRO != QF_PRO_POOL && !split_off && p.T > 64u && NT == 2 && n_out_cols % 16u == 0) {
+        // GeGLU over 64 tokens: row blocks of 32 (72 column tiles x 8 blocks of 16 rows = 576 workgroups of 90 KB were 2.25
+        // rounds on 256 CUs; x 4 blocks of 32 rows = 288)
+        const size_t lds = (size_t)(32 + NT * 16) * (NCH * 256 + kQfPad) * sizeof(bf16_t) + (size_t)8 * NT * 2 * 64 * 16;
+        static DynLdsOnce once32;
+        return qf_launch(qf_gemm_kernel<NCH, PRO == QF_PRO_POOL ? QF_PRO_ADDNORM : PRO, EPI, 16, 4, 2, 8>, once32, p, n_out_cols / 16u, lds, st,
+                         512u, (p.T + 31u) / 32u);
+    }
     if (PRO != QF_PRO_POOL && !split_off && p.T > 16u && n_out_cols % 16u == 0) {
         const size_t lds = (size_t)(16 + NT * 16) * (NCH * 256 + kQfPad) * sizeof(bf16_t) + (size_t)8 * NT * 64 * 16;
         static DynLdsOnce once;
         return qf_launch(qf_gemm_kernel<NCH, PRO == QF_PRO_POOL ? QF_PRO_ADDNORM : PRO, EPI, 16, 2, 1, 8>, once, p, n_out_cols / 16u, lds, st,
                          512u, (p.T + 15u) / 16u);
     }
+    if (PRO != QF_PRO_POOL && p.T > 64u) return hipErrorNotSupported;     // (only the pooled head keeps all rows in one workgroup)
     QF_BY_T(p.T, QF_CALL);
 #undef QF_CALL
 }
@@ -1063,6 +1300,7 @@ hipError_t qf_launch_plain(const QfGemmParams& p, uint32_t n_out_cols, hipStream
         if (e == hipErrorNotSupported && rows > 32u) e = qf_launch_staged<2, EPI, NC, 0>(p, n_out_cols, st, (rows + 31u) / 32u);   // two blocks of 32 rows
         if (e != hipErrorNotSupported) return e;
     }
+    if (rows > 64u) return hipErrorNotSupported;                    // (the gather kernel holds at most four row tiles)
     if (rows <= 16u) return qf_launch_plain_ch<1, EPI, NC>(p, n_out_cols, st);
     if (rows <= 32u) return qf_launch_plain_ch<2, EPI, NC>(p, n_out_cols, st);
     if (rows <= 48u) return qf_launch_plain_ch<3, EPI, NC>(p, n_out_cols, st);
@@ -1075,6 +1313,7 @@ hipError_t qf_launch_attention(const QfAttnParams& a, hipStream_t st) {       //
         static DynLdsOnce once;                                                                            \
         return qf_launch(qf_attention_kernel<MTV, RBV>, once, a, a.heads, qf_attn_lds<MTV>(1), st);        \
     }()
+    if (a.T > 64u) return hipErrorNotSupported;
     if (a.T <= 4u) return QF_ATT(1, 1);
     if (a.T <= 8u) return QF_ATT(2, 1);
     if (a.T <= 16u) return QF_ATT(4, 1);
@@ -1094,6 +1333,22 @@ hipError_t qf_launch_attn_oproj_h(const QfAttnParams& a, hipStream_t st) {
                          qf_attn_lds<MTV>(NH) + (size_t)NWV * MTV * 64 * 16 +                                               \
                              (MTV < 3 ? (size_t)NC * (NH * kQfHD + 8) * sizeof(bf16_t) : 0), st, 64u * NWV);                \
     }()
+    if (a.T > 64u) {                                               // 65-128 tokens: the keys in two halves (online softmax across them)
+        if (a.H % 32u || a.T > 128u || !a.pos) return hipErrorNotSupported;
+        // q / k heads normalised + rotated (q scaled) once, in place on the qkv rows: the workgroups below only copy them
+        hipError_t e = launch_qk_norm_rope(const_cast<bf16_t*>(a.qkv), a.pos, a.wq, a.wk, a.cos_sin, a.eps, a.q_scale, a.T, a.heads, a.kv_heads, 0, st);
+        if (e != hipSuccess) return e;
+#define QF_AOL(MTV)                                                                                                         \
+    [&]() {                                                                                                                 \
+        static DynLdsOnce once;                                                                                             \
+        const size_t lds = ((size_t)(NH * 16 + 16 * MTV) * kQfKRow + (size_t)kQfHD * qf_vrow<MTV>()) * sizeof(bf16_t) +     \
+                           (size_t)8 * 2 * 64 * 16 + (size_t)32 * (NH * kQfHD + 8) * sizeof(bf16_t);                        \
+        return qf_launch(qf_attn_oproj_long_kernel<MTV, NH, 8>, once, a, a.H / 32u, lds, st, 512u, (a.T + 15u) / 16u);      \
+    }()
+        if (a.T <= 96u) return QF_AOL(3);                           // two halves of 48 keys
+        return QF_AOL(4);                                           // two halves of 64
+#undef QF_AOL
+    }
     if (a.T <= 4u) return QF_AO(1, 1, 4);
     if (a.T <= 8u) return QF_AO(2, 1, 4);
     static const bool split_off = [] { const char* e = getenv("CQS_HIP_QUERY_ROW_SPLIT"); return e && e[0] == '0'; }();
@@ -1158,7 +1413,7 @@ hipError_t qf_forward_t(const QueryFwd& f, hipStream_t st) {
         const bool full = ((l + 1u) % f.sliding_pattern) == 0u;
         a.cos_sin = full ? f.rope_global : f.rope_local;
         a.eps = f.eps; a.q_scale = f.q_scale; a.heads = f.heads; a.kv_heads = f.kv_heads; a.window = full ? 0u : f.window;
-        a.wo = w.wo; a.y = f.y; a.H = H;
+        a.wo = w.wo; a.y = f.y; a.H = H; a.pos = f.pos;
         e = qf_launch_attn_oproj(a, st);                 // attention + o_proj in one launch where it fits ...
         if (e == hipErrorNotSupported) {                 // ... else two
             if ((e = qf_launch_attention(a, st)) != hipSuccess) return e;
@@ -1203,7 +1458,7 @@ hipError_t qf_forward_t(const QueryFwd& f, hipStream_t st) {
 hipError_t launch_gemm_small_rows(const bf16_t* A, const bf16_t* W, const float* bias, void* C, uint32_t M, uint32_t N,
                                   uint32_t K, uint32_t ldc, GemmOut out, hipStream_t st) {
     if (M == 0) return hipSuccess;
-    if (M > 64u || N % 8u || K % 128u || K < 128u) return hipErrorNotSupported;
+    if (M > 64u || N % 8u || K % 128u || K < 128u) return hipErrorNotSupported;   // (the BERT engines' search-time shapes; the Gemma chain itself goes to 128 rows)
     if (out != GEMM_OUT_BF16 && out != GEMM_OUT_BF16_GELU && out != GEMM_OUT_F32) return hipErrorNotSupported;
     QfGemmParams p{};
     p.T = M; p.A = A; p.K = K; p.W = W; p.C = C; p.ldc = ldc; p.bias = bias; p.act = out == GEMM_OUT_BF16_GELU ? 1 : 0;
@@ -1232,6 +1487,18 @@ bool query_forward_supported(const EmbedGeom& g) {
     const uint32_t HQ = g.heads * 256u;
     return (g.hidden == 256u || g.hidden == 768u) && g.head_dim == 256u && g.kv_heads && g.heads % g.kv_heads == 0 &&
            g.inter % 128u == 0 && HQ % 128u == 0 && g.dense_hidden % 128u == 0 && g.hidden % 128u == 0;
+}
+
+// Longest query the chain serves for this geometry: 128 tokens where the two-half attention + o_proj kernel and the staged
+// GEMMs apply (2 or 3 q heads on one kv head, K in the staged kernel's classes), else 64.
+uint32_t query_forward_max_tokens(const EmbedGeom& g) {
+    static const bool fuse_off = [] { const char* e = getenv("CQS_HIP_QUERY_FUSE_ATTN"); return e && e[0] == '0'; }();
+    static const bool staged_off = [] { const char* e = getenv("CQS_HIP_QUERY_STAGED"); return e && e[0] == '0'; }();
+    static const bool split_off = [] { const char* e = getenv("CQS_HIP_QUERY_ROW_SPLIT"); return e && e[0] == '0'; }();
+    auto staged_k = [](uint32_t k) { return k == 768u || k == 1152u || k == 3072u || k == 512u || k == 384u || k == 256u; };
+    const bool long_ok = !fuse_off && !staged_off && !split_off && g.kv_heads == 1u && (g.heads == 2u || g.heads == 3u) && g.hidden % 16u == 0 &&
+                         g.inter % 16u == 0 && staged_k(g.heads * 256u) && staged_k(g.inter);
+    return long_ok ? kQueryFwdMaxTokens : 64u;
 }
 
 hipError_t launch_query_forward(const QueryFwd& f, hipStream_t st) {

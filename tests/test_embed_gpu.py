@@ -77,14 +77,14 @@ def test_sentence_embeddings_gemma_dims(hip):
 
 def test_padding_and_batch_invariance(hip):
     """Packed execution: a sequence's embedding does not depend on its batch neighbours or on padding.  Rows that
-    take the same kernels agree to 1e-6; ONE row of <= 64 tokens takes the search-time kernels (query_kernels.hip,
+    take the same kernels agree to 1e-6; ONE row of <= 128 tokens takes the search-time kernels (query_kernels.hip,
     another f32 association of the same products): cosine >= 0.9999 there (tests/test_query_path_gpu.py)."""
     eng, w = make(SMALL, seed=5)
-    ids, mask = batch(SMALL, [50, 9, 120], seed=6)
+    ids, mask = batch(SMALL, [50, 9, 120, 200], seed=6)
     full = eng.run(ids, mask)
-    for i, n in enumerate([50, 9, 120]):
+    for i, n in enumerate([50, 9, 120, 200]):
         alone = eng.run(ids[i:i + 1, :n], mask[i:i + 1, :n])
-        if n <= 64:
+        if n <= 128:
             assert cos(alone[0], full[i]) > 0.9999
         else:
             assert np.max(np.abs(alone[0] - full[i])) < 1e-6

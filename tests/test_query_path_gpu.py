@@ -1,6 +1,6 @@
-"""The search-time forward (cqs_amd/csrc/query_kernels.hip): ONE sequence of <= 64 tokens runs 4 launches per layer +
+"""The search-time forward (cqs_amd/csrc/query_kernels.hip): ONE sequence of <= 128 tokens runs 4 launches per layer +
 2 for the head, replayed from a hipGraph - what `Embedder::embed_query` (src/embedder/core.rs:768-856) costs on every
-search.  Checked: (1) against the fp32 oracle (oracle/gemma3_ref.py) at lengths {1, 8, 33, 64}, tiny and full
+search.  Checked: (1) against the fp32 oracle (oracle/gemma3_ref.py) at lengths {1, 8, 33, 64, 65, 96, 128}, tiny and full
 geometry - the reference holds no golden vector for the forward, so numerics stay "parity unpinned" as everywhere on
 the embedding path; (2) against the batch path of the same engine build (CQS_HIP_QUERY_PATH=0): cosine >= 0.9999 -
 NOT bit-identical, by design: the query kernels split K over a workgroup's four waves, so f32 sums associate
@@ -14,7 +14,7 @@ from test_embed_gpu import SMALL, batch, cos, make
 
 pytestmark = pytest.mark.gpu
 
-LENS = [1, 8, 33, 64]
+LENS = [1, 8, 33, 64, 65, 96, 128]
 
 
 def _one(cfg, n, seed):
@@ -27,7 +27,9 @@ def test_query_path_matches_the_oracle_and_the_batch_path(hip, monkeypatch):
     monkeypatch.setenv("CQS_HIP_QUERY_PATH", "0")
     eng_b, _ = make(SMALL, seed=31)                      # the same weights through the batch chain only
     monkeypatch.delenv("CQS_HIP_QUERY_PATH")
-    for n in LENS + [2, 4, 5, 9, 15, 16, 17, 24, 25, 31, 32, 40, 48, 49, 56, 63]:      # every row-block edge (blocks of 8 / 16 rows)
+    # every row-block edge (blocks of 8 / 16 rows); 65-128: the keys in two halves of 48 / 64 (online softmax across them),
+    # incl. the edges of the halves (80 / 81: the last block of 16 queries partly filled; 97: first length with 64-key halves)
+    for n in LENS + [2, 4, 5, 9, 15, 16, 17, 24, 25, 31, 32, 40, 48, 49, 56, 63, 66, 80, 81, 95, 97, 112, 113, 127]:
         ids, mask = _one(SMALL, n, seed=100 + n)
         got = eng_q.run(ids, mask)[0]
         ref = G.forward(SMALL, w, ids, mask)[0]
@@ -36,8 +38,8 @@ def test_query_path_matches_the_oracle_and_the_batch_path(hip, monkeypatch):
         assert cos(got, ref) > 0.999, (n, cos(got, ref))          # bf16 matrix-core operands vs an fp32 oracle
         assert cos(got, bat) > 0.9999, (n, cos(got, bat))         # same operands, different f32 association
         assert np.max(np.abs(got - bat)) < 3e-2 * np.abs(bat).max(), (n, float(np.max(np.abs(got - bat))))
-    # 65 tokens and 2-row batches stay on the batch chain: both engines agree bit for bit there
-    ids, mask = _one(SMALL, 65, seed=9)
+    # 129 tokens and 2-row batches stay on the batch chain: both engines agree bit for bit there
+    ids, mask = _one(SMALL, 129, seed=9)
     assert np.array_equal(eng_q.run(ids, mask), eng_b.run(ids, mask))
     ids, mask = batch(SMALL, [8, 33], seed=10)
     assert np.array_equal(eng_q.run(ids, mask), eng_b.run(ids, mask))
@@ -54,7 +56,7 @@ def test_graph_replay_equals_eager_across_lengths(hip, monkeypatch):
     monkeypatch.setenv("CQS_HIP_QUERY_GRAPH", "0")
     eng_e, _ = make(SMALL, seed=33)
     monkeypatch.delenv("CQS_HIP_QUERY_GRAPH")
-    order = [8, 64, 1, 33, 5, 17, 64, 2, 40, 16, 1, 50, 8, 64, 1, 8, 64, 1]
+    order = [8, 64, 1, 33, 5, 17, 64, 2, 40, 16, 1, 50, 8, 64, 1, 8, 64, 1, 100, 128, 70, 100, 128, 100]
     for j, n in enumerate(order):
         ids, mask = _one(SMALL, n, seed=200 + j)
         a, b = eng_g.run(ids, mask), eng_e.run(ids, mask)
@@ -84,11 +86,11 @@ def test_warm_builds_every_graph_and_the_first_query_replays(hip):
     is a graph replay - no eager chain, no capture on the query's clock - and answers what a cold engine answers."""
     eng_w, w = make(SMALL, seed=39)
     eng_c, _ = make(SMALL, seed=39)
-    eng_w.warm(64)
+    eng_w.warm(128)
     st0 = eng_w.query_graph_stats()
     assert st0["failed"] == 0, (st0, eng_w.last_error())
-    assert st0["captured"] >= 2 * 64, st0                            # every length, at least the blocking call's variant on both contexts
-    for j, n in enumerate([37, 5, 64, 1, 22]):
+    assert st0["captured"] >= 2 * 128, st0                           # every length, at least the blocking call's variant on both contexts
+    for j, n in enumerate([37, 5, 64, 1, 22, 128, 77]):
         ids, mask = _one(SMALL, n, seed=700 + j)
         a = eng_w.run(ids, mask)
         st = eng_w.query_graph_stats()
