@@ -537,6 +537,19 @@ def other_configs(torch, np, HipIndex, idx, rows, queries, dim, dev, st):
     out["batch256_1M"] = {"queries_per_sec": round(256 / t, 1), "ms_per_batch": round(t * 1e3, 3), "checked": True,
                           "roofline": {"bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                                        "frac": round(tf / MFMA_F32_PEAK_TF, 4), "dtype": "f32"}}
+    for bsmall in (64, 32):                                     # smaller blocks on the matrix cores
+        qs = qb[:bsmall].contiguous()
+        t, hk, hc = timed(idx, qs, bsmall, 20, 100, 15)
+        for qi in (0, bsmall // 2, bsmall - 1):
+            check_topk(torch, np, rows, qs[qi], hk[qi], hc[qi], 20, what="batch%d_1M[%d]" % (bsmall, qi))
+        tf = 2.0 * bsmall * n * dim / t / 1e12
+        gbs = n * dim * 4 / t / 1e9
+        out["batch%d_1M" % bsmall] = {"queries_per_sec": round(bsmall / t, 1), "ms_per_batch": round(t * 1e3, 3), "checked": True,
+                                       "roofline": {"bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                                                    "frac": round(tf / MFMA_F32_PEAK_TF, 4), "dtype": "f32",
+                                                    "hbm_frac": round(gbs / HBM_PEAK_GBS, 4),
+                                                    "note": "B / 2 flop per corpus byte: at 32 queries the block sits below the ridge (~23 flop/B) and "
+                                                            "is HBM-bound (hbm_frac), at 64 just above it"}}
     small = make_unit_rows(torch, 17523, dim, 0xC950004, dev)  # configs[0] shape (cache resident: not judged against HBM)
     si = HipIndex.build_from_device(None, small.data_ptr(), 17523, dim, device=dev.index or 0, borrow=True, keepalive=small)
     t, hk, hc = timed(si, q1, 1, 20, 500, 50)

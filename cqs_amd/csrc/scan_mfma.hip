@@ -262,13 +262,16 @@ __global__ __launch_bounds__(64 * WQ * WR, WQ * WR / 4) void scan_mfma_kernel(co
 // to LDS one stage later (a whole stage of MFMAs = 4 096 clocks covers the HBM latency).
 constexpr int kBK16 = 16, kLDK16 = 20;
 
-template <int QW, int WQ, int RW, int WR, bool NT>
-__global__ __launch_bounds__(256, 2) void scan_mfma16_kernel(const MfmaParams p) {
+// OCC = workgroups per CU the register allocation leaves room for: 2 (the 128-query tiles: 64 q x 64 rows per wave), 3 for
+// query blocks of <= 64 (<= 168 VGPRs; LDS 46-51 KB each): a 32 / 64-query block is HBM-bound or close to the ridge
+// (2 B n dim flops over n dim 4 bytes = B / 2 flop per byte against ~23 at the ridge), and a third workgroup per CU keeps
+// more of the corpus in flight under the two that multiply.
+template <int QW, int WQ, int RW, int WR, bool NT, int OCC = 2>
+__global__ __launch_bounds__(256, OCC) void scan_mfma16_kernel(const MfmaParams p) {
     constexpr int QT = 32 * QW * WQ, RT = 32 * RW * WR;
     static_assert(WQ * WR == 4, "4 waves per workgroup");
     constexpr int NF4 = (QT + RT) * (kBK16 / 4);
-    constexpr int PER_T = NF4 / 256;
-    static_assert(NF4 % 256 == 0, "stage divides over the workgroup");
+    constexpr int PER_T = (NF4 + 255) / 256;       // (a stage that does not divide over the workgroup: the surplus slots re-copy the last float4)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sQ = smem;                            // [2][QT][kLDK16]
     float* sR = smem + 2 * QT * kLDK16;          // [2][RT][kLDK16]
@@ -284,7 +287,8 @@ __global__ __launch_bounds__(256, 2) void scan_mfma16_kernel(const MfmaParams p)
     uint32_t st_row[PER_T], st_c4[PER_T];        // float4 f of a stage -> (tile row, 16-B column): 4 threads per row
 #pragma unroll
     for (int u = 0; u < PER_T; ++u) {
-        const uint32_t f = (uint32_t)u * 256u + (uint32_t)tid;
+        uint32_t f = (uint32_t)u * 256u + (uint32_t)tid;
+        f = f < (uint32_t)NF4 ? f : (uint32_t)NF4 - 1u;
         st_row[u] = f >> 2;
         st_c4[u] = f & 3u;
     }
@@ -435,7 +439,7 @@ __global__ __launch_bounds__(256, 2) void scan_mfma16_kernel(const MfmaParams p)
     }
 }
 
-template <int QW, int WQ, int RW, int WR>
+template <int QW, int WQ, int RW, int WR, int OCC = 2>
 static hipError_t launch_mfma16_cfg(const ScanArgs& a, uint32_t q0, uint32_t nq, uint32_t slot, hipStream_t st) {
     constexpr int QT = 32 * QW * WQ, RT = 32 * RW * WR;
     MfmaParams p;
@@ -449,9 +453,9 @@ static hipError_t launch_mfma16_cfg(const ScanArgs& a, uint32_t q0, uint32_t nq,
     p.q_blocks = (nq + (uint32_t)QT - 1u) / (uint32_t)QT;
     p.n_tasks = (a.n_pad / (uint32_t)RT) * p.q_blocks;
     const size_t lds = (size_t)2 * (QT + RT) * kLDK16 * sizeof(float);
-    const uint32_t want = 2u * a.n_cu;                      // two workgroups per CU
+    const uint32_t want = (uint32_t)OCC * a.n_cu;           // OCC workgroups per CU
     uint32_t blocks = want < p.n_tasks ? want : p.n_tasks;
-    auto kern = a.nontemporal ? scan_mfma16_kernel<QW, WQ, RW, WR, true> : scan_mfma16_kernel<QW, WQ, RW, WR, false>;
+    auto kern = a.nontemporal ? scan_mfma16_kernel<QW, WQ, RW, WR, true, OCC> : scan_mfma16_kernel<QW, WQ, RW, WR, false, OCC>;
     static DynLdsOnce once[2];
     hipError_t e = once[a.nontemporal ? 1 : 0].ensure((const void*)kern, lds);
     if (e != hipSuccess) return e;
@@ -487,7 +491,19 @@ hipError_t launch_scan_mfma(const ScanArgs& a, uint32_t q0, uint32_t nq, uint32_
     static const int waves = [] { const char* e = getenv("CQS_HIP_SCAN_MFMA_WAVES"); return e ? atoi(e) : 16; }();   // A/B hook: 4 = round-2 kernels, 8 = one 8-wave workgroup per CU
     if (waves == 16) {                                       // 2 workgroups of 4 waves per CU, K staged 16 at a time
         if (nq > 64) return launch_mfma16_cfg<2, 2, 2, 2>(a, q0, nq, slot, st);   // 128 q x 128 rows (x 2 query blocks for 129-256)
-        if (nq > 32) return launch_mfma16_cfg<2, 1, 2, 4>(a, q0, nq, slot, st);   //  64 q x 256 rows
+        // Measured (1M x 768, scan + select, round 4): three workgroups per CU need <= 168 VGPRs - the 64-query tile then spills
+        // 139 registers (1.05 ms against 0.94 at two per CU), the 32-query tile 20 (0.75 against 0.69); two per CU for both.
+        // 9-32 queries used to take round 2's one-workgroup-per-CU kernel: 0.78 -> 0.69 ms at 32 queries, 0.77 -> 0.65 at 16.
+#ifndef CQS_SCAN_MFMA_OCC64
+#define CQS_SCAN_MFMA_OCC64 2
+#endif
+#ifndef CQS_SCAN_MFMA_OCC32
+#define CQS_SCAN_MFMA_OCC32 2
+#endif
+        if (nq > 32) return launch_mfma16_cfg<2, 1, 2, 4, CQS_SCAN_MFMA_OCC64>(a, q0, nq, slot, st);   //  64 q x 256 rows
+#if CQS_SCAN_MFMA_OCC32 > 0
+        return launch_mfma16_cfg<1, 1, 2, 4, CQS_SCAN_MFMA_OCC32>(a, q0, nq, slot, st);                //  32 q x 256 rows
+#endif
     }
     if (waves == 8) {
         if (nq > 128) return launch_mfma_cfg<2, 4, 2, 2>(a, q0, nq, slot, st);   // 256 q x 128 rows, 8 waves of 64 q x 64 rows
