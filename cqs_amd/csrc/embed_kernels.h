@@ -68,7 +68,9 @@ hipError_t launch_gemm_addnorm_pair(const bf16_t* A, const bf16_t* Wp, float* x,
 //                   channels; C bf16 [M, ldc] gets N/2 columns = gelu_tanh(gate) * up
 // Requires N % 128 == 0, K % 64 == 0.
 enum GemmOut { GEMM_OUT_BF16 = 0, GEMM_OUT_F32 = 1, GEMM_OUT_GEGLU = 2, GEMM_OUT_BF16_GELU = 3 /* bf16(gelu_erf(x + bias)): launch_gemm_p8 / _bias only */,
-               GEMM_OUT_ROWMAX = 4 /* launch_gemm_rowmax only */, GEMM_OUT_QKV = 5 /* launch_gemm_qkv_rope only */ };
+               GEMM_OUT_ROWMAX = 4 /* launch_gemm_rowmax only */, GEMM_OUT_QKV = 5 /* launch_gemm_qkv_rope only */,
+               GEMM_OUT_GEGLU4 = 6 /* the 256-row kernel's GeGLU with gate / up rows interleaved per 4 (launch_permute_geglu_rows): the
+                                     pairing happens in registers (one v_permlane16_swap per two accumulators), bf16 stage */ };
 
 // What the QKV projection's fused epilogue needs (GEMM_OUT_QKV): per-head RMSNorm (1 + w), RoPE and the q scale applied
 // to the tile before it is stored - the work of kv_prep_kernel (k heads) and of the attention kernels' Q prologue.
@@ -91,7 +93,13 @@ hipError_t launch_permute_qkv_rows(const bf16_t* wqkv, bf16_t* wf, uint32_t head
 hipError_t launch_gemm_qkv_rope(const bf16_t* A, const bf16_t* W, bf16_t* qkv, uint32_t M, uint32_t K, int tn, const QkvEpilogue& epi,
                                 hipStream_t st);
 hipError_t launch_gemm_bf16(const bf16_t* A, const bf16_t* W, void* C, uint32_t M, uint32_t N, uint32_t K,
-                            uint32_t ldc, GemmOut out, hipStream_t st, const float* bias = nullptr /*[N] f32; not with GEGLU*/);
+                            uint32_t ldc, GemmOut out, hipStream_t st, const float* bias = nullptr /*[N] f32; not with GEGLU*/,
+                            const bf16_t* W_geglu4 = nullptr /*GEGLU: the same rows interleaved per 4 (launch_permute_geglu_rows):
+                                                               the parts the 256-row kernel takes then pair gate / up in registers*/);
+// dst = the GeGLU projection's rows (interleaved per 32: 32 gate rows, the same channels' 32 up rows) re-interleaved per 4:
+// every 16-row tile = [gate c..c+3 | up c..c+3 | gate c+4..c+7 | up c+4..c+7].  Any multiple of 64 rows holds the same
+// channels in both orders, so a projection may be cut there between kernels that read different orders.
+hipError_t launch_permute_geglu_rows(const bf16_t* src, bf16_t* dst, uint32_t N, uint32_t K, hipStream_t st);
 
 // A few rows against a big matrix (the Dense head: M = sequences of the batch): one workgroup per 16 x 16 output tile,
 // K split over its 4 waves.  GEMM_OUT_BF16 / GEMM_OUT_F32; N % 16 == 0, K % 32 == 0; M > 256 goes to launch_gemm_bf16.

@@ -1322,12 +1322,27 @@ int gemm_qkv_rope_tile(uint32_t M, uint32_t hidden, uint32_t heads, uint32_t kv_
 }
 
 hipError_t launch_gemm_bf16(const bf16_t* A, const bf16_t* W, void* C, uint32_t M, uint32_t N, uint32_t K,
-                            uint32_t ldc, GemmOut out, hipStream_t st, const float* bias) {
+                            uint32_t ldc, GemmOut out, hipStream_t st, const float* bias, const bf16_t* W_geglu4) {
     if (M == 0) return hipSuccess;
     if (N % 128u || K % 64u || (bias && out == GEMM_OUT_GEGLU)) return hipErrorInvalidValue;
     const GemmPlan pl = plan_gemm(M, N, K, out);
     const uint32_t n1 = pl.n1;
     const int tn1 = pl.tn1, tn2 = pl.tn2;
+    if (out == GEMM_OUT_GEGLU && W_geglu4) {
+        // parts the 256-row kernel takes read the per-4 interleave and pair gate / up in registers; a part on the 128 x 128 /
+        // few-rows kernels keeps the per-32 order (cuts are multiples of 64 rows: the same channels on either side in both)
+        const size_t coff = n1 / 2u;
+        if (n1 == N) return launch_gemm_one(A, tn1 ? W_geglu4 : W, C, M, N, K, ldc, tn1 ? GEMM_OUT_GEGLU4 : GEMM_OUT_GEGLU, tn1, st, nullptr);
+        if (n1 % 64u) return hipErrorInvalidValue;
+        static const bool no_dual4 = getenv("CQS_HIP_GEMM_NO_DUAL") != nullptr;
+        if (tn1 >= 3 && tn2 >= 3 && tn1 != tn2 && !no_dual4) {
+            const hipError_t d = launch_gemm_p8_dual(A, W_geglu4, C, n1, tn1, W_geglu4 + (size_t)n1 * K, (bf16_t*)C + coff, N - n1, tn2, M, K, ldc, GEMM_OUT_GEGLU4, st);
+            if (d != hipErrorNotSupported) return d;
+        }
+        hipError_t e = launch_gemm_one(A, tn1 ? W_geglu4 : W, C, M, n1, K, ldc, tn1 ? GEMM_OUT_GEGLU4 : GEMM_OUT_GEGLU, tn1, st, nullptr);
+        if (e != hipSuccess) return e;
+        return launch_gemm_one(A, (tn2 ? W_geglu4 : W) + (size_t)n1 * K, (bf16_t*)C + coff, M, N - n1, K, ldc, tn2 ? GEMM_OUT_GEGLU4 : GEMM_OUT_GEGLU, tn2, st, nullptr);
+    }
     if (n1 == N) return launch_gemm_one(A, W, C, M, N, K, ldc, out, tn1, st, bias);
     const size_t coff = out == GEMM_OUT_GEGLU ? n1 / 2u : n1;    // output columns of the first part
     void* c2 = out == GEMM_OUT_F32 ? (void*)((float*)C + coff) : (void*)((bf16_t*)C + coff);

@@ -40,6 +40,7 @@ uint16_t f32_to_bf16_bits(float f) {
 struct LayerW {
     bf16_t *wqkv = nullptr, *wo = nullptr, *wgu = nullptr, *wd = nullptr;
     bf16_t *wo_p = nullptr, *wd_p = nullptr;      // wo / wd in the block order of the pair-split fused kernel (made at finalize)
+    bf16_t* wgu_f = nullptr;                      // wgu rows interleaved per 4 (the 256-row kernel's in-register GeGLU pairing; made at finalize)
     bf16_t* wqkv_f = nullptr;                     // wqkv rows in tile order for the fused norm + RoPE epilogue (made at finalize)
     float *n_in = nullptr, *n_post_attn = nullptr, *n_pre_ffw = nullptr, *n_post_ffw = nullptr, *n_q = nullptr, *n_k = nullptr;
 };
@@ -67,6 +68,7 @@ struct cqs_hip_embedder {
     int fuse_norm = 2;                    // 0 = two launches, 1 = the 64-row kernel of round 3, 2 = the pair-split kernel (128 rows x 384 columns)
     uint32_t fuse_min_rows = 4096;        // token count from which the fused kernel runs (pair-split kernel, ragged 10k-token batches, tickets in
                                           // flight: 9.6 k chunks/s at 1024-4096, 9.4 k at 2048 / 8192, 8.3 k at 12288; round 3's 64-row kernel needed 12288)
+    bool geglu4 = true;                   // CQS_HIP_GEGLU4=0: the 256-row kernel's GeGLU pairs gate / up through an f32 LDS stage (round 2) instead of in registers
     bool fuse_qkv = true;                 // CQS_HIP_QKV_FUSE=0: QKV GEMM + kv_prep + the attention kernel's own Q norm instead of the fused epilogue
     unsigned* fuse_err = nullptr;         // pinned host word (device-visible at fuse_err_dev): set by the pair kernel if an exchange timed out
     unsigned* fuse_err_dev = nullptr;
@@ -376,7 +378,7 @@ int32_t run_layers(cqs_hip_embedder* e, Ctx& c, Slot& sl) {
         };
         // o_proj, then x += norm(y)(1 + w); xn = norm(x)(1 + w'): one launch where workgroups can own whole rows
         if ((rc = proj_norm(c.attn, w.wo, w.wo_p, g.heads * g.head_dim, w.n_post_attn, w.n_pre_ffw, nullptr, 0)) != CQS_HIP_OK) return rc;
-        E_TRY(e, cqs::launch_gemm_bf16(c.xn, w.wgu, c.h, M, 2u * g.inter, H, g.inter, cqs::GEMM_OUT_GEGLU, st));
+        E_TRY(e, cqs::launch_gemm_bf16(c.xn, w.wgu, c.h, M, 2u * g.inter, H, g.inter, cqs::GEMM_OUT_GEGLU, st, nullptr, e->geglu4 ? w.wgu_f : nullptr));
         const bool last = (l + 1u == g.layers);
         const float* w_next = last ? e->n_final : e->L[l + 1].n_in;
         if ((rc = proj_norm(c.h, w.wd, w.wd_p, g.inter, w.n_post_ffw, w_next, c.hidden, last ? 1 : 0)) != CQS_HIP_OK) return rc;
@@ -674,6 +676,15 @@ int32_t cqs_hip_embedder_finalize(cqs_hip_embedder* e) CQS_ABI_TRY {
         E_TRY(e, hipDeviceSynchronize());
     }
     if (const char* fq = getenv("CQS_HIP_QKV_FUSE")) e->fuse_qkv = fq[0] != '0';
+    if (const char* g4 = getenv("CQS_HIP_GEGLU4")) e->geglu4 = g4[0] != '0';
+    if ((2u * e->g.inter) % 64u == 0u) {                               // gate / up rows interleaved per 4 for the in-register pairing
+        if (hipSetDevice(e->device) != hipSuccess) return efail(e, CQS_HIP_ERR_DEVICE, "hipSetDevice");
+        for (LayerW& w : e->L) {
+            if (!w.wgu_f) E_TRY(e, dmalloc(&w.wgu_f, (size_t)2 * e->g.inter * e->g.hidden));
+            E_TRY(e, cqs::launch_permute_geglu_rows(w.wgu, w.wgu_f, 2u * e->g.inter, e->g.hidden, nullptr));
+        }
+        E_TRY(e, hipDeviceSynchronize());
+    }
     e->QL.resize(e->L.size());
     for (size_t l = 0; l < e->L.size(); ++l) {
         const LayerW& w = e->L[l];
@@ -760,7 +771,7 @@ void cqs_hip_embedder_destroy(cqs_hip_embedder* e) CQS_ABI_TRY {
         if (sl.done) (void)hipEventDestroy(sl.done);
     }
     for (LayerW& w : e->L) {
-        void* ws[] = {w.wqkv_f, w.wo_p, w.wd_p, w.wqkv, w.wo, w.wgu, w.wd, w.n_in, w.n_post_attn, w.n_pre_ffw, w.n_post_ffw, w.n_q, w.n_k};
+        void* ws[] = {w.wgu_f, w.wqkv_f, w.wo_p, w.wd_p, w.wqkv, w.wo, w.wgu, w.wd, w.n_in, w.n_post_attn, w.n_pre_ffw, w.n_post_ffw, w.n_q, w.n_k};
         for (void* p : ws) (void)hipFree(p);
     }
     for (Ctx& c : e->ctx)
@@ -1023,6 +1034,13 @@ void cqs_hip_debug_embedder_set_fuse_norm(cqs_hip_embedder* e, int32_t on, uint3
     std::lock_guard<std::mutex> lk(e->mu);
     e->fuse_norm = on < 0 ? 0 : (on > 2 ? 2 : on);     // 0 = two launches, 1 = the 64-row kernel, 2 = the pair-split kernel
     if (min_rows) e->fuse_min_rows = min_rows;
+} CQS_ABI_CATCH_VOID
+
+// Test hook (not part of the public header): the 256-row kernel's in-register GeGLU pairing on / off for THIS engine.
+void cqs_hip_debug_embedder_set_geglu4(cqs_hip_embedder* e, int32_t on) CQS_ABI_TRY {
+    if (!e) return;
+    std::lock_guard<std::mutex> lk(e->mu);
+    e->geglu4 = on != 0;
 } CQS_ABI_CATCH_VOID
 
 // Test hook (not part of the public header): the QKV projection's fused norm + RoPE epilogue on / off for THIS engine.

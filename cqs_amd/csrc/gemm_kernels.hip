@@ -44,6 +44,23 @@ __device__ __forceinline__ float p8_gelu_erf(float x) {
     const float e = 1.0f - poly * __expf(-z * z);            // erf(|x| / sqrt 2)
     return 0.5f * x * (1.0f + __builtin_copysignf(e, x));
 }
+// gelu_tanh(g) * u for two channels at once, in packed f32 arithmetic (v_pk_mul / v_pk_fma: two lanes' worth per instruction;
+// the epilogue holds no MFMAs for them to disturb): x sigmoid(2 k0 (x + k1 x^3)) = x / (1 + 2^(x (c0 + c1 x^2))),
+// c0 = -2 k0 log2(e), c1 = c0 k1: per pair 2 v_exp + 2 v_rcp + 6 packed operations.
+typedef float p8_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ p8_f2 p8_geglu2(p8_f2 g, p8_f2 u) {
+    const float c0 = -2.0f * 0.7978845608028654f * 1.4426950408889634f, c1 = c0 * 0.044715f;
+    const p8_f2 t = g * g;
+    const p8_f2 w = g * __builtin_elementwise_fma(t, (p8_f2)(c1), (p8_f2)(c0));
+    p8_f2 e;
+    e[0] = __builtin_amdgcn_exp2f(w[0]);
+    e[1] = __builtin_amdgcn_exp2f(w[1]);
+    const p8_f2 d = e + (p8_f2)(1.0f);
+    p8_f2 r;
+    r[0] = __builtin_amdgcn_rcpf(d[0]);
+    r[1] = __builtin_amdgcn_rcpf(d[1]);
+    return g * r * u;
+}
 __device__ __forceinline__ float p8_gelu_tanh(float x) {
     const float k0 = 0.7978845608028654f, k1 = 0.044715f;
     const float u2 = 2.0f * k0 * (x + k1 * x * x * x);
@@ -237,6 +254,17 @@ __device__ __forceinline__ void gemm_pp_body(const bf16_t* __restrict__ A, const
     }
     if (wm == 0) P8_BARRIER();                                 // wave row 0 waits for row 1's last interval
 
+#if defined(P8_ABLATE_NOEPI)     // timing experiment (wrong results): the main loop alone
+    {
+        float sacc = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) sacc += acc[i][j][0] + acc[i][j][3];
+        if (sacc == 12345.678f) *(float*)Cv = sacc;
+        return;
+    }
+#endif
     // ---- epilogue: acc[i][j][r] = C[m = wm*128 + i*16 + l15][n = wn*16TN + j*16 + 4 lg + r]
     if (OUT == GEMM_OUT_F32) {           // (only the two tiny Dense GEMMs of the head: direct 16-byte stores)
 #pragma unroll
@@ -371,25 +399,36 @@ __device__ __forceinline__ void gemm_pp_body(const bf16_t* __restrict__ A, const
                 const uint32_t sr = (uint32_t)(16 * wid + 2 * it + hw);
                 const bf4 lo = *(const bf4*)(stage + (size_t)sr * kStride + 4 * l31);
                 const bf4 hi = *(const bf4*)(stage + (size_t)sr * kStride + 128 + 4 * l31);
-                float vlo[4], vhi[4], ss = 0.f;
+                // packed f32 arithmetic (two elements per instruction; the same operations in the same order per element
+                // as the scalar form: v * inv * (1 + w), then the rotation, then the scale)
+                p8_f2 vlo[2], vhi[2];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { vlo[e] = (float)lo[e]; vhi[e] = (float)hi[e]; }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) ss += vlo[e] * vlo[e];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) ss += vhi[e] * vhi[e];
+                for (int h = 0; h < 2; ++h) {
+                    vlo[h][0] = (float)lo[2 * h]; vlo[h][1] = (float)lo[2 * h + 1];
+                    vhi[h][0] = (float)hi[2 * h]; vhi[h][1] = (float)hi[2 * h + 1];
+                }
+                p8_f2 s2 = vlo[0] * vlo[0];
+                s2 = __builtin_elementwise_fma(vlo[1], vlo[1], s2);
+                s2 = __builtin_elementwise_fma(vhi[0], vhi[0], s2);
+                s2 = __builtin_elementwise_fma(vhi[1], vhi[1], s2);
+                float ss = s2[0] + s2[1];
 #pragma unroll
                 for (int off = 16; off >= 1; off >>= 1) ss += __shfl_xor(ss, off, 64);   // over the row's 32 lanes
                 const float inv = rsqrtf(ss / 256.0f + eps);
-                const float c4[4] = {cs0[it][0], cs0[it][2], cs1[it][0], cs1[it][2]};
-                const float s4[4] = {cs0[it][1], cs0[it][3], cs1[it][1], cs1[it][3]};
+                const p8_f2 inv2 = (p8_f2)(inv), qs2 = (p8_f2)(qs);
+                // (cos, sin) x 4 dims: cs0 = (c0, s0, c1, s1), cs1 = (c2, s2, c3, s3)
+                const p8_f2 c2[2] = {{cs0[it][0], cs0[it][2]}, {cs1[it][0], cs1[it][2]}};
+                const p8_f2 n2[2] = {{cs0[it][1], cs0[it][3]}, {cs1[it][1], cs1[it][3]}};
                 bf4 olo, ohi;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float nlo = vlo[e] * inv * w1lo[e];
-                    const float nhi = vhi[e] * inv * w1hi[e];
-                    olo[e] = (bf16_t)((nlo * c4[e] - nhi * s4[e]) * qs);     // d < 128: n cos - x[d + 128] sin
-                    ohi[e] = (bf16_t)((nhi * c4[e] + nlo * s4[e]) * qs);     // d >= 128: n cos + x[d - 128] sin
+                for (int h = 0; h < 2; ++h) {
+                    const p8_f2 w1l = {w1lo[2 * h], w1lo[2 * h + 1]}, w1h = {w1hi[2 * h], w1hi[2 * h + 1]};
+                    const p8_f2 nlo = vlo[h] * inv2 * w1l;
+                    const p8_f2 nhi = vhi[h] * inv2 * w1h;
+                    const p8_f2 rl = (nlo * c2[h] - nhi * n2[h]) * qs2;       // d < 128: n cos - x[d + 128] sin
+                    const p8_f2 rh = (nhi * c2[h] + nlo * n2[h]) * qs2;       // d >= 128: n cos + x[d - 128] sin
+                    olo[2 * h] = (bf16_t)rl[0]; olo[2 * h + 1] = (bf16_t)rl[1];
+                    ohi[2 * h] = (bf16_t)rh[0]; ohi[2 * h + 1] = (bf16_t)rh[1];
                 }
                 if (grow[it] < M) {
                     bf16_t* dst = Cq + (size_t)grow[it] * ldc + tcol * 256u + 4u * (uint32_t)l31;
@@ -415,6 +454,54 @@ __device__ __forceinline__ void gemm_pp_body(const bf16_t* __restrict__ A, const
                     const uint32_t row = m0 + (sr >> 6) * 128u + (uint32_t)(64 * p) + (sr & 63u);
                     if (row < M) *(bf4*)(Cq + (size_t)row * ldc + vcol0 + ch * 4u) = *(const bf4*)(stage + (size_t)sr * kStride + ch * 4u);
                 }
+            }
+            if (p == 0) __syncthreads();
+        }
+        return;
+    }
+    if constexpr (OUT == GEMM_OUT_GEGLU4) {
+        // W rows interleaved per 4 (launch_permute_geglu_rows): in a 16-column n-tile, lane group lg holds gate channels
+        // c + 0..3 (lg = 0), up c + 0..3 (lg = 1), gate c + 4..7 (lg = 2), up c + 4..7 (lg = 3), c = 8 x the tile's index.
+        // v_permlane16_swap(a, b) exchanges a's odd 16-lane rows with b's even rows: applied to accumulator registers (0, 2)
+        // and (1, 3) it leaves lane group lg with gate AND up of channels c + 2 lg and c + 2 lg + 1 - the pairing costs two
+        // instructions per tile, gelu runs on the accumulators themselves, and the stage holds the bf16 result (half the
+        // columns, two passes) instead of f32 pairs (four passes): round 4, after timing builds put the old epilogue at 24 of
+        // the GeGLU projection's 68 us (6.5 us of them the f32 stage).
+        constexpr int ON = BN / 2;                                  // output channels of the tile
+        constexpr int kStride = ON + 4;                             // elements
+        constexpr int kCPR = ON / 4;                                // 8-byte chunks per row
+        bf16_t* const stage = p8smem;                               // 128 x kStride elements <= 42 KiB
+        typedef unsigned pu2 __attribute__((ext_vector_type(2)));
+        typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                bf16_t* rowp = stage + (size_t)(wm * 64 + t * 16 + l15) * kStride;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const f4 a = acc[4 * p + t][j];
+                    const pu2 s02 = __builtin_amdgcn_permlane16_swap(__float_as_uint(a[0]), __float_as_uint(a[2]), false, false);
+                    const pu2 s13 = __builtin_amdgcn_permlane16_swap(__float_as_uint(a[1]), __float_as_uint(a[3]), false, false);
+                    p8_f2 gt, up;
+                    gt[0] = __uint_as_float(s02[0]); gt[1] = __uint_as_float(s13[0]);                 // gate of channels c + 2 lg, + 1
+                    up[0] = __uint_as_float(s02[1]); up[1] = __uint_as_float(s13[1]);
+#if defined(P8_GEGLU4_SCALAR_GELU)   // (round 2's formula, one channel at a time: bit-identical to the f32-stage epilogue)
+                    const p8_f2 res = {p8_gelu_tanh(gt[0]) * up[0], p8_gelu_tanh(gt[1]) * up[1]};
+#else
+                    const p8_f2 res = p8_geglu2(gt, up);
+#endif
+                    bf2 o;
+                    o[0] = (bf16_t)res[0];
+                    o[1] = (bf16_t)res[1];
+                    *(bf2*)(rowp + (wn * TN + j) * 8 + 2 * lg) = o;
+                }
+            }
+            __syncthreads();
+            for (uint32_t c = (uint32_t)tid; c < 128u * (uint32_t)kCPR; c += 512u) {
+                const uint32_t r = c / (uint32_t)kCPR, cc = c % (uint32_t)kCPR;
+                const uint32_t row = m0 + (r >> 6) * 128u + (uint32_t)(4 * p) * 16u + (r & 63u);
+                if (row < M) *(bf4*)((bf16_t*)Cv + (size_t)row * ldc + n0 / 2u + cc * 4u) = *(const bf4*)(stage + (size_t)r * kStride + cc * 4u);
             }
             if (p == 0) __syncthreads();
         }
@@ -532,6 +619,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_dual_kernel(const bf16_t* __re
                                                               const bf16_t* __restrict__ Wb, void* __restrict__ Cb,
                                                               uint32_t Nb, uint32_t M, uint32_t K, uint32_t ldc,
                                                               uint32_t n_first) {
+    // (Round 4 tried the two problems' workgroups interleaved in groups of 8, so that each round holds wide and narrow tiles
+    // and the CUs' load / store bursts drift apart: 68.1 -> 72.0 us for the GeGLU projection - the four column tiles of a
+    // row block no longer run side by side on one XCD and its A panel is fetched into more L2s.  One after the other it stays.)
     if (blockIdx.x < n_first) gemm_pp_body<TNA, OUT>(A, Wa, Ca, M, Na, K, ldc, blockIdx.x);
     else gemm_pp_body<TNB, OUT>(A, Wb, Cb, M, Nb, K, ldc, blockIdx.x - n_first);
 }
@@ -570,6 +660,22 @@ hipError_t launch_p8(const bf16_t* A, const bf16_t* W, void* C, uint32_t M, uint
 }
 
 }  // namespace
+
+// gate / up rows: interleave per 32 (src) -> per 4 (dst); one thread per 16 bytes
+__global__ __launch_bounds__(256) void permute_geglu_rows_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, uint32_t N, uint32_t K) {
+    const uint32_t chunk = blockIdx.x * 256u + threadIdx.x, cpr = K / 8u;
+    if (chunk >= N * cpr) return;
+    const uint32_t d = chunk / cpr, c = chunk % cpr;
+    const uint32_t jt = d / 16u, q = (d % 16u) / 4u, r = d % 4u;
+    const uint32_t ch = 8u * jt + 4u * (q >> 1) + r, up = q & 1u;
+    const uint32_t srow = 64u * (ch / 32u) + 32u * up + ch % 32u;
+    *(bf8*)(dst + (size_t)d * K + (size_t)c * 8u) = *(const bf8*)(src + (size_t)srow * K + (size_t)c * 8u);
+}
+hipError_t launch_permute_geglu_rows(const bf16_t* src, bf16_t* dst, uint32_t N, uint32_t K, hipStream_t st) {
+    if (!src || !dst || N % 64u || K % 8u) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(permute_geglu_rows_kernel, dim3((N * (K / 8u) + 255u) / 256u), dim3(256), 0, st, src, dst, N, K);
+    return hipGetLastError();
+}
 
 hipError_t launch_permute_qkv_rows(const bf16_t* wqkv, bf16_t* wf, uint32_t heads, uint32_t kv_heads, uint32_t K, hipStream_t st) {
     if (!wqkv || !wf || heads != 3u * kv_heads || K % 8u) return hipErrorInvalidValue;
@@ -615,6 +721,7 @@ hipError_t launch_gemm_p8(const bf16_t* A, const bf16_t* W, void* C, uint32_t M,
         if (out == GEMM_OUT_F32) return launch_p8<TNV, GEMM_OUT_F32>(A, W, C, M, N, K, ldc, bias, st);    \
         if (out == GEMM_OUT_BF16_GELU) return launch_p8<TNV, GEMM_OUT_BF16_GELU>(A, W, C, M, N, K, ldc, bias, st); \
         if (bias) return hipErrorInvalidValue;                                                            \
+        if (out == GEMM_OUT_GEGLU4) return launch_p8<TNV, GEMM_OUT_GEGLU4>(A, W, C, M, N, K, ldc, nullptr, st); \
         return launch_p8<TNV, GEMM_OUT_GEGLU>(A, W, C, M, N, K, ldc, nullptr, st);
     switch (tn) {
         P8_CASE(3)
@@ -652,7 +759,8 @@ hipError_t launch_gemm_p8_dual(const bf16_t* A, const bf16_t* Wa, void* Ca, uint
 #define P8_DUAL(TA, TB)                                                                                              \
     if (tn_a == TA && tn_b == TB)                                                                                    \
         return out == GEMM_OUT_BF16 ? launch_p8_dual<TA, TB, GEMM_OUT_BF16>(A, Wa, Ca, Na, Wb, Cb, Nb, M, K, ldc, st) \
-                                    : launch_p8_dual<TA, TB, GEMM_OUT_GEGLU>(A, Wa, Ca, Na, Wb, Cb, Nb, M, K, ldc, st);
+               : out == GEMM_OUT_GEGLU4 ? launch_p8_dual<TA, TB, GEMM_OUT_GEGLU4>(A, Wa, Ca, Na, Wb, Cb, Nb, M, K, ldc, st) \
+                                        : launch_p8_dual<TA, TB, GEMM_OUT_GEGLU>(A, Wa, Ca, Na, Wb, Cb, Nb, M, K, ldc, st);
     P8_DUAL(5, 4)
     P8_DUAL(5, 3)
     P8_DUAL(4, 3)

@@ -595,3 +595,33 @@ def test_fused_qkv_epilogue_matches_the_three_launch_chain_and_the_oracle(hip, m
     for i in range(32):
         assert cos(fused[i], plain[i]) > 0.99999, (i, cos(fused[i], plain[i]))
     eng.close()
+
+
+def test_geglu_in_register_pairing_matches_the_f32_stage(hip, monkeypatch):
+    """Round 4: the 256-row GEMM kernel's GeGLU epilogue reads gate / up rows interleaved per 4 and pairs them in registers
+    (`v_permlane16_swap`), gelu on the accumulators (packed f32 arithmetic, the sigmoid form of the tanh approximation),
+    bf16 stage - instead of staging f32 pairs through LDS.  Same accumulators; the gelu's last bits differ (with the scalar
+    formula - build flag P8_GEGLU4_SCALAR_GELU - the two epilogues were bit-identical: that is how the pairing was checked),
+    so the embeddings agree to rounding: cosine >= 0.99999, max |d| tiny.  32 x 512 tokens (the dual launch of 256 x 320 and
+    256 x 256 tiles), a ragged batch (other tile plans, a partly filled row tile) and forced tile widths."""
+    import ctypes as C
+    cfg = G.GemmaConfig(vocab_size=4096, hidden=768, layers=2, heads=3, kv_heads=1, head_dim=256, intermediate=1152,
+                        dense_hidden=3072, sliding_window=512, sliding_pattern=2, max_seq=2048)
+    eng, w = make(cfg, seed=47)
+    f = eng._lib.cqs_hip_debug_embedder_set_geglu4
+    f.restype = None
+    f.argtypes = [C.c_void_p, C.c_int32]
+    for lens, tile in (([512] * 32, None), ([700, 650, 33, 517, 2048, 1900, 1000], None), ([400, 300, 277], "pp:3"), ([400, 300, 277], "pp:4")):
+        if tile:
+            monkeypatch.setenv("CQS_HIP_GEMM_TILE", tile)
+        ids, mask = batch(cfg, lens, seed=sum(lens))
+        f(eng._h, 0)
+        old = eng.run(ids, mask)
+        f(eng._h, 1)
+        new = eng.run(ids, mask)
+        for i in range(len(lens)):
+            assert cos(old[i], new[i]) > 0.99999, (lens, tile, i, cos(old[i], new[i]))
+        assert np.max(np.abs(old - new)) < 1e-2 * np.abs(old).max(), (lens, tile, float(np.max(np.abs(old - new))))
+        if tile:
+            monkeypatch.delenv("CQS_HIP_GEMM_TILE")
+    eng.close()
