@@ -20,6 +20,7 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <condition_variable>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -88,9 +89,16 @@ struct cqs_hip_bert {
         void* out = nullptr;         // pinned results: kind 1: ids [B cap] u32 | weights [B cap] f32 | counts [B] u32; kind 2: [B, H] f32
         size_t out_cap = 0;          // bytes
         hipEvent_t done = nullptr;
+        bool collecting = false;     // a collect is waiting on this ticket (a second collector of the same ticket is refused)
     };
+    // Three TICKET slots (the public contract: up to 3 tickets in flight) + one slot RESERVED for the blocking calls
+    // (cqs_hip_splade_encode, _encode_sparse, cqs_hip_rerank_logits, cqs_hip_bert_embed, _hidden), so that a search-time
+    // query or rerank never fails because an index run holds every ticket; a blocking call that finds the reserved slot
+    // taken by another thread's blocking call waits for it (cv).
     static constexpr int kSlots = 3;
-    Slot slot[kSlots];
+    static constexpr int kReserved = kSlots;
+    Slot slot[kSlots + 1];
+    std::condition_variable slot_cv;
     uint64_t next_ticket = 1;
     int last_ctx = 1;                    // context of the previous ticket (ties alternate)
 
@@ -274,11 +282,24 @@ int32_t run_encoder(cqs_hip_bert* e, BCtx& c, BSlot& sl, const int32_t* tokens, 
     return CQS_HIP_OK;
 }
 
-// A free submission slot + the context the next ticket runs on (consecutive tickets alternate).
-int32_t take_slot(cqs_hip_bert* e, BSlot** sl, BCtx** c) {
+// Set (per thread) by the blocking forms around their submit: the submission takes the reserved slot.
+thread_local bool tl_blocking_call = false;
+struct BlockingScope {
+    BlockingScope() { tl_blocking_call = true; }
+    ~BlockingScope() { tl_blocking_call = false; }
+};
+// The reserved slot, waiting (mu released meanwhile) while another thread's blocking call holds it.
+void wait_reserved(cqs_hip_bert* e, std::unique_lock<std::mutex>& lk) {
+    e->slot_cv.wait(lk, [&] { return e->slot[cqs_hip_bert::kReserved].ticket == 0; });
+}
+// A free submission slot + the context the next ticket runs on (consecutive tickets alternate).  reserved: the blocking
+// calls' own slot (the caller has waited for it under the lock).
+int32_t take_slot(cqs_hip_bert* e, BSlot** sl, BCtx** c, bool reserved = false) {
     *sl = nullptr;
-    for (BSlot& s : e->slot)
-        if (s.ticket == 0) { *sl = &s; break; }
+    if (reserved) *sl = &e->slot[cqs_hip_bert::kReserved];
+    else
+        for (int i = 0; i < cqs_hip_bert::kSlots; ++i)
+            if (e->slot[i].ticket == 0) { *sl = &e->slot[i]; break; }
     if (!*sl) return bfail(e, CQS_HIP_ERR_INVALID, "bert: every submission slot is in flight (collect a ticket first)");
     // the context with fewer tickets in flight; ties alternate, an idle engine takes context 0 (one blocking call at a time
     // keeps re-using ONE set of activation scratch instead of two taking turns in L2 / the Infinity Cache)
@@ -490,14 +511,15 @@ int32_t splade_forward(cqs_hip_bert* e, BCtx& c, BSlot& sl, const int32_t* token
 int32_t cqs_hip_splade_encode(cqs_hip_bert* e, const int32_t* tokens, const uint32_t* lens, uint32_t batch, float* out_dense) CQS_ABI_TRY {
     CQS_ROCTX_RANGE("cqs_hip_splade_encode");
     if (!e) return CQS_HIP_ERR_INVALID;
-    std::lock_guard<std::mutex> lk(e->mu);
+    std::unique_lock<std::mutex> lk(e->mu);
     int32_t rc = check_ready(e, CQS_HIP_BERT_HEAD_MLM);
     if (rc != CQS_HIP_OK) return rc;
     if (batch == 0) return CQS_HIP_OK;
     if (!lens || !out_dense) return bfail(e, CQS_HIP_ERR_INVALID, "splade: null buffer");
     B_TRY(e, hipSetDevice(e->device));
     BSlot* sl; BCtx* c;
-    if ((rc = take_slot(e, &sl, &c)) != CQS_HIP_OK) return rc;
+    wait_reserved(e, lk);                                     // (another thread's blocking call may hold it: mu is released meanwhile)
+    if ((rc = take_slot(e, &sl, &c, true)) != CQS_HIP_OK) return rc;
     uint32_t M = 0;
     rc = splade_forward(e, *c, *sl, tokens, lens, batch, &M);
     if (rc != CQS_HIP_OK) return rc;
@@ -519,7 +541,7 @@ int32_t cqs_hip_splade_submit_sparse(cqs_hip_bert* e, const int32_t* tokens, con
                                      uint32_t cap, uint64_t* ticket) CQS_ABI_TRY {
     CQS_ROCTX_RANGE("cqs_hip_splade_submit_sparse");
     if (!e) return CQS_HIP_ERR_INVALID;
-    std::lock_guard<std::mutex> lk(e->mu);
+    std::unique_lock<std::mutex> lk(e->mu);
     int32_t rc = check_ready(e, CQS_HIP_BERT_HEAD_MLM);
     if (rc != CQS_HIP_OK) return rc;
     if (!ticket) return bfail(e, CQS_HIP_ERR_INVALID, "splade: null ticket");
@@ -527,7 +549,9 @@ int32_t cqs_hip_splade_submit_sparse(cqs_hip_bert* e, const int32_t* tokens, con
     if (batch == 0 || !lens || cap == 0) return bfail(e, CQS_HIP_ERR_INVALID, "splade: empty batch / null buffer / zero cap");
     B_TRY(e, hipSetDevice(e->device));
     BSlot* sl; BCtx* c;
-    if ((rc = take_slot(e, &sl, &c)) != CQS_HIP_OK) return rc;
+    const bool reserved = tl_blocking_call;                   // the blocking form (submit + collect) takes the reserved slot
+    if (reserved) wait_reserved(e, lk);
+    if ((rc = take_slot(e, &sl, &c, reserved)) != CQS_HIP_OK) return rc;
     uint32_t M = 0;
     rc = splade_forward(e, *c, *sl, tokens, lens, batch, &M);
     if (rc != CQS_HIP_OK) return rc;
@@ -567,19 +591,25 @@ int32_t cqs_hip_splade_collect_sparse(cqs_hip_bert* e, uint64_t ticket, uint32_t
         std::lock_guard<std::mutex> lk(e->mu);
         sl = find_ticket(e, ticket, 1);
         if (!sl) return bfail(e, CQS_HIP_ERR_INVALID, "splade collect: unknown ticket");
+        if (sl->collecting) return bfail(e, CQS_HIP_ERR_INVALID, "splade collect: this ticket is already being collected");
+        sl->collecting = true;
     }
+    struct Release {                                         // whatever path leaves: the slot is free again and waiters hear of it
+        cqs_hip_bert* e; BSlot* sl;
+        ~Release() { sl->collecting = false; sl->ticket = 0; e->slot_cv.notify_all(); }
+    };
     (void)hipSetDevice(e->device);
     const hipError_t he = hipEventSynchronize(sl->done);     // outside the lock: other threads may submit meanwhile
     std::lock_guard<std::mutex> lk(e->mu);
-    if (he != hipSuccess) { sl->ticket = 0; return bfail(e, CQS_HIP_ERR_DEVICE, "splade collect: device failure", he); }
+    Release release{e, sl};
+    if (he != hipSuccess) return bfail(e, CQS_HIP_ERR_DEVICE, "splade collect: device failure", he);
     if (out_ids) {                                           // NULL: abandon the ticket
-        if (!out_weights || !out_counts) { sl->ticket = 0; return bfail(e, CQS_HIP_ERR_INVALID, "splade collect: null buffer"); }
+        if (!out_weights || !out_counts) return bfail(e, CQS_HIP_ERR_INVALID, "splade collect: null buffer");
         const size_t n = (size_t)sl->B * sl->cap;
         memcpy(out_ids, sl->out, n * 4);
         memcpy(out_weights, (char*)sl->out + n * 4, n * 4);
         memcpy(out_counts, (char*)sl->out + n * 8, (size_t)sl->B * 4);
     }
-    sl->ticket = 0;
     return CQS_HIP_OK;
 } CQS_ABI_CATCH(e)
 
@@ -594,6 +624,7 @@ int32_t cqs_hip_splade_encode_sparse(cqs_hip_bert* e, const int32_t* tokens, con
     }
     if (!out_ids || !out_weights || !out_counts) { std::lock_guard<std::mutex> lk(e->mu); return bfail(e, CQS_HIP_ERR_INVALID, "splade: null buffer / zero cap"); }
     uint64_t t = 0;
+    BlockingScope reserved_slot;
     const int32_t rc = cqs_hip_splade_submit_sparse(e, tokens, lens, batch, threshold, cap, &t);
     if (rc != CQS_HIP_OK) return rc;
     return cqs_hip_splade_collect_sparse(e, t, out_ids, out_weights, out_counts);
@@ -605,7 +636,7 @@ int32_t cqs_hip_rerank_logits(cqs_hip_bert* e, const int32_t* tokens, const int3
                               uint32_t batch, float* out_logits) CQS_ABI_TRY {
     CQS_ROCTX_RANGE("cqs_hip_rerank_logits");
     if (!e) return CQS_HIP_ERR_INVALID;
-    std::lock_guard<std::mutex> lk(e->mu);
+    std::unique_lock<std::mutex> lk(e->mu);
     int32_t rc = check_ready(e, CQS_HIP_BERT_HEAD_CLASSIFIER);
     if (rc != CQS_HIP_OK) return rc;
     if (batch == 0) return CQS_HIP_OK;
@@ -614,7 +645,8 @@ int32_t cqs_hip_rerank_logits(cqs_hip_bert* e, const int32_t* tokens, const int3
         if (lens[b] == 0) return bfail(e, CQS_HIP_ERR_INVALID, "rerank: empty sequence (no [CLS] row to pool)");
     B_TRY(e, hipSetDevice(e->device));
     BSlot* sl; BCtx* c;
-    if ((rc = take_slot(e, &sl, &c)) != CQS_HIP_OK) return rc;
+    wait_reserved(e, lk);                                     // (another thread's blocking call may hold it: mu is released meanwhile)
+    if ((rc = take_slot(e, &sl, &c, true)) != CQS_HIP_OK) return rc;
     uint32_t M = 0;
     rc = run_encoder(e, *c, *sl, tokens, type_ids, lens, batch, &M);
     if (rc != CQS_HIP_OK) return rc;
@@ -642,7 +674,7 @@ int32_t cqs_hip_bert_embed_submit(cqs_hip_bert* e, const int32_t* tokens, const 
                                   uint32_t pooling, uint64_t* ticket) CQS_ABI_TRY {
     CQS_ROCTX_RANGE("cqs_hip_bert_embed_submit");
     if (!e) return CQS_HIP_ERR_INVALID;
-    std::lock_guard<std::mutex> lk(e->mu);
+    std::unique_lock<std::mutex> lk(e->mu);
     int32_t rc = check_ready(e, CQS_HIP_BERT_HEAD_NONE);
     if (rc != CQS_HIP_OK) return rc;
     if (!ticket) return bfail(e, CQS_HIP_ERR_INVALID, "bert_embed: null ticket");
@@ -655,7 +687,9 @@ int32_t cqs_hip_bert_embed_submit(cqs_hip_bert* e, const int32_t* tokens, const 
     }
     B_TRY(e, hipSetDevice(e->device));
     BSlot* sl; BCtx* c;
-    if ((rc = take_slot(e, &sl, &c)) != CQS_HIP_OK) return rc;
+    const bool reserved = tl_blocking_call;                   // the blocking form (submit + collect) takes the reserved slot
+    if (reserved) wait_reserved(e, lk);
+    if ((rc = take_slot(e, &sl, &c, reserved)) != CQS_HIP_OK) return rc;
     uint32_t M = 0;
     rc = run_encoder(e, *c, *sl, tokens, type_ids, lens, batch, &M);
     if (rc != CQS_HIP_OK) return rc;
@@ -683,13 +717,19 @@ int32_t cqs_hip_bert_embed_collect(cqs_hip_bert* e, uint64_t ticket, float* out)
         std::lock_guard<std::mutex> lk(e->mu);
         sl = find_ticket(e, ticket, 2);
         if (!sl) return bfail(e, CQS_HIP_ERR_INVALID, "bert_embed collect: unknown ticket");
+        if (sl->collecting) return bfail(e, CQS_HIP_ERR_INVALID, "bert_embed collect: this ticket is already being collected");
+        sl->collecting = true;
     }
+    struct Release {
+        cqs_hip_bert* e; BSlot* sl;
+        ~Release() { sl->collecting = false; sl->ticket = 0; e->slot_cv.notify_all(); }
+    };
     (void)hipSetDevice(e->device);
     const hipError_t he = hipEventSynchronize(sl->done);
     std::lock_guard<std::mutex> lk(e->mu);
-    if (he != hipSuccess) { sl->ticket = 0; return bfail(e, CQS_HIP_ERR_DEVICE, "bert_embed collect: device failure", he); }
+    Release release{e, sl};
+    if (he != hipSuccess) return bfail(e, CQS_HIP_ERR_DEVICE, "bert_embed collect: device failure", he);
     if (out) memcpy(out, sl->out, (size_t)sl->B * e->cfg.hidden * 4);               // NULL: abandon the ticket
-    sl->ticket = 0;
     return CQS_HIP_OK;
 } CQS_ABI_CATCH(e)
 
@@ -703,6 +743,7 @@ int32_t cqs_hip_bert_embed(cqs_hip_bert* e, const int32_t* tokens, const int32_t
     }
     if (!out) { std::lock_guard<std::mutex> lk(e->mu); return bfail(e, CQS_HIP_ERR_INVALID, "bert_embed: null buffer / unknown pooling"); }
     uint64_t t = 0;
+    BlockingScope reserved_slot;
     const int32_t rc = cqs_hip_bert_embed_submit(e, tokens, type_ids, lens, batch, pooling, &t);
     if (rc != CQS_HIP_OK) return rc;
     return cqs_hip_bert_embed_collect(e, t, out);
@@ -712,14 +753,15 @@ int32_t cqs_hip_bert_embed(cqs_hip_bert* e, const int32_t* tokens, const int32_t
 int32_t cqs_hip_bert_hidden(cqs_hip_bert* e, const int32_t* tokens, const int32_t* type_ids, const uint32_t* lens,
                             uint32_t batch, float* out_hidden) CQS_ABI_TRY {
     if (!e) return CQS_HIP_ERR_INVALID;
-    std::lock_guard<std::mutex> lk(e->mu);
+    std::unique_lock<std::mutex> lk(e->mu);
     int32_t rc = check_ready(e, 0xFFFFFFFFu);
     if (rc != CQS_HIP_OK) return rc;
     if (batch == 0) return CQS_HIP_OK;
     if (!lens || !out_hidden || !tokens) return bfail(e, CQS_HIP_ERR_INVALID, "bert: null buffer");
     B_TRY(e, hipSetDevice(e->device));
     BSlot* sl; BCtx* c;
-    if ((rc = take_slot(e, &sl, &c)) != CQS_HIP_OK) return rc;
+    wait_reserved(e, lk);                                     // (another thread's blocking call may hold it: mu is released meanwhile)
+    if ((rc = take_slot(e, &sl, &c, true)) != CQS_HIP_OK) return rc;
     uint32_t M = 0;
     rc = run_encoder(e, *c, *sl, tokens, type_ids, lens, batch, &M);
     if (rc != CQS_HIP_OK || M == 0) return rc;

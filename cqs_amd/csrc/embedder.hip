@@ -136,6 +136,7 @@ struct cqs_hip_embedder {
         uint64_t ticket = 0;       // 0 = free
         int ctx = 0;               // execution context the ticket runs on
         bool direct = false;       // the result is in the context's q_out_pin, not in `out`
+        bool collecting = false;   // a collect is waiting on this ticket: a second collector of the same ticket is refused
     };
     static constexpr int kSlots = 3;
     Slot slot[kSlots];
@@ -888,11 +889,14 @@ int32_t cqs_hip_embed_collect(cqs_hip_embedder* e, uint64_t ticket, float* out) 
         for (cqs_hip_embedder::Slot& c : e->slot)
             if (c.ticket == ticket) { sl = &c; break; }
         if (!sl) return efail(e, CQS_HIP_ERR_INVALID, "collect: unknown ticket");
+        if (sl->collecting) return efail(e, CQS_HIP_ERR_INVALID, "collect: this ticket is already being collected");
+        sl->collecting = true;
     }
     // wait outside the lock: other threads may submit meanwhile; the slot stays ours until its ticket is cleared
     (void)hipSetDevice(e->device);
     const hipError_t he = hipEventSynchronize(sl->done);
     std::lock_guard<std::mutex> lk(e->mu);
+    sl->collecting = false;
     if (he != hipSuccess) { sl->ticket = 0; return efail(e, CQS_HIP_ERR_DEVICE, "collect: device failure", he); }
     if (e->fuse_err && *(volatile unsigned*)e->fuse_err != 0u) {   // a pair of the fused projection kernel never met: the rows are garbage
         sl->ticket = 0;

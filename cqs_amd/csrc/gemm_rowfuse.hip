@@ -352,6 +352,8 @@ __global__ __launch_bounds__(512, 2) void gemm_rowfuse2_kernel(const bf16_t* __r
     };
     const uint32_t wring = (uint32_t)(wid * 6 * kR2Slot);
     const uint32_t ntile0 = half * 24u + (uint32_t)(3 * wid);   // first of this wave's three 16-column tiles
+    // (Timing experiment, round 4: workgroups starting their k loop at different k-steps, so that an XCD's 32 workgroups do
+    // not all ask its L2 for the same W lines at the same time - main loop 17.7 vs 18.1 us: no effect, removed.)
     auto fill_w = [&](uint32_t kt, uint32_t par, int j) {  // slot (par, j) <- k-step kt
         const char* src = gW + ((ntile0 + (uint32_t)j) * nk + kt) * (uint32_t)kR2Slot;   // (32-bit: a 64-bit multiply would leave the scalar unit)
         const uint32_t lb = wring + (par * 3u + (uint32_t)j) * (uint32_t)kR2Slot;

@@ -498,7 +498,12 @@ def test_tickets_match_blocking_calls_and_release_slots(hip):
     want = [eng.splade_sparse(b, thr, 512) for b in batches]
     hs = [eng.submit_sparse(b, thr, 512) for b in batches[:3]]
     with pytest.raises(BertError):
-        eng.submit_sparse(batches[3], thr, 512)                      # every slot in flight
+        eng.submit_sparse(batches[3], thr, 512)                      # every ticket slot in flight
+    # ... but the BLOCKING calls have a slot of their own: a search-time query beside a pipelined index run
+    ids3, wts3, cnt3 = eng.splade_sparse(batches[3], thr, 512)
+    assert np.array_equal(cnt3, want[3][2])
+    dense3 = eng.splade_dense(batches[3])
+    assert dense3.shape[0] == len(batches[3]) and np.all(np.isfinite(dense3))
     for j in (2, 0, 1):
         ids, wts, cnt = eng.collect_sparse(hs[j])
         assert np.array_equal(cnt, want[j][2])
@@ -529,6 +534,8 @@ def test_tickets_match_blocking_calls_and_release_slots(hip):
     bs = [_seqs(cfg2, lens, seed=40 + i) for i, lens in enumerate(([33, 100], [5, 6, 7], [128]))]
     want = [e2.embed(b, None, "mean") for b in bs]
     hs = [e2.embed_submit(b, None, "mean") for b in bs]
+    assert np.array_equal(e2.embed(bs[1], None, "mean"), want[1])    # blocking call with three tickets in flight
+    assert e2.hidden(bs[2]).shape[1] == cfg2.hidden
     for j in (1, 2, 0):
         assert np.array_equal(e2.embed_collect(hs[j]), want[j])
     e2.embed_abandon(e2.embed_submit(bs[0], None, "cls"))

@@ -12,6 +12,7 @@ if [ "$1" = build ]; then
 else
   OUT=$PWD/gpurun_out; REPO=$PWD; mkdir -p $OUT
   cd /tmp && export TMPDIR=/tmp
+  shopt -s nullglob   # no variant built: the loop runs the default library only (an unmatched glob used to become a file name)
   for f in $REPO/cqs_amd/libcqs_hip.so $REPO/build/variants/lib_batt_*.so; do
     n=$(basename $f .so)
     export CQS_HIP_LIB=$f

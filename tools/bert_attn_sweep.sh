@@ -4,7 +4,7 @@
 set -e
 out=${1:-gpurun_out/bert_attn}
 mkdir -p $out
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?}"
 for cfg in "256 64" "512 32"; do
   set -- $cfg
   for q in auto 1 2 4 old; do

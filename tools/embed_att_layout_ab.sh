@@ -1,3 +1,5 @@
+#!/bin/bash
+# (A/B helper from round 3; run on the GPU box from the repo root)
 for i in 1 2; do
 for L in default shared; do
 if [ $L = shared ]; then export CQS_HIP_ATT_LAYOUT=shared; else unset CQS_HIP_ATT_LAYOUT; fi

@@ -1,3 +1,5 @@
+#!/bin/bash
+# (A/B helper from round 3; run on the GPU box from the repo root)
 for i in 1 2; do
 for f in 1 0; do
 CQS_HIP_GEMM_FUSE_NORM=$f python bench.py --steps 5 --warmup 2 --extras 0 --e2e-chunks 0 --cpu-seconds 0 --embed-steps 16 2>/dev/null | python -c "
