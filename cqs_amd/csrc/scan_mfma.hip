@@ -439,6 +439,13 @@ __global__ __launch_bounds__(256, OCC) void scan_mfma16_kernel(const MfmaParams 
     }
 }
 
+// (Round 4 built and removed a STREAMING kernel for blocks of <= 32 queries - queries resident in LDS, every wave feeding
+// v_mfma_f32_16x16x4_f32 with corpus rows loaded straight from global memory, 128 KB in flight per CU, no barrier in the
+// loop: bit-correct, 0.70 ms at 32 queries x 1M rows with default-policy loads (0.80 streaming-policy; a 32x32x2 form with
+// 32-byte pieces per row 1.13) against 0.68 for the LDS-tiled kernel below.  A lane-per-row operand layout reads 64 bytes
+// of each of 64 rows per instruction: HBM sees ~10^5 concurrent row streams advancing one sector at a time and gives
+// ~4.3 TB/s, where the one-query scan's 1-KiB-per-row loads get 6.8.  A block this small wants the gemv kernel's access
+// pattern and the matrix cores' arithmetic; the transpose between the two is what the LDS stage is.)
 template <int QW, int WQ, int RW, int WR, int OCC = 2>
 static hipError_t launch_mfma16_cfg(const ScanArgs& a, uint32_t q0, uint32_t nq, uint32_t slot, hipStream_t st) {
     constexpr int QT = 32 * QW * WQ, RT = 32 * RW * WR;
