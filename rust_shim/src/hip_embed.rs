@@ -61,6 +61,16 @@ extern "C" {
     fn cqs_hip_embedder_max_seq(e: *const CqsHipEmbedder) -> u32;
     fn cqs_hip_embedder_poisoned(e: *const CqsHipEmbedder) -> i32;
     fn cqs_hip_embedder_last_error(e: *const CqsHipEmbedder, buf: *mut c_char, cap: usize) -> usize;
+    // `Embedder::warm()` (src/embedder/core.rs:933-957): build + replay the search-time chain's graphs for every query
+    // length up to `max_tokens` before the first real query; the counters say which path queries really take
+    fn cqs_hip_embedder_warm(e: *mut CqsHipEmbedder, max_tokens: u32) -> i32;
+    fn cqs_hip_embedder_query_graph_stats(
+        e: *const CqsHipEmbedder,
+        captured: *mut u64,
+        failed: *mut u64,
+        replays: *mut u64,
+        eager: *mut u64,
+    );
     fn cqs_hip_embed(
         e: *mut CqsHipEmbedder,
         input_ids: *const i64,
@@ -136,6 +146,26 @@ impl HipEmbedSession {
         let n = unsafe { cqs_hip_embedder_last_error(self.handle, buf.as_mut_ptr() as *mut c_char, buf.len()) };
         buf.truncate(n.min(buf.len()));
         String::from_utf8_lossy(&buf).into_owned()
+    }
+
+    /// What `Embedder::warm()` (core.rs:933-957) calls before its dummy inference: every `embed_query` length up to
+    /// 128 tokens then replays a ready hipGraph (first call within a few percent of steady state) instead of paying
+    /// an eager chain + capture + instantiate on the first query of each length.  Takes about half a second.
+    pub fn warm(&mut self) -> Result<(), EmbedderError> {
+        // SAFETY: the handle is live for the lifetime of self.
+        let rc = unsafe { cqs_hip_embedder_warm(self.handle, 128) };
+        if rc != CQS_HIP_OK {
+            return Err(EmbedderError::InferenceFailed(format!("cqs_hip_embedder_warm failed: status {rc}: {}", self.last_error())));
+        }
+        let (mut captured, mut failed, mut replays, mut eager) = (0u64, 0u64, 0u64, 0u64);
+        // SAFETY: four valid out-pointers.
+        unsafe { cqs_hip_embedder_query_graph_stats(self.handle, &mut captured, &mut failed, &mut replays, &mut eager) };
+        if failed > 0 {
+            tracing::warn!(captured, failed, detail = %self.last_error(), "HIP embedder: some query lengths run without a captured graph");
+        } else {
+            tracing::debug!(captured, replays, eager, "HIP embedder warmed");
+        }
+        Ok(())
     }
 
     /// The `session.run` replacement: `input_ids` / `attention_mask` are the row-major `[batch, max_len]`
