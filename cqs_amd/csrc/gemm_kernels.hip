@@ -61,6 +61,27 @@ __device__ __forceinline__ p8_f2 p8_geglu2(p8_f2 g, p8_f2 u) {
     r[1] = __builtin_amdgcn_rcpf(d[1]);
     return g * r * u;
 }
+// erf GELU for two values at once in packed f32 arithmetic (same polynomial and operation order per element as p8_gelu_erf)
+__device__ __forceinline__ p8_f2 p8_gelu_erf2(p8_f2 x) {
+    p8_f2 ax;
+    ax[0] = __builtin_fabsf(x[0]); ax[1] = __builtin_fabsf(x[1]);
+    const p8_f2 z = ax * (p8_f2)(0.70710678118654752f);
+    const p8_f2 d = __builtin_elementwise_fma(z, (p8_f2)(0.3275911f), (p8_f2)(1.0f));
+    p8_f2 t;
+    t[0] = __frcp_rn(d[0]); t[1] = __frcp_rn(d[1]);
+    p8_f2 poly = __builtin_elementwise_fma(t, (p8_f2)(1.061405429f), (p8_f2)(-1.453152027f));
+    poly = __builtin_elementwise_fma(poly, t, (p8_f2)(1.421413741f));
+    poly = __builtin_elementwise_fma(poly, t, (p8_f2)(-0.284496736f));
+    poly = __builtin_elementwise_fma(poly, t, (p8_f2)(0.254829592f));
+    poly = poly * t;
+    const p8_f2 nz2 = -(z * z);
+    p8_f2 ex;
+    ex[0] = __expf(nz2[0]); ex[1] = __expf(nz2[1]);
+    const p8_f2 e = (p8_f2)(1.0f) - poly * ex;               // erf(|x| / sqrt 2)
+    p8_f2 se;
+    se[0] = __builtin_copysignf(e[0], x[0]); se[1] = __builtin_copysignf(e[1], x[1]);
+    return (p8_f2)(0.5f) * x * ((p8_f2)(1.0f) + se);
+}
 __device__ __forceinline__ float p8_gelu_tanh(float x) {
     const float k0 = 0.7978845608028654f, k1 = 0.044715f;
     const float u2 = 2.0f * k0 * (x + k1 * x * x * x);
@@ -525,11 +546,13 @@ __device__ __forceinline__ void gemm_pp_body(const bf16_t* __restrict__ A, const
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     bf4 o;
+                    if (OUT == GEMM_OUT_BF16_GELU) {               // two values per instruction (round 4: the epilogue is VALU-bound)
+                        const f4 v = acc[4 * p + t][j] + bv[j];
+                        const p8_f2 g0 = p8_gelu_erf2((p8_f2){v[0], v[1]}), g1 = p8_gelu_erf2((p8_f2){v[2], v[3]});
+                        o[0] = (bf16_t)g0[0]; o[1] = (bf16_t)g0[1]; o[2] = (bf16_t)g1[0]; o[3] = (bf16_t)g1[1];
+                    } else {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float v = acc[4 * p + t][j][r] + bv[j][r];
-                        if (OUT == GEMM_OUT_BF16_GELU) v = p8_gelu_erf(v);
-                        o[r] = (bf16_t)v;
+                        for (int r = 0; r < 4; ++r) o[r] = (bf16_t)(acc[4 * p + t][j][r] + bv[j][r]);
                     }
                     *(bf4*)(rowp + wn * 16 * TN + j * 16 + 4 * lg) = o;
                 }

@@ -9,10 +9,11 @@ OUT=$PWD/gpurun_out
 REPO=$PWD
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 900 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_kt -o kt --output-format csv -- python3 $REPO/bench.py --cpu-seconds 0 --embed-steps 3 --extras 0 --e2e-chunks 0 > $OUT/${TAG}_bench_under_profiler.json 2> $OUT/${TAG}_kt.err
-timeout -k 10 600 rocprofv3 --pmc FETCH_SIZE -d $OUT/${TAG}_fetch -o pmc --output-format csv -- python3 $REPO/bench.py --cpu-seconds 0 --embed-steps 0 --extras 0 --e2e-chunks 0 --steps 50 > /dev/null 2> $OUT/${TAG}_fetch.err
-timeout -k 10 600 rocprofv3 --pmc WRITE_SIZE -d $OUT/${TAG}_write -o pmc --output-format csv -- python3 $REPO/bench.py --cpu-seconds 0 --embed-steps 0 --extras 0 --e2e-chunks 0 --steps 50 > /dev/null 2> $OUT/${TAG}_write.err
+timeout -k 10 900 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_kt -o kt --output-format csv -- python3 $REPO/bench.py --cpu-seconds 0 --embed-steps 3 --extras 0 --e2e-chunks 0 --abi-devices '' > $OUT/${TAG}_bench_under_profiler.json 2> $OUT/${TAG}_kt.err
+timeout -k 10 600 rocprofv3 --pmc FETCH_SIZE -d $OUT/${TAG}_fetch -o pmc --output-format csv -- python3 $REPO/bench.py --cpu-seconds 0 --embed-steps 0 --extras 0 --e2e-chunks 0 --abi-devices '' --steps 50 > /dev/null 2> $OUT/${TAG}_fetch.err
+timeout -k 10 600 rocprofv3 --pmc WRITE_SIZE -d $OUT/${TAG}_write -o pmc --output-format csv -- python3 $REPO/bench.py --cpu-seconds 0 --embed-steps 0 --extras 0 --e2e-chunks 0 --abi-devices '' --steps 50 > /dev/null 2> $OUT/${TAG}_write.err
 cd $REPO
+# (--abi-devices '': the sharded leg launches the same scan instantiation on 250k-row shards and would dilute the per-launch means)
 python3 tools/summarize_prof.py $OUT/${TAG}_kt $OUT/${TAG}_fetch $OUT/${TAG}_write > $OUT/${TAG}_scan_summary.txt
 python3 tools/summarize_prof.py --scan-traffic $OUT/${TAG}_fetch $OUT/${TAG}_write 3072000000 $OUT/${TAG}_scan_traffic.json $COMMIT
 bash tools/profile_embed.sh ${TAG} > /dev/null 2>&1
