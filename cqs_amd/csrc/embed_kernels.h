@@ -5,6 +5,7 @@
 #include <stdint.h>
 
 #include <atomic>
+#include "lane_swap.h"
 
 namespace cqs {
 
@@ -22,6 +23,26 @@ inline hipError_t set_max_dynamic_lds(const void* kernel, size_t bytes, std::ato
     if (e == hipSuccess && dev < 64) done_mask.fetch_or(bit, std::memory_order_release);
     return e;
 }
+
+// Sum over the 32 lanes of this lane's half-wave, the same bits in all of them, VALU only: four DPP steps inside each
+// 16-lane row (quad_perm xor 1, xor 2, row_half_mirror, row_mirror), then one v_permlane16_swap between the two rows of the
+// half.  (As __shfl_xor these were 5 ds_bpermute round trips through the LDS queue per sum.)  ONE definition: the row
+// norms of add_norm_kernel, of the pair-split fused kernel and of the QKV epilogue must add in the same order.
+#if defined(__HIPCC__)
+template <int CTRL>
+__device__ __forceinline__ float half_sum_dpp(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float half_wave_sum32(float v) {
+    v += half_sum_dpp<0xB1>(v);
+    v += half_sum_dpp<0x4E>(v);
+    v += half_sum_dpp<0x141>(v);
+    v += half_sum_dpp<0x140>(v);
+    const lane_u2 a = swap16_self(__builtin_bit_cast(unsigned, v));
+    const unsigned even = a[0], odd = a[1];                   // locals: see lane_swap.h on bit_cast of a vector element
+    return __builtin_bit_cast(float, even) + __builtin_bit_cast(float, odd);
+}
+#endif
 
 // Model geometry (Gemma3 text encoder + sentence-transformers head); see
 // oracle/gemma3_ref.py for the semantics each field drives.

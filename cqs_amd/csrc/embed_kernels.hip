@@ -70,15 +70,11 @@ __global__ __launch_bounds__(256) void embed_norm_kernel(const int32_t* __restri
 // c = 0..NCH-1; a half's partial is summed over its 32 lanes (butterfly 16, 8, 4, 2, 1) and the row's sum of squares is
 // left + right.  That is the order in which the pair-split fused kernel (gemm_rowfuse.hip: two workgroups own the two
 // column halves of a row block and exchange their partials) can also sum - so the two stay bit-identical.
-__device__ __forceinline__ float half_row_sum(float v) {      // over the 32 lanes of this lane's half-wave; same bits in all of them
-#pragma unroll
-    for (int off = 16; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
+__device__ __forceinline__ float half_row_sum(float v) { return half_wave_sum32(v); }   // over the 32 lanes of this lane's half-wave
 __device__ __forceinline__ float row_sum_of_halves(float v, int lane) {
     v = half_row_sum(v);
-    const float o = __shfl_xor(v, 32, 64);
-    return lane < 32 ? v + o : o + v;                          // left + right on both sides
+    const lane_u2 a = swap32_self(__float_as_uint(v));   // a[0] = left, a[1] = right in every lane
+    return __uint_as_float(a[0]) + __uint_as_float(a[1]);     // left + right on both sides
 }
 template <int NCH, int FINAL>
 __global__ __launch_bounds__(256) void add_norm_kernel(float* __restrict__ x, const bf16_t* __restrict__ y,

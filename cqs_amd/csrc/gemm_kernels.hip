@@ -432,9 +432,7 @@ __device__ __forceinline__ void gemm_pp_body(const bf16_t* __restrict__ A, const
                 s2 = __builtin_elementwise_fma(vlo[1], vlo[1], s2);
                 s2 = __builtin_elementwise_fma(vhi[0], vhi[0], s2);
                 s2 = __builtin_elementwise_fma(vhi[1], vhi[1], s2);
-                float ss = s2[0] + s2[1];
-#pragma unroll
-                for (int off = 16; off >= 1; off >>= 1) ss += __shfl_xor(ss, off, 64);   // over the row's 32 lanes
+                const float ss = half_wave_sum32(s2[0] + s2[1]);             // over the row's 32 lanes (DPP + one permlane swap)
                 const float inv = rsqrtf(ss / 256.0f + eps);
                 const p8_f2 inv2 = (p8_f2)(inv), qs2 = (p8_f2)(qs);
                 // (cos, sin) x 4 dims: cs0 = (c0, s0, c1, s1), cs1 = (c2, s2, c3, s3)

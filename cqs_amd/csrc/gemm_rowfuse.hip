@@ -506,11 +506,7 @@ __global__ __launch_bounds__(512, 2) void gemm_rowfuse2_kernel(const bf16_t* __r
         }
         return theirs;
     };
-    auto half_sum = [&](float v) -> float {               // over the 32 lanes of the half-wave (same bits in all of them)
-#pragma unroll
-        for (int off = 16; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-        return v;
-    };
+    auto half_sum = [&](float v) -> float { return half_wave_sum32(v); };   // over the 32 lanes of the half-wave (same bits in all of them)
 
     // phase 1: this half's sum of squares of every y row
     float mine1 = 0.f;
