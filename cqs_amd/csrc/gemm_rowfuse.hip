@@ -377,6 +377,10 @@ __global__ __launch_bounds__(512, 2) void gemm_rowfuse2_kernel(const bf16_t* __r
         for (int t = 0; t < 8; ++t) acc[j][t] = (f4)(0.f);
 
     const uint32_t klast = nk - 1u;
+    // (Tried in round 4 and dropped: pulling the epilogue's x rows into L2 from inside the main loop - each wave touching
+    // the 192 lines of its 16 x-row halves by DMA loads into a dump slot, 1-8 k-steps before the end.  The launch got
+    // SLOWER: 41.5 us without, 44.6 with two thirds of the lines, 46.3-47.4 with all of them at any distance - the main
+    // loop is not indifferent to HBM traffic beside it, and 6 MB of x per XCD do not survive in a 4 MB L2.)
     // One k-step.  DMA issue order of a wave, step after step: A (kt + 2) x 2, then W (kt + 2, j) x 2 behind the fragment
     // reads of slot (kt, j), j = 0, 1, 2 - eight instructions per step.  They complete in issue order, so:
     //   A (kt), issued at the top of step kt - 2: behind it W (kt, 0..2) = 6 and step kt - 1's 8          -> vmcnt(14)

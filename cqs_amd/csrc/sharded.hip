@@ -246,6 +246,17 @@ int32_t search_block(cqs_hip_index* p, uint32_t nb, uint32_t k_eff, const uint32
         if (nr != ncclSuccess)
             return pfail(p, CQS_HIP_ERR_DEVICE, std::string("ncclAllGather: ") + (api->GetErrorString ? api->GetErrorString(nr) : "error"));
         ss->gathers_rccl++;
+    } else if (direct) {
+        // every select kernel has written its list into the pinned gather buffer itself: nothing is left to order on
+        // device 0's stream, so the host waits for each shard's stream in turn - the first wait is the scan, the others
+        // return at once.  (Until round 4 device 0's stream waited on one event per shard and the host on that stream:
+        // G - 1 cross-stream barrier packets in front of the wake-up, 64 us between a query's last kernel and the next
+        // query's first one against 28 us on a single-device handle - rocprofv3 kernel trace, tools/r04_shard_trace.sh.)
+        for (size_t s = 0; s < G; ++s) {
+            cqs_hip_index* c = ss->shard[s];
+            P_TRY(p, hipSetDevice(c->device));
+            P_TRY(p, hipStreamSynchronize(c->stream));
+        }
     } else {
         cqs_hip_index* c0 = ss->shard[0];
         for (size_t s = 0; s < G; ++s) {
@@ -258,8 +269,7 @@ int32_t search_block(cqs_hip_index* p, uint32_t nb, uint32_t k_eff, const uint32
             } else {
                 P_TRY(p, hipSetDevice(c0->device));
             }
-            if (!direct)
-                P_TRY(p, hipMemcpyAsync(ss->d_gather[0] + s * keys, c->d_out_keys, keys * sizeof(uint64_t), hipMemcpyDefault, c0->stream));
+            P_TRY(p, hipMemcpyAsync(ss->d_gather[0] + s * keys, c->d_out_keys, keys * sizeof(uint64_t), hipMemcpyDefault, c0->stream));
         }
     }
     // 3. one D2H from the first device and ONE host wait, on that device's stream: its copy of the gathered lists is
@@ -268,12 +278,11 @@ int32_t search_block(cqs_hip_index* p, uint32_t nb, uint32_t k_eff, const uint32
     // done too.  What the other devices still run (their own, unused, receive side) is ordered on THEIR streams before
     // anything the next search enqueues there; extend / save / destroy quiesce every stream themselves.  (Round 2 also
     // synchronised the other G - 1 streams here: G - 1 host round trips per query for nothing.)
-    {
+    if (!direct) {
         cqs_hip_index* c0 = ss->shard[0];
         P_TRY(p, hipSetDevice(c0->device));
-        if (!direct)
-            P_TRY(p, hipMemcpyAsync(ss->h_gather, ss->d_gather[0], G * keys * sizeof(uint64_t), hipMemcpyDeviceToHost, c0->stream));
-        P_TRY(p, hipStreamSynchronize(c0->stream));   // (direct: the stream has waited on every shard's event above)
+        P_TRY(p, hipMemcpyAsync(ss->h_gather, ss->d_gather[0], G * keys * sizeof(uint64_t), hipMemcpyDeviceToHost, c0->stream));
+        P_TRY(p, hipStreamSynchronize(c0->stream));
     }
     // 4. host k-way merge per query (lists of query q: h_gather + s * keys + q * k_eff, zero padded)
     std::vector<uint32_t> counts(G);
