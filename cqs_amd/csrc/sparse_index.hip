@@ -1,0 +1,447 @@
+// sparse_index.hip — the SPLADE sparse retrieval leg on gfx950: `SpladeIndex` (src/splade/index.rs:177-306) behind the C ABI
+// (include/cqs_hip.h, "sparse index" section).
+//
+// The reference keeps `postings: HashMap<u32, Vec<(usize, f32)>>` (token -> [(chunk_index, weight)], chunk order) and, per
+// query, walks the posting list of every query term IN QUERY ORDER adding `query_weight * doc_weight` into a
+// `HashMap<usize, f32>` (index.rs:248-258), then pushes every scored chunk through `BoundedScoreHeap` (:265-281).
+//
+// HBM layout here: ONE array of 8-byte postings {chunk, weight bits}, the lists of all tokens back to back, each list in
+// ascending chunk order (= the reference's push order); the token -> (start, length) table stays on the host (a query
+// names a few dozen tokens).  "chunk" is the chunk's RANK in ascending id order when the caller gives `id_rank`, so that
+// the select's (score desc, position asc) order is BoundedScoreHeap's (score desc, id asc).
+//
+// One launch accumulates a query: a WAVE owns a contiguous range of `rw` chunks and keeps their scores in LDS.  For every
+// query term it finds the part of the term's list that falls into its range (two binary searches, 64 terms at a time, one
+// per lane), then walks the terms in query order: 64 postings per step, `s = s + qw * dw` in LDS with separate f32 multiply
+// and add - every chunk's sum is built in exactly the reference's order, so the scores are bit-identical, not "close".
+// Postings of one token name distinct chunks unless a document lists a token twice; a step that sees such a pair runs
+// its lanes one after the other (posting order again).  No atomics, no barriers: a wave's LDS operations retire in order.
+// The kernel is bound by the touched postings' bytes (8 B each) + the score row it writes (4 B per chunk); the exact
+// top-k is the dense index's select_finish_kernel over that score row and its 64-chunk maxima.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "abi_guard.h"
+#include "scan_kernels.h"
+
+namespace {
+
+constexpr uint32_t kSparsePad = 1024;          // n_pad granule (a multiple of every wave range)
+constexpr uint32_t kUnscored = 0xFFFFFFFFu;    // LDS marker: `scores.entry(chunk)` does not exist yet (a NaN no arithmetic here produces:
+                                               // weights with that bit pattern are refused at build / search)
+constexpr uint32_t kMaxTerms = 1u << 20;
+
+struct SparseTerm {            // one query term, resolved on the host
+    unsigned long long start;  // first posting of the token's list
+    uint32_t len;              // postings in the list
+    float w;                   // query weight
+};
+
+__device__ __forceinline__ uint32_t lower_bound_chunk(const uint2* __restrict__ p, uint32_t a, uint32_t b, uint32_t c) {
+    while (a < b) {
+        const uint32_t m = (a + b) >> 1;
+        if (p[m].x < c) a = m + 1u; else b = m;
+    }
+    return a;
+}
+
+// grid: ceil(n_pad / rw / 4) workgroups of 4 waves; dynamic LDS = 4 * rw * 4 bytes
+__global__ __launch_bounds__(256) void sparse_accumulate_kernel(const uint2* __restrict__ post, const SparseTerm* __restrict__ terms,
+                                                                uint32_t n_terms, uint32_t n, uint32_t n_pad, uint32_t rw,
+                                                                const uint32_t* __restrict__ keep, const uint32_t* __restrict__ chunk_of_rank,
+                                                                float* __restrict__ scores, float* __restrict__ gmax) {
+    extern __shared__ uint32_t sp_lds[];
+    const int lane = threadIdx.x & 63;
+    const uint32_t wid = threadIdx.x >> 6;
+    const uint32_t c0 = (blockIdx.x * 4u + wid) * rw;
+    if (c0 >= n_pad) return;                              // (wave-uniform; no barrier anywhere in this kernel)
+    const uint32_t c1 = c0 + rw;
+    uint32_t* const my = sp_lds + wid * rw;
+    for (uint32_t i = lane; i < rw; i += 64u) my[i] = kUnscored;
+
+    for (uint32_t t0 = 0; t0 < n_terms; t0 += 64u) {
+        // this wave's slice [lo, hi) of each of the next 64 terms' lists, one term per lane
+        uint32_t lo = 0u, hi = 0u, st_lo = 0u, st_hi = 0u;
+        float w = 0.f;
+        if (t0 + (uint32_t)lane < n_terms) {
+            const SparseTerm tm = terms[t0 + lane];
+            const uint2* const p = post + tm.start;
+            st_lo = (uint32_t)tm.start;
+            st_hi = (uint32_t)(tm.start >> 32);
+            w = tm.w;
+            lo = lower_bound_chunk(p, 0u, tm.len, c0);
+            uint32_t b = tm.len;
+            if (lo + rw < b && p[lo + rw].x >= c1) b = lo + rw;   // the usual case: no more than one posting per chunk
+            hi = lower_bound_chunk(p, lo, b, c1);
+        }
+        const uint32_t cnt = n_terms - t0 < 64u ? n_terms - t0 : 64u;
+        for (uint32_t j = 0; j < cnt; ++j) {              // query order
+            const uint32_t jlo = __builtin_amdgcn_readlane(lo, j), jhi = __builtin_amdgcn_readlane(hi, j);
+            if (jlo == jhi) continue;
+            const unsigned long long jst = (unsigned long long)__builtin_amdgcn_readlane(st_lo, j) |
+                                           ((unsigned long long)__builtin_amdgcn_readlane(st_hi, j) << 32);
+            const float jw = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(uint32_t, w), j));
+            const uint2* const p = post + jst;
+            for (uint32_t i = jlo; i < jhi; i += 64u) {
+                const uint32_t idx = i + (uint32_t)lane;
+                const bool active = idx < jhi;
+                uint2 e = make_uint2(0xFFFFFFFFu, 0u);
+                if (active) e = p[idx];
+                const uint32_t prev = __shfl_up(e.x, 1, 64);
+                const bool dup = active && lane != 0 && e.x == prev;   // (a pair split over two steps is ordered by the steps)
+                const float prod = __fmul_rn(jw, __builtin_bit_cast(float, e.y));
+                if (__builtin_amdgcn_ballot_w64(dup) == 0ull) {
+                    if (active) {
+                        const uint32_t s = my[e.x - c0];
+                        my[e.x - c0] = __builtin_bit_cast(uint32_t, __fadd_rn(s == kUnscored ? 0.f : __builtin_bit_cast(float, s), prod));
+                    }
+                } else {                                  // a document that lists a token twice: posting order, lane by lane
+                    for (int l = 0; l < 64; ++l) {
+                        if (lane == l && active) {
+                            const uint32_t s = my[e.x - c0];
+                            my[e.x - c0] = __builtin_bit_cast(uint32_t, __fadd_rn(s == kUnscored ? 0.f : __builtin_bit_cast(float, s), prod));
+                        }
+                    }
+                }
+            }
+        }
+    }
+    // the score row + the maxima of its 64-chunk groups (what select_finish_kernel reads); a chunk that was never scored,
+    // is filtered out, or whose score is not finite (BoundedScoreHeap refuses it, candidate.rs:245-247) = -inf
+    for (uint32_t i = lane; i < rw; i += 64u) {
+        const uint32_t r = c0 + i;
+        const uint32_t s = my[i];
+        float v = __builtin_bit_cast(float, s);
+        bool ok = r < n && s != kUnscored && __builtin_isfinite(v);
+        if (ok && keep) {
+            const uint32_t c = chunk_of_rank ? chunk_of_rank[r] : r;
+            ok = (keep[c >> 5] >> (c & 31u)) & 1u;
+        }
+        v = ok ? v : -INFINITY;
+        scores[r] = v;
+        float m = v;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+        if (lane == 0) gmax[r >> 6] = m;
+    }
+}
+
+}  // namespace
+
+struct cqs_hip_sparse_index {
+    std::mutex mu;
+    std::string last_error;
+    bool poisoned = false;
+    int device = 0;
+    uint64_t n = 0, n_postings = 0;
+    uint32_t n_pad = 0, rw = 64, n_cu = 256;
+    bool ranked = false;
+    std::vector<uint32_t> tok;               // sorted distinct token ids
+    std::vector<uint64_t> off;               // [tok.size() + 1]
+    std::vector<uint32_t> chunk_of_rank;     // host copy (empty: identity)
+    hipStream_t stream = nullptr;
+    uint2* d_post = nullptr;
+    uint32_t* d_chunk_of_rank = nullptr;
+    float* d_scores = nullptr;
+    float* d_gmax = nullptr;
+    uint32_t* d_work = nullptr;
+    uint32_t* d_keep = nullptr;
+    SparseTerm* d_terms = nullptr;
+    uint32_t terms_cap = 0;
+    SparseTerm* h_terms = nullptr;           // pinned
+    uint32_t* h_keep = nullptr;              // pinned, ceil(n / 32) words
+    uint64_t* d_out_keys = nullptr;
+    uint32_t* d_out_count = nullptr;
+    uint64_t* h_out_keys = nullptr;          // pinned, kMaxK + 1 words (the last one: the count)
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    float last_ms = 0.f;
+    uint64_t last_touched = 0;
+};
+
+namespace {
+
+int32_t sfail(cqs_hip_sparse_index* s, int32_t code, const std::string& what, hipError_t he = hipSuccess) {
+    s->last_error = what;
+    if (he != hipSuccess) s->last_error += std::string(": ") + hipGetErrorString(he);
+    if (code == CQS_HIP_ERR_DEVICE) s->poisoned = true;
+    return code;
+}
+#define S_TRY(s, expr)                                                                   \
+    do {                                                                                 \
+        const hipError_t he_ = (expr);                                                   \
+        if (he_ != hipSuccess) return sfail((s), he_ == hipErrorOutOfMemory ? CQS_HIP_ERR_NOMEM : CQS_HIP_ERR_DEVICE, #expr, he_); \
+    } while (0)
+
+void release(cqs_hip_sparse_index* s) {
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    if (s->stream) (void)hipStreamSynchronize(s->stream);
+    for (void* p : {(void*)s->d_post, (void*)s->d_chunk_of_rank, (void*)s->d_scores, (void*)s->d_gmax, (void*)s->d_work,
+                    (void*)s->d_keep, (void*)s->d_terms, (void*)s->d_out_keys, (void*)s->d_out_count})
+        if (p) (void)hipFree(p);
+    for (void* p : {(void*)s->h_terms, (void*)s->h_keep, (void*)s->h_out_keys})
+        if (p) (void)hipHostFree(p);
+    if (s->ev0) (void)hipEventDestroy(s->ev0);
+    if (s->ev1) (void)hipEventDestroy(s->ev1);
+    if (s->stream) (void)hipStreamDestroy(s->stream);
+    delete s;
+}
+
+int32_t ensure_terms(cqs_hip_sparse_index* s, uint32_t t) {
+    if (t <= s->terms_cap) return CQS_HIP_OK;
+    const uint32_t cap = std::max(256u, t + t / 2u);
+    if (s->d_terms) { (void)hipFree(s->d_terms); s->d_terms = nullptr; }
+    if (s->h_terms) { (void)hipHostFree(s->h_terms); s->h_terms = nullptr; }
+    s->terms_cap = 0;
+    S_TRY(s, hipMalloc((void**)&s->d_terms, (size_t)cap * sizeof(SparseTerm)));
+    S_TRY(s, hipHostMalloc((void**)&s->h_terms, (size_t)cap * sizeof(SparseTerm), hipHostMallocDefault));
+    s->terms_cap = cap;
+    return CQS_HIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t cqs_hip_sparse_index_create(const uint64_t* doc_off, const uint32_t* tokens, const float* weights, uint64_t n,
+                                    const uint32_t* id_rank, int32_t device, cqs_hip_sparse_index** out) CQS_ABI_TRY {
+    if (!out) return CQS_HIP_ERR_INVALID;
+    *out = nullptr;
+    if (n && !doc_off) return CQS_HIP_ERR_INVALID;
+    if (n >= 0xFFFFFFFFull - kSparsePad) return CQS_HIP_ERR_INVALID;
+    const uint64_t P = n ? doc_off[n] : 0;
+    if (n && doc_off[0] != 0) return CQS_HIP_ERR_INVALID;
+    for (uint64_t i = 0; i < n; ++i)
+        if (doc_off[i + 1] < doc_off[i]) return CQS_HIP_ERR_INVALID;
+    if (P && (!tokens || !weights)) return CQS_HIP_ERR_INVALID;
+    for (uint64_t e = 0; e < P; ++e) {
+        uint32_t bits;
+        memcpy(&bits, &weights[e], 4);
+        if (bits == kUnscored) return CQS_HIP_ERR_INVALID;      // the one NaN payload the kernel reserves
+    }
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return CQS_HIP_ERR_NO_DEVICE;
+    cqs_hip_sparse_index* s = new cqs_hip_sparse_index();
+    s->device = device;
+    s->n = n;
+    s->n_postings = P;
+    s->n_pad = (uint32_t)((n + kSparsePad - 1) / kSparsePad * kSparsePad);
+    if (s->n_pad == 0) s->n_pad = kSparsePad;
+    // id order: chunk_of_rank[r] = the chunk whose id is the r-th smallest
+    if (id_rank) {
+        s->chunk_of_rank.assign((size_t)n, 0xFFFFFFFFu);
+        for (uint64_t i = 0; i < n; ++i) {
+            if (id_rank[i] >= n || s->chunk_of_rank[id_rank[i]] != 0xFFFFFFFFu) { delete s; return CQS_HIP_ERR_INVALID; }   // not a permutation
+            s->chunk_of_rank[id_rank[i]] = (uint32_t)i;
+        }
+        s->ranked = true;
+    }
+    // the token table: sorted distinct ids; a dense counting pass when the ids are small (every real vocabulary), a sort otherwise
+    uint32_t max_tok = 0;
+    for (uint64_t e = 0; e < P; ++e) max_tok = std::max(max_tok, tokens[e]);
+    std::vector<uint64_t> dense;                          // token -> slot + 1 (dense path)
+    std::unordered_map<uint32_t, uint32_t> sparse_slot;   // (sort path)
+    const bool use_dense = P && max_tok < (1u << 24);
+    if (use_dense) {
+        dense.assign((size_t)max_tok + 1, 0);
+        for (uint64_t e = 0; e < P; ++e) dense[tokens[e]]++;
+        for (uint32_t t = 0; t <= max_tok; ++t)
+            if (dense[t]) { s->tok.push_back(t); s->off.push_back(dense[t]); }
+    } else if (P) {
+        std::vector<uint32_t> sorted(tokens, tokens + P);
+        std::sort(sorted.begin(), sorted.end());
+        for (uint64_t e = 0; e < P;) {
+            uint64_t f = e;
+            while (f < P && sorted[f] == sorted[e]) ++f;
+            s->tok.push_back(sorted[e]);
+            s->off.push_back(f - e);
+            e = f;
+        }
+    }
+    {   // counts -> offsets
+        uint64_t run = 0;
+        for (size_t t = 0; t < s->off.size(); ++t) { const uint64_t c = s->off[t]; s->off[t] = run; run += c; }
+        s->off.push_back(run);
+    }
+    if (use_dense) {
+        for (size_t t = 0; t < s->tok.size(); ++t) dense[s->tok[t]] = t + 1;
+    } else {
+        sparse_slot.reserve(s->tok.size());
+        for (size_t t = 0; t < s->tok.size(); ++t) sparse_slot[s->tok[t]] = (uint32_t)t;
+    }
+    // the postings, list by list; inside a list ascending position (rank order = the order the documents are walked in)
+    std::vector<uint2> post((size_t)P);
+    {
+        std::vector<uint64_t> cur(s->off.begin(), s->off.end() - 1);
+        for (uint64_t r = 0; r < n; ++r) {
+            const uint64_t d = s->ranked ? s->chunk_of_rank[r] : r;
+            for (uint64_t e = doc_off[d]; e < doc_off[d + 1]; ++e) {
+                const size_t slot = use_dense ? (size_t)(dense[tokens[e]] - 1) : (size_t)sparse_slot[tokens[e]];
+                uint32_t bits;
+                memcpy(&bits, &weights[e], 4);
+                post[cur[slot]++] = make_uint2((uint32_t)r, bits);
+            }
+        }
+    }
+    auto dfail = [&](hipError_t he) -> int32_t {
+        release(s);
+        return he == hipErrorOutOfMemory ? CQS_HIP_ERR_NOMEM : CQS_HIP_ERR_DEVICE;
+    };
+    hipError_t he = hipSetDevice(device);
+    if (he != hipSuccess) return dfail(he);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) s->n_cu = (uint32_t)prop.multiProcessorCount;
+    // chunks per wave: enough waves to keep ~16 per CU in flight, 64 ... 1024 chunks each
+    s->rw = 1024;
+    while (s->rw > 64u && s->n_pad / s->rw < s->n_cu * 16u) s->rw >>= 1;
+    if ((he = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking)) != hipSuccess) return dfail(he);
+    if ((he = hipEventCreate(&s->ev0)) != hipSuccess || (he = hipEventCreate(&s->ev1)) != hipSuccess) return dfail(he);
+    if ((he = hipMalloc((void**)&s->d_post, std::max<size_t>((size_t)P, 1) * sizeof(uint2))) != hipSuccess) return dfail(he);
+    if (P && (he = hipMemcpy(s->d_post, post.data(), (size_t)P * sizeof(uint2), hipMemcpyHostToDevice)) != hipSuccess) return dfail(he);
+    if (s->ranked) {
+        if ((he = hipMalloc((void**)&s->d_chunk_of_rank, std::max<size_t>((size_t)n, 1) * 4)) != hipSuccess) return dfail(he);
+        if (n && (he = hipMemcpy(s->d_chunk_of_rank, s->chunk_of_rank.data(), (size_t)n * 4, hipMemcpyHostToDevice)) != hipSuccess) return dfail(he);
+    }
+    if ((he = hipMalloc((void**)&s->d_scores, (size_t)s->n_pad * 4)) != hipSuccess) return dfail(he);
+    if ((he = hipMalloc((void**)&s->d_gmax, (size_t)(s->n_pad / 64u) * 4)) != hipSuccess) return dfail(he);
+    if ((he = hipMalloc((void**)&s->d_work, cqs::kWorkWords * 4)) != hipSuccess) return dfail(he);
+    if ((he = hipMemset(s->d_work, 0, cqs::kWorkWords * 4)) != hipSuccess) return dfail(he);
+    if ((he = hipMalloc((void**)&s->d_keep, (size_t)(s->n_pad / 32u) * 4)) != hipSuccess) return dfail(he);
+    if ((he = hipHostMalloc((void**)&s->h_keep, (size_t)(s->n_pad / 32u) * 4, hipHostMallocDefault)) != hipSuccess) return dfail(he);
+    if ((he = hipMalloc((void**)&s->d_out_keys, (size_t)cqs::kMaxK * 8)) != hipSuccess) return dfail(he);
+    if ((he = hipMalloc((void**)&s->d_out_count, 4)) != hipSuccess) return dfail(he);
+    if ((he = hipHostMalloc((void**)&s->h_out_keys, (size_t)(cqs::kMaxK + 1) * 8, hipHostMallocDefault)) != hipSuccess) return dfail(he);
+    *out = s;
+    return CQS_HIP_OK;
+} CQS_ABI_CATCH_NOHANDLE
+
+void cqs_hip_sparse_index_destroy(cqs_hip_sparse_index* s) CQS_ABI_TRY {
+    release(s);
+} CQS_ABI_CATCH_VOID
+
+uint64_t cqs_hip_sparse_index_len(const cqs_hip_sparse_index* s) CQS_ABI_TRY {
+    return s ? s->n : 0;
+} CQS_ABI_CATCH_VAL(0)
+
+uint64_t cqs_hip_sparse_index_unique_tokens(const cqs_hip_sparse_index* s) CQS_ABI_TRY {
+    return s ? (uint64_t)s->tok.size() : 0;
+} CQS_ABI_CATCH_VAL(0)
+
+uint64_t cqs_hip_sparse_index_postings(const cqs_hip_sparse_index* s) CQS_ABI_TRY {
+    return s ? s->n_postings : 0;
+} CQS_ABI_CATCH_VAL(0)
+
+int32_t cqs_hip_sparse_index_poisoned(const cqs_hip_sparse_index* s) CQS_ABI_TRY {
+    if (!s) return 0;
+    std::lock_guard<std::mutex> g(const_cast<cqs_hip_sparse_index*>(s)->mu);
+    return s->poisoned ? 1 : 0;
+} CQS_ABI_CATCH_VAL(0)
+
+size_t cqs_hip_sparse_index_last_error(const cqs_hip_sparse_index* s, char* buf, size_t cap) CQS_ABI_TRY {
+    if (!s) return 0;
+    std::lock_guard<std::mutex> g(const_cast<cqs_hip_sparse_index*>(s)->mu);
+    if (buf && cap) {
+        const size_t m = std::min(cap - 1, s->last_error.size());
+        memcpy(buf, s->last_error.data(), m);
+        buf[m] = 0;
+    }
+    return s->last_error.size();
+} CQS_ABI_CATCH_VAL(0)
+
+int32_t cqs_hip_sparse_index_search(cqs_hip_sparse_index* s, const uint32_t* q_tokens, const float* q_weights, uint32_t n_terms,
+                                    uint32_t k, const uint32_t* keep_bitset, uint64_t* out_chunks, float* out_scores,
+                                    uint32_t* out_count) CQS_ABI_TRY {
+    if (!s) return CQS_HIP_ERR_INVALID;
+    std::lock_guard<std::mutex> g(s->mu);
+    if (!out_count) return sfail(s, CQS_HIP_ERR_INVALID, "sparse search: null out_count");
+    *out_count = 0;
+    if (s->poisoned) return CQS_HIP_ERR_POISONED;
+    if (k > cqs::kMaxK) return sfail(s, CQS_HIP_ERR_INVALID, "sparse search: k > CQS_HIP_MAX_K");
+    if (n_terms > kMaxTerms) return sfail(s, CQS_HIP_ERR_INVALID, "sparse search: too many query terms");
+    if (n_terms && (!q_tokens || !q_weights)) return sfail(s, CQS_HIP_ERR_INVALID, "sparse search: null query");
+    s->last_ms = 0.f;
+    s->last_touched = 0;
+    if (n_terms == 0 || s->n == 0 || k == 0) return CQS_HIP_OK;        // index.rs:237-239; BoundedScoreHeap::new(0) keeps nothing
+    if (!out_chunks || !out_scores) return sfail(s, CQS_HIP_ERR_INVALID, "sparse search: null output");
+    S_TRY(s, hipSetDevice(s->device));
+    int32_t rc = ensure_terms(s, n_terms);
+    if (rc != CQS_HIP_OK) return rc;
+    // resolve the terms (`self.postings.get(&token_id)`, index.rs:249): a token without a list scores nothing
+    uint32_t nt = 0;
+    uint64_t touched = 0;
+    for (uint32_t i = 0; i < n_terms; ++i) {
+        uint32_t bits;
+        memcpy(&bits, &q_weights[i], 4);
+        if (bits == kUnscored) return sfail(s, CQS_HIP_ERR_INVALID, "sparse search: reserved NaN payload in a query weight");
+        const auto it = std::lower_bound(s->tok.begin(), s->tok.end(), q_tokens[i]);
+        if (it == s->tok.end() || *it != q_tokens[i]) continue;
+        const size_t slot = (size_t)(it - s->tok.begin());
+        const uint64_t len = s->off[slot + 1] - s->off[slot];
+        if (len == 0) continue;
+        if (len > 0xFFFFFFFFull) return sfail(s, CQS_HIP_ERR_INVALID, "sparse search: posting list longer than 2^32");
+        s->h_terms[nt].start = s->off[slot];
+        s->h_terms[nt].len = (uint32_t)len;
+        s->h_terms[nt].w = q_weights[i];
+        ++nt;
+        touched += len;
+    }
+    if (nt == 0) return CQS_HIP_OK;
+    s->last_touched = touched;
+    hipStream_t st = s->stream;
+    S_TRY(s, hipMemcpyAsync(s->d_terms, s->h_terms, (size_t)nt * sizeof(SparseTerm), hipMemcpyHostToDevice, st));
+    const uint32_t* d_keep = nullptr;
+    if (keep_bitset) {
+        const size_t words = (size_t)((s->n + 31) / 32);
+        memcpy(s->h_keep, keep_bitset, words * 4);
+        S_TRY(s, hipMemcpyAsync(s->d_keep, s->h_keep, words * 4, hipMemcpyHostToDevice, st));
+        d_keep = s->d_keep;
+    }
+    const uint32_t waves = s->n_pad / s->rw;
+    S_TRY(s, hipEventRecord(s->ev0, st));
+    hipLaunchKernelGGL(sparse_accumulate_kernel, dim3((waves + 3u) / 4u), dim3(256), (size_t)4 * s->rw * 4, st, s->d_post, s->d_terms, nt,
+                       (uint32_t)s->n, s->n_pad, s->rw, d_keep, s->ranked ? s->d_chunk_of_rank : nullptr, s->d_scores, s->d_gmax);
+    S_TRY(s, hipGetLastError());
+    S_TRY(s, hipEventRecord(s->ev1, st));
+    cqs::ScanArgs a{};
+    a.n = (uint32_t)s->n;
+    a.n_pad = s->n_pad;
+    a.b = 1;
+    a.scores = s->d_scores;
+    a.gmax = s->d_gmax;
+    a.tiers = cqs::plan_tiers(s->n_pad, s->n_cu, true);
+    a.k = k;
+    a.linear_bins = false;
+    a.work = s->d_work;
+    a.n_cu = s->n_cu;
+    a.dbg = nullptr;
+    S_TRY(s, cqs::launch_select(a, 0u, s->d_out_keys, s->d_out_count, st));
+    S_TRY(s, hipMemcpyAsync(s->h_out_keys, s->d_out_keys, (size_t)k * 8, hipMemcpyDeviceToHost, st));
+    S_TRY(s, hipMemcpyAsync(s->h_out_keys + cqs::kMaxK, s->d_out_count, 4, hipMemcpyDeviceToHost, st));
+    S_TRY(s, hipStreamSynchronize(st));
+    (void)hipEventElapsedTime(&s->last_ms, s->ev0, s->ev1);
+    uint32_t cnt = (uint32_t)(s->h_out_keys[cqs::kMaxK] & 0xFFFFFFFFull);
+    if (cnt > k) cnt = k;
+    cqs_hip_unpack_keys(s->h_out_keys, cnt, out_chunks, out_scores);
+    if (s->ranked)
+        for (uint32_t i = 0; i < cnt; ++i) out_chunks[i] = s->chunk_of_rank[(size_t)out_chunks[i]];
+    *out_count = cnt;
+    return CQS_HIP_OK;
+} CQS_ABI_CATCH(s)
+
+int32_t cqs_hip_sparse_index_last_search(const cqs_hip_sparse_index* s, float* accumulate_ms, uint64_t* touched_postings) CQS_ABI_TRY {
+    if (!s) return CQS_HIP_ERR_INVALID;
+    std::lock_guard<std::mutex> g(const_cast<cqs_hip_sparse_index*>(s)->mu);
+    if (accumulate_ms) *accumulate_ms = s->last_ms;
+    if (touched_postings) *touched_postings = s->last_touched;
+    return CQS_HIP_OK;
+} CQS_ABI_CATCH_VAL(CQS_HIP_ERR_INVALID)
+
+}  // extern "C"

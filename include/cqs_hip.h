@@ -416,6 +416,44 @@ uint32_t cqs_hip_bert_vocab(const cqs_hip_bert* e);
 int32_t  cqs_hip_bert_poisoned(const cqs_hip_bert* e);
 size_t   cqs_hip_bert_last_error(cqs_hip_bert* e, char* buf, size_t cap);
 
+/* ---- sparse index: the SPLADE retrieval leg (`SpladeIndex`, src/splade/index.rs:177-306) ---------------------------
+ * The consumer of the sparse vectors cqs_hip_splade_encode_sparse produces: `search_hybrid_inner` asks it for
+ * candidate_count_for(limit) >= 500 chunks per query next to the dense leg (src/search/query.rs:898-901) and fuses the
+ * two lists itself (:909-1010, stays in Rust).  Replaces the in-memory `postings: HashMap<u32, Vec<(usize, f32)>>` +
+ * `HashMap<usize, f32>` accumulation by an HBM-resident posting array and one accumulate launch + the dense index's exact
+ * select.  Scores are BIT-IDENTICAL to the reference's: every chunk's sum is built as 0.0 + qw*dw + ... in query-term order,
+ * then posting order, f32 multiply and f32 add (index.rs:248-258).
+ *
+ * create (`SpladeIndex::build`, index.rs:191-212): the n chunks' sparse vectors in chunk-index order as a forward CSR -
+ * doc_off [n + 1] (doc_off[0] = 0), tokens / weights [doc_off[n]]; any u32 token id, repeated tokens inside a document
+ * kept (each occurrence is its own posting, as in the reference).  id_rank: NULL, or n u32 - a permutation of 0..n-1,
+ * id_rank[i] = how many chunk ids sort before chunk i's id (bytes; equal ids in chunk order): equal scores are then
+ * ordered by id like `BoundedScoreHeap` (src/search/scoring/candidate.rs:299-334); NULL orders them by chunk index.
+ * The one weight bit pattern 0xFFFFFFFF (a NaN) is refused (-> CQS_HIP_ERR_INVALID); every other f32 is accepted.
+ * n < 2^32 - 1024. */
+typedef struct cqs_hip_sparse_index cqs_hip_sparse_index;
+int32_t cqs_hip_sparse_index_create(const uint64_t* doc_off, const uint32_t* tokens, const float* weights, uint64_t n,
+                                    const uint32_t* id_rank, int32_t device, cqs_hip_sparse_index** out);
+void     cqs_hip_sparse_index_destroy(cqs_hip_sparse_index* idx);
+uint64_t cqs_hip_sparse_index_len(const cqs_hip_sparse_index* idx);            /* index.rs:294-296 */
+uint64_t cqs_hip_sparse_index_unique_tokens(const cqs_hip_sparse_index* idx);  /* index.rs:304-306 */
+uint64_t cqs_hip_sparse_index_postings(const cqs_hip_sparse_index* idx);
+/* `search_with_filter` (index.rs:223-290; `search` = keep_bitset NULL, :214-216).  The query's (token, weight) terms in
+ * the caller's order; keep_bitset: NULL or ceil(n / 32) host words, bit i of word i / 32 = the filter predicate on chunk i
+ * (evaluated by the caller on the chunk's id, as `search_hybrid_inner` builds its predicate, src/search/query.rs:861-877).
+ * Writes min(k, scored chunks) entries, best first: out_chunks = chunk indices (positions in the build order = id_map
+ * indices), out_scores = the raw dot products.  Chunks no posting of the query reaches are not candidates (even at score
+ * 0 others may be); non-finite scores are dropped (`would_accept`, candidate.rs:245-247); an empty query, an empty index or
+ * k = 0 give *out_count = 0 (index.rs:237-239).  k <= CQS_HIP_MAX_K. */
+int32_t cqs_hip_sparse_index_search(cqs_hip_sparse_index* idx, const uint32_t* q_tokens, const float* q_weights, uint32_t n_terms,
+                                    uint32_t k, const uint32_t* keep_bitset, uint64_t* out_chunks, float* out_scores,
+                                    uint32_t* out_count);
+/* Profiling aid: device time of the last search's accumulate launch (HIP events on its stream) and the postings it read
+ * (the sum of its terms' list lengths: 8 bytes each = the launch's algorithmic bytes, with 4 bytes per chunk of score row). */
+int32_t cqs_hip_sparse_index_last_search(const cqs_hip_sparse_index* idx, float* accumulate_ms, uint64_t* touched_postings);
+int32_t cqs_hip_sparse_index_poisoned(const cqs_hip_sparse_index* idx);
+size_t  cqs_hip_sparse_index_last_error(const cqs_hip_sparse_index* idx, char* buf, size_t cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -636,3 +636,117 @@ size_t cqs_oracle_brute_force_mt(const float* rows, size_t n, size_t dim, const 
     free(th);
     return c;
 }
+
+/* ================= (f)5 SpladeIndex (src/splade/index.rs:177-290) ================= */
+struct cqs_oracle_splade {
+    uint64_t n;                 /* id_map.len() */
+    size_t n_tokens;            /* postings.len() */
+    uint32_t* tok;              /* sorted distinct token ids (the HashMap's keys) */
+    uint64_t* off;              /* [n_tokens + 1] */
+    uint32_t* p_chunk;          /* postings in push order per token */
+    float* p_w;
+};
+
+static int cmp_u32(const void* a, const void* b) {
+    const uint32_t x = *(const uint32_t*)a, y = *(const uint32_t*)b;
+    return x < y ? -1 : (x > y ? 1 : 0);
+}
+static size_t splade_find(const cqs_oracle_splade* s, uint32_t token) {   /* postings.get(&token_id): index or (size_t)-1 */
+    size_t a = 0, b = s->n_tokens;
+    while (a < b) {
+        const size_t m = (a + b) / 2;
+        if (s->tok[m] < token) a = m + 1; else b = m;
+    }
+    return (a < s->n_tokens && s->tok[a] == token) ? a : (size_t)-1;
+}
+
+cqs_oracle_splade* cqs_oracle_splade_build(const uint64_t* doc_off, const uint32_t* tokens, const float* weights, uint64_t n) {
+    cqs_oracle_splade* s = (cqs_oracle_splade*)calloc(1, sizeof *s);
+    if (!s) return NULL;
+    const uint64_t P = n ? doc_off[n] : 0;
+    s->n = n;
+    uint32_t* sorted = (uint32_t*)malloc((P ? P : 1) * sizeof(uint32_t));
+    if (P) memcpy(sorted, tokens, P * sizeof(uint32_t));
+    qsort(sorted, P, sizeof(uint32_t), cmp_u32);
+    size_t u = 0;
+    for (uint64_t i = 0; i < P; ++i)
+        if (i == 0 || sorted[i] != sorted[i - 1]) sorted[u++] = sorted[i];
+    s->n_tokens = u;
+    s->tok = sorted;
+    s->off = (uint64_t*)calloc(u + 1, sizeof(uint64_t));
+    s->p_chunk = (uint32_t*)malloc((P ? P : 1) * sizeof(uint32_t));
+    s->p_w = (float*)malloc((P ? P : 1) * sizeof(float));
+    for (uint64_t i = 0; i < P; ++i) s->off[splade_find(s, tokens[i]) + 1]++;
+    for (size_t t = 0; t < u; ++t) s->off[t + 1] += s->off[t];
+    uint64_t* cur = (uint64_t*)malloc((u ? u : 1) * sizeof(uint64_t));
+    memcpy(cur, s->off, u * sizeof(uint64_t));
+    for (uint64_t d = 0; d < n; ++d)                                     /* index.rs:197-202: chunk by chunk, entry by entry */
+        for (uint64_t e = doc_off[d]; e < doc_off[d + 1]; ++e) {
+            const uint64_t at = cur[splade_find(s, tokens[e])]++;
+            s->p_chunk[at] = (uint32_t)d;
+            s->p_w[at] = weights[e];
+        }
+    free(cur);
+    return s;
+}
+void cqs_oracle_splade_free(cqs_oracle_splade* s) {
+    if (!s) return;
+    free(s->tok); free(s->off); free(s->p_chunk); free(s->p_w); free(s);
+}
+size_t cqs_oracle_splade_len(const cqs_oracle_splade* s) { return (size_t)s->n; }
+size_t cqs_oracle_splade_unique_tokens(const cqs_oracle_splade* s) { return s->n_tokens; }
+uint64_t cqs_oracle_splade_touched(const cqs_oracle_splade* s, const uint32_t* q_tokens, size_t n_terms) {
+    uint64_t t = 0;
+    for (size_t i = 0; i < n_terms; ++i) {
+        const size_t j = splade_find(s, q_tokens[i]);
+        if (j != (size_t)-1) t += s->off[j + 1] - s->off[j];
+    }
+    return t;
+}
+
+size_t cqs_oracle_splade_search(const cqs_oracle_splade* s, const uint32_t* q_tokens, const float* q_weights, size_t n_terms,
+                                size_t k, const uint8_t* keep, const char* const* ids, const uint32_t* id_rank,
+                                uint64_t* chunks_out, float* scores_out) {
+    if (n_terms == 0 || s->n == 0) return 0;                              /* index.rs:237-239 */
+    /* `scores: HashMap<usize, f32>` as a dense array + a presence flag: same values, and the heap below does not
+     * depend on the order the map is walked in (ids are distinct, its order is total) */
+    float* score = (float*)calloc((size_t)s->n, sizeof(float));
+    uint8_t* scored = (uint8_t*)calloc((size_t)s->n, 1);
+    for (size_t i = 0; i < n_terms; ++i) {                                 /* :248 */
+        const size_t j = splade_find(s, q_tokens[i]);
+        if (j == (size_t)-1) continue;                                     /* :249 */
+        const float qw = q_weights[i];
+        for (uint64_t e = s->off[j]; e < s->off[j + 1]; ++e) {             /* :250 */
+            const uint32_t c = s->p_chunk[e];
+            if (c >= s->n || (keep && !keep[c])) continue;                 /* :252-254 */
+            const float prod = qw * s->p_w[e];                             /* :256 (-ffp-contract=off: no fma) */
+            if (!scored[c]) { scored[c] = 1; score[c] = 0.0f; }
+            score[c] = score[c] + prod;
+        }
+    }
+    cqs_oracle_heap* h = cqs_oracle_heap_new(k);                           /* :265 */
+    /* string ids: into_sorted returns push order, so remember which chunk each push was */
+    uint64_t* pushed = ids ? (uint64_t*)malloc((size_t)s->n * sizeof(uint64_t)) : NULL;
+    size_t np = 0;
+    for (uint64_t c = 0; c < s->n; ++c) {
+        if (!scored[c]) continue;
+        if (!cqs_oracle_heap_would_accept(h, score[c])) continue;          /* :270-272 */
+        if (ids) { cqs_oracle_heap_push_str(h, ids[c], score[c]); pushed[np++] = c; }   /* :273-278 */
+        else cqs_oracle_heap_push_u64(h, id_rank ? (uint64_t)id_rank[c] : c, score[c]);
+    }
+    uint64_t* tmp = (uint64_t*)malloc((k ? k : 1) * sizeof(uint64_t));
+    const size_t cnt = cqs_oracle_heap_into_sorted(h, tmp, scores_out, k); /* :281 */
+    if (ids) {
+        for (size_t i = 0; i < cnt; ++i) chunks_out[i] = pushed[tmp[i]];
+    } else if (id_rank) {
+        uint64_t* of_rank = (uint64_t*)malloc((size_t)s->n * sizeof(uint64_t));
+        for (uint64_t c = 0; c < s->n; ++c) of_rank[id_rank[c]] = c;
+        for (size_t i = 0; i < cnt; ++i) chunks_out[i] = of_rank[tmp[i]];
+        free(of_rank);
+    } else {
+        for (size_t i = 0; i < cnt; ++i) chunks_out[i] = tmp[i];
+    }
+    free(tmp); free(pushed); free(score); free(scored);
+    cqs_oracle_heap_free(h);
+    return cnt;
+}

@@ -114,6 +114,29 @@ float cqs_oracle_dist_dot_clamped(const float* a, const float* b, size_t n); /* 
  * Returns kept count. */
 size_t cqs_oracle_prepare_index_keep(const float* rows, size_t n, size_t dim, uint8_t* keep);
 
+/* ---- (f)5: SpladeIndex - the sparse retrieval leg (src/splade/index.rs:177-290) ---------------
+ * build (index.rs:191-212): chunks in input order, `postings: token -> [(chunk_index, weight)]` in push order
+ * (chunk order, and a document's own order for a token it names twice); id_map[chunk_index] = id.
+ * Input here: the documents' sparse vectors as a forward CSR (doc_off[n + 1], tokens, weights). */
+typedef struct cqs_oracle_splade cqs_oracle_splade;
+cqs_oracle_splade* cqs_oracle_splade_build(const uint64_t* doc_off, const uint32_t* tokens, const float* weights, uint64_t n);
+void   cqs_oracle_splade_free(cqs_oracle_splade*);
+size_t cqs_oracle_splade_len(const cqs_oracle_splade*);             /* index.rs:294-296 */
+size_t cqs_oracle_splade_unique_tokens(const cqs_oracle_splade*);   /* index.rs:304-306 */
+/* search_with_filter (index.rs:223-290): empty query / empty index -> 0 (:237-239); for each query term IN QUERY ORDER,
+ * for each posting of its token in list order: skip chunks the filter rejects (:253-255), `*scores.entry(chunk)
+ * .or_insert(0.0) += query_weight * doc_weight` (:256; f32 multiply, then f32 add - no fma); then every SCORED chunk
+ * through BoundedScoreHeap::would_accept / push (:267-279; non-finite scores never enter, ties keep the smaller id) and
+ * into_sorted_vec (:281).  keep: nullable, one byte per chunk (the predicate evaluated on its id).  Chunk ids: `ids`
+ * (n C strings, compared as bytes) if non-NULL, else `id_rank` (n u32: the rank of the chunk's id among all ids) if
+ * non-NULL, else the chunk index itself.  Writes min(k, scored) chunk indices + scores, best first; returns the count. */
+size_t cqs_oracle_splade_search(const cqs_oracle_splade*, const uint32_t* q_tokens, const float* q_weights, size_t n_terms,
+                                size_t k, const uint8_t* keep, const char* const* ids, const uint32_t* id_rank,
+                                uint64_t* chunks_out, float* scores_out);
+/* postings the search above reads for this query (sum of the posting-list lengths of its terms): the unit of the
+ * sparse leg's algorithmic bytes (bench.py) */
+uint64_t cqs_oracle_splade_touched(const cqs_oracle_splade*, const uint32_t* q_tokens, size_t n_terms);
+
 /* ---- limits / batch sizing ------------------------------------------------ */
 size_t cqs_oracle_dim_scaled_batch(size_t baseline, size_t dim, size_t min, size_t max); /* limits.rs:292-300 */
 size_t cqs_oracle_candidate_count_for(size_t limit, size_t floor);                       /* limits.rs:315-320 */

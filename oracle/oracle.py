@@ -64,6 +64,12 @@ def lib() -> C.CDLL:
             "cqs_oracle_brute_force_mt": (sz, [vp, sz, sz, vp, sz, f, i, i, vp, vp]),
             "cqs_oracle_set_worker_cpus": (None, [vp, i]),
             "cqs_oracle_first_touch_copy": (None, [vp, vp, sz, sz, i]),
+            "cqs_oracle_splade_build": (vp, [vp, vp, vp, C.c_uint64]),
+            "cqs_oracle_splade_free": (None, [vp]),
+            "cqs_oracle_splade_len": (sz, [vp]),
+            "cqs_oracle_splade_unique_tokens": (sz, [vp]),
+            "cqs_oracle_splade_search": (sz, [vp, vp, vp, sz, sz, vp, vp, vp, vp, vp]),
+            "cqs_oracle_splade_touched": (C.c_uint64, [vp, vp, sz]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(L, name)
@@ -251,3 +257,87 @@ def last_token_pool(hidden, mask):
     out = np.zeros((b, d), dtype=np.float32)
     lib().cqs_oracle_last_token_pool(_p(hidden), _p(mask), b, s, d, _p(out))
     return out
+
+
+def forward_csr(docs):
+    """[(token, weight), ...] per chunk -> (doc_off u64 [n + 1], tokens u32, weights f32): the documents' sparse vectors
+    (`SparseVector = Vec<(u32, f32)>`, src/splade/mod.rs) as the flat arrays both the oracle and the C ABI take."""
+    off = np.zeros(len(docs) + 1, dtype=np.uint64)
+    for i, d in enumerate(docs):
+        off[i + 1] = off[i] + len(d)
+    tok = np.zeros(int(off[-1]), dtype=np.uint32)
+    w = np.zeros(int(off[-1]), dtype=np.float32)
+    at = 0
+    for d in docs:
+        for t, x in d:
+            tok[at] = t
+            w[at] = x
+            at += 1
+    return off, tok, w
+
+
+class SpladeIndex:
+    """`SpladeIndex` (src/splade/index.rs:177-306): build / search / search_with_filter / len / is_empty /
+    unique_tokens, over the C restatement.  `ids`: chunk id strings (None = the chunk index is the id)."""
+
+    def __init__(self, doc_off, tokens, weights, ids=None, id_rank=None):
+        self._off = np.ascontiguousarray(doc_off, dtype=np.uint64)
+        self._tok = np.ascontiguousarray(tokens, dtype=np.uint32)
+        self._w = np.ascontiguousarray(weights, dtype=np.float32)
+        self.n = len(self._off) - 1
+        self.ids = None if ids is None else list(ids)
+        self._rank = None if id_rank is None else np.ascontiguousarray(id_rank, dtype=np.uint32)
+        self._cids = None
+        if self.ids is not None:
+            enc = [s.encode("utf-8") for s in self.ids]
+            self._cids = (C.c_char_p * len(enc))(*enc)
+        self._h = C.c_void_p(lib().cqs_oracle_splade_build(_p(self._off), _p(self._tok), _p(self._w), self.n))
+
+    @classmethod
+    def build(cls, chunks):
+        """`SpladeIndex::build(Vec<(String, SparseVector)>)` (index.rs:191-212)."""
+        off, tok, w = forward_csr([sv for _id, sv in chunks])
+        return cls(off, tok, w, ids=[cid for cid, _sv in chunks])
+
+    def __len__(self):
+        return int(lib().cqs_oracle_splade_len(self._h))
+
+    def is_empty(self):
+        return len(self) == 0
+
+    def unique_tokens(self):
+        return int(lib().cqs_oracle_splade_unique_tokens(self._h))
+
+    def touched(self, q_tokens):
+        qt = np.ascontiguousarray(q_tokens, dtype=np.uint32)
+        return int(lib().cqs_oracle_splade_touched(self._h, _p(qt), qt.size))
+
+    def search_raw(self, q_tokens, q_weights, k, keep=None):
+        """-> (chunk indices u64, scores f32), best first."""
+        qt = np.ascontiguousarray(q_tokens, dtype=np.uint32)
+        qw = np.ascontiguousarray(q_weights, dtype=np.float32)
+        kp = None if keep is None else np.ascontiguousarray(keep, dtype=np.uint8)
+        out = np.zeros(max(k, 1), dtype=np.uint64)
+        sc = np.zeros(max(k, 1), dtype=np.float32)
+        ids = None if self._cids is None else C.cast(self._cids, C.c_void_p)
+        c = lib().cqs_oracle_splade_search(self._h, _p(qt), _p(qw), qt.size, k, _p(kp), ids, _p(self._rank), _p(out), _p(sc))
+        return out[:c], sc[:c]
+
+    def search(self, query, k):
+        """`search(&SparseVector, k)` (index.rs:214-216) -> [(id, score)]."""
+        return self.search_with_filter(query, k, None)
+
+    def search_with_filter(self, query, k, pred):
+        keep = None
+        if pred is not None:
+            keep = np.array([1 if pred(self.ids[i] if self.ids is not None else i) else 0 for i in range(self.n)], dtype=np.uint8)
+        ch, sc = self.search_raw([t for t, _w in query], [w for _t, w in query], k, keep)
+        return [((self.ids[int(c)] if self.ids is not None else int(c)), float(s)) for c, s in zip(ch, sc)]
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().cqs_oracle_splade_free(self._h)
+                self._h = None
+        except Exception:
+            pass

@@ -1,0 +1,160 @@
+"""Parity of the HIP sparse index (cqs_hip_sparse_index_*, through the C ABI via cqs_amd.splade_index) with the oracle
+restatement of `SpladeIndex` (src/splade/index.rs:177-290): chunk order and score BITS identical (integer / f32-sum work:
+the bar is bit-exact), on the reference's own known-answer cases, on seeded corpora from 1 chunk to 1M, and through
+size-independent properties."""
+import numpy as np
+import pytest
+
+import sparse_cases as sc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def S(hip):
+    from cqs_amd import splade_index
+    return splade_index
+
+
+def _same(oracle_ix, hip_ix, qt, qw, k, keep=None):
+    oc, os_ = oracle_ix.search_raw(qt, qw, k, keep)
+    hc, hs, rc = hip_ix.search_raw(qt, qw, k, keep)
+    assert rc == 0
+    assert hc.size == oc.size, (hc.size, oc.size)
+    assert np.array_equal(hs.view(np.uint32), os_.view(np.uint32)), "score bits differ"
+    assert np.array_equal(hc, oc), "chunk order differs"
+    return hc, hs
+
+
+def test_reference_kats_through_the_abi(S, oracle):    # src/splade/index.rs:1113-1242
+    from test_sparse_oracle import _check_case
+    k = sc.kats()
+    chunks = [(cid, [(int(t), float(w)) for t, w in sv]) for cid, sv in k["index"]]
+    ix = S.HipSpladeIndex.build(chunks)
+    assert len(ix) == k["len"] and not ix.is_empty() and ix.unique_tokens() == 5 and ix.postings() == 8
+    for case in k["cases"]:
+        _check_case(ix, case)
+    empty = S.HipSpladeIndex.build([])
+    assert empty.is_empty() and empty.unique_tokens() == 0 and empty.search([(1, 1.0)], 10) == []
+    ix.close(); empty.close()
+
+
+@pytest.mark.parametrize("n,vocab,nnz,terms,k", [
+    (1, 50, (1, 8), 6, 10), (63, 80, (0, 12), 20, 500), (64, 80, (1, 12), 20, 64), (65, 200, (1, 30), 70, 1024),
+    (1000, 300, (5, 40), 65, 500), (5000, 2000, (20, 120), 130, 500), (70001, 30522, (40, 160), 90, 1000),
+])
+def test_seeded_corpora_bit_exact(S, oracle, n, vocab, nnz, terms, k):
+    rng = np.random.default_rng(n * 7919 + terms)
+    off, tok, w = sc.corpus(rng, n, vocab, nnz[0], nnz[1], dup_frac=0.3, special=True)
+    rank = rng.permutation(n).astype(np.uint32)
+    o = oracle.SpladeIndex(off, tok, w, id_rank=rank)
+    h = S.HipSpladeIndex.build_from_csr(None, off, tok, w, id_rank=rank)
+    assert len(h) == n and h.unique_tokens() == o.unique_tokens()
+    for trial in range(4):
+        qt, qw = sc.query(rng, vocab, terms, shuffle=trial != 1, dups=3 if trial == 2 else 0, absent=4)
+        if trial == 3:
+            qw[::5] *= np.float32(-1.0)
+        _same(o, h, qt, qw, k)
+        keep = rng.random(n) < (0.5 if trial % 2 else 0.05)
+        _same(o, h, qt, qw, k, keep)
+    _same(o, h, qt, qw, 1)
+    _same(o, h, qt, qw, k, np.zeros(n, bool))            # nothing kept
+    h.close()
+
+
+def test_equal_scores_follow_id_order_and_string_ids(S, oracle):
+    """Many identical documents (duplicated code chunks): every score ties; the cut at k must keep the smallest ids
+    (BoundedScoreHeap, candidate.rs:299-334) - with string ids, and with duplicate ids too (the reference allows them)."""
+    rng = np.random.default_rng(5)
+    base = [(3, 0.5), (9, 1.25), (11, 0.75)]
+    ids = ["c%05d" % i for i in rng.permutation(3000)]
+    ids[10] = ids[20]                                      # a duplicate id
+    chunks = [(cid, base if i % 3 else base + [(40, 0.1)]) for i, cid in enumerate(ids)]
+    o = oracle.SpladeIndex.build(chunks)
+    h = S.HipSpladeIndex.build(chunks)
+    q = [(9, 2.0), (3, 1.0), (40, 5.0)]
+    for k in (1, 7, 500, 1024):
+        got = h.search(q, k)
+        want = o.search(q, k)
+        assert [(r.id, r.score) for r in got] == want
+    flt = lambda cid: cid.endswith("7")
+    assert [(r.id, r.score) for r in h.search_with_filter(q, 300, flt)] == o.search_with_filter(q, 300, flt)
+    h.close()
+
+
+def test_non_finite_weights_and_guards(S, oracle, hip):
+    rng = np.random.default_rng(11)
+    off, tok, w = sc.corpus(rng, 4000, 500, 5, 40)
+    w[rng.integers(0, w.size, 50)] = np.float32("inf")
+    w[rng.integers(0, w.size, 50)] = np.float32("nan")
+    w[rng.integers(0, w.size, 50)] = np.float32("-inf")
+    o = oracle.SpladeIndex(off, tok, w)
+    h = S.HipSpladeIndex.build_from_csr(None, off, tok, w)
+    for trial in range(3):
+        qt, qw = sc.query(rng, 500, 40)
+        if trial == 1:
+            qw[3] = np.float32("nan")
+        if trial == 2:
+            qw[5] = np.float32("inf"); qw[6] = np.float32(0.0)
+        hc, hs = _same(o, h, qt, qw, 500)
+        assert np.all(np.isfinite(hs))
+    # guards: k = 0, empty query, k over the cap (refused, the mirror returns nothing and keeps the message)
+    assert h.search_raw(qt, qw, 0)[0].size == 0 and h.search_raw([], [], 10)[0].size == 0
+    _c, _s, rc = h.search_raw(qt, qw, 1025)
+    assert rc == -1 and "MAX_K" in h.last_error
+    # the reserved NaN payload is refused at build and in a query
+    bad = w.copy(); bad.view(np.uint32)[7] = 0xFFFFFFFF
+    with pytest.raises(S.HipError):
+        S.HipSpladeIndex.build_from_csr(None, off, tok, bad)
+    qbad = qw.copy(); qbad.view(np.uint32)[0] = 0xFFFFFFFF
+    assert h.search_raw(qt, qbad, 10)[2] == -1
+    # not a permutation
+    with pytest.raises(S.HipError):
+        S.HipSpladeIndex.build_from_csr(None, off, tok, w, id_rank=np.zeros(4000, np.uint32))
+    h.close()
+
+
+def test_full_u32_token_ids(S, oracle):
+    """Token ids are any u32 (the reference's proptest draws from the whole range, index.rs:1750-1753): the sort path of
+    the token table."""
+    rng = np.random.default_rng(21)
+    off, tok, w = sc.corpus(rng, 3000, 400, 3, 30, dup_frac=0.2)
+    remap = rng.choice(np.arange(0, 2 ** 32, dtype=np.uint64), size=400, replace=False).astype(np.uint32)
+    remap[0] = 0; remap[1] = 0xFFFFFFFF
+    o = oracle.SpladeIndex(off, remap[tok], w)
+    h = S.HipSpladeIndex.build_from_csr(None, off, remap[tok], w)
+    for _ in range(3):
+        qt, qw = sc.query(rng, 400, 50)
+        _same(o, h, remap[qt], qw, 500)
+    h.close()
+
+
+def test_one_million_chunks_against_the_oracle_and_properties(S, oracle):
+    """BASELINE-size corpus (1M chunks, ~96 postings each): the oracle still answers in seconds, so this is parity proper;
+    plus properties that need no oracle: linearity in the query weights (exact for powers of two), a filter that keeps
+    exactly the winners returns them unchanged, sortedness."""
+    rng = np.random.default_rng(1234)
+    n, vocab = 1_000_000, 30522
+    lens = rng.integers(64, 129, size=n)
+    off = np.zeros(n + 1, np.uint64); off[1:] = np.cumsum(lens)
+    P = int(off[-1])
+    # Zipf-like token draw without per-document loops: ids = floor(vocab * u^3); duplicates inside a document are left in
+    # (each is its own posting, as in the reference)
+    tok = np.minimum((vocab * rng.random(P) ** 3).astype(np.uint32), vocab - 1)
+    w = (rng.random(P, dtype=np.float32) * 2.0 + 0.01).astype(np.float32)
+    o = oracle.SpladeIndex(off, tok, w)
+    h = S.HipSpladeIndex.build_from_csr(None, off, tok, w)
+    qt = np.unique(np.minimum((vocab * rng.random(80) ** 3).astype(np.uint32), vocab - 1))
+    rng.shuffle(qt)
+    qw = (rng.random(qt.size, dtype=np.float32) + 0.1).astype(np.float32)
+    hc, hs = _same(o, h, qt, qw, 500)
+    assert np.all(hs[:-1] >= hs[1:])
+    ms, touched = h.last_search()
+    assert touched == o.touched(qt) and ms > 0
+    hc2, hs2, _ = h.search_raw(qt, qw * np.float32(4.0), 500)
+    assert np.array_equal(hc2, hc) and np.array_equal(hs2, hs * np.float32(4.0))
+    keep = np.zeros(n, bool); keep[hc.astype(np.int64)] = True
+    hc3, hs3, _ = h.search_raw(qt, qw, 500, keep)
+    assert np.array_equal(hc3, hc) and np.array_equal(hs3, hs)
+    _same(o, h, qt, qw, 1000, rng.random(n) < 0.3)
+    h.close()
