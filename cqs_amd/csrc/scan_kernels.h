@@ -46,6 +46,7 @@ struct ScanArgs {
     float threshold;
     bool nontemporal;       // stream the corpus past L2 (corpus >> Infinity Cache)
     bool linear_bins;       // scores bounded in [-1,1] (cosine / pipeline mode): linear histogram bins
+    bool range_bins = false;// select only: linear bins over the range of the row's own group maxima (the sparse index)
     uint32_t k;
     float* gmax;            // [b, tiers.total()] per-task maxima (written by the scan)
     TaskTiers tiers;        // plan_tiers(n_pad, n_cu, uniform_groups(b, dim))

@@ -54,6 +54,19 @@ __device__ __forceinline__ uint32_t bin_of(float s, bool linear) {
     }
     return okey(s) >> 20;
 }
+// Third form (select mode 2, the sparse index): linear bins over the range the GROUP MAXIMA of this very row span - sums of
+// SPLADE products crowd into two or three octaves, where the log-spaced bins above put thousands of groups into the
+// threshold bin.  Any monotone map is correct (the candidates are re-ranked on their full keys); this one is sharp where
+// the top-k lives.  Scores below `lo` fall into bin 0.
+__device__ __forceinline__ uint32_t bin_of_range(float s, float lo, float scale) {
+    if (!(scale > 0.f)) return 0u;                        // degenerate range: one bin
+    const float t = (s - lo) * scale;
+    if (!(t < 4095.0f)) return 4095u;                     // (also an overflowed difference)
+    return t > 0.f ? (uint32_t)(int)t : 0u;
+}
+__device__ __forceinline__ uint32_t bin_any(float s, uint32_t mode, float lo, float scale) {
+    return mode == 2u ? bin_of_range(s, lo, scale) : bin_of(s, mode != 0u);
+}
 
 // ---- transposed butterfly reduction ---------------------------------------
 // v[0..NV) hold per-lane partial sums of NV independent dot products.  After
@@ -456,13 +469,34 @@ __global__ __launch_bounds__(1024) void select_finish_kernel(const float* __rest
     const float* s = scores + (size_t)qi * n_pad;
     const float* gm = gmax + (size_t)qi * n_tasks;
     const int lane = threadIdx.x & 63;
-    const bool lin = linear != 0u;
+    float r_lo = 0.f, r_scale = 0.f;                       // mode 2: the bins' range (see bin_of_range)
 
 #define CQS_STAMP(i) do { if (dbg && threadIdx.x == 0 && blockIdx.x == 0) dbg[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
     CQS_STAMP(0);
     for (uint32_t i = threadIdx.x; i < kHistBins; i += 1024u) s_hist[i] = 0u;
     if (threadIdx.x == 0) { s_cnt = 0; s_ng = 0; }
     __syncthreads();
+    if (linear == 2u) {                                    // phase 0: smallest and largest finite group maximum
+        float lo = INFINITY, hi = -INFINITY;
+        for (uint32_t t = threadIdx.x; t < n_tasks; t += 1024u) {
+            const float v = gm[t];
+            if (v != -INFINITY) { lo = fminf(lo, v); hi = fmaxf(hi, v); }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            lo = fminf(lo, __shfl_xor(lo, off, 64));
+            hi = fmaxf(hi, __shfl_xor(hi, off, 64));
+        }
+        float* const f_part = reinterpret_cast<float*>(s_part);
+        if (lane == 0) { f_part[threadIdx.x >> 6] = lo; f_part[16 + (threadIdx.x >> 6)] = hi; }
+        __syncthreads();
+        lo = f_part[0]; hi = f_part[16];
+        for (int w = 1; w < 16; ++w) { lo = fminf(lo, f_part[w]); hi = fmaxf(hi, f_part[16 + w]); }
+        __syncthreads();                                   // s_part is reused by block_decide
+        r_lo = lo;
+        r_scale = (hi > lo) ? 4096.0f / (hi - lo) : 0.f;   // (no finite maximum at all: nothing is histogrammed below)
+        if (!(r_scale < INFINITY)) r_scale = 0.f;          // a range narrower than 4096 ulps of a subnormal: one bin, the exact path sorts it out
+    }
 
     // phase 1: histogram of the group maxima
     float m[kGB];
@@ -476,7 +510,7 @@ __global__ __launch_bounds__(1024) void select_finish_kernel(const float* __rest
         }
 #pragma unroll
         for (int u = 0; u < kGB; ++u)
-            if (m[u] != -INFINITY) atomicAdd(&s_hist[bin_of(m[u], lin)], 1u);
+            if (m[u] != -INFINITY) atomicAdd(&s_hist[bin_any(m[u], linear, r_lo, r_scale)], 1u);
     }
     __syncthreads();
     CQS_STAMP(1);
@@ -498,7 +532,7 @@ __global__ __launch_bounds__(1024) void select_finish_kernel(const float* __rest
         bool take[kGB];
         uint32_t slot[kGB];
 #pragma unroll
-        for (int u = 0; u < kGB; ++u) take[u] = (m[u] != -INFINITY) && (bin_of(m[u], lin) >= T);
+        for (int u = 0; u < kGB; ++u) take[u] = (m[u] != -INFINITY) && (bin_any(m[u], linear, r_lo, r_scale) >= T);
         wave_slots<kGB>(take, &s_ng, lane, slot);
 #pragma unroll
         for (int u = 0; u < kGB; ++u)
@@ -537,7 +571,7 @@ __global__ __launch_bounds__(1024) void select_finish_kernel(const float* __rest
             bool take[kGB];
             uint32_t slot[kGB];
 #pragma unroll
-            for (int u = 0; u < kGB; ++u) take[u] = (v[u] != -INFINITY) && (bin_of(v[u], lin) >= T);
+            for (int u = 0; u < kGB; ++u) take[u] = (v[u] != -INFINITY) && (bin_any(v[u], linear, r_lo, r_scale) >= T);
             wave_slots<kGB>(take, &s_cnt, lane, slot);
 #pragma unroll
             for (int u = 0; u < kGB; ++u)
@@ -782,7 +816,7 @@ hipError_t launch_select(const ScanArgs& a, uint32_t row_base, uint64_t* out_key
     if (a.b == 0 || a.k == 0) return hipSuccess;
     hipLaunchKernelGGL(select_finish_kernel, dim3(a.b), dim3(1024), 0, st, a.scores, a.gmax, a.n_pad,
                        a.tiers, tier_slot_log2(a.tiers), a.k, row_base,
-                       a.linear_bins ? 1u : 0u, out_keys, out_counts, a.work,
+                       a.range_bins ? 2u : (a.linear_bins ? 1u : 0u), out_keys, out_counts, a.work,
                        (unsigned long long*)a.dbg);
     return hipGetLastError();
 }

@@ -10,14 +10,13 @@
 // names a few dozen tokens).  "chunk" is the chunk's RANK in ascending id order when the caller gives `id_rank`, so that
 // the select's (score desc, position asc) order is BoundedScoreHeap's (score desc, id asc).
 //
-// One launch accumulates a query: a WAVE owns a contiguous range of `rw` chunks and keeps their scores in LDS.  For every
-// query term it finds the part of the term's list that falls into its range (two binary searches, 64 terms at a time, one
-// per lane), then walks the terms in query order: 64 postings per step, `s = s + qw * dw` in LDS with separate f32 multiply
-// and add - every chunk's sum is built in exactly the reference's order, so the scores are bit-identical, not "close".
-// Postings of one token name distinct chunks unless a document lists a token twice; a step that sees such a pair runs
-// its lanes one after the other (posting order again).  No atomics, no barriers: a wave's LDS operations retire in order.
-// The kernel is bound by the touched postings' bytes (8 B each) + the score row it writes (4 B per chunk); the exact
-// top-k is the dense index's select_finish_kernel over that score row and its 64-chunk maxima.
+// Two launches score a query (the kernels' own comments have the details): sparse_slice_kernel walks the touched postings
+// once and notes where every term's list crosses the wave ranges; sparse_accumulate_kernel gives every WAVE a contiguous
+// range of chunks with their scores in LDS and streams the range's postings term after term, 64 per step, adding
+// `s = s + qw * dw` with separate f32 multiply and add - every chunk's sum is built in exactly the reference's order, so
+// the scores are bit-identical, not "close".  No global atomics, no barriers.  Both are bound by the touched postings'
+// bytes (8 B each, read twice) + the score row (4 B per chunk); the exact top-k is the dense index's select_finish_kernel
+// over that score row and its 64-chunk maxima, with bins laid over the row's own range of maxima (scan_kernels.hip).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -37,79 +36,165 @@ namespace {
 constexpr uint32_t kSparsePad = 1024;          // n_pad granule (a multiple of every wave range)
 constexpr uint32_t kUnscored = 0xFFFFFFFFu;    // LDS marker: `scores.entry(chunk)` does not exist yet (a NaN no arithmetic here produces:
                                                // weights with that bit pattern are refused at build / search)
-constexpr uint32_t kMaxTerms = 1u << 20;
+constexpr uint32_t kMaxTerms = 1u << 16;
 
 struct SparseTerm {            // one query term, resolved on the host
     unsigned long long start;  // first posting of the token's list
+    unsigned long long cum;    // postings of the terms before this one (the query's touched postings, term after term)
     uint32_t len;              // postings in the list
     float w;                   // query weight
 };
 
-__device__ __forceinline__ uint32_t lower_bound_chunk(const uint2* __restrict__ p, uint32_t a, uint32_t b, uint32_t c) {
-    while (a < b) {
-        const uint32_t m = (a + b) >> 1;
-        if (p[m].x < c) a = m + 1u; else b = m;
+// ---- launch 1: where every term's list crosses the wave ranges ------------------------------------------------------
+// One thread per touched posting (the concatenation of the query's lists).  A posting that is the first / last of its
+// list inside a range of `1 << sh` chunks writes its list-relative position into slices[range][term].x / its position
+// + 1 into .y; ranges a list does not reach keep (0, 0) from the memset in front of this launch.
+constexpr uint32_t kSliceTermsLds = 2048;   // running counts kept in LDS up to this many terms (a query has a few dozen)
+__global__ __launch_bounds__(256) void sparse_slice_kernel(const uint2* __restrict__ post, const SparseTerm* __restrict__ terms,
+                                                           uint32_t n_terms, unsigned long long touched, uint32_t sh,
+                                                           uint2* __restrict__ slices) {
+    __shared__ unsigned long long s_cum[kSliceTermsLds];
+    const bool in_lds = n_terms <= kSliceTermsLds;
+    if (in_lds) {
+        for (uint32_t t = threadIdx.x; t < n_terms; t += 256u) s_cum[t] = terms[t].cum;
+        __syncthreads();
     }
-    return a;
+    // four consecutive postings of the concatenation per thread (they mostly share a term and a range)
+    const unsigned long long g0 = ((unsigned long long)blockIdx.x * 256ull + threadIdx.x) * 4ull;
+    if (g0 >= touched) return;
+    uint32_t a = 0, b = n_terms;                           // the last term whose cum <= g0
+    while (b - a > 1u) {
+        const uint32_t m = (a + b) >> 1;
+        if ((in_lds ? s_cum[m] : terms[m].cum) <= g0) a = m; else b = m;
+    }
+    SparseTerm tm = terms[a];
+    uint32_t i = (uint32_t)(g0 - tm.cum);
+    const uint2* p = post + tm.start;
+    uint32_t r_prev = i == 0u ? 0xFFFFFFFFu : (p[i - 1u].x >> sh);
+    uint32_t r = p[i].x >> sh;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        if (g0 + (unsigned long long)u >= touched) break;
+        const uint32_t r_next = i + 1u == tm.len ? 0xFFFFFFFFu : (p[i + 1u].x >> sh);
+        uint2* const s = slices + (size_t)r * n_terms + a;
+        if (r_prev != r) s->x = i;
+        if (r_next != r) s->y = i + 1u;
+        if (i + 1u == tm.len) {                            // on to the next term's list
+            if (++a >= n_terms) break;
+            tm = terms[a];
+            p = post + tm.start;
+            i = 0u;
+            r_prev = 0xFFFFFFFFu;
+            r = p[0].x >> sh;
+        } else {
+            ++i;
+            r_prev = r;
+            r = r_next;
+        }
+    }
 }
 
-// grid: ceil(n_pad / rw / 4) workgroups of 4 waves; dynamic LDS = 4 * rw * 4 bytes
+// (Tried: the table term-major, so that a list's consecutive ranges share cache lines: this launch 11.9 -> 10.0 us at 64
+// terms, the next one 11.4 -> 14.2 - its 64 lanes then read 64 different lines.  Range-major stays.)
+
+// ---- launch 2: the sums ------------------------------------------------------------------------------------------------
+// A wave owns `rw = 1 << sh` chunks and their scores in LDS.  64 terms at a time: lane t reads its term's slice, a wave
+// prefix sum lays the slices end to end (term order, inside a term posting order = the order the reference adds in), and the
+// wave streams that sequence 64 postings per step - every lane finds its term by a search over the 64 running counts in
+// LDS, so all lanes carry a posting whatever the slices' lengths, and the loads of one step do not wait for the sums of the
+// step before.  Two postings of a step may name the same chunk (different terms, or a token a document lists twice): each
+// pending lane posts its lane number into claim[chunk] with an LDS minimum, the lowest lane (= the earlier posting) adds
+// and clears the claim, the others go round again.  No barriers, no global atomics.
+constexpr int kSpUnroll = 4;
+// dynamic LDS per wave: rw scores + rw claims + 64 x (count, address lo, address hi, weight)
+__host__ __device__ constexpr uint32_t sparse_wave_lds_words(uint32_t rw) { return 2u * rw + 4u * 64u; }
+
 __global__ __launch_bounds__(256) void sparse_accumulate_kernel(const uint2* __restrict__ post, const SparseTerm* __restrict__ terms,
-                                                                uint32_t n_terms, uint32_t n, uint32_t n_pad, uint32_t rw,
+                                                                uint32_t n_terms, uint2* __restrict__ slices,
+                                                                uint32_t n, uint32_t n_pad, uint32_t sh,
                                                                 const uint32_t* __restrict__ keep, const uint32_t* __restrict__ chunk_of_rank,
                                                                 float* __restrict__ scores, float* __restrict__ gmax) {
     extern __shared__ uint32_t sp_lds[];
+    const uint32_t rw = 1u << sh;
     const int lane = threadIdx.x & 63;
     const uint32_t wid = threadIdx.x >> 6;
-    const uint32_t c0 = (blockIdx.x * 4u + wid) * rw;
+    const uint32_t range = blockIdx.x * 4u + wid;
+    const uint32_t c0 = range << sh;
     if (c0 >= n_pad) return;                              // (wave-uniform; no barrier anywhere in this kernel)
-    const uint32_t c1 = c0 + rw;
-    uint32_t* const my = sp_lds + wid * rw;
-    for (uint32_t i = lane; i < rw; i += 64u) my[i] = kUnscored;
+    uint32_t* const my = sp_lds + wid * sparse_wave_lds_words(rw);
+    uint32_t* const claim = my + rw;
+    uint32_t* const t_cum = claim + rw;                   // [64] postings of this group's terms before term j (in this range)
+    uint32_t* const t_alo = t_cum + 64;                   // [64] address of the slice's first posting, low / high word
+    uint32_t* const t_ahi = t_alo + 64;
+    uint32_t* const t_w = t_ahi + 64;
+    for (uint32_t i = lane; i < rw; i += 64u) { my[i] = kUnscored; claim[i] = 0xFFFFFFFFu; }
 
     for (uint32_t t0 = 0; t0 < n_terms; t0 += 64u) {
-        // this wave's slice [lo, hi) of each of the next 64 terms' lists, one term per lane
-        uint32_t lo = 0u, hi = 0u, st_lo = 0u, st_hi = 0u;
+        uint32_t len = 0u;
+        unsigned long long addr = 0ull;
         float w = 0.f;
         if (t0 + (uint32_t)lane < n_terms) {
+            uint2* const slot = slices + (size_t)range * n_terms + t0 + lane;
+            const uint2 sl = *slot;
+            if (sl.y != 0u) *slot = make_uint2(0u, 0u);   // clean for the next search: no memset per query
             const SparseTerm tm = terms[t0 + lane];
-            const uint2* const p = post + tm.start;
-            st_lo = (uint32_t)tm.start;
-            st_hi = (uint32_t)(tm.start >> 32);
+            len = sl.y - sl.x;
+            addr = tm.start + sl.x;
             w = tm.w;
-            lo = lower_bound_chunk(p, 0u, tm.len, c0);
-            uint32_t b = tm.len;
-            if (lo + rw < b && p[lo + rw].x >= c1) b = lo + rw;   // the usual case: no more than one posting per chunk
-            hi = lower_bound_chunk(p, lo, b, c1);
         }
-        const uint32_t cnt = n_terms - t0 < 64u ? n_terms - t0 : 64u;
-        for (uint32_t j = 0; j < cnt; ++j) {              // query order
-            const uint32_t jlo = __builtin_amdgcn_readlane(lo, j), jhi = __builtin_amdgcn_readlane(hi, j);
-            if (jlo == jhi) continue;
-            const unsigned long long jst = (unsigned long long)__builtin_amdgcn_readlane(st_lo, j) |
-                                           ((unsigned long long)__builtin_amdgcn_readlane(st_hi, j) << 32);
-            const float jw = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(uint32_t, w), j));
-            const uint2* const p = post + jst;
-            for (uint32_t i = jlo; i < jhi; i += 64u) {
-                const uint32_t idx = i + (uint32_t)lane;
-                const bool active = idx < jhi;
-                uint2 e = make_uint2(0xFFFFFFFFu, 0u);
-                if (active) e = p[idx];
-                const uint32_t prev = __shfl_up(e.x, 1, 64);
-                const bool dup = active && lane != 0 && e.x == prev;   // (a pair split over two steps is ordered by the steps)
-                const float prod = __fmul_rn(jw, __builtin_bit_cast(float, e.y));
-                if (__builtin_amdgcn_ballot_w64(dup) == 0ull) {
-                    if (active) {
-                        const uint32_t s = my[e.x - c0];
-                        my[e.x - c0] = __builtin_bit_cast(uint32_t, __fadd_rn(s == kUnscored ? 0.f : __builtin_bit_cast(float, s), prod));
+        uint32_t cum = len;                               // inclusive wave prefix sum
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t v = __shfl_up(cum, off, 64);
+            if (lane >= off) cum += v;
+        }
+        const uint32_t total = __builtin_amdgcn_readlane(cum, 63);
+        if (total == 0u) continue;
+        t_cum[lane] = cum - len;
+        t_alo[lane] = (uint32_t)addr;
+        t_ahi[lane] = (uint32_t)(addr >> 32);
+        t_w[lane] = __builtin_bit_cast(uint32_t, w);
+        for (uint32_t g0 = 0; g0 < total; g0 += 64u * kSpUnroll) {
+            uint2 e[kSpUnroll];
+            float prod[kSpUnroll];
+            bool pend[kSpUnroll];
+#pragma unroll
+            for (int u = 0; u < kSpUnroll; ++u) {
+                const uint32_t g = g0 + 64u * u + (uint32_t)lane;
+                pend[u] = g < total;
+                e[u] = make_uint2(c0, 0u);
+                prod[u] = 0.f;
+                if (pend[u]) {
+                    uint32_t a = 0u, b = 64u;             // the last term whose running count <= g
+#pragma unroll
+                    for (int step = 0; step < 6; ++step) {
+                        const uint32_t m = (a + b) >> 1;
+                        if (t_cum[m] <= g) a = m; else b = m;
                     }
-                } else {                                  // a document that lists a token twice: posting order, lane by lane
-                    for (int l = 0; l < 64; ++l) {
-                        if (lane == l && active) {
-                            const uint32_t s = my[e.x - c0];
-                            my[e.x - c0] = __builtin_bit_cast(uint32_t, __fadd_rn(s == kUnscored ? 0.f : __builtin_bit_cast(float, s), prod));
-                        }
+                    const unsigned long long at = ((unsigned long long)t_ahi[a] << 32 | t_alo[a]) + (g - t_cum[a]);
+                    e[u] = post[at];
+                    prod[u] = __fmul_rn(__builtin_bit_cast(float, t_w[a]), __builtin_bit_cast(float, e[u].y));
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < kSpUnroll; ++u) {
+                if (g0 + 64u * u >= total) break;         // (wave-uniform)
+                const uint32_t at = e[u].x - c0;
+                bool pending = pend[u];
+                while (__builtin_amdgcn_ballot_w64(pending) != 0ull) {
+                    // (compiler barriers: the other lanes' LDS stores are invisible to the single-thread view the optimiser
+                    // reasons in - no load of a score or a claim may move across a round)
+                    asm volatile("" ::: "memory");
+                    if (pending) atomicMin(&claim[at], (uint32_t)lane);
+                    asm volatile("" ::: "memory");
+                    if (pending && *(volatile uint32_t*)&claim[at] == (uint32_t)lane) {
+                        const uint32_t s = *(volatile uint32_t*)&my[at];
+                        *(volatile uint32_t*)&my[at] =
+                            __builtin_bit_cast(uint32_t, __fadd_rn(s == kUnscored ? 0.f : __builtin_bit_cast(float, s), prod[u]));
+                        *(volatile uint32_t*)&claim[at] = 0xFFFFFFFFu;
+                        pending = false;
                     }
+                    asm volatile("" ::: "memory");
                 }
             }
         }
@@ -142,7 +227,7 @@ struct cqs_hip_sparse_index {
     bool poisoned = false;
     int device = 0;
     uint64_t n = 0, n_postings = 0;
-    uint32_t n_pad = 0, rw = 64, n_cu = 256;
+    uint32_t n_pad = 0, rw = 64, sh = 6, n_cu = 256;
     bool ranked = false;
     std::vector<uint32_t> tok;               // sorted distinct token ids
     std::vector<uint64_t> off;               // [tok.size() + 1]
@@ -157,10 +242,12 @@ struct cqs_hip_sparse_index {
     SparseTerm* d_terms = nullptr;
     uint32_t terms_cap = 0;
     SparseTerm* h_terms = nullptr;           // pinned
+    uint2* d_slices = nullptr;               // [n_pad / rw][terms_cap]: (first, last + 1) of every term's list inside every wave range
     uint32_t* h_keep = nullptr;              // pinned, ceil(n / 32) words
     uint64_t* d_out_keys = nullptr;
     uint32_t* d_out_count = nullptr;
-    uint64_t* h_out_keys = nullptr;          // pinned, kMaxK + 1 words (the last one: the count)
+    uint64_t* h_out_keys = nullptr;          // pinned + device-visible, kMaxK + 1 words (the last one: the count): the select writes here
+    uint64_t* h_out_keys_dev = nullptr;      // its device address (null: not mappable -> device buffer + two copies)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     float last_ms = 0.f;
     uint64_t last_touched = 0;
@@ -185,7 +272,7 @@ void release(cqs_hip_sparse_index* s) {
     (void)hipSetDevice(s->device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     for (void* p : {(void*)s->d_post, (void*)s->d_chunk_of_rank, (void*)s->d_scores, (void*)s->d_gmax, (void*)s->d_work,
-                    (void*)s->d_keep, (void*)s->d_terms, (void*)s->d_out_keys, (void*)s->d_out_count})
+                    (void*)s->d_keep, (void*)s->d_terms, (void*)s->d_slices, (void*)s->d_out_keys, (void*)s->d_out_count})
         if (p) (void)hipFree(p);
     for (void* p : {(void*)s->h_terms, (void*)s->h_keep, (void*)s->h_out_keys})
         if (p) (void)hipHostFree(p);
@@ -199,9 +286,12 @@ int32_t ensure_terms(cqs_hip_sparse_index* s, uint32_t t) {
     if (t <= s->terms_cap) return CQS_HIP_OK;
     const uint32_t cap = std::max(256u, t + t / 2u);
     if (s->d_terms) { (void)hipFree(s->d_terms); s->d_terms = nullptr; }
+    if (s->d_slices) { (void)hipFree(s->d_slices); s->d_slices = nullptr; }
     if (s->h_terms) { (void)hipHostFree(s->h_terms); s->h_terms = nullptr; }
     s->terms_cap = 0;
     S_TRY(s, hipMalloc((void**)&s->d_terms, (size_t)cap * sizeof(SparseTerm)));
+    S_TRY(s, hipMalloc((void**)&s->d_slices, (size_t)(s->n_pad / s->rw) * cap * sizeof(uint2)));
+    S_TRY(s, hipMemset(s->d_slices, 0, (size_t)(s->n_pad / s->rw) * cap * sizeof(uint2)));   // every search leaves it zeroed again
     S_TRY(s, hipHostMalloc((void**)&s->h_terms, (size_t)cap * sizeof(SparseTerm), hipHostMallocDefault));
     s->terms_cap = cap;
     return CQS_HIP_OK;
@@ -302,6 +392,8 @@ int32_t cqs_hip_sparse_index_create(const uint64_t* doc_off, const uint32_t* tok
     // chunks per wave: enough waves to keep ~16 per CU in flight, 64 ... 1024 chunks each
     s->rw = 1024;
     while (s->rw > 64u && s->n_pad / s->rw < s->n_cu * 16u) s->rw >>= 1;
+    s->sh = 0;
+    while ((1u << s->sh) < s->rw) ++s->sh;
     if ((he = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking)) != hipSuccess) return dfail(he);
     if ((he = hipEventCreate(&s->ev0)) != hipSuccess || (he = hipEventCreate(&s->ev1)) != hipSuccess) return dfail(he);
     if ((he = hipMalloc((void**)&s->d_post, std::max<size_t>((size_t)P, 1) * sizeof(uint2))) != hipSuccess) return dfail(he);
@@ -318,7 +410,8 @@ int32_t cqs_hip_sparse_index_create(const uint64_t* doc_off, const uint32_t* tok
     if ((he = hipHostMalloc((void**)&s->h_keep, (size_t)(s->n_pad / 32u) * 4, hipHostMallocDefault)) != hipSuccess) return dfail(he);
     if ((he = hipMalloc((void**)&s->d_out_keys, (size_t)cqs::kMaxK * 8)) != hipSuccess) return dfail(he);
     if ((he = hipMalloc((void**)&s->d_out_count, 4)) != hipSuccess) return dfail(he);
-    if ((he = hipHostMalloc((void**)&s->h_out_keys, (size_t)(cqs::kMaxK + 1) * 8, hipHostMallocDefault)) != hipSuccess) return dfail(he);
+    if ((he = hipHostMalloc((void**)&s->h_out_keys, (size_t)(cqs::kMaxK + 1) * 8, hipHostMallocMapped)) != hipSuccess) return dfail(he);
+    if (hipHostGetDevicePointer((void**)&s->h_out_keys_dev, s->h_out_keys, 0) != hipSuccess) s->h_out_keys_dev = nullptr;
     *out = s;
     return CQS_HIP_OK;
 } CQS_ABI_CATCH_NOHANDLE
@@ -388,6 +481,7 @@ int32_t cqs_hip_sparse_index_search(cqs_hip_sparse_index* s, const uint32_t* q_t
         if (len == 0) continue;
         if (len > 0xFFFFFFFFull) return sfail(s, CQS_HIP_ERR_INVALID, "sparse search: posting list longer than 2^32");
         s->h_terms[nt].start = s->off[slot];
+        s->h_terms[nt].cum = touched;
         s->h_terms[nt].len = (uint32_t)len;
         s->h_terms[nt].w = q_weights[i];
         ++nt;
@@ -405,9 +499,14 @@ int32_t cqs_hip_sparse_index_search(cqs_hip_sparse_index* s, const uint32_t* q_t
         d_keep = s->d_keep;
     }
     const uint32_t waves = s->n_pad / s->rw;
+    if (touched >= (1ull << 32) * 256ull) return sfail(s, CQS_HIP_ERR_INVALID, "sparse search: the query touches too many postings");
     S_TRY(s, hipEventRecord(s->ev0, st));
-    hipLaunchKernelGGL(sparse_accumulate_kernel, dim3((waves + 3u) / 4u), dim3(256), (size_t)4 * s->rw * 4, st, s->d_post, s->d_terms, nt,
-                       (uint32_t)s->n, s->n_pad, s->rw, d_keep, s->ranked ? s->d_chunk_of_rank : nullptr, s->d_scores, s->d_gmax);
+    hipLaunchKernelGGL(sparse_slice_kernel, dim3((uint32_t)((touched + 1023ull) / 1024ull)), dim3(256), 0, st, s->d_post, s->d_terms, nt,
+                       (unsigned long long)touched, s->sh, s->d_slices);
+    S_TRY(s, hipGetLastError());
+    hipLaunchKernelGGL(sparse_accumulate_kernel, dim3((waves + 3u) / 4u), dim3(256), (size_t)4 * sparse_wave_lds_words(s->rw) * 4, st,
+                       s->d_post, s->d_terms, nt, s->d_slices, (uint32_t)s->n, s->n_pad, s->sh, d_keep,
+                       s->ranked ? s->d_chunk_of_rank : nullptr, s->d_scores, s->d_gmax);
     S_TRY(s, hipGetLastError());
     S_TRY(s, hipEventRecord(s->ev1, st));
     cqs::ScanArgs a{};
@@ -419,12 +518,17 @@ int32_t cqs_hip_sparse_index_search(cqs_hip_sparse_index* s, const uint32_t* q_t
     a.tiers = cqs::plan_tiers(s->n_pad, s->n_cu, true);
     a.k = k;
     a.linear_bins = false;
+    a.range_bins = true;
     a.work = s->d_work;
     a.n_cu = s->n_cu;
     a.dbg = nullptr;
-    S_TRY(s, cqs::launch_select(a, 0u, s->d_out_keys, s->d_out_count, st));
-    S_TRY(s, hipMemcpyAsync(s->h_out_keys, s->d_out_keys, (size_t)k * 8, hipMemcpyDeviceToHost, st));
-    S_TRY(s, hipMemcpyAsync(s->h_out_keys + cqs::kMaxK, s->d_out_count, 4, hipMemcpyDeviceToHost, st));
+    if (s->h_out_keys_dev) {
+        S_TRY(s, cqs::launch_select(a, 0u, s->h_out_keys_dev, (uint32_t*)(s->h_out_keys_dev + cqs::kMaxK), st));
+    } else {
+        S_TRY(s, cqs::launch_select(a, 0u, s->d_out_keys, s->d_out_count, st));
+        S_TRY(s, hipMemcpyAsync(s->h_out_keys, s->d_out_keys, (size_t)k * 8, hipMemcpyDeviceToHost, st));
+        S_TRY(s, hipMemcpyAsync(s->h_out_keys + cqs::kMaxK, s->d_out_count, 4, hipMemcpyDeviceToHost, st));
+    }
     S_TRY(s, hipStreamSynchronize(st));
     (void)hipEventElapsedTime(&s->last_ms, s->ev0, s->ev1);
     uint32_t cnt = (uint32_t)(s->h_out_keys[cqs::kMaxK] & 0xFFFFFFFFull);
