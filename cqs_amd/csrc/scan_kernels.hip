@@ -549,25 +549,26 @@ __global__ __launch_bounds__(1024) void select_finish_kernel(const float* __rest
         const uint32_t slots = 1u << slot_log2;
         const uint32_t total = ng << slot_log2;
         for (uint32_t e0 = 0; e0 < total; e0 += 1024u * kGB) {
+            // straight-line on purpose: addresses first, then all kGB loads back to back, then the masks.  (Until round 4 a
+            // block-uniform `continue` for the slices past `total` sat inside this unrolled loop; with it hipcc put an
+            // `s_waitcnt vmcnt(0)` behind every single load - 32 serial round trips, 18 of the kernel's 38 us at k = 500.)
             float v[kGB];
             uint32_t idx[kGB];
+            bool in[kGB];
 #pragma unroll
             for (int u = 0; u < kGB; ++u) {
-                if (e0 + (uint32_t)u * 1024u >= total) {  // block-uniform: nothing left for this slice
-                    v[u] = -INFINITY;
-                    idx[u] = 0u;
-                    continue;
-                }
                 const uint32_t e = e0 + (uint32_t)u * 1024u + threadIdx.x;
                 const uint32_t ec = e < total ? e : total - 1u;
                 uint32_t grows;
                 const uint32_t gbase = tiers.locate(s_groups[ec >> slot_log2], grows);
                 const uint32_t off = ec & (slots - 1u);
-                const bool in = e < total && off < grows;
-                idx[u] = gbase + (in ? off : 0u);
-                const float x = s[idx[u]];
-                v[u] = in ? x : -INFINITY;
+                in[u] = e < total && off < grows;
+                idx[u] = gbase + (in[u] ? off : 0u);
             }
+#pragma unroll
+            for (int u = 0; u < kGB; ++u) v[u] = s[idx[u]];
+#pragma unroll
+            for (int u = 0; u < kGB; ++u) v[u] = in[u] ? v[u] : -INFINITY;
             bool take[kGB];
             uint32_t slot[kGB];
 #pragma unroll

@@ -21,6 +21,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -249,6 +250,7 @@ struct cqs_hip_sparse_index {
     uint64_t* h_out_keys = nullptr;          // pinned + device-visible, kMaxK + 1 words (the last one: the count): the select writes here
     uint64_t* h_out_keys_dev = nullptr;      // its device address (null: not mappable -> device buffer + two copies)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    unsigned long long* d_dbg = nullptr;     // CQS_HIP_DEBUG_STAMPS=1: select_finish phase stamps of the last search (printed to stderr)
     float last_ms = 0.f;
     uint64_t last_touched = 0;
 };
@@ -272,7 +274,7 @@ void release(cqs_hip_sparse_index* s) {
     (void)hipSetDevice(s->device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     for (void* p : {(void*)s->d_post, (void*)s->d_chunk_of_rank, (void*)s->d_scores, (void*)s->d_gmax, (void*)s->d_work,
-                    (void*)s->d_keep, (void*)s->d_terms, (void*)s->d_slices, (void*)s->d_out_keys, (void*)s->d_out_count})
+                    (void*)s->d_keep, (void*)s->d_terms, (void*)s->d_slices, (void*)s->d_out_keys, (void*)s->d_out_count, (void*)s->d_dbg})
         if (p) (void)hipFree(p);
     for (void* p : {(void*)s->h_terms, (void*)s->h_keep, (void*)s->h_out_keys})
         if (p) (void)hipHostFree(p);
@@ -412,6 +414,8 @@ int32_t cqs_hip_sparse_index_create(const uint64_t* doc_off, const uint32_t* tok
     if ((he = hipMalloc((void**)&s->d_out_count, 4)) != hipSuccess) return dfail(he);
     if ((he = hipHostMalloc((void**)&s->h_out_keys, (size_t)(cqs::kMaxK + 1) * 8, hipHostMallocMapped)) != hipSuccess) return dfail(he);
     if (hipHostGetDevicePointer((void**)&s->h_out_keys_dev, s->h_out_keys, 0) != hipSuccess) s->h_out_keys_dev = nullptr;
+    if (const char* e = getenv("CQS_HIP_DEBUG_STAMPS"); e && *e == '1')
+        if (hipMalloc((void**)&s->d_dbg, 16 * 8) == hipSuccess) (void)hipMemset(s->d_dbg, 0, 16 * 8);
     *out = s;
     return CQS_HIP_OK;
 } CQS_ABI_CATCH_NOHANDLE
@@ -521,7 +525,7 @@ int32_t cqs_hip_sparse_index_search(cqs_hip_sparse_index* s, const uint32_t* q_t
     a.range_bins = true;
     a.work = s->d_work;
     a.n_cu = s->n_cu;
-    a.dbg = nullptr;
+    a.dbg = s->d_dbg;
     if (s->h_out_keys_dev) {
         S_TRY(s, cqs::launch_select(a, 0u, s->h_out_keys_dev, (uint32_t*)(s->h_out_keys_dev + cqs::kMaxK), st));
     } else {
@@ -531,6 +535,13 @@ int32_t cqs_hip_sparse_index_search(cqs_hip_sparse_index* s, const uint32_t* q_t
     }
     S_TRY(s, hipStreamSynchronize(st));
     (void)hipEventElapsedTime(&s->last_ms, s->ev0, s->ev1);
+    if (s->d_dbg) {
+        unsigned long long h[16];
+        if (hipMemcpy(h, s->d_dbg, sizeof h, hipMemcpyDeviceToHost) == hipSuccess)
+            fprintf(stderr, "[cqs_hip sparse] select phases (us): zero+range %.2f | histogram %.2f | decide %.2f | groups %.2f | gather %.2f | sort %.2f | out %.2f | groups=%llu candidates=%llu\n",
+                    0.0, (h[1] - h[0]) * 0.01, (h[2] - h[1]) * 0.01, (h[3] - h[2]) * 0.01, (h[4] - h[3]) * 0.01, (h[5] - h[4]) * 0.01,
+                    (h[6] - h[5]) * 0.01, h[8], h[9]);
+    }
     uint32_t cnt = (uint32_t)(s->h_out_keys[cqs::kMaxK] & 0xFFFFFFFFull);
     if (cnt > k) cnt = k;
     cqs_hip_unpack_keys(s->h_out_keys, cnt, out_chunks, out_scores);

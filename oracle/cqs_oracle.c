@@ -665,27 +665,47 @@ cqs_oracle_splade* cqs_oracle_splade_build(const uint64_t* doc_off, const uint32
     if (!s) return NULL;
     const uint64_t P = n ? doc_off[n] : 0;
     s->n = n;
-    uint32_t* sorted = (uint32_t*)malloc((P ? P : 1) * sizeof(uint32_t));
-    if (P) memcpy(sorted, tokens, P * sizeof(uint32_t));
-    qsort(sorted, P, sizeof(uint32_t), cmp_u32);
-    size_t u = 0;
-    for (uint64_t i = 0; i < P; ++i)
-        if (i == 0 || sorted[i] != sorted[i - 1]) sorted[u++] = sorted[i];
-    s->n_tokens = u;
-    s->tok = sorted;
+    /* the HashMap's key set, sorted; slot lookup through a direct table when the ids are small (every real vocabulary),
+     * else by bisection - which way the table is found does not change what it holds */
+    uint32_t max_tok = 0;
+    for (uint64_t i = 0; i < P; ++i) if (tokens[i] > max_tok) max_tok = tokens[i];
+    uint32_t* direct = NULL;                                   /* token -> slot + 1 */
+    if (P && max_tok < (1u << 24)) {
+        direct = (uint32_t*)calloc((size_t)max_tok + 1, sizeof(uint32_t));
+        for (uint64_t i = 0; i < P; ++i) direct[tokens[i]] = 1;
+        size_t u = 0;
+        for (uint32_t t = 0; t <= max_tok; ++t) if (direct[t]) u++;
+        s->tok = (uint32_t*)malloc((u ? u : 1) * sizeof(uint32_t));
+        u = 0;
+        for (uint32_t t = 0; t <= max_tok; ++t) if (direct[t]) { s->tok[u] = t; direct[t] = (uint32_t)(++u); }
+        s->n_tokens = u;
+    } else {
+        uint32_t* sorted = (uint32_t*)malloc((P ? P : 1) * sizeof(uint32_t));
+        if (P) memcpy(sorted, tokens, P * sizeof(uint32_t));
+        qsort(sorted, P, sizeof(uint32_t), cmp_u32);
+        size_t u = 0;
+        for (uint64_t i = 0; i < P; ++i)
+            if (i == 0 || sorted[i] != sorted[i - 1]) sorted[u++] = sorted[i];
+        s->n_tokens = u;
+        s->tok = sorted;
+    }
+    const size_t u = s->n_tokens;
+#define SPLADE_SLOT(tk) (direct ? (size_t)direct[(tk)] - 1 : splade_find(s, (tk)))
     s->off = (uint64_t*)calloc(u + 1, sizeof(uint64_t));
     s->p_chunk = (uint32_t*)malloc((P ? P : 1) * sizeof(uint32_t));
     s->p_w = (float*)malloc((P ? P : 1) * sizeof(float));
-    for (uint64_t i = 0; i < P; ++i) s->off[splade_find(s, tokens[i]) + 1]++;
+    for (uint64_t i = 0; i < P; ++i) s->off[SPLADE_SLOT(tokens[i]) + 1]++;
     for (size_t t = 0; t < u; ++t) s->off[t + 1] += s->off[t];
     uint64_t* cur = (uint64_t*)malloc((u ? u : 1) * sizeof(uint64_t));
     memcpy(cur, s->off, u * sizeof(uint64_t));
     for (uint64_t d = 0; d < n; ++d)                                     /* index.rs:197-202: chunk by chunk, entry by entry */
         for (uint64_t e = doc_off[d]; e < doc_off[d + 1]; ++e) {
-            const uint64_t at = cur[splade_find(s, tokens[e])]++;
+            const uint64_t at = cur[SPLADE_SLOT(tokens[e])]++;
             s->p_chunk[at] = (uint32_t)d;
             s->p_w[at] = weights[e];
         }
+#undef SPLADE_SLOT
+    free(direct);
     free(cur);
     return s;
 }
