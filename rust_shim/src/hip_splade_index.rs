@@ -1,0 +1,198 @@
+//! MI355X sparse retrieval leg over libcqs_hip.so (C ABI: include/cqs_hip.h, "sparse index"): the in-HBM replacement of
+//! `SpladeIndex` (src/splade/index.rs:177-306) - same constructor input, same `search` / `search_with_filter` / `len` /
+//! `is_empty` / `unique_tokens`, same result order (score desc, id asc) and bit-identical scores.
+//!
+//! Drop-in: `src/splade/hip_index.rs` behind the `hip-aux` feature.  `CommandContext::splade_index()`
+//! (src/cli/store.rs:367-400) and `BatchView::ensure_splade_index()` (src/cli/batch/view.rs:842-908) build it from the same
+//! `(chunk_id, SparseVector)` rows they hand to `SpladeIndex::load_or_build`; `search_hybrid_inner`
+//! (src/search/query.rs:898-901) calls `search_with_filter` on it unchanged - the fusion (:909-1010) stays in Rust.
+//!
+//! Not compiled here (no Rust toolchain in the build image); the same entry points are exercised by
+//! `cqs_amd/splade_index.py` and `tests/test_sparse_index_gpu.py`.
+
+use std::os::raw::c_char;
+
+use crate::index::IndexResult;
+use crate::splade::SparseVector;
+
+#[repr(C)]
+struct CqsHipSparseIndex {
+    _private: [u8; 0],
+}
+
+const CQS_HIP_OK: i32 = 0;
+/// `CQS_HIP_MAX_K`: the largest k one call serves (production asks for candidate_count_for(limit) >= 500).
+pub const MAX_K: usize = 1024;
+
+#[link(name = "cqs_hip")]
+extern "C" {
+    fn cqs_hip_sparse_index_create(
+        doc_off: *const u64,
+        tokens: *const u32,
+        weights: *const f32,
+        n: u64,
+        id_rank: *const u32,
+        device: i32,
+        out: *mut *mut CqsHipSparseIndex,
+    ) -> i32;
+    fn cqs_hip_sparse_index_destroy(idx: *mut CqsHipSparseIndex);
+    fn cqs_hip_sparse_index_len(idx: *const CqsHipSparseIndex) -> u64;
+    fn cqs_hip_sparse_index_unique_tokens(idx: *const CqsHipSparseIndex) -> u64;
+    fn cqs_hip_sparse_index_postings(idx: *const CqsHipSparseIndex) -> u64;
+    fn cqs_hip_sparse_index_search(
+        idx: *mut CqsHipSparseIndex,
+        q_tokens: *const u32,
+        q_weights: *const f32,
+        n_terms: u32,
+        k: u32,
+        keep_bitset: *const u32,
+        out_chunks: *mut u64,
+        out_scores: *mut f32,
+        out_count: *mut u32,
+    ) -> i32;
+    fn cqs_hip_sparse_index_last_search(idx: *const CqsHipSparseIndex, accumulate_ms: *mut f32, touched_postings: *mut u64) -> i32;
+    fn cqs_hip_sparse_index_poisoned(idx: *const CqsHipSparseIndex) -> i32;
+    fn cqs_hip_sparse_index_last_error(idx: *const CqsHipSparseIndex, buf: *mut c_char, cap: usize) -> usize;
+}
+
+/// In-HBM inverted index for SPLADE sparse vectors.
+pub struct HipSpladeIndex {
+    raw: *mut CqsHipSparseIndex,
+    /// Sequential chunk ID map (chunk_index -> chunk_id), as `SpladeIndex::id_map`.
+    id_map: Vec<Box<str>>,
+}
+
+// The handle serialises device work behind its own mutex (include/cqs_hip.h, threading note).
+unsafe impl Send for HipSpladeIndex {}
+unsafe impl Sync for HipSpladeIndex {}
+
+impl HipSpladeIndex {
+    /// `SpladeIndex::build` (index.rs:191-212).  `None` = no usable device / build refused: the caller keeps the CPU index.
+    pub fn build(chunks: Vec<(String, SparseVector)>, device: i32) -> Option<Self> {
+        let _span = tracing::info_span!("hip_splade_index_build", chunks = chunks.len()).entered();
+        let n = chunks.len();
+        let mut doc_off: Vec<u64> = Vec::with_capacity(n + 1);
+        doc_off.push(0);
+        let total: usize = chunks.iter().map(|(_, v)| v.len()).sum();
+        let mut tokens: Vec<u32> = Vec::with_capacity(total);
+        let mut weights: Vec<f32> = Vec::with_capacity(total);
+        let mut id_map: Vec<Box<str>> = Vec::with_capacity(n);
+        for (chunk_id, sparse) in chunks {
+            for &(token_id, weight) in &sparse {
+                tokens.push(token_id);
+                weights.push(weight);
+            }
+            doc_off.push(tokens.len() as u64);
+            id_map.push(chunk_id.into_boxed_str());
+        }
+        // rank of every id in ascending order (ties in chunk order): the order BoundedScoreHeap breaks score ties in
+        let mut order: Vec<u32> = (0..n as u32).collect();
+        order.sort_by(|&a, &b| id_map[a as usize].cmp(&id_map[b as usize]).then(a.cmp(&b)));
+        let mut id_rank = vec![0u32; n];
+        for (r, &i) in order.iter().enumerate() {
+            id_rank[i as usize] = r as u32;
+        }
+        let mut raw: *mut CqsHipSparseIndex = std::ptr::null_mut();
+        let rc = unsafe {
+            cqs_hip_sparse_index_create(doc_off.as_ptr(), tokens.as_ptr(), weights.as_ptr(), n as u64, id_rank.as_ptr(), device, &mut raw)
+        };
+        if rc != CQS_HIP_OK || raw.is_null() {
+            tracing::warn!(rc, "HIP SPLADE index build failed, keeping the in-memory index");
+            return None;
+        }
+        tracing::info!(chunks = n, postings = total, "HIP SPLADE index built");
+        Some(Self { raw, id_map })
+    }
+
+    /// Search the inverted index (unfiltered).
+    pub fn search(&self, query: &SparseVector, k: usize) -> Vec<IndexResult> {
+        self.search_with_filter(query, k, &|_: &str| true)
+    }
+
+    /// `SpladeIndex::search_with_filter` (index.rs:223-290).  The predicate is evaluated once per chunk id on the host
+    /// and handed over as a bitset; a device failure logs and returns no results (the caller's dense leg still answers).
+    pub fn search_with_filter(&self, query: &SparseVector, k: usize, filter: &dyn Fn(&str) -> bool) -> Vec<IndexResult> {
+        let _span = tracing::debug_span!("hip_splade_index_search", k, query_terms = query.len(), index_size = self.id_map.len()).entered();
+        if query.is_empty() || self.id_map.is_empty() || k == 0 {
+            return Vec::new();
+        }
+        let k = k.min(MAX_K);
+        let q_tokens: Vec<u32> = query.iter().map(|&(t, _)| t).collect();
+        let q_weights: Vec<f32> = query.iter().map(|&(_, w)| w).collect();
+        let mut keep = vec![0u32; (self.id_map.len() + 31) / 32];
+        let mut all = true;
+        for (i, id) in self.id_map.iter().enumerate() {
+            if filter(id) {
+                keep[i / 32] |= 1 << (i % 32);
+            } else {
+                all = false;
+            }
+        }
+        let mut chunks = vec![0u64; k];
+        let mut scores = vec![0f32; k];
+        let mut count = 0u32;
+        let rc = unsafe {
+            cqs_hip_sparse_index_search(
+                self.raw,
+                q_tokens.as_ptr(),
+                q_weights.as_ptr(),
+                q_tokens.len() as u32,
+                k as u32,
+                if all { std::ptr::null() } else { keep.as_ptr() },
+                chunks.as_mut_ptr(),
+                scores.as_mut_ptr(),
+                &mut count,
+            )
+        };
+        if rc != CQS_HIP_OK {
+            tracing::warn!(rc, error = %self.last_error(), "HIP SPLADE search failed");
+            return Vec::new();
+        }
+        (0..count as usize)
+            .filter_map(|i| self.id_map.get(chunks[i] as usize).map(|id| IndexResult { id: id.to_string(), score: scores[i] }))
+            .collect()
+    }
+
+    /// Number of chunks in the index.
+    pub fn len(&self) -> usize {
+        unsafe { cqs_hip_sparse_index_len(self.raw) as usize }
+    }
+
+    /// Whether the index is empty.
+    pub fn is_empty(&self) -> bool {
+        self.len() == 0
+    }
+
+    /// Number of unique tokens in the vocabulary.
+    pub fn unique_tokens(&self) -> usize {
+        unsafe { cqs_hip_sparse_index_unique_tokens(self.raw) as usize }
+    }
+
+    pub fn postings(&self) -> u64 {
+        unsafe { cqs_hip_sparse_index_postings(self.raw) }
+    }
+
+    pub fn is_poisoned(&self) -> bool {
+        unsafe { cqs_hip_sparse_index_poisoned(self.raw) != 0 }
+    }
+
+    /// (device milliseconds of the last search's scoring launches, postings they read)
+    pub fn last_search(&self) -> (f32, u64) {
+        let (mut ms, mut touched) = (0f32, 0u64);
+        unsafe { cqs_hip_sparse_index_last_search(self.raw, &mut ms, &mut touched) };
+        (ms, touched)
+    }
+
+    fn last_error(&self) -> String {
+        let mut buf = vec![0u8; 512];
+        let n = unsafe { cqs_hip_sparse_index_last_error(self.raw, buf.as_mut_ptr() as *mut c_char, buf.len()) };
+        buf.truncate(n.min(511));
+        String::from_utf8_lossy(&buf).into_owned()
+    }
+}
+
+impl Drop for HipSpladeIndex {
+    fn drop(&mut self) {
+        unsafe { cqs_hip_sparse_index_destroy(self.raw) }
+    }
+}

@@ -22,6 +22,7 @@ SHIM_DIR = os.path.join(ROOT, "rust_shim", "src")
 
 # Rust opaque / struct names -> the header's
 STRUCT_NAMES = {"CqsHipIndex": "cqs_hip_index", "CqsHipEmbedder": "cqs_hip_embedder", "CqsHipBert": "cqs_hip_bert",
+                "CqsHipSparseIndex": "cqs_hip_sparse_index",
                 "CqsHipEmbedConfig": "cqs_hip_embed_config", "CqsHipBertConfig": "cqs_hip_bert_config"}
 RUST_SCALARS = {"i8": "int8_t", "u8": "uint8_t", "i16": "int16_t", "u16": "uint16_t", "i32": "int32_t", "u32": "uint32_t",
                 "i64": "int64_t", "u64": "uint64_t", "f32": "float", "f64": "double", "usize": "size_t", "isize": "ptrdiff_t",
