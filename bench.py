@@ -743,7 +743,7 @@ def sparse_index_leg(a, np):
     t_build = time.perf_counter() - t0
     out = {"chunks": n, "postings": h.postings(), "unique_tokens": h.unique_tokens(), "k": k, "build_s": round(t_build, 2),
            "what": "cqs_hip_sparse_index_search, host query terms in / host (chunk, score) out, one call at a time; "
-                   "accumulate = HIP events around the slice + accumulate launches (the exact select and the copies are the rest)"}
+                   "accumulate = HIP events around the scoring launch (the exact select and the copies are the rest)"}
     ora = O.SpladeIndex(off, tok, w)
     for terms in (64, 200):
         qs = synth.sparse_queries(40, terms, vocab, seed=0x5BA2DF + terms)
@@ -776,7 +776,7 @@ def sparse_index_leg(a, np):
             "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 4),
                          "alg_bytes": int(np.mean(alg)),
                          "note": "algorithmic bytes = 8 B per touched posting + the 4 B/chunk score row and its maxima; the query touches "
-                                 "~1.5-3.5 % of the index, so both launches are short (10-30 us) and latency- rather than bandwidth-shaped"},
+                                 "~1.5-3.5 % of the index: the launch is short (15-40 us) and latency- rather than bandwidth-shaped"},
             "cpu_baseline": {"kind": "port", "cores": 1, "queries_per_sec": round(ncpu / cpu_el, 2), "ms_per_query": round(cpu_el / ncpu * 1e3, 3),
                              "sample": "%d of the timed queries through oracle.SpladeIndex.search_raw (dense score array in place of the HashMap)" % ncpu},
         }

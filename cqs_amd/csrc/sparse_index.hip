@@ -10,13 +10,13 @@
 // names a few dozen tokens).  "chunk" is the chunk's RANK in ascending id order when the caller gives `id_rank`, so that
 // the select's (score desc, position asc) order is BoundedScoreHeap's (score desc, id asc).
 //
-// Two launches score a query (the kernels' own comments have the details): sparse_slice_kernel walks the touched postings
-// once and notes where every term's list crosses the wave ranges; sparse_accumulate_kernel gives every WAVE a contiguous
-// range of chunks with their scores in LDS and streams the range's postings term after term, 64 per step, adding
+// One launch scores a query (sparse_accumulate_kernel; its comment has the details): every WAVE owns a contiguous range of
+// chunks with their scores in LDS, finds its slice of each query term's list in the list's range directory (built at
+// create: where the list crosses every range boundary) and streams the slices term after term, 64 postings per step, adding
 // `s = s + qw * dw` with separate f32 multiply and add - every chunk's sum is built in exactly the reference's order, so
-// the scores are bit-identical, not "close".  No global atomics, no barriers.  Both are bound by the touched postings'
-// bytes (8 B each, read twice) + the score row (4 B per chunk); the exact top-k is the dense index's select_finish_kernel
-// over that score row and its 64-chunk maxima, with bins laid over the row's own range of maxima (scan_kernels.hip).
+// the scores are bit-identical, not "close".  No global atomics, no barriers.  Bound by the touched postings' bytes (8 B
+// each) + the score row (4 B per chunk); the exact top-k is the dense index's select_finish_kernel over that score row and
+// its 64-chunk maxima, with bins laid over the row's own range of maxima (scan_kernels.hip).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -41,65 +41,31 @@ constexpr uint32_t kMaxTerms = 1u << 16;
 
 struct SparseTerm {            // one query term, resolved on the host
     unsigned long long start;  // first posting of the token's list
-    unsigned long long cum;    // postings of the terms before this one (the query's touched postings, term after term)
+    unsigned long long dir;    // first entry of the list's range directory (kNoDir: none - the wave bisects the list)
     uint32_t len;              // postings in the list
     float w;                   // query weight
 };
+constexpr unsigned long long kNoDir = ~0ull;
 
-// ---- launch 1: where every term's list crosses the wave ranges ------------------------------------------------------
-// One thread per touched posting (the concatenation of the query's lists).  A posting that is the first / last of its
-// list inside a range of `1 << sh` chunks writes its list-relative position into slices[range][term].x / its position
-// + 1 into .y; ranges a list does not reach keep (0, 0) from the memset in front of this launch.
-constexpr uint32_t kSliceTermsLds = 2048;   // running counts kept in LDS up to this many terms (a query has a few dozen)
-__global__ __launch_bounds__(256) void sparse_slice_kernel(const uint2* __restrict__ post, const SparseTerm* __restrict__ terms,
-                                                           uint32_t n_terms, unsigned long long touched, uint32_t sh,
-                                                           uint2* __restrict__ slices) {
-    __shared__ unsigned long long s_cum[kSliceTermsLds];
-    const bool in_lds = n_terms <= kSliceTermsLds;
-    if (in_lds) {
-        for (uint32_t t = threadIdx.x; t < n_terms; t += 256u) s_cum[t] = terms[t].cum;
-        __syncthreads();
-    }
-    // four consecutive postings of the concatenation per thread (they mostly share a term and a range)
-    const unsigned long long g0 = ((unsigned long long)blockIdx.x * 256ull + threadIdx.x) * 4ull;
-    if (g0 >= touched) return;
-    uint32_t a = 0, b = n_terms;                           // the last term whose cum <= g0
-    while (b - a > 1u) {
+__device__ __forceinline__ uint32_t lower_bound_chunk(const uint2* __restrict__ p, uint32_t a, uint32_t b, uint32_t c) {
+    while (a < b) {
         const uint32_t m = (a + b) >> 1;
-        if ((in_lds ? s_cum[m] : terms[m].cum) <= g0) a = m; else b = m;
+        if (p[m].x < c) a = m + 1u; else b = m;
     }
-    SparseTerm tm = terms[a];
-    uint32_t i = (uint32_t)(g0 - tm.cum);
-    const uint2* p = post + tm.start;
-    uint32_t r_prev = i == 0u ? 0xFFFFFFFFu : (p[i - 1u].x >> sh);
-    uint32_t r = p[i].x >> sh;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        if (g0 + (unsigned long long)u >= touched) break;
-        const uint32_t r_next = i + 1u == tm.len ? 0xFFFFFFFFu : (p[i + 1u].x >> sh);
-        uint2* const s = slices + (size_t)r * n_terms + a;
-        if (r_prev != r) s->x = i;
-        if (r_next != r) s->y = i + 1u;
-        if (i + 1u == tm.len) {                            // on to the next term's list
-            if (++a >= n_terms) break;
-            tm = terms[a];
-            p = post + tm.start;
-            i = 0u;
-            r_prev = 0xFFFFFFFFu;
-            r = p[0].x >> sh;
-        } else {
-            ++i;
-            r_prev = r;
-            r = r_next;
-        }
-    }
+    return a;
 }
 
-// (Tried: the table term-major, so that a list's consecutive ranges share cache lines: this launch 11.9 -> 10.0 us at 64
-// terms, the next one 11.4 -> 14.2 - its 64 lanes then read 64 different lines.  Range-major stays.)
+// (Round 4, first two forms of this file: (1) every wave bisecting every term's list and walking the terms one after the
+// other - one dependent memory round trip per term and wave, 126 us at 64 terms; (2) a `sparse_slice_kernel` in front that
+// walked the touched postings once and wrote where each list crosses the wave ranges into a [range][term] table - 12 us
+// for the extra launch, the postings read twice (the table term-major instead: that launch 11.9 -> 10.0 us, the scoring
+// launch 11.4 -> 14.2).  Now the crossings are precomputed at build time: the range directory.  Also tried on top of it and
+// dropped: fetching the slices of 4 x 64 terms together (200 terms: 35.7 -> 38.2 us; the LDS rounds bound it, not the trips).)
 
-// ---- launch 2: the sums ------------------------------------------------------------------------------------------------
-// A wave owns `rw = 1 << sh` chunks and their scores in LDS.  64 terms at a time: lane t reads its term's slice, a wave
+// ---- the scoring launch ------------------------------------------------------------------------------------------------
+// A wave owns `rw = 1 << sh` chunks and their scores in LDS.  64 terms at a time: lane t reads its term's slice - two
+// adjacent entries of the list's range directory (dir[r] = postings of the list with position < r * rw; built once, at
+// create), or two bisections for a list too short to have one - a wave
 // prefix sum lays the slices end to end (term order, inside a term posting order = the order the reference adds in), and the
 // wave streams that sequence 64 postings per step - every lane finds its term by a search over the 64 running counts in
 // LDS, so all lanes carry a posting whatever the slices' lengths, and the loads of one step do not wait for the sums of the
@@ -111,7 +77,7 @@ constexpr int kSpUnroll = 4;
 __host__ __device__ constexpr uint32_t sparse_wave_lds_words(uint32_t rw) { return 2u * rw + 4u * 64u; }
 
 __global__ __launch_bounds__(256) void sparse_accumulate_kernel(const uint2* __restrict__ post, const SparseTerm* __restrict__ terms,
-                                                                uint32_t n_terms, uint2* __restrict__ slices,
+                                                                uint32_t n_terms, const uint32_t* __restrict__ dir,
                                                                 uint32_t n, uint32_t n_pad, uint32_t sh,
                                                                 const uint32_t* __restrict__ keep, const uint32_t* __restrict__ chunk_of_rank,
                                                                 float* __restrict__ scores, float* __restrict__ gmax) {
@@ -135,12 +101,20 @@ __global__ __launch_bounds__(256) void sparse_accumulate_kernel(const uint2* __r
         unsigned long long addr = 0ull;
         float w = 0.f;
         if (t0 + (uint32_t)lane < n_terms) {
-            uint2* const slot = slices + (size_t)range * n_terms + t0 + lane;
-            const uint2 sl = *slot;
-            if (sl.y != 0u) *slot = make_uint2(0u, 0u);   // clean for the next search: no memset per query
             const SparseTerm tm = terms[t0 + lane];
-            len = sl.y - sl.x;
-            addr = tm.start + sl.x;
+            uint32_t lo, hi;
+            if (tm.dir != kNoDir) {
+                lo = dir[tm.dir + range];
+                hi = dir[tm.dir + range + 1u];
+            } else {
+                const uint2* const p = post + tm.start;
+                lo = lower_bound_chunk(p, 0u, tm.len, c0);
+                uint32_t b = tm.len;
+                if (lo + rw < b && p[lo + rw].x >= c0 + rw) b = lo + rw;   // the usual case: no more than one posting per chunk
+                hi = lower_bound_chunk(p, lo, b, c0 + rw);
+            }
+            len = hi - lo;
+            addr = tm.start + lo;
             w = tm.w;
         }
         uint32_t cum = len;                               // inclusive wave prefix sum
@@ -243,7 +217,9 @@ struct cqs_hip_sparse_index {
     SparseTerm* d_terms = nullptr;
     uint32_t terms_cap = 0;
     SparseTerm* h_terms = nullptr;           // pinned
-    uint2* d_slices = nullptr;               // [n_pad / rw][terms_cap]: (first, last + 1) of every term's list inside every wave range
+    uint32_t* d_dir = nullptr;               // range directories, list after list: n_pad / rw + 1 entries each
+    std::vector<uint64_t> dir_off;           // [tok.size()]: a list's first entry in d_dir, kNoDir = none
+    uint64_t dir_entries = 0;
     uint32_t* h_keep = nullptr;              // pinned, ceil(n / 32) words
     uint64_t* d_out_keys = nullptr;
     uint32_t* d_out_count = nullptr;
@@ -274,7 +250,7 @@ void release(cqs_hip_sparse_index* s) {
     (void)hipSetDevice(s->device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     for (void* p : {(void*)s->d_post, (void*)s->d_chunk_of_rank, (void*)s->d_scores, (void*)s->d_gmax, (void*)s->d_work,
-                    (void*)s->d_keep, (void*)s->d_terms, (void*)s->d_slices, (void*)s->d_out_keys, (void*)s->d_out_count, (void*)s->d_dbg})
+                    (void*)s->d_keep, (void*)s->d_terms, (void*)s->d_dir, (void*)s->d_out_keys, (void*)s->d_out_count, (void*)s->d_dbg})
         if (p) (void)hipFree(p);
     for (void* p : {(void*)s->h_terms, (void*)s->h_keep, (void*)s->h_out_keys})
         if (p) (void)hipHostFree(p);
@@ -288,12 +264,9 @@ int32_t ensure_terms(cqs_hip_sparse_index* s, uint32_t t) {
     if (t <= s->terms_cap) return CQS_HIP_OK;
     const uint32_t cap = std::max(256u, t + t / 2u);
     if (s->d_terms) { (void)hipFree(s->d_terms); s->d_terms = nullptr; }
-    if (s->d_slices) { (void)hipFree(s->d_slices); s->d_slices = nullptr; }
     if (s->h_terms) { (void)hipHostFree(s->h_terms); s->h_terms = nullptr; }
     s->terms_cap = 0;
     S_TRY(s, hipMalloc((void**)&s->d_terms, (size_t)cap * sizeof(SparseTerm)));
-    S_TRY(s, hipMalloc((void**)&s->d_slices, (size_t)(s->n_pad / s->rw) * cap * sizeof(uint2)));
-    S_TRY(s, hipMemset(s->d_slices, 0, (size_t)(s->n_pad / s->rw) * cap * sizeof(uint2)));   // every search leaves it zeroed again
     S_TRY(s, hipHostMalloc((void**)&s->h_terms, (size_t)cap * sizeof(SparseTerm), hipHostMallocDefault));
     s->terms_cap = cap;
     return CQS_HIP_OK;
@@ -396,6 +369,45 @@ int32_t cqs_hip_sparse_index_create(const uint64_t* doc_off, const uint32_t* tok
     while (s->rw > 64u && s->n_pad / s->rw < s->n_cu * 16u) s->rw >>= 1;
     s->sh = 0;
     while ((1u << s->sh) < s->rw) ++s->sh;
+    // Range directories: dir[r] = how many postings of the list sit below position r * rw, r = 0 .. n_pad / rw - what a wave
+    // needs to find its slice of the list with two adjacent loads.  Longest lists first, within a budget of entries equal
+    // to the postings' own bytes (never less than 256 MB): every list of a real vocabulary gets one (30 522 tokens x 3 907
+    // ranges = 0.48 GB at 1M chunks); lists left without (shorter than kDirMinLen, or past the budget) are bisected.
+    {
+        constexpr uint64_t kDirMinLen = 32;
+        const uint64_t R1 = (uint64_t)(s->n_pad / s->rw) + 1;
+        const uint64_t budget = std::max<uint64_t>(64ull << 20, 2ull * P);
+        s->dir_off.assign(s->tok.size(), kNoDir);
+        std::vector<uint32_t> order;
+        for (size_t t = 0; t < s->tok.size(); ++t)
+            if (s->off[t + 1] - s->off[t] >= kDirMinLen) order.push_back((uint32_t)t);
+        std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+            const uint64_t lx = s->off[x + 1] - s->off[x], ly = s->off[y + 1] - s->off[y];
+            return lx != ly ? lx > ly : x < y;
+        });
+        uint64_t used = 0;
+        for (uint32_t t : order) {
+            if (used + R1 > budget || s->off[t + 1] - s->off[t] > 0xFFFFFFFFull) break;
+            s->dir_off[t] = used;
+            used += R1;
+        }
+        s->dir_entries = used;
+        std::vector<uint32_t> dirs((size_t)used);
+        for (size_t t = 0; t < s->tok.size(); ++t) {
+            if (s->dir_off[t] == kNoDir) continue;
+            const uint2* const pl = post.data() + s->off[t];
+            const uint32_t len = (uint32_t)(s->off[t + 1] - s->off[t]);
+            uint32_t* const d = dirs.data() + s->dir_off[t];
+            uint32_t pos = 0;
+            for (uint64_t r = 0; r < R1; ++r) {
+                const uint64_t edge = r * s->rw;
+                while (pos < len && pl[pos].x < edge) ++pos;
+                d[r] = pos;
+            }
+        }
+        if ((he = hipMalloc((void**)&s->d_dir, std::max<size_t>((size_t)used, 1) * 4)) != hipSuccess) return dfail(he);
+        if (used && (he = hipMemcpy(s->d_dir, dirs.data(), (size_t)used * 4, hipMemcpyHostToDevice)) != hipSuccess) return dfail(he);
+    }
     if ((he = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking)) != hipSuccess) return dfail(he);
     if ((he = hipEventCreate(&s->ev0)) != hipSuccess || (he = hipEventCreate(&s->ev1)) != hipSuccess) return dfail(he);
     if ((he = hipMalloc((void**)&s->d_post, std::max<size_t>((size_t)P, 1) * sizeof(uint2))) != hipSuccess) return dfail(he);
@@ -485,7 +497,7 @@ int32_t cqs_hip_sparse_index_search(cqs_hip_sparse_index* s, const uint32_t* q_t
         if (len == 0) continue;
         if (len > 0xFFFFFFFFull) return sfail(s, CQS_HIP_ERR_INVALID, "sparse search: posting list longer than 2^32");
         s->h_terms[nt].start = s->off[slot];
-        s->h_terms[nt].cum = touched;
+        s->h_terms[nt].dir = s->dir_off[slot];
         s->h_terms[nt].len = (uint32_t)len;
         s->h_terms[nt].w = q_weights[i];
         ++nt;
@@ -503,13 +515,9 @@ int32_t cqs_hip_sparse_index_search(cqs_hip_sparse_index* s, const uint32_t* q_t
         d_keep = s->d_keep;
     }
     const uint32_t waves = s->n_pad / s->rw;
-    if (touched >= (1ull << 32) * 256ull) return sfail(s, CQS_HIP_ERR_INVALID, "sparse search: the query touches too many postings");
     S_TRY(s, hipEventRecord(s->ev0, st));
-    hipLaunchKernelGGL(sparse_slice_kernel, dim3((uint32_t)((touched + 1023ull) / 1024ull)), dim3(256), 0, st, s->d_post, s->d_terms, nt,
-                       (unsigned long long)touched, s->sh, s->d_slices);
-    S_TRY(s, hipGetLastError());
     hipLaunchKernelGGL(sparse_accumulate_kernel, dim3((waves + 3u) / 4u), dim3(256), (size_t)4 * sparse_wave_lds_words(s->rw) * 4, st,
-                       s->d_post, s->d_terms, nt, s->d_slices, (uint32_t)s->n, s->n_pad, s->sh, d_keep,
+                       s->d_post, s->d_terms, nt, s->d_dir, (uint32_t)s->n, s->n_pad, s->sh, d_keep,
                        s->ranked ? s->d_chunk_of_rank : nullptr, s->d_scores, s->d_gmax);
     S_TRY(s, hipGetLastError());
     S_TRY(s, hipEventRecord(s->ev1, st));
