@@ -32,7 +32,7 @@
 #include "abi_guard.h"
 #include "scan_kernels.h"
 
-namespace {
+namespace cqs {
 
 constexpr uint32_t kSparsePad = 1024;          // n_pad granule (a multiple of every wave range)
 constexpr uint32_t kUnscored = 0xFFFFFFFFu;    // LDS marker: `scores.entry(chunk)` does not exist yet (a NaN no arithmetic here produces:
@@ -194,7 +194,15 @@ __global__ __launch_bounds__(256) void sparse_accumulate_kernel(const uint2* __r
     }
 }
 
-}  // namespace
+}  // namespace cqs
+
+using cqs::kMaxTerms;
+using cqs::kNoDir;
+using cqs::kSparsePad;
+using cqs::kUnscored;
+using cqs::sparse_accumulate_kernel;
+using cqs::sparse_wave_lds_words;
+using cqs::SparseTerm;
 
 struct cqs_hip_sparse_index {
     std::mutex mu;
