@@ -147,7 +147,11 @@ __global__ __launch_bounds__(256) void sparse_accumulate_kernel(const uint2* __r
                         if (t_cum[m] <= g) a = m; else b = m;
                     }
                     const unsigned long long at = ((unsigned long long)t_ahi[a] << 32 | t_alo[a]) + (g - t_cum[a]);
+#if defined(CQS_SP_ABLATE_NOLOAD)      // timing experiment (wrong results): no posting is read
+                    e[u] = make_uint2(c0 + ((uint32_t)at & (rw - 1u)), 0x3f800000u);
+#else
                     e[u] = post[at];
+#endif
                     prod[u] = __fmul_rn(__builtin_bit_cast(float, t_w[a]), __builtin_bit_cast(float, e[u].y));
                 }
             }
@@ -156,6 +160,10 @@ __global__ __launch_bounds__(256) void sparse_accumulate_kernel(const uint2* __r
                 if (g0 + 64u * u >= total) break;         // (wave-uniform)
                 const uint32_t at = e[u].x - c0;
                 bool pending = pend[u];
+#if defined(CQS_SP_ABLATE_NORMW)       // timing experiment (wrong results): the loads alone
+                if (pending && prod[u] == 12345.678f) my[at] = 1u;
+                pending = false;
+#endif
                 while (__builtin_amdgcn_ballot_w64(pending) != 0ull) {
                     // (compiler barriers: the other lanes' LDS stores are invisible to the single-thread view the optimiser
                     // reasons in - no load of a score or a claim may move across a round)
