@@ -478,9 +478,16 @@ __global__ __launch_bounds__(1024) void select_finish_kernel(const float* __rest
     __syncthreads();
     if (linear == 2u) {                                    // phase 0: smallest and largest finite group maximum
         float lo = INFINITY, hi = -INFINITY;
-        for (uint32_t t = threadIdx.x; t < n_tasks; t += 1024u) {
-            const float v = gm[t];
-            if (v != -INFINITY) { lo = fminf(lo, v); hi = fmaxf(hi, v); }
+        for (uint32_t t0 = 0; t0 < n_tasks; t0 += 1024u * kGB) {   // kGB unconditional loads in flight (a conditional one per trip waited for each)
+            float v[kGB];
+#pragma unroll
+            for (int u = 0; u < kGB; ++u) {
+                const uint32_t t = t0 + (uint32_t)u * 1024u + threadIdx.x;
+                v[u] = gm[t < n_tasks ? t : n_tasks - 1u];
+            }
+#pragma unroll
+            for (int u = 0; u < kGB; ++u)
+                if (v[u] != -INFINITY) { lo = fminf(lo, v[u]); hi = fmaxf(hi, v[u]); }   // (a clamped repeat of the last group changes neither)
         }
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) {
@@ -592,6 +599,8 @@ __global__ __launch_bounds__(1024) void select_finish_kernel(const float* __rest
         // One key per thread, count broadcast LDS reads, no barriers inside the loop.
         uint64_t* s_sorted = reinterpret_cast<uint64_t*>(s_groups);  // group list is dead by now
         __syncthreads();
+        // (Two threads per key, each over half of the list, took as long: the loop is bound by LDS broadcast reads,
+        // waves x keys of them either way - 7 us at 510 keys.)
         if (threadIdx.x < count) {
             const uint64_t mine = s_keys[threadIdx.x];
             uint32_t rank = 0;
