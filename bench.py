@@ -726,7 +726,7 @@ def aux_models_leg(a, np):
     return out
 
 
-def sparse_index_leg(a, np):
+def sparse_index_leg(a, np, dense_idx=None, dense_queries=None):
     """The SPLADE retrieval leg (`SpladeIndex::search_with_filter`, src/splade/index.rs:223-290) behind the C ABI:
     1M synthetic chunk vectors (~96 distinct tokens each, skewed token frequencies), 64-term queries, k = 500
     (candidate_count_for(limit), src/limits.rs:315-320) through the blocking host API; every timed answer's chunk order
@@ -781,6 +781,50 @@ def sparse_index_leg(a, np):
                              "sample": "%d of the timed queries through oracle.SpladeIndex.search_raw (dense score array in place of the HashMap)" % ncpu},
         }
     out["corpus_gen_s"] = round(t_gen, 1)
+    if dense_idx is not None and len(dense_idx) == n:
+        # Both retrieval legs of `search_hybrid_inner` (src/search/query.rs:879-901) for one query at k = candidate_count = 500
+        # on the same 1M chunks: the dense scan and the sparse index, one after the other and from two threads (the handles
+        # are independent: different streams, different mutexes); then the fusion mirror (in cqs it stays in Rust).
+        import threading
+        from cqs_amd.index import IndexResult
+        from cqs_amd.splade_index import fuse_hybrid
+        qs = synth.sparse_queries(40, 64, vocab, seed=0x5BA2E1)
+        dq = dense_queries[:40]
+        for i in range(5):
+            dense_idx.search_batch(dq[i], k); h.search_raw(qs[i][0], qs[i][1], k)
+        t0 = time.perf_counter()
+        for i in range(40):
+            dense_idx.search_batch(dq[i], k)
+        t_d = (time.perf_counter() - t0) / 40
+        t0 = time.perf_counter()
+        for i in range(40):
+            h.search_raw(qs[i][0], qs[i][1], k)
+        t_s = (time.perf_counter() - t0) / 40
+        res = [None, None]
+
+        def dense_side():
+            res[0] = [dense_idx.search_batch(dq[i], k) for i in range(40)]
+
+        def sparse_side():
+            res[1] = [h.search_raw(qs[i][0], qs[i][1], k) for i in range(40)]
+
+        t0 = time.perf_counter()
+        th = [threading.Thread(target=dense_side), threading.Thread(target=sparse_side)]
+        [t.start() for t in th]; [t.join() for t in th]
+        t_both = (time.perf_counter() - t0) / 40
+        rows_d, sc_d, cnt_d = res[0][0]
+        hc, hs, _rc = res[1][0]
+        d = [IndexResult(str(int(r)), float(x)) for r, x in zip(rows_d[0, :cnt_d[0]], sc_d[0, :cnt_d[0]])]
+        sres = [IndexResult(str(int(c)), float(x)) for c, x in zip(hc, hs)]
+        t0 = time.perf_counter()
+        fused = fuse_hybrid(d, sres, 0.7, k)
+        t_f = time.perf_counter() - t0
+        out["hybrid"] = {"k": k, "dense_leg_ms": round(t_d * 1e3, 4), "sparse_leg_ms": round(t_s * 1e3, 4),
+                         "one_after_the_other_ms": round((t_d + t_s) * 1e3, 4), "two_threads_ms_per_query": round(t_both * 1e3, 4),
+                         "fused_candidates": len(fused), "fusion_python_mirror_ms": round(t_f * 1e3, 3),
+                         "what": "search_hybrid_inner's two retrieval legs for one query, k = 500 each, 1M chunks, blocking host APIs; "
+                                 "two_threads = 40 dense and 40 sparse searches issued from one thread each, wall time / 40; the fusion "
+                                 "(query.rs:909-1010) stays in Rust in cqs - the Python mirror's time is listed for completeness"}
     h.close()
     return out
 
@@ -1269,6 +1313,10 @@ def main():
     # multi-device run here, on rank 0, after every rank has let go of its shard and left the group - see below.
     abi_after_group = dist is not None and not rehearsal and a.abi_after and torch.cuda.device_count() >= world
 
+    sparse = None
+    if rank == 0 and world == 1 and mode == "single" and a.extras and a.sparse_chunks > 0:
+        sparse = sparse_index_leg(a, np, idx, queries[W:, 0].cpu().numpy())
+
     embed = e2e = None
     if a.embed_steps > 0:
         idx.close()
@@ -1282,9 +1330,6 @@ def main():
     aux = None
     if rank == 0 and world == 1 and mode == "single" and a.extras and a.embed_steps > 0:
         aux = aux_models_leg(a, np)
-    sparse = None
-    if rank == 0 and world == 1 and mode == "single" and a.extras and a.sparse_chunks > 0:
-        sparse = sparse_index_leg(a, np)
 
     if abi_after_group:
         # every rank drops its shard, the group dissolves, ranks != 0 leave; rank 0 then builds ONE handle over

@@ -341,3 +341,42 @@ class SpladeIndex:
                 self._h = None
         except Exception:
             pass
+
+
+def hybrid_fuse(dense, sparse, alpha, candidate_count):
+    """`search_hybrid_inner`'s fusion (src/search/query.rs:909-1010) restated over plain (id, score) lists - written
+    independently of the product's mirror (cqs_amd/splade_index.fuse_hybrid), as its checker.
+    :917-921 max_sparse = reduce(f32::max) over the sparse pool (0.0 if empty); :936-950 dense map (last insert wins),
+    sparse map = score / max_sparse when max_sparse > 0 else 0.0; :957-970 ids: dense first, then unseen sparse ones;
+    :979-997 alpha <= 0 -> d + s * 0.1, else alpha * d + (1 - alpha) * s, absent = 0.0; :1003 sort by (score desc
+    total_cmp, id asc); :1004 truncate."""
+    f32 = np.float32
+    scores = [f32(s) for _i, s in sparse]
+    mx = f32(0.0)
+    if scores:
+        mx = scores[0]
+        for s in scores[1:]:
+            mx = s if (mx != mx or s > mx) else mx
+    dmap, smap = {}, {}
+    for i, s in dense:
+        dmap[i] = f32(s)
+    for i, s in sparse:
+        smap[i] = (f32(s) / mx) if mx > 0 else f32(0.0)
+    order = []
+    for i, _s in list(dense) + list(sparse):
+        if i not in order:
+            order.append(i)
+    a = f32(alpha)
+    out = []
+    for i in order:
+        d, s = dmap.get(i, f32(0.0)), smap.get(i, f32(0.0))
+        v = (d + s * f32(0.1)) if a <= 0 else (a * d + (f32(1.0) - a) * s)
+        out.append((i, f32(v)))
+
+    def key(t):
+        bits = int(np.float32(t[1]).view(np.int32))
+        bits ^= (bits >> 31) & 0x7FFFFFFF                 # total_cmp order as an integer
+        return (-bits, t[0].encode("utf-8") if isinstance(t[0], str) else t[0])
+
+    out.sort(key=key)
+    return [(i, float(v)) for i, v in out[:candidate_count]]

@@ -92,3 +92,24 @@ def test_fuse_hybrid_mirror():
     tie = fuse_hybrid([R("q", 0.5), R("p", 0.5)], [], 1.0, 10)
     assert [r.id for r in tie] == ["p", "q"]
     assert math.isclose(tie[0].score, 0.5)
+
+
+def test_fuse_hybrid_mirror_equals_the_oracle_restatement(oracle):
+    """cqs_amd.splade_index.fuse_hybrid (product mirror) against oracle.hybrid_fuse (written separately from the same
+    lines of query.rs) on random pools: overlapping ids, negative sparse pools, tied scores, every alpha branch."""
+    from cqs_amd.index import IndexResult as R
+    from cqs_amd.splade_index import fuse_hybrid
+    rng = np.random.default_rng(0)
+    ids = ["c%03d" % i for i in range(60)]
+    for trial in range(300):
+        nd, ns = int(rng.integers(0, 30)), int(rng.integers(0, 30))
+        d = [(ids[i], float(np.float32(rng.uniform(-1, 1)))) for i in rng.choice(60, nd, replace=False)]
+        s = [(ids[i], float(np.float32(rng.uniform(-2, 20)))) for i in rng.choice(60, ns, replace=False)]
+        if trial % 7 == 0:
+            s = [(i, -abs(x)) for i, x in s]
+        if trial % 5 == 0 and len(d) > 1:
+            d[0] = (d[0][0], d[-1][1])
+        alpha = [0.0, 0.3, 0.7, 1.0, -0.5][trial % 5]
+        want = oracle.hybrid_fuse(d, s, alpha, 25)
+        got = [(r.id, r.score) for r in fuse_hybrid([R(*x) for x in d], [R(*x) for x in s], alpha, 25)]
+        assert got == want, trial
