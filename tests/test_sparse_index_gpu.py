@@ -158,3 +158,32 @@ def test_one_million_chunks_against_the_oracle_and_properties(S, oracle):
     assert np.array_equal(hc3, hc) and np.array_equal(hs3, hs)
     _same(o, h, qt, qw, 1000, rng.random(n) < 0.3)
     h.close()
+
+
+def test_many_terms_and_concurrent_callers(S, oracle):
+    """A query far longer than one 64-term group (with repeats: the same list is walked again, in order), a term table that
+    has to grow between calls, and four threads on one handle (the handle serialises them; every answer must still be the
+    oracle's)."""
+    import threading
+    rng = np.random.default_rng(77)
+    off, tok, w = sc.corpus(rng, 6000, 900, 10, 50, dup_frac=0.1)
+    o = oracle.SpladeIndex(off, tok, w)
+    h = S.HipSpladeIndex.build_from_csr(None, off, tok, w)
+    for terms in (10, 300, 1500, 40):
+        qt = rng.integers(0, 900, size=terms).astype(np.uint32)            # repeats included
+        qw = (rng.random(terms, dtype=np.float32) - np.float32(0.3)).astype(np.float32)
+        _same(o, h, qt, qw, 500)
+    queries = [sc.query(rng, 900, 30 + 5 * i) for i in range(16)]
+    want = [o.search_raw(qt, qw, 200) for qt, qw in queries]
+    got = [None] * len(queries)
+
+    def work(t):
+        for i in range(t, len(queries), 4):
+            for _ in range(5):
+                got[i] = h.search_raw(queries[i][0], queries[i][1], 200)
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+    [t.start() for t in th]; [t.join() for t in th]
+    for (oc, os_), (hc, hs, rc) in zip(want, got):
+        assert rc == 0 and np.array_equal(hc, oc) and np.array_equal(hs.view(np.uint32), os_.view(np.uint32))
+    h.close()
