@@ -311,6 +311,10 @@ int32_t cqs_hip_sparse_index_create(const uint64_t* doc_off, const uint32_t* tok
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return CQS_HIP_ERR_NO_DEVICE;
     cqs_hip_sparse_index* s = new cqs_hip_sparse_index();
+    struct Guard {                                         // an exception or an early return below frees what exists so far
+        cqs_hip_sparse_index* p;
+        ~Guard() { if (p) release(p); }
+    } guard{s};
     s->device = device;
     s->n = n;
     s->n_postings = P;
@@ -320,7 +324,7 @@ int32_t cqs_hip_sparse_index_create(const uint64_t* doc_off, const uint32_t* tok
     if (id_rank) {
         s->chunk_of_rank.assign((size_t)n, 0xFFFFFFFFu);
         for (uint64_t i = 0; i < n; ++i) {
-            if (id_rank[i] >= n || s->chunk_of_rank[id_rank[i]] != 0xFFFFFFFFu) { delete s; return CQS_HIP_ERR_INVALID; }   // not a permutation
+            if (id_rank[i] >= n || s->chunk_of_rank[id_rank[i]] != 0xFFFFFFFFu) return CQS_HIP_ERR_INVALID;   // not a permutation
             s->chunk_of_rank[id_rank[i]] = (uint32_t)i;
         }
         s->ranked = true;
@@ -372,8 +376,7 @@ int32_t cqs_hip_sparse_index_create(const uint64_t* doc_off, const uint32_t* tok
             }
         }
     }
-    auto dfail = [&](hipError_t he) -> int32_t {
-        release(s);
+    auto dfail = [&](hipError_t he) -> int32_t {           // (the guard releases)
         return he == hipErrorOutOfMemory ? CQS_HIP_ERR_NOMEM : CQS_HIP_ERR_DEVICE;
     };
     hipError_t he = hipSetDevice(device);
@@ -444,6 +447,7 @@ int32_t cqs_hip_sparse_index_create(const uint64_t* doc_off, const uint32_t* tok
     if (hipHostGetDevicePointer((void**)&s->h_out_keys_dev, s->h_out_keys, 0) != hipSuccess) s->h_out_keys_dev = nullptr;
     if (const char* e = getenv("CQS_HIP_DEBUG_STAMPS"); e && *e == '1')
         if (hipMalloc((void**)&s->d_dbg, 16 * 8) == hipSuccess) (void)hipMemset(s->d_dbg, 0, 16 * 8);
+    guard.p = nullptr;
     *out = s;
     return CQS_HIP_OK;
 } CQS_ABI_CATCH_NOHANDLE

@@ -187,3 +187,46 @@ def test_many_terms_and_concurrent_callers(S, oracle):
     for (oc, os_), (hc, hs, rc) in zip(want, got):
         assert rc == 0 and np.array_equal(hc, oc) and np.array_equal(hs.view(np.uint32), os_.view(np.uint32))
     h.close()
+
+
+def test_the_input_space_of_the_reference_proptest(S, oracle):
+    """The reference's own generators for `SpladeIndex` inputs (src/splade/index.rs:1717-1762): 0..8 chunks, 0..6 entries
+    each, token ids over the whole u32 range, DUPLICATE tokens inside a vector, weights from every f32 class (ordinary,
+    +-0, f32::MIN / MAX, MIN_POSITIVE, the smallest subnormal, +-inf, NaN), ids empty / ASCII / multi-byte and not unique.
+    There they feed the save / load round trip; here every such index is searched on both sides - same ids, same score bits."""
+    rng = np.random.default_rng(2024)
+    special = np.array([0.0, -0.0, np.finfo(np.float32).min, np.finfo(np.float32).max, np.finfo(np.float32).tiny,
+                        np.float32(1e-45), np.inf, -np.inf, np.nan], dtype=np.float32)
+    id_pool = ["", "a", "chunk_a", "src/lib.rs:12", "a/b-c.d_e", "été", "中文", "\U0001F600x", "zz", "a"]
+
+    def weight():
+        if rng.random() < 0.45:
+            return float(np.float32(rng.standard_normal() * 10.0 ** rng.integers(-3, 4)))
+        return float(special[rng.integers(0, special.size)])
+
+    def token(pool):
+        return int(pool[rng.integers(0, len(pool))])
+
+    checked = 0
+    for case in range(150):
+        pool = [0, 0xFFFFFFFF] + [int(x) for x in rng.integers(0, 2 ** 32, size=4, dtype=np.uint64)]
+        chunks = []
+        for _ in range(int(rng.integers(0, 9))):
+            vec = [(token(pool), weight()) for _ in range(int(rng.integers(0, 7)))]
+            chunks.append((id_pool[rng.integers(0, len(id_pool))], vec))
+        o = oracle.SpladeIndex.build(chunks)
+        h = S.HipSpladeIndex.build(chunks)
+        assert len(h) == len(o) and h.unique_tokens() == o.unique_tokens()
+        for _q in range(3):
+            query = [(token(pool), weight() if rng.random() < 0.5 else float(np.float32(rng.random() + 0.1)))
+                     for _ in range(int(rng.integers(0, 6)))]
+            k = int(rng.integers(0, 12))
+            got = [(r.id, r.score) for r in h.search(query, k)]
+            want = o.search(query, k)
+            # equal (score, id) pairs - duplicate ids - may come out in either order: compare as sorted lists of bit patterns
+            key = lambda t: (t[0], np.float32(t[1]).view(np.uint32).item())
+            assert sorted(map(key, got)) == sorted(map(key, want)), (case, chunks, query, k, got, want)
+            assert [key(t)[1] for t in got] == [key(t)[1] for t in want]
+            checked += 1
+        h.close()
+    assert checked == 450
