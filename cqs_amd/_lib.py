@@ -112,6 +112,8 @@ SIGNATURES = [
     ("cqs_hip_bert_last_error", C.c_size_t, [_c_idx, C.c_char_p, C.c_size_t]),
     ("cqs_hip_sparse_index_create", C.c_int32,
      [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int32, _pp(_c_idx)]),
+    ("cqs_hip_sparse_index_create_inverted", C.c_int32,
+     [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_int32, _pp(_c_idx)]),
     ("cqs_hip_sparse_index_destroy", None, [_c_idx]),
     ("cqs_hip_sparse_index_len", C.c_uint64, [_c_idx]),
     ("cqs_hip_sparse_index_unique_tokens", C.c_uint64, [_c_idx]),

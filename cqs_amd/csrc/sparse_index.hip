@@ -295,95 +295,11 @@ int32_t ensure_terms(cqs_hip_sparse_index* s, uint32_t t) {
     return CQS_HIP_OK;
 }
 
-}  // namespace
-
-extern "C" {
-
-int32_t cqs_hip_sparse_index_create(const uint64_t* doc_off, const uint32_t* tokens, const float* weights, uint64_t n,
-                                    const uint32_t* id_rank, int32_t device, cqs_hip_sparse_index** out) CQS_ABI_TRY {
-    if (!out) return CQS_HIP_ERR_INVALID;
-    *out = nullptr;
-    if (n && !doc_off) return CQS_HIP_ERR_INVALID;
-    if (n >= 0xFFFFFFFFull - kSparsePad) return CQS_HIP_ERR_INVALID;
-    const uint64_t P = n ? doc_off[n] : 0;
-    if (n && doc_off[0] != 0) return CQS_HIP_ERR_INVALID;
-    for (uint64_t i = 0; i < n; ++i)
-        if (doc_off[i + 1] < doc_off[i]) return CQS_HIP_ERR_INVALID;
-    if (P && (!tokens || !weights)) return CQS_HIP_ERR_INVALID;
-    for (uint64_t e = 0; e < P; ++e) {
-        uint32_t bits;
-        memcpy(&bits, &weights[e], 4);
-        if (bits == kUnscored) return CQS_HIP_ERR_INVALID;      // the one NaN payload the kernel reserves
-    }
-    int count = 0;
-    if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return CQS_HIP_ERR_NO_DEVICE;
-    cqs_hip_sparse_index* s = new cqs_hip_sparse_index();
-    struct Guard {                                         // an exception or an early return below frees what exists so far
-        cqs_hip_sparse_index* p;
-        ~Guard() { if (p) release(p); }
-    } guard{s};
-    s->device = device;
-    s->n = n;
-    s->n_postings = P;
-    s->n_pad = (uint32_t)((n + kSparsePad - 1) / kSparsePad * kSparsePad);
-    if (s->n_pad == 0) s->n_pad = kSparsePad;
-    // id order: chunk_of_rank[r] = the chunk whose id is the r-th smallest
-    if (id_rank) {
-        s->chunk_of_rank.assign((size_t)n, 0xFFFFFFFFu);
-        for (uint64_t i = 0; i < n; ++i) {
-            if (id_rank[i] >= n || s->chunk_of_rank[id_rank[i]] != 0xFFFFFFFFu) return CQS_HIP_ERR_INVALID;   // not a permutation
-            s->chunk_of_rank[id_rank[i]] = (uint32_t)i;
-        }
-        s->ranked = true;
-    }
-    // the token table: sorted distinct ids; a dense counting pass when the ids are small (every real vocabulary), a sort otherwise
-    uint32_t max_tok = 0;
-    for (uint64_t e = 0; e < P; ++e) max_tok = std::max(max_tok, tokens[e]);
-    std::vector<uint64_t> dense;                          // token -> slot + 1 (dense path)
-    std::unordered_map<uint32_t, uint32_t> sparse_slot;   // (sort path)
-    const bool use_dense = P && max_tok < (1u << 24);
-    if (use_dense) {
-        dense.assign((size_t)max_tok + 1, 0);
-        for (uint64_t e = 0; e < P; ++e) dense[tokens[e]]++;
-        for (uint32_t t = 0; t <= max_tok; ++t)
-            if (dense[t]) { s->tok.push_back(t); s->off.push_back(dense[t]); }
-    } else if (P) {
-        std::vector<uint32_t> sorted(tokens, tokens + P);
-        std::sort(sorted.begin(), sorted.end());
-        for (uint64_t e = 0; e < P;) {
-            uint64_t f = e;
-            while (f < P && sorted[f] == sorted[e]) ++f;
-            s->tok.push_back(sorted[e]);
-            s->off.push_back(f - e);
-            e = f;
-        }
-    }
-    {   // counts -> offsets
-        uint64_t run = 0;
-        for (size_t t = 0; t < s->off.size(); ++t) { const uint64_t c = s->off[t]; s->off[t] = run; run += c; }
-        s->off.push_back(run);
-    }
-    if (use_dense) {
-        for (size_t t = 0; t < s->tok.size(); ++t) dense[s->tok[t]] = t + 1;
-    } else {
-        sparse_slot.reserve(s->tok.size());
-        for (size_t t = 0; t < s->tok.size(); ++t) sparse_slot[s->tok[t]] = (uint32_t)t;
-    }
-    // the postings, list by list; inside a list ascending position (rank order = the order the documents are walked in)
-    std::vector<uint2> post((size_t)P);
-    {
-        std::vector<uint64_t> cur(s->off.begin(), s->off.end() - 1);
-        for (uint64_t r = 0; r < n; ++r) {
-            const uint64_t d = s->ranked ? s->chunk_of_rank[r] : r;
-            for (uint64_t e = doc_off[d]; e < doc_off[d + 1]; ++e) {
-                const size_t slot = use_dense ? (size_t)(dense[tokens[e]] - 1) : (size_t)sparse_slot[tokens[e]];
-                uint32_t bits;
-                memcpy(&bits, &weights[e], 4);
-                post[cur[slot]++] = make_uint2((uint32_t)r, bits);
-            }
-        }
-    }
-    auto dfail = [&](hipError_t he) -> int32_t {           // (the guard releases)
+// Second half of every constructor: `s->tok` / `s->off` and the host posting array are final; device, wave ranges, range
+// directories, scratch.  On failure the caller's guard releases the handle.
+int32_t finish_create(cqs_hip_sparse_index* s, const std::vector<uint2>& post, int32_t device) {
+    const uint64_t n = s->n, P = s->n_postings;
+    auto dfail = [&](hipError_t he) -> int32_t {           // (the caller's guard releases)
         return he == hipErrorOutOfMemory ? CQS_HIP_ERR_NOMEM : CQS_HIP_ERR_DEVICE;
     };
     hipError_t he = hipSetDevice(device);
@@ -457,6 +373,172 @@ int32_t cqs_hip_sparse_index_create(const uint64_t* doc_off, const uint32_t* tok
     if (hipHostGetDevicePointer((void**)&s->h_out_keys_dev, s->h_out_keys, 0) != hipSuccess) s->h_out_keys_dev = nullptr;
     if (const char* e = getenv("CQS_HIP_DEBUG_STAMPS"); e && *e == '1')
         if (hipMalloc((void**)&s->d_dbg, 16 * 8) == hipSuccess) (void)hipMemset(s->d_dbg, 0, 16 * 8);
+    return CQS_HIP_OK;
+}
+
+struct CreateGuard {                                       // an exception or an early return frees what exists so far
+    cqs_hip_sparse_index* p;
+    ~CreateGuard() { if (p) release(p); }
+};
+
+// First half: the handle with its chunk count and id order.  nullptr = id_rank is not a permutation.
+cqs_hip_sparse_index* begin_create(uint64_t n, const uint32_t* id_rank, int32_t device) {
+    cqs_hip_sparse_index* s = new cqs_hip_sparse_index();
+    CreateGuard guard{s};
+    s->device = device;
+    s->n = n;
+    s->n_pad = (uint32_t)((n + kSparsePad - 1) / kSparsePad * kSparsePad);
+    if (s->n_pad == 0) s->n_pad = kSparsePad;
+    if (id_rank) {                                         // chunk_of_rank[r] = the chunk whose id is the r-th smallest
+        s->chunk_of_rank.assign((size_t)n, 0xFFFFFFFFu);
+        for (uint64_t i = 0; i < n; ++i) {
+            if (id_rank[i] >= n || s->chunk_of_rank[id_rank[i]] != 0xFFFFFFFFu) return nullptr;
+            s->chunk_of_rank[id_rank[i]] = (uint32_t)i;
+        }
+        s->ranked = true;
+    }
+    guard.p = nullptr;
+    return s;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t cqs_hip_sparse_index_create(const uint64_t* doc_off, const uint32_t* tokens, const float* weights, uint64_t n,
+                                    const uint32_t* id_rank, int32_t device, cqs_hip_sparse_index** out) CQS_ABI_TRY {
+    if (!out) return CQS_HIP_ERR_INVALID;
+    *out = nullptr;
+    if (n && !doc_off) return CQS_HIP_ERR_INVALID;
+    if (n >= 0xFFFFFFFFull - kSparsePad) return CQS_HIP_ERR_INVALID;
+    const uint64_t P = n ? doc_off[n] : 0;
+    if (n && doc_off[0] != 0) return CQS_HIP_ERR_INVALID;
+    for (uint64_t i = 0; i < n; ++i)
+        if (doc_off[i + 1] < doc_off[i]) return CQS_HIP_ERR_INVALID;
+    if (P && (!tokens || !weights)) return CQS_HIP_ERR_INVALID;
+    for (uint64_t e = 0; e < P; ++e) {
+        uint32_t bits;
+        memcpy(&bits, &weights[e], 4);
+        if (bits == kUnscored) return CQS_HIP_ERR_INVALID;      // the one NaN payload the kernel reserves
+    }
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return CQS_HIP_ERR_NO_DEVICE;
+    cqs_hip_sparse_index* s = begin_create(n, id_rank, device);
+    if (!s) return CQS_HIP_ERR_INVALID;                     // id_rank is not a permutation of 0 .. n - 1
+    CreateGuard guard{s};
+    s->n_postings = P;
+    // the token table: sorted distinct ids; a dense counting pass when the ids are small (every real vocabulary), a sort otherwise
+    uint32_t max_tok = 0;
+    for (uint64_t e = 0; e < P; ++e) max_tok = std::max(max_tok, tokens[e]);
+    std::vector<uint64_t> dense;                          // token -> slot + 1 (dense path)
+    std::unordered_map<uint32_t, uint32_t> sparse_slot;   // (sort path)
+    const bool use_dense = P && max_tok < (1u << 24);
+    if (use_dense) {
+        dense.assign((size_t)max_tok + 1, 0);
+        for (uint64_t e = 0; e < P; ++e) dense[tokens[e]]++;
+        for (uint32_t t = 0; t <= max_tok; ++t)
+            if (dense[t]) { s->tok.push_back(t); s->off.push_back(dense[t]); }
+    } else if (P) {
+        std::vector<uint32_t> sorted(tokens, tokens + P);
+        std::sort(sorted.begin(), sorted.end());
+        for (uint64_t e = 0; e < P;) {
+            uint64_t f = e;
+            while (f < P && sorted[f] == sorted[e]) ++f;
+            s->tok.push_back(sorted[e]);
+            s->off.push_back(f - e);
+            e = f;
+        }
+    }
+    {   // counts -> offsets
+        uint64_t run = 0;
+        for (size_t t = 0; t < s->off.size(); ++t) { const uint64_t c = s->off[t]; s->off[t] = run; run += c; }
+        s->off.push_back(run);
+    }
+    if (use_dense) {
+        for (size_t t = 0; t < s->tok.size(); ++t) dense[s->tok[t]] = t + 1;
+    } else {
+        sparse_slot.reserve(s->tok.size());
+        for (size_t t = 0; t < s->tok.size(); ++t) sparse_slot[s->tok[t]] = (uint32_t)t;
+    }
+    // the postings, list by list; inside a list ascending position (rank order = the order the documents are walked in)
+    std::vector<uint2> post((size_t)P);
+    {
+        std::vector<uint64_t> cur(s->off.begin(), s->off.end() - 1);
+        for (uint64_t r = 0; r < n; ++r) {
+            const uint64_t d = s->ranked ? s->chunk_of_rank[r] : r;
+            for (uint64_t e = doc_off[d]; e < doc_off[d + 1]; ++e) {
+                const size_t slot = use_dense ? (size_t)(dense[tokens[e]] - 1) : (size_t)sparse_slot[tokens[e]];
+                uint32_t bits;
+                memcpy(&bits, &weights[e], 4);
+                post[cur[slot]++] = make_uint2((uint32_t)r, bits);
+            }
+        }
+    }
+    const int32_t rc = finish_create(s, post, device);
+    if (rc != CQS_HIP_OK) return rc;
+    guard.p = nullptr;
+    *out = s;
+    return CQS_HIP_OK;
+} CQS_ABI_CATCH_NOHANDLE
+
+int32_t cqs_hip_sparse_index_create_inverted(const uint32_t* token_ids, const uint64_t* list_off, const uint32_t* post_chunks,
+                                             const float* post_weights, uint64_t n_tokens, uint64_t n, const uint32_t* id_rank,
+                                             int32_t device, cqs_hip_sparse_index** out) CQS_ABI_TRY {
+    if (!out) return CQS_HIP_ERR_INVALID;
+    *out = nullptr;
+    if (n >= 0xFFFFFFFFull - kSparsePad || n_tokens > 0xFFFFFFFFull) return CQS_HIP_ERR_INVALID;
+    if (n_tokens && (!token_ids || !list_off)) return CQS_HIP_ERR_INVALID;
+    const uint64_t P_in = n_tokens ? list_off[n_tokens] : 0;
+    if (n_tokens && list_off[0] != 0) return CQS_HIP_ERR_INVALID;
+    for (uint64_t t = 0; t < n_tokens; ++t)
+        if (list_off[t + 1] < list_off[t]) return CQS_HIP_ERR_INVALID;
+    if (P_in && (!post_chunks || !post_weights)) return CQS_HIP_ERR_INVALID;
+    for (uint64_t e = 0; e < P_in; ++e) {
+        uint32_t bits;
+        memcpy(&bits, &post_weights[e], 4);
+        if (bits == kUnscored) return CQS_HIP_ERR_INVALID;
+    }
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return CQS_HIP_ERR_NO_DEVICE;
+    cqs_hip_sparse_index* s = begin_create(n, id_rank, device);
+    if (!s) return CQS_HIP_ERR_INVALID;
+    CreateGuard guard{s};
+    // the HashMap's keys in ascending order (a key given twice is refused: a map has each key once)
+    std::vector<uint32_t> order((size_t)n_tokens);
+    for (uint64_t t = 0; t < n_tokens; ++t) order[t] = (uint32_t)t;
+    std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return token_ids[x] < token_ids[y]; });
+    for (uint64_t t = 1; t < n_tokens; ++t)
+        if (token_ids[order[t]] == token_ids[order[t - 1]]) return CQS_HIP_ERR_INVALID;
+    std::vector<uint32_t> rank_of;                          // chunk -> position
+    if (s->ranked) {
+        rank_of.resize((size_t)n);
+        for (uint64_t r = 0; r < n; ++r) rank_of[s->chunk_of_rank[r]] = (uint32_t)r;
+    }
+    std::vector<uint2> post;
+    post.reserve((size_t)P_in);
+    s->off.push_back(0);
+    for (uint64_t t = 0; t < n_tokens; ++t) {
+        const uint32_t src = order[t];
+        const size_t first = post.size();
+        bool ascending = true;
+        for (uint64_t e = list_off[src]; e < list_off[src + 1]; ++e) {
+            const uint32_t c = post_chunks[e];
+            if (c >= n) continue;                           // the search skips such a posting (index.rs:252): it never scores
+            uint32_t bits;
+            memcpy(&bits, &post_weights[e], 4);
+            const uint32_t pos = s->ranked ? rank_of[c] : c;
+            if (post.size() > first && pos < post.back().x) ascending = false;
+            post.push_back(make_uint2(pos, bits));
+        }
+        if (post.size() == first) continue;                 // nothing usable under this token: no list
+        // ascending positions; postings of ONE chunk keep their order (the only order the sums depend on)
+        if (!ascending) std::stable_sort(post.begin() + (ptrdiff_t)first, post.end(), [](const uint2& x, const uint2& y) { return x.x < y.x; });
+        s->tok.push_back(token_ids[src]);
+        s->off.push_back(post.size());
+    }
+    s->n_postings = post.size();
+    const int32_t rc = finish_create(s, post, device);
+    if (rc != CQS_HIP_OK) return rc;
     guard.p = nullptr;
     *out = s;
     return CQS_HIP_OK;

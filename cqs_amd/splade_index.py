@@ -92,6 +92,38 @@ class HipSpladeIndex:
             raise HipError(rc, "cqs_hip_sparse_index_create failed")
         return cls(h.value, None if id_map is None else list(id_map))
 
+    @classmethod
+    def build_from_postings(cls, id_map: Optional[List[str]], postings, n_chunks: Optional[int] = None,
+                            id_rank: Optional[np.ndarray] = None, device: int = 0) -> "HipSpladeIndex":
+        """From the reference's in-memory form, `postings: HashMap<u32, Vec<(usize, f32)>>` (index.rs:177-187; what
+        `SpladeIndex::load` reconstructs from the persisted file): a mapping token -> [(chunk_index, weight), ...]."""
+        lib = _lib.load()
+        n = len(id_map) if id_map is not None else int(n_chunks)
+        keys = list(postings.keys())
+        off = np.zeros(len(keys) + 1, dtype=np.uint64)
+        for i, t in enumerate(keys):
+            off[i + 1] = off[i] + len(postings[t])
+        total = int(off[-1])
+        ch = np.zeros(total, dtype=np.uint32)
+        w = np.zeros(total, dtype=np.float32)
+        at = 0
+        for t in keys:
+            for c, x in postings[t]:
+                ch[at] = c
+                w[at] = x
+                at += 1
+        tok = np.asarray(keys, dtype=np.uint32)
+        if id_rank is None and id_map is not None:
+            id_rank = id_ranks(id_map)
+        if id_rank is not None:
+            id_rank = np.ascontiguousarray(id_rank, dtype=np.uint32)
+        h = C.c_void_p()
+        rc = lib.cqs_hip_sparse_index_create_inverted(_ptr(tok), _ptr(off), _ptr(ch), _ptr(w), len(keys), n, _ptr(id_rank), device,
+                                                      C.byref(h))
+        if rc != _lib.OK:
+            raise HipError(rc, "cqs_hip_sparse_index_create_inverted failed")
+        return cls(h.value, None if id_map is None else list(id_map))
+
     # ---- properties -----------------------------------------------------------
     def __len__(self) -> int:
         return int(self._lib.cqs_hip_sparse_index_len(self._h))

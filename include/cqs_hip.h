@@ -434,6 +434,15 @@ size_t   cqs_hip_bert_last_error(cqs_hip_bert* e, char* buf, size_t cap);
 typedef struct cqs_hip_sparse_index cqs_hip_sparse_index;
 int32_t cqs_hip_sparse_index_create(const uint64_t* doc_off, const uint32_t* tokens, const float* weights, uint64_t n,
                                     const uint32_t* id_rank, int32_t device, cqs_hip_sparse_index** out);
+/* The same index from the reference's OWN in-memory form - `postings: HashMap<u32, Vec<(usize, f32)>>` (index.rs:177-187), e.g.
+ * right after `SpladeIndex::load` read the persisted file (index.rs:677-1072): token_ids [n_tokens] distinct keys in any order,
+ * list_off [n_tokens + 1], post_chunks / post_weights [list_off[n_tokens]] = every key's list in its stored order.  Postings that
+ * name a chunk >= n are dropped (the search skips them, index.rs:252); a list need not be ascending (postings of ONE chunk keep
+ * their order, all the sums depend on); a key given twice -> CQS_HIP_ERR_INVALID.  Searches give the same bits as an index
+ * built by cqs_hip_sparse_index_create from the documents. */
+int32_t cqs_hip_sparse_index_create_inverted(const uint32_t* token_ids, const uint64_t* list_off, const uint32_t* post_chunks,
+                                             const float* post_weights, uint64_t n_tokens, uint64_t n, const uint32_t* id_rank,
+                                             int32_t device, cqs_hip_sparse_index** out);
 void     cqs_hip_sparse_index_destroy(cqs_hip_sparse_index* idx);
 uint64_t cqs_hip_sparse_index_len(const cqs_hip_sparse_index* idx);            /* index.rs:294-296 */
 uint64_t cqs_hip_sparse_index_unique_tokens(const cqs_hip_sparse_index* idx);  /* index.rs:304-306 */

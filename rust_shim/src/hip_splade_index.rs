@@ -35,6 +35,17 @@ extern "C" {
         device: i32,
         out: *mut *mut CqsHipSparseIndex,
     ) -> i32;
+    fn cqs_hip_sparse_index_create_inverted(
+        token_ids: *const u32,
+        list_off: *const u64,
+        post_chunks: *const u32,
+        post_weights: *const f32,
+        n_tokens: u64,
+        n: u64,
+        id_rank: *const u32,
+        device: i32,
+        out: *mut *mut CqsHipSparseIndex,
+    ) -> i32;
     fn cqs_hip_sparse_index_destroy(idx: *mut CqsHipSparseIndex);
     fn cqs_hip_sparse_index_len(idx: *const CqsHipSparseIndex) -> u64;
     fn cqs_hip_sparse_index_unique_tokens(idx: *const CqsHipSparseIndex) -> u64;
@@ -102,6 +113,44 @@ impl HipSpladeIndex {
         }
         tracing::info!(chunks = n, postings = total, "HIP SPLADE index built");
         Some(Self { raw, id_map })
+    }
+
+    /// From an index the CPU side already holds - e.g. right after `SpladeIndex::load` read `splade.index.bin` - without
+    /// going back to the store for the rows: the postings map and the id map as they are.
+    pub fn from_postings(postings: &std::collections::HashMap<u32, Vec<(usize, f32)>>, id_map: &[Box<str>], device: i32) -> Option<Self> {
+        let n = id_map.len();
+        let mut token_ids: Vec<u32> = Vec::with_capacity(postings.len());
+        let mut list_off: Vec<u64> = Vec::with_capacity(postings.len() + 1);
+        list_off.push(0);
+        let total: usize = postings.values().map(|l| l.len()).sum();
+        let mut chunks: Vec<u32> = Vec::with_capacity(total);
+        let mut weights: Vec<f32> = Vec::with_capacity(total);
+        for (&token, list) in postings {
+            token_ids.push(token);
+            for &(chunk_idx, weight) in list {
+                chunks.push(u32::try_from(chunk_idx).unwrap_or(u32::MAX)); // out of range: dropped by the library like index.rs:252
+                weights.push(weight);
+            }
+            list_off.push(chunks.len() as u64);
+        }
+        let mut order: Vec<u32> = (0..n as u32).collect();
+        order.sort_by(|&a, &b| id_map[a as usize].cmp(&id_map[b as usize]).then(a.cmp(&b)));
+        let mut id_rank = vec![0u32; n];
+        for (r, &i) in order.iter().enumerate() {
+            id_rank[i as usize] = r as u32;
+        }
+        let mut raw: *mut CqsHipSparseIndex = std::ptr::null_mut();
+        let rc = unsafe {
+            cqs_hip_sparse_index_create_inverted(
+                token_ids.as_ptr(), list_off.as_ptr(), chunks.as_ptr(), weights.as_ptr(), token_ids.len() as u64, n as u64,
+                id_rank.as_ptr(), device, &mut raw,
+            )
+        };
+        if rc != CQS_HIP_OK || raw.is_null() {
+            tracing::warn!(rc, "HIP SPLADE index build from postings failed, keeping the in-memory index");
+            return None;
+        }
+        Some(Self { raw, id_map: id_map.to_vec() })
     }
 
     /// Search the inverted index (unfiltered).

@@ -230,3 +230,46 @@ def test_the_input_space_of_the_reference_proptest(S, oracle):
             checked += 1
         h.close()
     assert checked == 450
+
+
+def test_built_from_the_postings_map_equals_built_from_the_documents(S, oracle):
+    """`cqs_hip_sparse_index_create_inverted`: the reference's in-memory form (token -> [(chunk, weight)] in push order,
+    index.rs:177-212) as input - keys in arbitrary order, one list handed over descending, a posting that names a chunk past
+    the end (skipped at search time by the reference, index.rs:252).  Same answers, bit for bit, as the index built from
+    the documents, and as the oracle."""
+    rng = np.random.default_rng(404)
+    n = 5000
+    off, tok, w = sc.corpus(rng, n, 700, 5, 40, dup_frac=0.3, special=True)
+    ids = ["id%05d" % i for i in rng.permutation(n)]
+    postings = {}
+    for d in range(n):                                                       # SpladeIndex::build's loop (index.rs:197-202)
+        for e in range(int(off[d]), int(off[d + 1])):
+            postings.setdefault(int(tok[e]), []).append((d, float(w[e])))
+    keys = list(postings.keys())
+    rng.shuffle(keys)
+    shuffled = {k: postings[k] for k in keys}
+    some = keys[0]
+    shuffled[some] = sorted(shuffled[some], key=lambda cw: -cw[0])           # descending chunks; no chunk twice under this token?
+    if len({c for c, _ in shuffled[some]}) != len(shuffled[some]):           # (a repeated chunk's postings must keep their order)
+        shuffled[some] = postings[some]
+    shuffled[keys[1]] = shuffled[keys[1]] + [(n + 7, 3.0)]                   # corrupt posting: chunk past the end
+    a = S.HipSpladeIndex.build_from_csr(ids, off, tok, w)
+    b = S.HipSpladeIndex.build_from_postings(ids, shuffled)
+    o = oracle.SpladeIndex(off, tok, w, ids=ids)
+    assert len(b) == n and b.unique_tokens() == a.unique_tokens() == o.unique_tokens() and b.postings() == a.postings()
+    for trial in range(4):
+        qt, qw = sc.query(rng, 700, 45, dups=2 if trial == 1 else 0, absent=3)
+        keep = None if trial < 2 else rng.random(n) < 0.4
+        ac, as_, _ = a.search_raw(qt, qw, 500, keep)
+        bc, bs, rc = b.search_raw(qt, qw, 500, keep)
+        oc, os_ = o.search_raw(qt, qw, 500, keep)
+        assert rc == 0 and np.array_equal(ac, bc) and np.array_equal(as_.view(np.uint32), bs.view(np.uint32))
+        assert np.array_equal(bc, oc) and np.array_equal(bs.view(np.uint32), os_.view(np.uint32))
+    with pytest.raises(S.HipError):                                          # a key twice is not a map
+        lib = S._lib.load()
+        t2 = np.array([5, 5], np.uint32); o2 = np.array([0, 1, 2], np.uint64); c2 = np.array([0, 1], np.uint32); w2 = np.ones(2, np.float32)
+        hh = S.C.c_void_p()
+        rc = lib.cqs_hip_sparse_index_create_inverted(t2.ctypes.data, o2.ctypes.data, c2.ctypes.data, w2.ctypes.data, 2, 10, None, 0, S.C.byref(hh))
+        if rc != 0:
+            raise S.HipError(rc, "refused")
+    a.close(); b.close()
