@@ -780,6 +780,20 @@ def sparse_index_leg(a, np, dense_idx=None, dense_queries=None):
             "cpu_baseline": {"kind": "port", "cores": 1, "queries_per_sec": round(ncpu / cpu_el, 2), "ms_per_query": round(cpu_el / ncpu * 1e3, 3),
                              "sample": "%d of the timed queries through oracle.SpladeIndex.search_raw (dense score array in place of the HashMap)" % ncpu},
         }
+    # several queries per call (cqs_hip_sparse_index_search_batch): evaluation runs, or a caller that gathers its clients
+    qs = synth.sparse_queries(64, 64, vocab, seed=0x5BA2E3)
+    out["batched_64_terms"] = {}
+    for bsz in (8, 32):
+        groups = [qs[i:i + bsz] for i in range(0, 64, bsz)]
+        h.search_batch_raw(groups[0], k)
+        t0 = time.perf_counter()
+        res = [h.search_batch_raw(g, k) for g in groups]
+        el = time.perf_counter() - t0
+        ch, scs, cnt, rc = res[0]
+        oc, os_ = ora.search_raw(groups[0][3][0], groups[0][3][1], k)
+        assert rc == 0 and np.array_equal(ch[3, :cnt[3]], oc) and np.array_equal(scs[3, :cnt[3]].view(np.uint32), os_.view(np.uint32))
+        out["batched_64_terms"][str(bsz)] = {"queries_per_sec": round(64 / el, 1), "ms_per_call": round(el / len(groups) * 1e3, 4),
+                                             "checked_bit_exact": True}
     out["corpus_gen_s"] = round(t_gen, 1)
     if dense_idx is not None and len(dense_idx) == n:
         # Both retrieval legs of `search_hybrid_inner` (src/search/query.rs:879-901) for one query at k = candidate_count = 500

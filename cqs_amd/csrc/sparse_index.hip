@@ -37,7 +37,8 @@ namespace cqs {
 constexpr uint32_t kSparsePad = 1024;          // n_pad granule (a multiple of every wave range)
 constexpr uint32_t kUnscored = 0xFFFFFFFFu;    // LDS marker: `scores.entry(chunk)` does not exist yet (a NaN no arithmetic here produces:
                                                // weights with that bit pattern are refused at build / search)
-constexpr uint32_t kMaxTerms = 1u << 16;
+constexpr uint32_t kMaxTerms = 1u << 16;        // per query
+constexpr uint32_t kSparseMaxBatch = 64;       // queries per cqs_hip_sparse_index_search_batch call
 
 struct SparseTerm {            // one query term, resolved on the host
     unsigned long long start;  // first posting of the token's list
@@ -76,12 +77,17 @@ constexpr int kSpUnroll = 4;
 // dynamic LDS per wave: rw scores + rw claims + 64 x (count, address lo, address hi, weight)
 __host__ __device__ constexpr uint32_t sparse_wave_lds_words(uint32_t rw) { return 2u * rw + 4u * 64u; }
 
-__global__ __launch_bounds__(256) void sparse_accumulate_kernel(const uint2* __restrict__ post, const SparseTerm* __restrict__ terms,
-                                                                uint32_t n_terms, const uint32_t* __restrict__ dir,
+__global__ __launch_bounds__(256) void sparse_accumulate_kernel(const uint2* __restrict__ post, const SparseTerm* __restrict__ terms_all,
+                                                                const uint32_t* __restrict__ q_term_off /*[queries + 1]*/, const uint32_t* __restrict__ dir,
                                                                 uint32_t n, uint32_t n_pad, uint32_t sh,
                                                                 const uint32_t* __restrict__ keep, const uint32_t* __restrict__ chunk_of_rank,
                                                                 float* __restrict__ scores, float* __restrict__ gmax, uint32_t group16) {
     extern __shared__ uint32_t sp_lds[];
+    // blockIdx.y = the query of a batch: its terms, its score row, its maxima
+    const SparseTerm* const terms = terms_all + q_term_off[blockIdx.y];
+    const uint32_t n_terms = q_term_off[blockIdx.y + 1u] - q_term_off[blockIdx.y];
+    scores += (size_t)blockIdx.y * n_pad;
+    gmax += (size_t)blockIdx.y * (group16 ? n_pad >> 4 : n_pad >> 6);
     const uint32_t rw = 1u << sh;
     const int lane = threadIdx.x & 63;
     const uint32_t wid = threadIdx.x >> 6;
@@ -211,6 +217,7 @@ __global__ __launch_bounds__(256) void sparse_accumulate_kernel(const uint2* __r
 }  // namespace cqs
 
 using cqs::kMaxTerms;
+using cqs::kSparseMaxBatch;
 using cqs::kNoDir;
 using cqs::kSparsePad;
 using cqs::kUnscored;
@@ -238,6 +245,9 @@ struct cqs_hip_sparse_index {
     uint32_t* d_work = nullptr;
     uint32_t* d_keep = nullptr;
     SparseTerm* d_terms = nullptr;
+    uint32_t* d_qoff = nullptr;              // [kSparseMaxBatch + 1] first term of every query of a batch
+    uint32_t* h_qoff = nullptr;              // pinned
+    uint32_t b_cap = 0;                      // queries the score / maxima / key scratch holds
     uint32_t terms_cap = 0;
     SparseTerm* h_terms = nullptr;           // pinned
     uint32_t* d_dir = nullptr;               // range directories, list after list: n_pad / rw + 1 entries each
@@ -273,9 +283,9 @@ void release(cqs_hip_sparse_index* s) {
     (void)hipSetDevice(s->device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     for (void* p : {(void*)s->d_post, (void*)s->d_chunk_of_rank, (void*)s->d_scores, (void*)s->d_gmax, (void*)s->d_work,
-                    (void*)s->d_keep, (void*)s->d_terms, (void*)s->d_dir, (void*)s->d_out_keys, (void*)s->d_out_count, (void*)s->d_dbg})
+                    (void*)s->d_keep, (void*)s->d_terms, (void*)s->d_qoff, (void*)s->d_dir, (void*)s->d_out_keys, (void*)s->d_out_count, (void*)s->d_dbg})
         if (p) (void)hipFree(p);
-    for (void* p : {(void*)s->h_terms, (void*)s->h_keep, (void*)s->h_out_keys})
+    for (void* p : {(void*)s->h_terms, (void*)s->h_keep, (void*)s->h_out_keys, (void*)s->h_qoff})
         if (p) (void)hipHostFree(p);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
@@ -292,6 +302,25 @@ int32_t ensure_terms(cqs_hip_sparse_index* s, uint32_t t) {
     S_TRY(s, hipMalloc((void**)&s->d_terms, (size_t)cap * sizeof(SparseTerm)));
     S_TRY(s, hipHostMalloc((void**)&s->h_terms, (size_t)cap * sizeof(SparseTerm), hipHostMallocDefault));
     s->terms_cap = cap;
+    return CQS_HIP_OK;
+}
+
+// score rows, maxima and result keys for `b` queries (grown on demand; one query's worth exists from create on)
+int32_t ensure_batch(cqs_hip_sparse_index* s, uint32_t b) {
+    if (b <= s->b_cap) return CQS_HIP_OK;
+    for (void** p : {(void**)&s->d_scores, (void**)&s->d_gmax, (void**)&s->d_out_keys, (void**)&s->d_out_count})
+        if (*p) { (void)hipFree(*p); *p = nullptr; }
+    if (s->h_out_keys) { (void)hipHostFree(s->h_out_keys); s->h_out_keys = nullptr; s->h_out_keys_dev = nullptr; }
+    s->b_cap = 0;
+    const size_t groups = s->n_pad / (s->group16 ? 16u : 64u);
+    S_TRY(s, hipMalloc((void**)&s->d_scores, (size_t)b * s->n_pad * 4));
+    S_TRY(s, hipMalloc((void**)&s->d_gmax, (size_t)b * groups * 4));
+    S_TRY(s, hipMalloc((void**)&s->d_out_keys, (size_t)b * cqs::kMaxK * 8));
+    S_TRY(s, hipMalloc((void**)&s->d_out_count, (size_t)b * 4));
+    // keys [b][k] then the b counts, in one pinned + device-visible block: the select writes there
+    S_TRY(s, hipHostMalloc((void**)&s->h_out_keys, (size_t)b * (cqs::kMaxK + 1) * 8, hipHostMallocMapped));
+    if (hipHostGetDevicePointer((void**)&s->h_out_keys_dev, s->h_out_keys, 0) != hipSuccess) s->h_out_keys_dev = nullptr;
+    s->b_cap = b;
     return CQS_HIP_OK;
 }
 
@@ -358,19 +387,19 @@ int32_t finish_create(cqs_hip_sparse_index* s, const std::vector<uint2>& post, i
         if ((he = hipMalloc((void**)&s->d_chunk_of_rank, std::max<size_t>((size_t)n, 1) * 4)) != hipSuccess) return dfail(he);
         if (n && (he = hipMemcpy(s->d_chunk_of_rank, s->chunk_of_rank.data(), (size_t)n * 4, hipMemcpyHostToDevice)) != hipSuccess) return dfail(he);
     }
-    if ((he = hipMalloc((void**)&s->d_scores, (size_t)s->n_pad * 4)) != hipSuccess) return dfail(he);
     // measured (select at k = 500): 20k chunks 40 -> 24 us, 100k 29 -> 23, 1M 29 -> 45: 16-chunk groups while their maxima fit
     // one pass of the select's workgroup (1024 threads x 16 registers)
     s->group16 = s->n_pad / 16u <= 16384u;
-    if ((he = hipMalloc((void**)&s->d_gmax, (size_t)(s->n_pad / (s->group16 ? 16u : 64u)) * 4)) != hipSuccess) return dfail(he);
+    if ((he = hipMalloc((void**)&s->d_qoff, (kSparseMaxBatch + 1) * 4)) != hipSuccess) return dfail(he);
+    if ((he = hipHostMalloc((void**)&s->h_qoff, (kSparseMaxBatch + 1) * 4, hipHostMallocDefault)) != hipSuccess) return dfail(he);
     if ((he = hipMalloc((void**)&s->d_work, cqs::kWorkWords * 4)) != hipSuccess) return dfail(he);
     if ((he = hipMemset(s->d_work, 0, cqs::kWorkWords * 4)) != hipSuccess) return dfail(he);
     if ((he = hipMalloc((void**)&s->d_keep, (size_t)(s->n_pad / 32u) * 4)) != hipSuccess) return dfail(he);
     if ((he = hipHostMalloc((void**)&s->h_keep, (size_t)(s->n_pad / 32u) * 4, hipHostMallocDefault)) != hipSuccess) return dfail(he);
-    if ((he = hipMalloc((void**)&s->d_out_keys, (size_t)cqs::kMaxK * 8)) != hipSuccess) return dfail(he);
-    if ((he = hipMalloc((void**)&s->d_out_count, 4)) != hipSuccess) return dfail(he);
-    if ((he = hipHostMalloc((void**)&s->h_out_keys, (size_t)(cqs::kMaxK + 1) * 8, hipHostMallocMapped)) != hipSuccess) return dfail(he);
-    if (hipHostGetDevicePointer((void**)&s->h_out_keys_dev, s->h_out_keys, 0) != hipSuccess) s->h_out_keys_dev = nullptr;
+    {
+        const int32_t rc = ensure_batch(s, 1u);
+        if (rc != CQS_HIP_OK) return rc;
+    }
     if (const char* e = getenv("CQS_HIP_DEBUG_STAMPS"); e && *e == '1')
         if (hipMalloc((void**)&s->d_dbg, 16 * 8) == hipSuccess) (void)hipMemset(s->d_dbg, 0, 16 * 8);
     return CQS_HIP_OK;
@@ -577,48 +606,59 @@ size_t cqs_hip_sparse_index_last_error(const cqs_hip_sparse_index* s, char* buf,
     return s->last_error.size();
 } CQS_ABI_CATCH_VAL(0)
 
-int32_t cqs_hip_sparse_index_search(cqs_hip_sparse_index* s, const uint32_t* q_tokens, const float* q_weights, uint32_t n_terms,
-                                    uint32_t k, const uint32_t* keep_bitset, uint64_t* out_chunks, float* out_scores,
-                                    uint32_t* out_count) CQS_ABI_TRY {
-    if (!s) return CQS_HIP_ERR_INVALID;
-    std::lock_guard<std::mutex> g(s->mu);
-    if (!out_count) return sfail(s, CQS_HIP_ERR_INVALID, "sparse search: null out_count");
-    *out_count = 0;
+namespace {
+
+// Shared by the two search entry points; the caller holds s->mu.  q_off [b + 1]: the terms of query q are
+// q_tokens / q_weights [q_off[q], q_off[q + 1]).
+int32_t search_locked(cqs_hip_sparse_index* s, const uint64_t* q_off, const uint32_t* q_tokens, const float* q_weights, uint32_t b,
+                      uint32_t k, const uint32_t* keep_bitset, uint64_t* out_chunks, float* out_scores, uint32_t* out_counts) {
+    for (uint32_t q = 0; q < b; ++q) out_counts[q] = 0;
     if (s->poisoned) return CQS_HIP_ERR_POISONED;
     if (k > cqs::kMaxK) return sfail(s, CQS_HIP_ERR_INVALID, "sparse search: k > CQS_HIP_MAX_K");
-    if (n_terms > kMaxTerms) return sfail(s, CQS_HIP_ERR_INVALID, "sparse search: too many query terms");
-    if (n_terms && (!q_tokens || !q_weights)) return sfail(s, CQS_HIP_ERR_INVALID, "sparse search: null query");
+    if (b > kSparseMaxBatch) return sfail(s, CQS_HIP_ERR_INVALID, "sparse search: more than 64 queries in a batch");
+    const uint64_t total_terms = q_off[b] - q_off[0];
+    for (uint32_t q = 0; q < b; ++q) {
+        if (q_off[q + 1] < q_off[q]) return sfail(s, CQS_HIP_ERR_INVALID, "sparse search: query offsets not ascending");
+        if (q_off[q + 1] - q_off[q] > kMaxTerms) return sfail(s, CQS_HIP_ERR_INVALID, "sparse search: too many query terms");
+    }
+    if (total_terms && (!q_tokens || !q_weights)) return sfail(s, CQS_HIP_ERR_INVALID, "sparse search: null query");
     s->last_ms = 0.f;
     s->last_touched = 0;
-    if (n_terms == 0 || s->n == 0 || k == 0) return CQS_HIP_OK;        // index.rs:237-239; BoundedScoreHeap::new(0) keeps nothing
+    if (total_terms == 0 || s->n == 0 || k == 0) return CQS_HIP_OK;    // index.rs:237-239; BoundedScoreHeap::new(0) keeps nothing
     if (!out_chunks || !out_scores) return sfail(s, CQS_HIP_ERR_INVALID, "sparse search: null output");
     S_TRY(s, hipSetDevice(s->device));
-    int32_t rc = ensure_terms(s, n_terms);
+    int32_t rc = ensure_terms(s, (uint32_t)total_terms);
     if (rc != CQS_HIP_OK) return rc;
+    if ((rc = ensure_batch(s, b)) != CQS_HIP_OK) return rc;
     // resolve the terms (`self.postings.get(&token_id)`, index.rs:249): a token without a list scores nothing
     uint32_t nt = 0;
     uint64_t touched = 0;
-    for (uint32_t i = 0; i < n_terms; ++i) {
-        uint32_t bits;
-        memcpy(&bits, &q_weights[i], 4);
-        if (bits == kUnscored) return sfail(s, CQS_HIP_ERR_INVALID, "sparse search: reserved NaN payload in a query weight");
-        const auto it = std::lower_bound(s->tok.begin(), s->tok.end(), q_tokens[i]);
-        if (it == s->tok.end() || *it != q_tokens[i]) continue;
-        const size_t slot = (size_t)(it - s->tok.begin());
-        const uint64_t len = s->off[slot + 1] - s->off[slot];
-        if (len == 0) continue;
-        if (len > 0xFFFFFFFFull) return sfail(s, CQS_HIP_ERR_INVALID, "sparse search: posting list longer than 2^32");
-        s->h_terms[nt].start = s->off[slot];
-        s->h_terms[nt].dir = s->dir_off[slot];
-        s->h_terms[nt].len = (uint32_t)len;
-        s->h_terms[nt].w = q_weights[i];
-        ++nt;
-        touched += len;
+    for (uint32_t q = 0; q < b; ++q) {
+        s->h_qoff[q] = nt;
+        for (uint64_t i = q_off[q]; i < q_off[q + 1]; ++i) {
+            uint32_t bits;
+            memcpy(&bits, &q_weights[i], 4);
+            if (bits == kUnscored) return sfail(s, CQS_HIP_ERR_INVALID, "sparse search: reserved NaN payload in a query weight");
+            const auto it = std::lower_bound(s->tok.begin(), s->tok.end(), q_tokens[i]);
+            if (it == s->tok.end() || *it != q_tokens[i]) continue;
+            const size_t slot = (size_t)(it - s->tok.begin());
+            const uint64_t len = s->off[slot + 1] - s->off[slot];
+            if (len == 0) continue;
+            if (len > 0xFFFFFFFFull) return sfail(s, CQS_HIP_ERR_INVALID, "sparse search: posting list longer than 2^32");
+            s->h_terms[nt].start = s->off[slot];
+            s->h_terms[nt].dir = s->dir_off[slot];
+            s->h_terms[nt].len = (uint32_t)len;
+            s->h_terms[nt].w = q_weights[i];
+            ++nt;
+            touched += len;
+        }
     }
+    s->h_qoff[b] = nt;
     if (nt == 0) return CQS_HIP_OK;
     s->last_touched = touched;
     hipStream_t st = s->stream;
     S_TRY(s, hipMemcpyAsync(s->d_terms, s->h_terms, (size_t)nt * sizeof(SparseTerm), hipMemcpyHostToDevice, st));
+    S_TRY(s, hipMemcpyAsync(s->d_qoff, s->h_qoff, (size_t)(b + 1) * 4, hipMemcpyHostToDevice, st));
     const uint32_t* d_keep = nullptr;
     if (keep_bitset) {
         const size_t words = (size_t)((s->n + 31) / 32);
@@ -628,15 +668,15 @@ int32_t cqs_hip_sparse_index_search(cqs_hip_sparse_index* s, const uint32_t* q_t
     }
     const uint32_t waves = s->n_pad / s->rw;
     S_TRY(s, hipEventRecord(s->ev0, st));
-    hipLaunchKernelGGL(sparse_accumulate_kernel, dim3((waves + 3u) / 4u), dim3(256), (size_t)4 * sparse_wave_lds_words(s->rw) * 4, st,
-                       s->d_post, s->d_terms, nt, s->d_dir, (uint32_t)s->n, s->n_pad, s->sh, d_keep,
+    hipLaunchKernelGGL(sparse_accumulate_kernel, dim3((waves + 3u) / 4u, b), dim3(256), (size_t)4 * sparse_wave_lds_words(s->rw) * 4, st,
+                       s->d_post, s->d_terms, s->d_qoff, s->d_dir, (uint32_t)s->n, s->n_pad, s->sh, d_keep,
                        s->ranked ? s->d_chunk_of_rank : nullptr, s->d_scores, s->d_gmax, s->group16 ? 1u : 0u);
     S_TRY(s, hipGetLastError());
     S_TRY(s, hipEventRecord(s->ev1, st));
     cqs::ScanArgs a{};
     a.n = (uint32_t)s->n;
     a.n_pad = s->n_pad;
-    a.b = 1;
+    a.b = b;
     a.scores = s->d_scores;
     a.gmax = s->d_gmax;
     a.tiers = s->group16 ? cqs::TaskTiers{0u, 0u, s->n_pad / 16u} : cqs::TaskTiers{s->n_pad / 64u, 0u, 0u};
@@ -646,12 +686,13 @@ int32_t cqs_hip_sparse_index_search(cqs_hip_sparse_index* s, const uint32_t* q_t
     a.work = s->d_work;
     a.n_cu = s->n_cu;
     a.dbg = s->d_dbg;
+    uint32_t* const h_counts = (uint32_t*)(s->h_out_keys + (size_t)s->b_cap * cqs::kMaxK);     // after the key block
     if (s->h_out_keys_dev) {
-        S_TRY(s, cqs::launch_select(a, 0u, s->h_out_keys_dev, (uint32_t*)(s->h_out_keys_dev + cqs::kMaxK), st));
+        S_TRY(s, cqs::launch_select(a, 0u, s->h_out_keys_dev, (uint32_t*)(s->h_out_keys_dev + (size_t)s->b_cap * cqs::kMaxK), st));
     } else {
         S_TRY(s, cqs::launch_select(a, 0u, s->d_out_keys, s->d_out_count, st));
-        S_TRY(s, hipMemcpyAsync(s->h_out_keys, s->d_out_keys, (size_t)k * 8, hipMemcpyDeviceToHost, st));
-        S_TRY(s, hipMemcpyAsync(s->h_out_keys + cqs::kMaxK, s->d_out_count, 4, hipMemcpyDeviceToHost, st));
+        S_TRY(s, hipMemcpyAsync(s->h_out_keys, s->d_out_keys, (size_t)b * k * 8, hipMemcpyDeviceToHost, st));
+        S_TRY(s, hipMemcpyAsync(h_counts, s->d_out_count, (size_t)b * 4, hipMemcpyDeviceToHost, st));
     }
     S_TRY(s, hipStreamSynchronize(st));
     (void)hipEventElapsedTime(&s->last_ms, s->ev0, s->ev1);
@@ -662,13 +703,38 @@ int32_t cqs_hip_sparse_index_search(cqs_hip_sparse_index* s, const uint32_t* q_t
                     0.0, (h[1] - h[0]) * 0.01, (h[2] - h[1]) * 0.01, (h[3] - h[2]) * 0.01, (h[4] - h[3]) * 0.01, (h[5] - h[4]) * 0.01,
                     (h[6] - h[5]) * 0.01, h[8], h[9]);
     }
-    uint32_t cnt = (uint32_t)(s->h_out_keys[cqs::kMaxK] & 0xFFFFFFFFull);
-    if (cnt > k) cnt = k;
-    cqs_hip_unpack_keys(s->h_out_keys, cnt, out_chunks, out_scores);
-    if (s->ranked)
-        for (uint32_t i = 0; i < cnt; ++i) out_chunks[i] = s->chunk_of_rank[(size_t)out_chunks[i]];
-    *out_count = cnt;
+    for (uint32_t q = 0; q < b; ++q) {                     // the select packs query q's keys at [q * k, (q + 1) * k)
+        uint32_t cnt = h_counts[q];
+        if (cnt > k) cnt = k;
+        uint64_t* const oc = out_chunks + (size_t)q * k;
+        cqs_hip_unpack_keys(s->h_out_keys + (size_t)q * k, cnt, oc, out_scores + (size_t)q * k);
+        if (s->ranked)
+            for (uint32_t i = 0; i < cnt; ++i) oc[i] = s->chunk_of_rank[(size_t)oc[i]];
+        out_counts[q] = cnt;
+    }
     return CQS_HIP_OK;
+}
+
+}  // namespace
+
+int32_t cqs_hip_sparse_index_search(cqs_hip_sparse_index* s, const uint32_t* q_tokens, const float* q_weights, uint32_t n_terms,
+                                    uint32_t k, const uint32_t* keep_bitset, uint64_t* out_chunks, float* out_scores,
+                                    uint32_t* out_count) CQS_ABI_TRY {
+    if (!s) return CQS_HIP_ERR_INVALID;
+    std::lock_guard<std::mutex> g(s->mu);
+    if (!out_count) return sfail(s, CQS_HIP_ERR_INVALID, "sparse search: null out_count");
+    const uint64_t q_off[2] = {0, n_terms};
+    return search_locked(s, q_off, q_tokens, q_weights, 1u, k, keep_bitset, out_chunks, out_scores, out_count);
+} CQS_ABI_CATCH(s)
+
+int32_t cqs_hip_sparse_index_search_batch(cqs_hip_sparse_index* s, const uint64_t* q_off, const uint32_t* q_tokens,
+                                          const float* q_weights, uint32_t b, uint32_t k, const uint32_t* keep_bitset,
+                                          uint64_t* out_chunks, float* out_scores, uint32_t* out_counts) CQS_ABI_TRY {
+    if (!s) return CQS_HIP_ERR_INVALID;
+    std::lock_guard<std::mutex> g(s->mu);
+    if (b == 0) return CQS_HIP_OK;
+    if (!q_off || !out_counts) return sfail(s, CQS_HIP_ERR_INVALID, "sparse search: null offsets / counts");
+    return search_locked(s, q_off, q_tokens, q_weights, b, k, keep_bitset, out_chunks, out_scores, out_counts);
 } CQS_ABI_CATCH(s)
 
 int32_t cqs_hip_sparse_index_last_search(const cqs_hip_sparse_index* s, float* accumulate_ms, uint64_t* touched_postings) CQS_ABI_TRY {

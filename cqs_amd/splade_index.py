@@ -171,6 +171,33 @@ class HipSpladeIndex:
             return out[:0], sc[:0], rc
         return out[:cnt.value], sc[:cnt.value], rc
 
+    def search_batch_raw(self, queries, k: int, keep: Optional[np.ndarray] = None):
+        """`cqs_hip_sparse_index_search_batch`: queries = [(tokens, weights), ...] (at most 64).
+        -> (chunks u64 [b, k], scores f32 [b, k], counts u32 [b], status)."""
+        b = len(queries)
+        off = np.zeros(b + 1, dtype=np.uint64)
+        for i, (t, _w) in enumerate(queries):
+            off[i + 1] = off[i] + len(t)
+        qt = np.concatenate([np.asarray(t, dtype=np.uint32) for t, _w in queries]) if b else np.zeros(0, np.uint32)
+        qw = np.concatenate([np.asarray(w, dtype=np.float32) for _t, w in queries]) if b else np.zeros(0, np.float32)
+        bits = None
+        if keep is not None:
+            keep = np.asarray(keep).astype(bool)
+            packed = np.packbits(keep, bitorder="little")
+            bits = np.zeros((keep.size + 31) // 32 * 4, dtype=np.uint8)
+            bits[:packed.size] = packed
+            bits = bits.view(np.uint32)
+        out = np.zeros((max(b, 1), max(k, 1)), dtype=np.uint64)
+        sc = np.zeros((max(b, 1), max(k, 1)), dtype=np.float32)
+        cnt = np.zeros(max(b, 1), dtype=np.uint32)
+        rc = self._lib.cqs_hip_sparse_index_search_batch(self._h, _ptr(off), _ptr(qt), _ptr(qw), b, k, _ptr(bits), _ptr(out), _ptr(sc),
+                                                        _ptr(cnt))
+        if rc != _lib.OK:
+            buf = C.create_string_buffer(512)
+            self._lib.cqs_hip_sparse_index_last_error(self._h, buf, 512)
+            self.last_error = buf.value.decode("utf-8", "replace")
+        return out[:b, :k], sc[:b, :k], cnt[:b], rc
+
     def search(self, query: SparseVector, k: int) -> List[IndexResult]:
         """`search(&self, query, k)` (index.rs:214-216)."""
         return self.search_with_filter(query, k, None)

@@ -457,6 +457,13 @@ uint64_t cqs_hip_sparse_index_postings(const cqs_hip_sparse_index* idx);
 int32_t cqs_hip_sparse_index_search(cqs_hip_sparse_index* idx, const uint32_t* q_tokens, const float* q_weights, uint32_t n_terms,
                                     uint32_t k, const uint32_t* keep_bitset, uint64_t* out_chunks, float* out_scores,
                                     uint32_t* out_count);
+/* The same for a batch of b <= 64 queries in ONE pair of launches (evaluation runs, or a caller that gathers its clients'
+ * queries): query q's terms are q_tokens / q_weights [q_off[q], q_off[q + 1]) (q_off [b + 1], ascending); one optional filter for
+ * all; out_chunks / out_scores [b][k] (row q holds out_counts[q] entries), out_counts [b].  Every query's answer is the one
+ * cqs_hip_sparse_index_search gives for it alone, bit for bit. */
+int32_t cqs_hip_sparse_index_search_batch(cqs_hip_sparse_index* idx, const uint64_t* q_off, const uint32_t* q_tokens,
+                                          const float* q_weights, uint32_t b, uint32_t k, const uint32_t* keep_bitset,
+                                          uint64_t* out_chunks, float* out_scores, uint32_t* out_counts);
 /* Profiling aid: device time of the last search's accumulate launch (HIP events on its stream) and the postings it read
  * (the sum of its terms' list lengths: 8 bytes each = the launch's algorithmic bytes, with 4 bytes per chunk of score row). */
 int32_t cqs_hip_sparse_index_last_search(const cqs_hip_sparse_index* idx, float* accumulate_ms, uint64_t* touched_postings);

@@ -61,6 +61,18 @@ extern "C" {
         out_scores: *mut f32,
         out_count: *mut u32,
     ) -> i32;
+    fn cqs_hip_sparse_index_search_batch(
+        idx: *mut CqsHipSparseIndex,
+        q_off: *const u64,
+        q_tokens: *const u32,
+        q_weights: *const f32,
+        b: u32,
+        k: u32,
+        keep_bitset: *const u32,
+        out_chunks: *mut u64,
+        out_scores: *mut f32,
+        out_counts: *mut u32,
+    ) -> i32;
     fn cqs_hip_sparse_index_last_search(idx: *const CqsHipSparseIndex, accumulate_ms: *mut f32, touched_postings: *mut u64) -> i32;
     fn cqs_hip_sparse_index_poisoned(idx: *const CqsHipSparseIndex) -> i32;
     fn cqs_hip_sparse_index_last_error(idx: *const CqsHipSparseIndex, buf: *mut c_char, cap: usize) -> usize;
@@ -200,6 +212,47 @@ impl HipSpladeIndex {
         (0..count as usize)
             .filter_map(|i| self.id_map.get(chunks[i] as usize).map(|id| IndexResult { id: id.to_string(), score: scores[i] }))
             .collect()
+    }
+
+    /// Several queries in one pair of launches (`cqs eval`, or a daemon that gathers its clients' queries): each answer is the
+    /// one `search` gives for that query alone.  At most 64 queries per call; more are served in slices.
+    pub fn search_batch(&self, queries: &[&SparseVector], k: usize) -> Vec<Vec<IndexResult>> {
+        let k = k.min(MAX_K);
+        let mut all = Vec::with_capacity(queries.len());
+        for slice in queries.chunks(64) {
+            let mut q_off: Vec<u64> = Vec::with_capacity(slice.len() + 1);
+            q_off.push(0);
+            let mut toks: Vec<u32> = Vec::new();
+            let mut wts: Vec<f32> = Vec::new();
+            for q in slice {
+                toks.extend(q.iter().map(|&(t, _)| t));
+                wts.extend(q.iter().map(|&(_, w)| w));
+                q_off.push(toks.len() as u64);
+            }
+            let b = slice.len();
+            let mut chunks = vec![0u64; b * k.max(1)];
+            let mut scores = vec![0f32; b * k.max(1)];
+            let mut counts = vec![0u32; b];
+            let rc = unsafe {
+                cqs_hip_sparse_index_search_batch(
+                    self.raw, q_off.as_ptr(), toks.as_ptr(), wts.as_ptr(), b as u32, k as u32, std::ptr::null(),
+                    chunks.as_mut_ptr(), scores.as_mut_ptr(), counts.as_mut_ptr(),
+                )
+            };
+            if rc != CQS_HIP_OK {
+                tracing::warn!(rc, error = %self.last_error(), "HIP SPLADE batch search failed");
+                all.extend((0..b).map(|_| Vec::new()));
+                continue;
+            }
+            for q in 0..b {
+                all.push(
+                    (0..counts[q] as usize)
+                        .filter_map(|i| self.id_map.get(chunks[q * k + i] as usize).map(|id| IndexResult { id: id.to_string(), score: scores[q * k + i] }))
+                        .collect(),
+                );
+            }
+        }
+        all
     }
 
     /// Number of chunks in the index.

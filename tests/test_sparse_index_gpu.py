@@ -273,3 +273,33 @@ def test_built_from_the_postings_map_equals_built_from_the_documents(S, oracle):
         if rc != 0:
             raise S.HipError(rc, "refused")
     a.close(); b.close()
+
+
+def test_batched_queries_equal_the_single_calls(S, oracle):
+    """`cqs_hip_sparse_index_search_batch`: 1, 7, 33 and 64 queries per call (one of them empty, one naming only absent
+    tokens, very different lengths), with and without a filter - every row identical, bit for bit, to that query's own
+    call and to the oracle; 65 queries are refused."""
+    rng = np.random.default_rng(909)
+    n = 30000
+    off, tok, w = sc.corpus(rng, n, 1200, 8, 60, dup_frac=0.1)
+    rank = rng.permutation(n).astype(np.uint32)
+    o = oracle.SpladeIndex(off, tok, w, id_rank=rank)
+    h = S.HipSpladeIndex.build_from_csr(None, off, tok, w, id_rank=rank)
+    for b in (1, 7, 33, 64):
+        qs = [sc.query(rng, 1200, int(rng.integers(1, 150)), absent=2) for _ in range(b)]
+        if b >= 7:
+            qs[2] = (np.zeros(0, np.uint32), np.zeros(0, np.float32))
+            qs[5] = (np.array([5000, 5001], np.uint32), np.ones(2, np.float32))
+        for keep in (None, rng.random(n) < 0.3):
+            ch, scs, cnt, rc = h.search_batch_raw(qs, 200, keep)
+            assert rc == 0
+            for i, (qt, qw) in enumerate(qs):
+                oc, os_ = o.search_raw(qt, qw, 200, keep)
+                assert cnt[i] == oc.size
+                assert np.array_equal(ch[i, :cnt[i]], oc) and np.array_equal(scs[i, :cnt[i]].view(np.uint32), os_.view(np.uint32))
+                if i % 9 == 0:
+                    hc, hs, _ = h.search_raw(qt, qw, 200, keep)
+                    assert np.array_equal(hc, oc) and np.array_equal(hs.view(np.uint32), os_.view(np.uint32))
+    qs = [sc.query(rng, 1200, 5) for _ in range(65)]
+    assert h.search_batch_raw(qs, 10)[3] == -1 and "64" in h.last_error
+    h.close()
