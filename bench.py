@@ -794,6 +794,30 @@ def sparse_index_leg(a, np, dense_idx=None, dense_queries=None):
         assert rc == 0 and np.array_equal(ch[3, :cnt[3]], oc) and np.array_equal(scs[3, :cnt[3]].view(np.uint32), os_.view(np.uint32))
         out["batched_64_terms"][str(bsz)] = {"queries_per_sec": round(64 / el, 1), "ms_per_call": round(el / len(groups) * 1e3, 4),
                                              "checked_bit_exact": True}
+    # concurrent callers of the single-query entry point (the daemon's threads): combined into shared batches
+    import threading
+    qs = synth.sparse_queries(48, 64, vocab, seed=0x5BA2E5)
+    lone = [h.search_raw(qt, qw, k) for qt, qw in qs]
+    out["concurrent_clients"] = {"what": "N Python threads, each one blocking cqs_hip_sparse_index_search at a time (ctypes releases the "
+                                         "interpreter lock inside the call); every answer bit-identical to the lone call's (checked)"}
+    for nthreads in (1, 8):
+        p0, q0 = h.combine_stats()
+        ok = [True] * nthreads
+
+        def work(t):
+            for rep in range(25):
+                i = (t * 5 + rep) % len(qs)
+                c, sc_, rc = h.search_raw(qs[i][0], qs[i][1], k)
+                ok[t] &= rc == 0 and np.array_equal(c, lone[i][0]) and np.array_equal(sc_.view(np.uint32), lone[i][1].view(np.uint32))
+
+        th = [threading.Thread(target=work, args=(t,)) for t in range(nthreads)]
+        t0 = time.perf_counter()
+        [t.start() for t in th]; [t.join() for t in th]
+        el = time.perf_counter() - t0
+        p1, q1 = h.combine_stats()
+        assert all(ok), "a combined sparse search differs from the lone call"
+        out["concurrent_clients"][str(nthreads)] = {"queries_per_sec": round(25 * nthreads / el, 1), "ms_per_call": round(el / 25 * 1e3, 4),
+                                                    "mean_callers_per_pass": round((q1 - q0) / max(1, p1 - p0), 2), "checked": True}
     out["corpus_gen_s"] = round(t_gen, 1)
     if dense_idx is not None and len(dense_idx) == n:
         # Both retrieval legs of `search_hybrid_inner` (src/search/query.rs:879-901) for one query at k = candidate_count = 500

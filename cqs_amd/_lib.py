@@ -122,6 +122,7 @@ SIGNATURES = [
      [_c_idx, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, _pp(C.c_uint32)]),
     ("cqs_hip_sparse_index_search_batch", C.c_int32,
      [_c_idx, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("cqs_hip_sparse_index_combine_stats", None, [_c_idx, _pp(C.c_uint64), _pp(C.c_uint64)]),
     ("cqs_hip_sparse_index_last_search", C.c_int32, [_c_idx, _pp(C.c_float), _pp(C.c_uint64)]),
     ("cqs_hip_sparse_index_poisoned", C.c_int32, [_c_idx]),
     ("cqs_hip_sparse_index_last_error", C.c_size_t, [_c_idx, C.c_char_p, C.c_size_t]),

@@ -20,6 +20,10 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <deque>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -225,10 +229,32 @@ using cqs::sparse_accumulate_kernel;
 using cqs::sparse_wave_lds_words;
 using cqs::SparseTerm;
 
+// One single-query search waiting for a shared pair of launches (the combining queue of cqs_hip_sparse_index_search).
+// Lives on its caller's stack; the pointers are the caller's own buffers.
+struct cqs_sparse_req {
+    const uint32_t* q_tokens;
+    const float* q_weights;
+    uint32_t n_terms, k;
+    uint64_t* out_chunks;
+    float* out_scores;
+    uint32_t* out_count;
+    int32_t rc = 0;
+    bool done = false;
+};
+
 struct cqs_hip_sparse_index {
     std::mutex mu;
+    // combining queue (as the dense index's, index.hip): concurrent unfiltered single-query calls share launches
+    std::mutex cmu;
+    std::condition_variable ccv;
+    std::deque<cqs_sparse_req*> pending;
+    bool leader = false;
+    bool combine = true;                     // CQS_HIP_COMBINE=0 turns it off (read at create)
+    uint32_t combine_wait_us = 100;          // CQS_HIP_COMBINE_WAIT_US
+    uint32_t expect = 1;                     // like-parameter callers recent passes saw
+    std::atomic<uint64_t> stat_passes{0}, stat_queries{0};
     std::string last_error;
-    bool poisoned = false;
+    std::atomic<bool> poisoned{false};
     int device = 0;
     uint64_t n = 0, n_postings = 0;
     uint32_t n_pad = 0, rw = 64, sh = 6, n_cu = 256;
@@ -402,6 +428,8 @@ int32_t finish_create(cqs_hip_sparse_index* s, const std::vector<uint2>& post, i
     }
     if (const char* e = getenv("CQS_HIP_DEBUG_STAMPS"); e && *e == '1')
         if (hipMalloc((void**)&s->d_dbg, 16 * 8) == hipSuccess) (void)hipMemset(s->d_dbg, 0, 16 * 8);
+    if (const char* e = getenv("CQS_HIP_COMBINE")) s->combine = !(e[0] == '0');
+    if (const char* e = getenv("CQS_HIP_COMBINE_WAIT_US")) s->combine_wait_us = (uint32_t)strtoul(e, nullptr, 10);
     return CQS_HIP_OK;
 }
 
@@ -591,8 +619,7 @@ uint64_t cqs_hip_sparse_index_postings(const cqs_hip_sparse_index* s) CQS_ABI_TR
 
 int32_t cqs_hip_sparse_index_poisoned(const cqs_hip_sparse_index* s) CQS_ABI_TRY {
     if (!s) return 0;
-    std::lock_guard<std::mutex> g(const_cast<cqs_hip_sparse_index*>(s)->mu);
-    return s->poisoned ? 1 : 0;
+    return s->poisoned.load(std::memory_order_acquire) ? 1 : 0;
 } CQS_ABI_CATCH_VAL(0)
 
 size_t cqs_hip_sparse_index_last_error(const cqs_hip_sparse_index* s, char* buf, size_t cap) CQS_ABI_TRY {
@@ -717,10 +744,142 @@ int32_t search_locked(cqs_hip_sparse_index* s, const uint64_t* q_off, const uint
 
 }  // namespace
 
+namespace {
+
+// ---- the combining queue: the dense index's scheme (index.hip) over the batched launches -----------------
+// The reference's daemon calls `search_with_filter(&self)` from one thread per client on a shared index
+// (src/cli/batch/view.rs:1621, src/search/query.rs:898-901).  An unfiltered single-query call parks its request; whoever
+// leads next takes the device mutex first, gathers the parked requests with the same k (oldest first, up to 64) and runs
+// them as one batch - every caller gets exactly the bits its own call would have produced (the kernels treat the queries
+// of a batch independently).  Requests are validated BEFORE they park, so a batch can only fail for the device.
+uint32_t count_like_front(const cqs_hip_sparse_index* s) {
+    uint32_t n = 0;
+    for (const cqs_sparse_req* r : s->pending) n += r->k == s->pending.front()->k ? 1u : 0u;
+    return n;
+}
+
+// Lead one batch.  `lk` holds cmu on entry and on exit; s->leader is set by the caller.
+void sparse_combine_lead(cqs_hip_sparse_index* s, std::unique_lock<std::mutex>& lk) {
+    lk.unlock();
+    std::unique_lock<std::mutex> dev(s->mu);
+    lk.lock();
+    const uint32_t target = s->expect < kSparseMaxBatch ? s->expect : kSparseMaxBatch;
+    if (s->combine_wait_us && count_like_front(s) < target) {     // stragglers of the last pass are on their way back
+        const auto t_end = std::chrono::steady_clock::now() + std::chrono::microseconds(s->combine_wait_us);
+        for (;;) {
+            lk.unlock();
+            for (int i = 0; i < 64; ++i) __builtin_ia32_pause();
+            lk.lock();
+            if (count_like_front(s) >= target || std::chrono::steady_clock::now() >= t_end) break;
+        }
+    }
+    cqs_sparse_req* batch[kSparseMaxBatch];
+    uint32_t nb = 0, left_like = 0;
+    {
+        const uint32_t k0 = s->pending.front()->k;
+        std::deque<cqs_sparse_req*> keep;
+        for (cqs_sparse_req* r : s->pending) {
+            if (r->k == k0) {
+                if (nb < kSparseMaxBatch) { batch[nb++] = r; continue; }
+                ++left_like;
+            }
+            keep.push_back(r);
+        }
+        s->pending.swap(keep);
+    }
+    s->expect = nb + left_like;
+    lk.unlock();
+
+    int32_t rc = CQS_HIP_OK;
+    const uint32_t k = batch[0]->k;
+    std::vector<uint32_t> counts(nb, 0u);
+    std::vector<uint64_t> chunks;
+    std::vector<float> scores;
+    try {
+        std::vector<uint64_t> q_off(nb + 1, 0);
+        for (uint32_t i = 0; i < nb; ++i) q_off[i + 1] = q_off[i] + batch[i]->n_terms;
+        std::vector<uint32_t> toks((size_t)q_off[nb]);
+        std::vector<float> wts((size_t)q_off[nb]);
+        for (uint32_t i = 0; i < nb; ++i) {
+            if (batch[i]->n_terms == 0) continue;
+            memcpy(toks.data() + q_off[i], batch[i]->q_tokens, (size_t)batch[i]->n_terms * 4);
+            memcpy(wts.data() + q_off[i], batch[i]->q_weights, (size_t)batch[i]->n_terms * 4);
+        }
+        chunks.resize((size_t)nb * k);
+        scores.resize((size_t)nb * k);
+        rc = search_locked(s, q_off.data(), toks.data(), wts.data(), nb, k, nullptr, chunks.data(), scores.data(), counts.data());
+    } catch (const std::bad_alloc&) {
+        rc = sfail(s, CQS_HIP_ERR_NOMEM, "sparse search: out of host memory");
+    } catch (...) {
+        rc = sfail(s, CQS_HIP_ERR_INVALID, "sparse search: unexpected C++ exception");
+    }
+    s->stat_passes.fetch_add(1, std::memory_order_relaxed);
+    s->stat_queries.fetch_add(nb, std::memory_order_relaxed);
+    const bool poisoned = s->poisoned.load(std::memory_order_acquire);
+    if (rc == CQS_HIP_OK)
+        for (uint32_t i = 0; i < nb; ++i) {
+            memcpy(batch[i]->out_chunks, chunks.data() + (size_t)i * k, (size_t)counts[i] * 8);
+            memcpy(batch[i]->out_scores, scores.data() + (size_t)i * k, (size_t)counts[i] * 4);
+            *batch[i]->out_count = counts[i];
+        }
+    dev.unlock();
+
+    lk.lock();
+    for (uint32_t i = 0; i < nb; ++i) {
+        batch[i]->rc = (rc != CQS_HIP_OK && i > 0 && poisoned) ? CQS_HIP_ERR_POISONED : rc;
+        batch[i]->done = true;
+    }
+    if (poisoned) {                                        // nobody stays parked on a dead handle
+        for (cqs_sparse_req* r : s->pending) { r->rc = CQS_HIP_ERR_POISONED; r->done = true; }
+        s->pending.clear();
+    } else if (!s->pending.empty()) {
+        uint32_t like = 0;
+        for (const cqs_sparse_req* r : s->pending) like += r->k == k ? 1u : 0u;
+        if (nb + like > s->expect) s->expect = nb + like;
+    }
+}
+
+int32_t sparse_combine_search(cqs_hip_sparse_index* s, cqs_sparse_req& r) {
+    std::unique_lock<std::mutex> lk(s->cmu);
+    s->pending.push_back(&r);
+    while (!r.done) {
+        if (!s->leader) {
+            s->leader = true;
+            struct Reset {                                 // whatever happens in there, the next caller can lead
+                cqs_hip_sparse_index* s; std::unique_lock<std::mutex>& lk;
+                ~Reset() { if (!lk.owns_lock()) lk.lock(); s->leader = false; s->ccv.notify_all(); }
+            } reset{s, lk};
+            sparse_combine_lead(s, lk);
+        } else {
+            s->ccv.wait(lk);
+        }
+    }
+    return r.rc;
+}
+
+}  // namespace
+
 int32_t cqs_hip_sparse_index_search(cqs_hip_sparse_index* s, const uint32_t* q_tokens, const float* q_weights, uint32_t n_terms,
                                     uint32_t k, const uint32_t* keep_bitset, uint64_t* out_chunks, float* out_scores,
                                     uint32_t* out_count) CQS_ABI_TRY {
     if (!s) return CQS_HIP_ERR_INVALID;
+    // One unfiltered query with its arguments in order: the combining queue.  Everything a batch could refuse for ONE of
+    // its members is checked here, before the request parks.
+    if (s->combine && !keep_bitset && out_count && out_chunks && out_scores && k >= 1 && k <= cqs::kMaxK && n_terms >= 1 &&
+        n_terms <= kMaxTerms && q_tokens && q_weights && s->n != 0) {
+        if (s->poisoned.load(std::memory_order_acquire)) { *out_count = 0; return CQS_HIP_ERR_POISONED; }
+        bool reserved = false;
+        for (uint32_t i = 0; i < n_terms; ++i) {
+            uint32_t bits;
+            memcpy(&bits, &q_weights[i], 4);
+            reserved |= bits == kUnscored;
+        }
+        if (!reserved) {
+            *out_count = 0;
+            cqs_sparse_req r{q_tokens, q_weights, n_terms, k, out_chunks, out_scores, out_count};
+            return sparse_combine_search(s, r);
+        }
+    }
     std::lock_guard<std::mutex> g(s->mu);
     if (!out_count) return sfail(s, CQS_HIP_ERR_INVALID, "sparse search: null out_count");
     const uint64_t q_off[2] = {0, n_terms};
@@ -736,6 +895,11 @@ int32_t cqs_hip_sparse_index_search_batch(cqs_hip_sparse_index* s, const uint64_
     if (!q_off || !out_counts) return sfail(s, CQS_HIP_ERR_INVALID, "sparse search: null offsets / counts");
     return search_locked(s, q_off, q_tokens, q_weights, b, k, keep_bitset, out_chunks, out_scores, out_counts);
 } CQS_ABI_CATCH(s)
+
+void cqs_hip_sparse_index_combine_stats(const cqs_hip_sparse_index* s, uint64_t* passes, uint64_t* queries) CQS_ABI_TRY {
+    if (passes) *passes = s ? s->stat_passes.load(std::memory_order_relaxed) : 0;
+    if (queries) *queries = s ? s->stat_queries.load(std::memory_order_relaxed) : 0;
+} CQS_ABI_CATCH_VOID
 
 int32_t cqs_hip_sparse_index_last_search(const cqs_hip_sparse_index* s, float* accumulate_ms, uint64_t* touched_postings) CQS_ABI_TRY {
     if (!s) return CQS_HIP_ERR_INVALID;

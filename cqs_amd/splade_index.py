@@ -137,6 +137,12 @@ class HipSpladeIndex:
     def postings(self) -> int:
         return int(self._lib.cqs_hip_sparse_index_postings(self._h))
 
+    def combine_stats(self) -> Tuple[int, int]:
+        """(batches the combining queue ran, queries they carried) since the handle was made"""
+        p, q = C.c_uint64(), C.c_uint64()
+        self._lib.cqs_hip_sparse_index_combine_stats(self._h, C.byref(p), C.byref(q))
+        return int(p.value), int(q.value)
+
     def last_search(self) -> Tuple[float, int]:
         """(device ms of the last accumulate launch, postings it read)"""
         ms, touched = C.c_float(), C.c_uint64()

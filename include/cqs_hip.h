@@ -464,6 +464,11 @@ int32_t cqs_hip_sparse_index_search(cqs_hip_sparse_index* idx, const uint32_t* q
 int32_t cqs_hip_sparse_index_search_batch(cqs_hip_sparse_index* idx, const uint64_t* q_off, const uint32_t* q_tokens,
                                           const float* q_weights, uint32_t b, uint32_t k, const uint32_t* keep_bitset,
                                           uint64_t* out_chunks, float* out_scores, uint32_t* out_counts);
+/* Concurrent callers: unfiltered single-query cqs_hip_sparse_index_search calls on one handle are combined into shared
+ * batches like the dense index's (CQS_HIP_COMBINE=0 / CQS_HIP_COMBINE_WAIT_US, read at create); every caller gets the bits
+ * its own call would have produced.  Counters since the handle was made: batches run through the queue and the queries they
+ * carried.  Either pointer may be NULL.  Diagnostic. */
+void cqs_hip_sparse_index_combine_stats(const cqs_hip_sparse_index* idx, uint64_t* passes, uint64_t* queries);
 /* Profiling aid: device time of the last search's accumulate launch (HIP events on its stream) and the postings it read
  * (the sum of its terms' list lengths: 8 bytes each = the launch's algorithmic bytes, with 4 bytes per chunk of score row). */
 int32_t cqs_hip_sparse_index_last_search(const cqs_hip_sparse_index* idx, float* accumulate_ms, uint64_t* touched_postings);

@@ -303,3 +303,47 @@ def test_batched_queries_equal_the_single_calls(S, oracle):
     qs = [sc.query(rng, 1200, 5) for _ in range(65)]
     assert h.search_batch_raw(qs, 10)[3] == -1 and "64" in h.last_error
     h.close()
+
+
+def test_concurrent_single_query_callers_share_batches(S, oracle):
+    """The combining queue of `cqs_hip_sparse_index_search`: eight threads on one handle - every answer the oracle's, bit
+    for bit, whatever batch it rode in; the queue's counters show shared batches; mixed k, a filtered caller (serial path) and
+    a caller with an invalid weight (refused alone, nobody else disturbed) in the mix."""
+    import threading
+    rng = np.random.default_rng(31)
+    n = 40000
+    off, tok, w = sc.corpus(rng, n, 1500, 8, 60)
+    o = oracle.SpladeIndex(off, tok, w)
+    h = S.HipSpladeIndex.build_from_csr(None, off, tok, w)
+    queries = [sc.query(rng, 1500, int(rng.integers(5, 90))) for _ in range(24)]
+    keep = rng.random(n) < 0.5
+    want = {}
+    for i, (qt, qw) in enumerate(queries):
+        for k in (100, 500):
+            want[(i, k, False)] = o.search_raw(qt, qw, k)
+        want[(i, 100, True)] = o.search_raw(qt, qw, 100, keep)
+    bad = []
+
+    def work(t):
+        for rep in range(30):
+            i = (7 * t + rep) % len(queries)
+            qt, qw = queries[i]
+            k = 500 if (t + rep) % 3 == 0 else 100
+            flt = t == 5 and rep % 4 == 0
+            if t == 6 and rep % 10 == 0:                          # reserved NaN payload: refused, alone
+                qbad = qw.copy(); qbad.view(np.uint32)[0] = 0xFFFFFFFF
+                if h.search_raw(qt, qbad, k)[2] != -1:
+                    bad.append(("not refused", t, rep))
+                continue
+            c, s_, rc = h.search_raw(qt, qw, 100 if flt else k, keep if flt else None)
+            oc, os_ = want[(i, 100 if flt else k, flt)]
+            if rc != 0 or not np.array_equal(c, oc) or not np.array_equal(s_.view(np.uint32), os_.view(np.uint32)):
+                bad.append((t, rep, rc))
+
+    p0, q0 = h.combine_stats()
+    th = [threading.Thread(target=work, args=(t,)) for t in range(8)]
+    [t.start() for t in th]; [t.join() for t in th]
+    p1, q1 = h.combine_stats()
+    assert not bad, bad[:5]
+    assert q1 - q0 >= 200 and p1 - p0 <= q1 - q0
+    h.close()
