@@ -400,9 +400,7 @@ def embed_leg(a, rank, world, dist, torch, np, dev, all_reduce_max):
         qlat["random_lengths"] = {"calls": int(len(walls)), "lengths": "uniform 1..128", "p50_ms": round(float(np.percentile(walls, 50)), 4),
                                   "p99_ms": round(float(np.percentile(walls, 99)), 4), "max_ms": round(float(walls.max()), 4),
                                   "eager_chains_during": gsr["eager"] - gsw["eager"], "captures_during": gsr["captured"] - gsw["captured"]}
-    cpu = None
-    if rank == 0 and world == 1 and a.cpu_seconds > 0:
-        cpu = embed_cpu_baseline(np, cfg, weights, a.cpu_seconds, a.embed_len)
+    cpu = None          # filled in by main() after the last GPU leg (see the note at the scan's cpu_baseline)
     out = {"model": "EmbeddingGemma-300m geometry (24 x [768 | 3x256 q, 1 kv | 1152], vocab 262144), seeded weights",
            "steps": a.embed_steps, "fixed_len_%d" % a.embed_len: fixed, "lognormal_len": ragged,
            "fixed_len_%d_batch%d" % (a.embed_len, 4 * a.embed_batch): big,
@@ -1327,10 +1325,15 @@ def main():
         qc = make_unit_rows(torch, 48, dim, 0xC950031, dev).cpu().numpy()
         clients = concurrent_clients_leg(np, idx, qc, k, dim)
 
+    # The CPU baseline runs LAST (after every GPU leg; only its inputs are taken here, while the corpus is still resident):
+    # 10-20 s of one AVX-512 worker per physical core, pinned, over a first-touched 3 GB copy leave the host in a state in
+    # which the ticketed embedding leg measured 3 % lower (6 072 against 6 198-6 242 chunks/s, same box, four orders tried:
+    # tools/r04_embed_order.sh) - a baseline must not move the thing it is the baseline of.
     cpu = None
+    cpu_inputs = None
     if rank == 0 and world == 1 and a.cpu_seconds > 0:
         nqc = min(8, K)
-        cpu = cpu_baseline(rows.cpu().numpy(), queries[W:W + nqc, 0].cpu().numpy(), k, a.cpu_seconds)
+        cpu_inputs = (rows.cpu().numpy(), queries[W:W + nqc, 0].cpu().numpy())
 
     other = None
     if rank == 0 and world == 1 and mode == "single" and a.extras:
@@ -1361,13 +1364,19 @@ def main():
         del rows
         torch.cuda.empty_cache()
         embed, eng, ecfg, eweights = embed_leg(a, rank, world, dist, torch, np, dev, all_reduce_max)
+    aux = None
+    if rank == 0 and world == 1 and mode == "single" and a.extras and a.embed_steps > 0:
+        aux = aux_models_leg(a, np)       # (before the end-to-end leg: that one ends with a minute of CPU forwards for its recall check)
+    if a.embed_steps > 0:
         if rank == 0 and world == 1 and a.e2e_chunks > 0:
             e2e = e2e_leg(a, torch, np, dev, eng, ecfg, eweights)
         eng.close()
 
-    aux = None
-    if rank == 0 and world == 1 and mode == "single" and a.extras and a.embed_steps > 0:
-        aux = aux_models_leg(a, np)
+    if cpu_inputs is not None:
+        cpu = cpu_baseline(cpu_inputs[0], cpu_inputs[1], k, a.cpu_seconds)
+        cpu_inputs = None
+    if embed is not None and rank == 0 and world == 1 and a.cpu_seconds > 0:
+        embed["cpu_baseline"] = embed_cpu_baseline(np, ecfg, eweights, a.cpu_seconds, a.embed_len)
 
     if abi_after_group:
         # every rank drops its shard, the group dissolves, ranks != 0 leave; rank 0 then builds ONE handle over
