@@ -642,7 +642,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_dual_kernel(const bf16_t* __re
                                                               uint32_t n_first) {
     // (Round 4 tried the two problems' workgroups interleaved in groups of 8, so that each round holds wide and narrow tiles
     // and the CUs' load / store bursts drift apart: 68.1 -> 72.0 us for the GeGLU projection - the four column tiles of a
-    // row block no longer run side by side on one XCD and its A panel is fetched into more L2s.  One after the other it stays.)
+    // row block no longer run side by side on one XCD and its A panel is fetched into more L2s.  One after the other it stays.
+    // Also tried: 256 persistent workgroups, each walking its wide tile and then the narrow tile of the same row block -
+    // 57.7-58.6 us against 57.4-57.7 for this kernel: a second round of workgroup launches costs nothing measurable, so the
+    // only thing a persistent form could still win is the next tile's ~2 us prologue under this tile's epilogue.)
     if (blockIdx.x < n_first) gemm_pp_body<TNA, OUT>(A, Wa, Ca, M, Na, K, ldc, blockIdx.x);
     else gemm_pp_body<TNB, OUT>(A, Wb, Cb, M, Nb, K, ldc, blockIdx.x - n_first);
 }
