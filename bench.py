@@ -816,6 +816,33 @@ def sparse_index_leg(a, np, dense_idx=None, dense_queries=None):
         assert all(ok), "a combined sparse search differs from the lone call"
         out["concurrent_clients"][str(nthreads)] = {"queries_per_sec": round(25 * nthreads / el, 1), "ms_per_call": round(el / 25 * 1e3, 4),
                                                     "mean_callers_per_pass": round((q1 - q0) / max(1, p1 - p0), 2), "checked": True}
+    # the same from NATIVE threads (the interpreter lock out of the way): cqs_hip_debug_sparse_client_storm
+    import ctypes as C
+    from cqs_amd import _lib
+    storm = _lib.load().cqs_hip_debug_sparse_client_storm
+    storm.restype = C.c_double
+    storm.argtypes = [C.c_void_p] * 4 + [C.c_uint32] * 4 + [C.c_void_p] * 3
+    nq = len(qs)
+    q_off = np.zeros(nq + 1, np.uint64)
+    for i, (qt, _qw) in enumerate(qs):
+        q_off[i + 1] = q_off[i] + qt.size
+    qt_all = np.concatenate([qt for qt, _ in qs]).astype(np.uint32)
+    qw_all = np.concatenate([qw for _, qw in qs]).astype(np.float32)
+    out["concurrent_clients"]["native_threads"] = {}
+    for nthreads in (1, 2, 4, 8, 16):
+        oc = np.zeros((nq, k), np.uint64); osc = np.zeros((nq, k), np.float32); ocn = np.zeros(nq, np.uint32)
+        p0, q0 = h.combine_stats()
+        per = 120
+        el = storm(h._h, q_off.ctypes.data, qt_all.ctypes.data, qw_all.ctypes.data, nq, k, nthreads, per, oc.ctypes.data, osc.ctypes.data,
+                   ocn.ctypes.data)
+        p1, q1 = h.combine_stats()
+        assert el > 0
+        for i in range(nq):
+            if ocn[i]:
+                assert np.array_equal(oc[i, :ocn[i]], lone[i][0]) and np.array_equal(osc[i, :ocn[i]].view(np.uint32), lone[i][1].view(np.uint32))
+        out["concurrent_clients"]["native_threads"][str(nthreads)] = {
+            "queries_per_sec": round(nthreads * per / el, 1), "ms_per_call": round(el / per * 1e3, 4),
+            "mean_callers_per_pass": round((q1 - q0) / max(1, p1 - p0), 2), "checked": True}
     out["corpus_gen_s"] = round(t_gen, 1)
     if dense_idx is not None and len(dense_idx) == n:
         # Both retrieval legs of `search_hybrid_inner` (src/search/query.rs:879-901) for one query at k = candidate_count = 500

@@ -30,6 +30,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -908,5 +909,38 @@ int32_t cqs_hip_sparse_index_last_search(const cqs_hip_sparse_index* s, float* a
     if (touched_postings) *touched_postings = s->last_touched;
     return CQS_HIP_OK;
 } CQS_ABI_CATCH_VAL(CQS_HIP_ERR_INVALID)
+
+// Diagnostic (not in the header): n_threads native threads, each calling the public single-query entry point per_thread
+// times over its own residue class of the query set (query q's terms: [q_off[q], q_off[q + 1])); results land in the
+// query's own output slot.  Returns the wall time in seconds, < 0 on a failed call.  What bench.py's Python threads cannot
+// show behind the interpreter lock.
+double cqs_hip_debug_sparse_client_storm(cqs_hip_sparse_index* s, const uint64_t* q_off, const uint32_t* q_tokens, const float* q_weights,
+                                         uint32_t n_queries, uint32_t k, uint32_t n_threads, uint32_t per_thread,
+                                         uint64_t* out_chunks, float* out_scores, uint32_t* out_counts) CQS_ABI_TRY {
+    if (!s || !q_off || !q_tokens || !q_weights || !n_queries || !n_threads || !out_chunks || !out_scores || !out_counts) return -1.0;
+    std::atomic<int32_t> bad{0};
+    std::atomic<uint32_t> ready{0};
+    std::atomic<bool> go{false};
+    std::vector<std::thread> th;
+    th.reserve(n_threads);
+    for (uint32_t t = 0; t < n_threads; ++t)
+        th.emplace_back([&, t]() {
+            ready.fetch_add(1);
+            while (!go.load(std::memory_order_acquire)) std::this_thread::yield();
+            uint32_t qi = t % n_queries;
+            for (uint32_t i = 0; i < per_thread; ++i) {
+                const int32_t rc = cqs_hip_sparse_index_search(s, q_tokens + q_off[qi], q_weights + q_off[qi], (uint32_t)(q_off[qi + 1] - q_off[qi]),
+                                                               k, nullptr, out_chunks + (size_t)qi * k, out_scores + (size_t)qi * k, out_counts + qi);
+                if (rc != CQS_HIP_OK) { bad.store(rc); break; }
+                qi = (qi + n_threads) % n_queries;
+            }
+        });
+    while (ready.load() < n_threads) std::this_thread::yield();
+    const auto t0 = std::chrono::steady_clock::now();
+    go.store(true, std::memory_order_release);
+    for (std::thread& t : th) t.join();
+    const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return bad.load() ? -1.0 : el;
+} CQS_ABI_CATCH_VAL(-1.0)
 
 }  // extern "C"
