@@ -822,9 +822,13 @@ int32_t submit_locked(cqs_hip_embedder* e, uint32_t B, const std::function<int32
     for (const cqs_hip_embedder::Slot& s2 : e->slot)
         if (s2.ticket != 0) load[s2.ctx]++;
     int ci = load[0] == load[1] ? (load[0] == 0 ? 0 : 1 - e->last_ctx) : (load[0] < load[1] ? 0 : 1);
+    // A batch whose kernels are EXACT rounds of the 256 CUs (16 384 or 32 768 tokens: 128 / 256 row blocks x 2 workgroups) leaves a
+    // second chain nothing to fill - side by side the two only contend.  Tickets in flight, chunks/s, two contexts | one | blocking
+    // calls (tools/r04_ctx_sweep.py, same box): 12 288 tokens 6 370 | 5 480 | 5 510; 14 336: 6 530 | 6 175 | 6 130; 16 384: 6 220-6 450 |
+    // 6 400 | 6 440; 18 432: 5 975-6 300 | 4 845 | 4 820; 24 576: 6 050 | 5 690 | 5 740; 32 768: 6 340 | 6 530 | 6 600; 49 152: 6 220 | 6 110 |
+    // 6 200; 65 536: 6 100 | 5 970 | 6 060.  So: those two sizes stay on context 0, everything else alternates.
+    if (sl->M == 16384u || sl->M == 32768u) ci = 0;
     if (e->single_ctx) ci = 0;            // CQS_HIP_EMBED_CONTEXTS=1: every ticket on one stream (tickets still overlap host packing / copies)
-    // (Tried in round 4 and dropped: batches of >= 32 768 tokens all on context 0 - "stop alternating contexts" - measured
-    // 5 600 chunks/s against 5 650 for blocking calls and 5 660-5 745 for alternating contexts at 128 x 512 tokens.)
     e->last_ctx = ci;
     sl->ctx = ci;
     Ctx& c = e->ctx[ci];
