@@ -40,8 +40,8 @@
 namespace cqs {
 
 constexpr uint32_t kSparsePad = 1024;          // n_pad granule (a multiple of every wave range)
-constexpr uint32_t kUnscored = 0xFFFFFFFFu;    // LDS marker: `scores.entry(chunk)` does not exist yet (a NaN no arithmetic here produces:
-                                               // weights with that bit pattern are refused at build / search)
+constexpr uint32_t kUnscored = 0xFFFFFFFFu;    // LDS marker: `scores.entry(chunk)` does not exist yet (a NaN bit pattern: weights that
+                                               // carry it are refused at build / search, a sum that lands on it is stored as 0x7FC00000)
 constexpr uint32_t kMaxTerms = 1u << 16;        // per query
 constexpr uint32_t kSparseMaxBatch = 64;       // queries per cqs_hip_sparse_index_search_batch call
 
@@ -183,8 +183,10 @@ __global__ __launch_bounds__(256) void sparse_accumulate_kernel(const uint2* __r
                     asm volatile("" ::: "memory");
                     if (pending && *(volatile uint32_t*)&claim[at] == (uint32_t)lane) {
                         const uint32_t s = *(volatile uint32_t*)&my[at];
-                        *(volatile uint32_t*)&my[at] =
-                            __builtin_bit_cast(uint32_t, __fadd_rn(s == kUnscored ? 0.f : __builtin_bit_cast(float, s), prod[u]));
+                        const uint32_t sum = __builtin_bit_cast(uint32_t, __fadd_rn(s == kUnscored ? 0.f : __builtin_bit_cast(float, s), prod[u]));
+                        // a NaN sum that happens to carry the marker's bits (the sign of a NaN result is the hardware's
+                        // choice) is stored as the canonical NaN: still NaN for every later add, still dropped at the end
+                        *(volatile uint32_t*)&my[at] = sum == kUnscored ? 0x7FC00000u : sum;
                         *(volatile uint32_t*)&claim[at] = 0xFFFFFFFFu;
                         pending = false;
                     }

@@ -347,3 +347,24 @@ def test_concurrent_single_query_callers_share_batches(S, oracle):
     assert not bad, bad[:5]
     assert q1 - q0 >= 200 and p1 - p0 <= q1 - q0
     h.close()
+
+
+def test_nan_payloads_next_to_the_marker(S, oracle):
+    """The kernel marks "not scored yet" with the bit pattern 0xFFFFFFFF (refused as an input).  A NaN weight with every
+    other payload - 0x7FFFFFFF included, times a negative query weight - must behave like any NaN: the chunk's sum stays NaN
+    through later adds and the chunk is dropped (`would_accept`), never mistaken for an unscored one that starts over."""
+    f = lambda bits: float(np.array([bits], dtype=np.uint32).view(np.float32)[0])
+    w = np.array([f(0x7FFFFFFF), 2.0, 0.5, 1.0, f(0xFFFFFFFE), 3.0], dtype=np.float32)
+    w.view(np.uint32)[0] = 0x7FFFFFFF
+    w.view(np.uint32)[4] = 0xFFFFFFFE
+    off = np.array([0, 2, 4, 6], dtype=np.uint64)
+    tok = np.array([1, 2, 1, 2, 1, 2], dtype=np.uint32)
+    o = oracle.SpladeIndex(off, tok, w)
+    h = S.HipSpladeIndex.build_from_csr(None, off, tok, w)
+    for qw in ([-1.0, 1.0], [1.0, 1.0], [-2.5, -1.0]):
+        qt = np.array([1, 2], np.uint32)
+        oc, os_ = o.search_raw(qt, np.array(qw, np.float32), 10)
+        hc, hs, rc = h.search_raw(qt, np.array(qw, np.float32), 10)
+        assert rc == 0 and np.array_equal(hc, oc) and np.array_equal(hs.view(np.uint32), os_.view(np.uint32))
+        assert list(hc) == [1]                                 # only the chunk without a NaN weight survives
+    h.close()
