@@ -778,6 +778,22 @@ def sparse_index_leg(a, np, dense_idx=None, dense_queries=None):
             "cpu_baseline": {"kind": "port", "cores": 1, "queries_per_sec": round(ncpu / cpu_el, 2), "ms_per_query": round(cpu_el / ncpu * 1e3, 3),
                              "sample": "%d of the timed queries through oracle.SpladeIndex.search_raw (dense score array in place of the HashMap)" % ncpu},
         }
+    # persistence: what a daemon restart costs instead of the rebuild (own format, cqs_hip_sparse_index_save / _load)
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        pth = os.path.join(td, "splade.hip.bin")
+        t0 = time.perf_counter()
+        h.save(pth, 1)
+        t_save = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        h2 = HipSpladeIndex.load(pth, 1)
+        t_load = time.perf_counter() - t0
+        qt, qw = synth.sparse_queries(1, 64, vocab, seed=0x5BA2E9)[0]
+        a1, a2 = h.search_raw(qt, qw, k), h2.search_raw(qt, qw, k)
+        assert np.array_equal(a1[0], a2[0]) and np.array_equal(a1[1].view(np.uint32), a2[1].view(np.uint32))
+        out["persist"] = {"file_mb": round(os.path.getsize(pth) / 1e6, 1), "save_s": round(t_save, 2), "load_s": round(t_load, 2),
+                          "build_s": round(t_build, 2), "checked_bit_exact": True}
+        h2.close()
     # several queries per call (cqs_hip_sparse_index_search_batch): evaluation runs, or a caller that gathers its clients
     qs = synth.sparse_queries(64, 64, vocab, seed=0x5BA2E3)
     out["batched_64_terms"] = {}

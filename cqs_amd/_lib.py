@@ -114,6 +114,8 @@ SIGNATURES = [
      [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int32, _pp(_c_idx)]),
     ("cqs_hip_sparse_index_create_inverted", C.c_int32,
      [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_int32, _pp(_c_idx)]),
+    ("cqs_hip_sparse_index_save", C.c_int32, [_c_idx, C.c_char_p, C.c_uint64, _pp(C.c_uint64)]),
+    ("cqs_hip_sparse_index_load", C.c_int32, [C.c_char_p, C.c_uint64, C.c_uint64, C.c_int32, _pp(_c_idx)]),
     ("cqs_hip_sparse_index_destroy", None, [_c_idx]),
     ("cqs_hip_sparse_index_len", C.c_uint64, [_c_idx]),
     ("cqs_hip_sparse_index_unique_tokens", C.c_uint64, [_c_idx]),

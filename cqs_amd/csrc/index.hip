@@ -29,6 +29,7 @@
 #include "abi_guard.h"
 #include "roctx.h"
 #include "index_internal.h"
+#include "persist_util.h"
 
 using cqs::kMaxK;
 using cqs::kRowsPerBlock;
@@ -313,6 +314,12 @@ int32_t cqs_hip_index_extend(cqs_hip_index* x, const float* rows, uint64_t n_new
 }  // extern "C"
 
 namespace {
+using cqs_persist::Checksum;
+using cqs_persist::exists;
+using cqs_persist::fsync_parent;
+using cqs_persist::read_all;
+using cqs_persist::write_all;
+
 struct FlatHeader {
     char magic[8];
     uint32_t version, dim, metric, pad;
@@ -322,63 +329,7 @@ struct FlatHeader {
 static_assert(sizeof(FlatHeader) == 64, "header is 64 bytes");
 const char kFlatMagic[8] = {'C', 'Q', 'S', 'H', 'I', 'P', 'F', '1'};
 
-// 64-bit multiply-rotate hash over the 8-byte words of the content, computable in pieces: every piece
-// but the last must be a multiple of 8 bytes (the streaming save / load use <= 64 MiB pieces of whole rows).
-struct Checksum {
-    static constexpr uint64_t P1 = 0x9E3779B185EBCA87ull, P2 = 0xC2B2AE3D27D4EB4Full;
-    uint64_t h;
-    explicit Checksum(uint64_t total_bytes) : h(0x27D4EB2F165667C5ull ^ total_bytes) {}
-    void update(const void* data, size_t bytes, bool last) {
-        const uint8_t* p = (const uint8_t*)data;
-        size_t i = 0;
-        for (; i + 8 <= bytes; i += 8) {
-            uint64_t w;
-            memcpy(&w, p + i, 8);
-            h ^= w * P1;
-            h = ((h << 31) | (h >> 33)) * P2;
-        }
-        if (last) {
-            uint64_t tail = 0;
-            if (i < bytes) memcpy(&tail, p + i, bytes - i);
-            h ^= tail * P1;
-        }
-    }
-    uint64_t finish() {
-        h ^= h >> 29;
-        h *= P2;
-        h ^= h >> 32;
-        return h;
-    }
-};
-
 constexpr size_t kIoPiece = 64ull << 20;   // pinned staging piece (x2: copy of piece i+1 overlaps file I/O of piece i)
-
-bool write_all(int fd, const void* data, size_t bytes) {
-    const uint8_t* p = (const uint8_t*)data;
-    while (bytes) {
-        const ssize_t w = write(fd, p, bytes);
-        if (w < 0) { if (errno == EINTR) continue; return false; }
-        p += w; bytes -= (size_t)w;
-    }
-    return true;
-}
-bool read_all(int fd, void* data, size_t bytes) {
-    uint8_t* p = (uint8_t*)data;
-    while (bytes) {
-        const ssize_t r = read(fd, p, bytes);
-        if (r < 0) { if (errno == EINTR) continue; return false; }
-        if (r == 0) return false;
-        p += r; bytes -= (size_t)r;
-    }
-    return true;
-}
-void fsync_parent(const std::string& path) {   // make a rename durable (src/cagra.rs:1526-1537)
-    std::string tmp = path;
-    const char* dir = dirname(&tmp[0]);
-    const int fd = open(dir, O_RDONLY | O_DIRECTORY);
-    if (fd >= 0) { (void)fsync(fd); close(fd); }
-}
-bool exists(const std::string& p) { struct stat st; return stat(p.c_str(), &st) == 0; }
 
 // The rows of one or more device segments (row order) cut into pieces of <= 64 MiB that never straddle a segment.
 struct Piece { const cqs_idx::Segment* seg; size_t off, len; };

@@ -35,6 +35,7 @@
 #include <vector>
 
 #include "abi_guard.h"
+#include "persist_util.h"
 #include "scan_kernels.h"
 
 namespace cqs {
@@ -597,6 +598,144 @@ int32_t cqs_hip_sparse_index_create_inverted(const uint32_t* token_ids, const ui
         s->off.push_back(post.size());
     }
     s->n_postings = post.size();
+    const int32_t rc = finish_create(s, post, device);
+    if (rc != CQS_HIP_OK) return rc;
+    guard.p = nullptr;
+    *out = s;
+    return CQS_HIP_OK;
+} CQS_ABI_CATCH_NOHANDLE
+
+// ---- persistence (the role of `SpladeIndex::save` / `load`, src/splade/index.rs:346-1072: skip the rebuild after a restart;
+// invalidated by the store's `splade_generation` counter).  Own format - the reference's file is not read or written:
+// 64-byte header {magic "CQSHIPS1", version, ranked, chunks, tokens, postings, generation, checksum} + four sections,
+// each zero-padded to 8 bytes: token ids (u32, ascending), list offsets (u64, tokens + 1), postings ({position, weight
+// bits}, 8 B each), and - ranked indexes only - chunk_of_rank (u32 per chunk).  The checksum covers the sections.
+namespace {
+struct SparseFileHeader {
+    char magic[8];
+    uint32_t version, ranked;
+    uint64_t chunks, tokens, postings, generation, checksum;
+    uint8_t reserved[8];
+};
+static_assert(sizeof(SparseFileHeader) == 64, "header is 64 bytes");
+const char kSparseMagic[8] = {'C', 'Q', 'S', 'H', 'I', 'P', 'S', '1'};
+inline size_t pad8(size_t b) { return (b + 7) & ~(size_t)7; }
+}  // namespace
+
+int32_t cqs_hip_sparse_index_save(cqs_hip_sparse_index* s, const char* path, uint64_t generation, uint64_t* out_checksum) CQS_ABI_TRY {
+    if (!s || !path) return CQS_HIP_ERR_INVALID;
+    std::lock_guard<std::mutex> g(s->mu);
+    if (s->poisoned.load(std::memory_order_acquire)) return CQS_HIP_ERR_POISONED;
+    S_TRY(s, hipSetDevice(s->device));
+    S_TRY(s, hipStreamSynchronize(s->stream));
+    std::vector<uint2> post((size_t)s->n_postings);
+    if (s->n_postings) S_TRY(s, hipMemcpy(post.data(), s->d_post, (size_t)s->n_postings * sizeof(uint2), hipMemcpyDeviceToHost));
+    const size_t U = s->tok.size();
+    struct Sec { const void* p; size_t bytes; };
+    const Sec secs[4] = {{s->tok.data(), U * 4}, {s->off.data(), (U + 1) * 8}, {post.data(), post.size() * 8},
+                         {s->chunk_of_rank.data(), s->ranked ? (size_t)s->n * 4 : 0}};
+    size_t total = 0;
+    for (const Sec& c : secs) total += pad8(c.bytes);
+    SparseFileHeader h{};
+    memcpy(h.magic, kSparseMagic, 8);
+    h.version = 1;
+    h.ranked = s->ranked ? 1u : 0u;
+    h.chunks = s->n; h.tokens = U; h.postings = s->n_postings; h.generation = generation;
+    cqs_persist::Checksum ck(total);
+    const std::string live(path), tmp = live + ".tmp";
+    const int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    if (fd < 0) return sfail(s, CQS_HIP_ERR_INVALID, "sparse save: cannot create " + tmp);
+    bool ok = cqs_persist::write_all(fd, &h, sizeof h);           // checksum patched in below
+    const uint64_t zero = 0;
+    for (int i = 0; i < 4 && ok; ++i) {
+        const size_t padded = pad8(secs[i].bytes);
+        if (padded == secs[i].bytes) {
+            ck.update(secs[i].p, secs[i].bytes, false);
+            ok = cqs_persist::write_all(fd, secs[i].p, secs[i].bytes);
+        } else {                                                  // (only a u32 section of odd length: copy its last word)
+            const size_t whole = secs[i].bytes & ~(size_t)7;
+            ck.update(secs[i].p, whole, false);
+            uint64_t tail = 0;
+            memcpy(&tail, (const uint8_t*)secs[i].p + whole, secs[i].bytes - whole);
+            ck.update(&tail, 8, false);
+            ok = cqs_persist::write_all(fd, secs[i].p, secs[i].bytes) && cqs_persist::write_all(fd, &zero, padded - secs[i].bytes);
+        }
+    }
+    ck.update(nullptr, 0, true);
+    h.checksum = ck.finish();
+    ok = ok && lseek(fd, 0, SEEK_SET) == 0 && cqs_persist::write_all(fd, &h, sizeof h) && fsync(fd) == 0;
+    close(fd);
+    if (!ok) { unlink(tmp.c_str()); return sfail(s, CQS_HIP_ERR_INVALID, "sparse save: write failed"); }
+    if (rename(tmp.c_str(), live.c_str()) != 0) { unlink(tmp.c_str()); return sfail(s, CQS_HIP_ERR_INVALID, "sparse save: rename failed"); }
+    cqs_persist::fsync_parent(live);
+    if (out_checksum) *out_checksum = h.checksum;
+    return CQS_HIP_OK;
+} CQS_ABI_CATCH(s)
+
+int32_t cqs_hip_sparse_index_load(const char* path, uint64_t expected_chunks, uint64_t generation, int32_t device,
+                                  cqs_hip_sparse_index** out) CQS_ABI_TRY {
+    if (!out) return CQS_HIP_ERR_INVALID;
+    *out = nullptr;
+    if (!path) return CQS_HIP_ERR_INVALID;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return CQS_HIP_ERR_NO_DEVICE;
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return CQS_HIP_ERR_INVALID;                        // missing file: the caller builds (index.rs:1073-1107)
+    struct Closer { int fd; ~Closer() { close(fd); } } closer{fd};
+    SparseFileHeader h;
+    struct stat st;
+    if (fstat(fd, &st) != 0 || !cqs_persist::read_all(fd, &h, sizeof h)) return CQS_HIP_ERR_INVALID;
+    if (memcmp(h.magic, kSparseMagic, 8) != 0 || h.version != 1 || h.ranked > 1) return CQS_HIP_ERR_INVALID;
+    if (h.generation != generation) return CQS_HIP_ERR_INVALID;    // the store changed since the file was written (index.rs:1011-1019)
+    if (expected_chunks && h.chunks != expected_chunks) return CQS_HIP_ERR_INVALID;
+    if (h.chunks >= 0xFFFFFFFFull - kSparsePad || h.tokens > 0xFFFFFFFFull || h.postings > (1ull << 40)) return CQS_HIP_ERR_INVALID;
+    const size_t b_tok = (size_t)h.tokens * 4, b_off = ((size_t)h.tokens + 1) * 8, b_post = (size_t)h.postings * 8,
+                 b_rank = h.ranked ? (size_t)h.chunks * 4 : 0;
+    const size_t total = pad8(b_tok) + pad8(b_off) + pad8(b_post) + pad8(b_rank);
+    if ((uint64_t)st.st_size != sizeof h + total) return CQS_HIP_ERR_INVALID;     // truncated or grown
+    cqs_hip_sparse_index* s = new cqs_hip_sparse_index();
+    CreateGuard guard{s};
+    s->device = device;
+    s->n = h.chunks;
+    s->n_postings = h.postings;
+    s->n_pad = (uint32_t)((h.chunks + kSparsePad - 1) / kSparsePad * kSparsePad);
+    if (s->n_pad == 0) s->n_pad = kSparsePad;
+    s->ranked = h.ranked != 0;
+    std::vector<uint64_t> tokbuf(pad8(b_tok) / 8), rankbuf(pad8(b_rank) / 8);
+    s->off.resize((size_t)h.tokens + 1);
+    std::vector<uint2> post((size_t)h.postings);
+    cqs_persist::Checksum ck(total);
+    if (!cqs_persist::read_all(fd, tokbuf.data(), tokbuf.size() * 8) || !cqs_persist::read_all(fd, s->off.data(), b_off) ||
+        !cqs_persist::read_all(fd, post.data(), b_post) || !cqs_persist::read_all(fd, rankbuf.data(), rankbuf.size() * 8))
+        return CQS_HIP_ERR_INVALID;
+    ck.update(tokbuf.data(), tokbuf.size() * 8, false);
+    ck.update(s->off.data(), b_off, false);
+    ck.update(post.data(), b_post, false);
+    ck.update(rankbuf.data(), rankbuf.size() * 8, false);
+    ck.update(nullptr, 0, true);
+    if (ck.finish() != h.checksum) return CQS_HIP_ERR_INVALID;     // corrupt body (index.rs:1035-1049)
+    // structure: what the kernels rely on - ascending distinct tokens, offsets that tile the postings, positions inside the
+    // index and ascending inside every list, a permutation for the id order
+    s->tok.resize((size_t)h.tokens);
+    memcpy(s->tok.data(), tokbuf.data(), b_tok);
+    for (size_t t = 1; t < s->tok.size(); ++t)
+        if (s->tok[t] <= s->tok[t - 1]) return CQS_HIP_ERR_INVALID;
+    if (s->off[0] != 0 || s->off[(size_t)h.tokens] != h.postings) return CQS_HIP_ERR_INVALID;
+    for (size_t t = 0; t < (size_t)h.tokens; ++t) {
+        if (s->off[t + 1] < s->off[t] || s->off[t + 1] > h.postings) return CQS_HIP_ERR_INVALID;
+        for (uint64_t e = s->off[t]; e < s->off[t + 1]; ++e) {
+            if (post[e].x >= h.chunks || (e > s->off[t] && post[e].x < post[e - 1].x) || post[e].y == kUnscored) return CQS_HIP_ERR_INVALID;
+        }
+    }
+    if (s->ranked) {
+        s->chunk_of_rank.resize((size_t)h.chunks);
+        memcpy(s->chunk_of_rank.data(), rankbuf.data(), b_rank);
+        std::vector<uint8_t> seen((size_t)h.chunks, 0);
+        for (uint32_t c : s->chunk_of_rank) {
+            if (c >= h.chunks || seen[c]) return CQS_HIP_ERR_INVALID;
+            seen[c] = 1;
+        }
+    }
     const int32_t rc = finish_create(s, post, device);
     if (rc != CQS_HIP_OK) return rc;
     guard.p = nullptr;

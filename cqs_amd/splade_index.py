@@ -124,6 +124,44 @@ class HipSpladeIndex:
             raise HipError(rc, "cqs_hip_sparse_index_create_inverted failed")
         return cls(h.value, None if id_map is None else list(id_map))
 
+    # ---- persistence (SpladeIndex::save / load / load_or_build, index.rs:346-1107) -------------
+    def save(self, path: str, generation: int) -> int:
+        """-> the content checksum.  Raises HipError when the file cannot be written."""
+        ck = C.c_uint64()
+        rc = self._lib.cqs_hip_sparse_index_save(self._h, str(path).encode(), int(generation), C.byref(ck))
+        if rc != _lib.OK:
+            raise HipError(rc, "cqs_hip_sparse_index_save failed")
+        return int(ck.value)
+
+    @classmethod
+    def load(cls, path: str, generation: int, id_map: Optional[List[str]] = None, device: int = 0) -> Optional["HipSpladeIndex"]:
+        """`Ok(None)` of the reference = None here: missing file, another generation, anything damaged - the caller rebuilds."""
+        lib = _lib.load()
+        h = C.c_void_p()
+        rc = lib.cqs_hip_sparse_index_load(str(path).encode(), 0 if id_map is None else len(id_map), int(generation), device, C.byref(h))
+        if rc != _lib.OK or not h.value:
+            return None
+        return cls(h.value, None if id_map is None else list(id_map))
+
+    @classmethod
+    def load_or_build(cls, path: str, generation: int, rows: Callable[[], Sequence[Tuple[str, SparseVector]]],
+                      device: int = 0) -> Tuple["HipSpladeIndex", bool]:
+        """`SpladeIndex::load_or_build(path, generation, rows)` (index.rs:1073-1107) -> (index, rebuilt): the persisted
+        file when it is current, else built from `rows()` and persisted (a failed save is logged, not fatal).  The chunk ids
+        are not in the file: `rows()` is only called for a rebuild, so a loaded index takes its id_map from the caller's
+        `ids` attribute when `rows` carries one (`rows.ids`), else stays integer-addressed."""
+        ids = getattr(rows, "ids", None)
+        got = cls.load(path, generation, ids, device)
+        if got is not None:
+            return got, False
+        idx = cls.build(list(rows()), device)
+        try:
+            idx.save(path, generation)
+        except HipError as e:           # "SPLADE index persist failed, continuing with in-memory index only" (index.rs:1097-1104)
+            import logging
+            logging.getLogger("cqs.hip").warning("sparse index persist failed: %s", e)
+        return idx, True
+
     # ---- properties -----------------------------------------------------------
     def __len__(self) -> int:
         return int(self._lib.cqs_hip_sparse_index_len(self._h))

@@ -443,6 +443,16 @@ int32_t cqs_hip_sparse_index_create(const uint64_t* doc_off, const uint32_t* tok
 int32_t cqs_hip_sparse_index_create_inverted(const uint32_t* token_ids, const uint64_t* list_off, const uint32_t* post_chunks,
                                              const float* post_weights, uint64_t n_tokens, uint64_t n, const uint32_t* id_rank,
                                              int32_t device, cqs_hip_sparse_index** out);
+/* Persistence - the role of `SpladeIndex::save` / `load` / `load_or_build` (index.rs:346-1107): a restart skips the rebuild; the
+ * file is tied to the store's `splade_generation` counter (bumped on every write to `sparse_vectors`).  OWN format (the
+ * reference's blake3-checksummed `splade.index.bin` is neither read nor written): 64-byte header {magic "CQSHIPS1", version,
+ * ranked, chunks, tokens, postings, generation, checksum} + token ids, list offsets, postings and the id order, written to
+ * `<path>.tmp`, fsync'ed and renamed over `path`.  load: wrong magic / version / generation / chunk count (expected_chunks
+ * 0 = any) / size / checksum / structure -> CQS_HIP_ERR_INVALID, *out stays NULL and the caller builds from the rows
+ * (index.rs:1073-1107); a missing file likewise. */
+int32_t cqs_hip_sparse_index_save(cqs_hip_sparse_index* idx, const char* path, uint64_t generation, uint64_t* out_checksum);
+int32_t cqs_hip_sparse_index_load(const char* path, uint64_t expected_chunks, uint64_t generation, int32_t device,
+                                  cqs_hip_sparse_index** out);
 void     cqs_hip_sparse_index_destroy(cqs_hip_sparse_index* idx);
 uint64_t cqs_hip_sparse_index_len(const cqs_hip_sparse_index* idx);            /* index.rs:294-296 */
 uint64_t cqs_hip_sparse_index_unique_tokens(const cqs_hip_sparse_index* idx);  /* index.rs:304-306 */

@@ -46,6 +46,8 @@ extern "C" {
         device: i32,
         out: *mut *mut CqsHipSparseIndex,
     ) -> i32;
+    fn cqs_hip_sparse_index_save(idx: *mut CqsHipSparseIndex, path: *const c_char, generation: u64, out_checksum: *mut u64) -> i32;
+    fn cqs_hip_sparse_index_load(path: *const c_char, expected_chunks: u64, generation: u64, device: i32, out: *mut *mut CqsHipSparseIndex) -> i32;
     fn cqs_hip_sparse_index_destroy(idx: *mut CqsHipSparseIndex);
     fn cqs_hip_sparse_index_len(idx: *const CqsHipSparseIndex) -> u64;
     fn cqs_hip_sparse_index_unique_tokens(idx: *const CqsHipSparseIndex) -> u64;
@@ -163,6 +165,25 @@ impl HipSpladeIndex {
             return None;
         }
         Some(Self { raw, id_map: id_map.to_vec() })
+    }
+
+    /// `SpladeIndex::save` (index.rs:346): the device-ready arrays under `path` (own format), tied to `generation`.
+    pub fn save(&self, path: &std::path::Path, generation: u64) -> bool {
+        let Ok(c) = std::ffi::CString::new(path.to_string_lossy().as_bytes()) else { return false };
+        let mut ck = 0u64;
+        unsafe { cqs_hip_sparse_index_save(self.raw, c.as_ptr(), generation, &mut ck) == CQS_HIP_OK }
+    }
+
+    /// `SpladeIndex::load` (index.rs:677): `None` = missing / stale generation / damaged - rebuild.  The id map comes from
+    /// the store (`chunk ids in index order`), as for the dense index's sidecar.
+    pub fn load(path: &std::path::Path, generation: u64, id_map: Vec<Box<str>>, device: i32) -> Option<Self> {
+        let c = std::ffi::CString::new(path.to_string_lossy().as_bytes()).ok()?;
+        let mut raw: *mut CqsHipSparseIndex = std::ptr::null_mut();
+        let rc = unsafe { cqs_hip_sparse_index_load(c.as_ptr(), id_map.len() as u64, generation, device, &mut raw) };
+        if rc != CQS_HIP_OK || raw.is_null() {
+            return None;
+        }
+        Some(Self { raw, id_map })
     }
 
     /// Search the inverted index (unfiltered).

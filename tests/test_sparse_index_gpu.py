@@ -368,3 +368,65 @@ def test_nan_payloads_next_to_the_marker(S, oracle):
         assert rc == 0 and np.array_equal(hc, oc) and np.array_equal(hs.view(np.uint32), os_.view(np.uint32))
         assert list(hc) == [1]                                 # only the chunk without a NaN weight survives
     h.close()
+
+
+def test_persistence_round_trip_and_rejections(S, oracle, tmp_path):
+    """save / load / load_or_build in the library's own format, after the reference's persistence tests (index.rs:1243-1375,
+    :1646-1700): a round trip answers bit for bit like the index it came from (ranked and unranked); another generation, a
+    bad magic, a flipped body byte, a truncated file and a missing file all load as "rebuild"; load_or_build persists on the
+    first call and loads on the second; a save over a live file replaces it atomically."""
+    rng = np.random.default_rng(612)
+    n = 7000
+    off, tok, w = sc.corpus(rng, n, 900, 5, 50, dup_frac=0.2, special=True)
+    ids = ["k%05d" % i for i in rng.permutation(n)]
+    o = oracle.SpladeIndex(off, tok, w, ids=ids)
+    a = S.HipSpladeIndex.build_from_csr(ids, off, tok, w)
+    path = tmp_path / "splade.hip.bin"
+    ck = a.save(path, generation=41)
+    assert ck != 0 and path.exists() and not (tmp_path / "splade.hip.bin.tmp").exists()
+    b = S.HipSpladeIndex.load(path, 41, ids)
+    assert b is not None and len(b) == n and b.unique_tokens() == a.unique_tokens() and b.postings() == a.postings()
+    for _ in range(3):
+        qt, qw = sc.query(rng, 900, 40)
+        keep = rng.random(n) < 0.5
+        for kp in (None, keep):
+            bc, bs, rc = b.search_raw(qt, qw, 300, kp)
+            oc, os_ = o.search_raw(qt, qw, 300, kp)
+            assert rc == 0 and np.array_equal(bc, oc) and np.array_equal(bs.view(np.uint32), os_.view(np.uint32))
+    b.close()
+    assert S.HipSpladeIndex.load(path, 42, ids) is None                          # generation mismatch (index.rs:1279-1297)
+    assert S.HipSpladeIndex.load(path, 41, ids[:-1]) is None                     # another chunk count
+    assert S.HipSpladeIndex.load(tmp_path / "nothing.bin", 41, ids) is None      # missing file (index.rs:1333-1338)
+    raw = path.read_bytes()
+    (tmp_path / "magic.bin").write_bytes(b"NOTASPDX" + raw[8:])
+    assert S.HipSpladeIndex.load(tmp_path / "magic.bin", 41, ids) is None        # bad magic (index.rs:1300-1310)
+    flipped = bytearray(raw); flipped[len(raw) // 2] ^= 0x40
+    (tmp_path / "corrupt.bin").write_bytes(bytes(flipped))
+    assert S.HipSpladeIndex.load(tmp_path / "corrupt.bin", 41, ids) is None      # corrupt body (index.rs:1313-1330)
+    (tmp_path / "short.bin").write_bytes(raw[:-16])
+    assert S.HipSpladeIndex.load(tmp_path / "short.bin", 41, ids) is None        # truncated
+    # unranked index (integer ids) round trip
+    u = S.HipSpladeIndex.build_from_csr(None, off, tok, w)
+    u.save(tmp_path / "u.bin", 1)
+    u2 = S.HipSpladeIndex.load(tmp_path / "u.bin", 1)
+    qt, qw = sc.query(rng, 900, 30)
+    assert all(np.array_equal(x, y) for x, y in zip(u.search_raw(qt, qw, 100)[:2], u2.search_raw(qt, qw, 100)[:2]))
+    u.close(); u2.close()
+    # load_or_build (index.rs:1341-1375): first call builds + persists, second call loads
+    chunks = [(ids[i], [(int(tok[e]), float(w[e])) for e in range(int(off[i]), int(off[i + 1]))]) for i in range(300)]
+    calls = []
+    def rows():
+        calls.append(1)
+        return chunks
+    rows.ids = [c for c, _ in chunks]
+    p2 = tmp_path / "lob.bin"
+    i1, rebuilt1 = S.HipSpladeIndex.load_or_build(p2, 7, rows)
+    i2, rebuilt2 = S.HipSpladeIndex.load_or_build(p2, 7, rows)
+    i3, rebuilt3 = S.HipSpladeIndex.load_or_build(p2, 8, rows)                   # the store moved on: rebuild + replace
+    assert (rebuilt1, rebuilt2, rebuilt3) == (True, False, True) and len(calls) == 2
+    q = [(int(tok[0]), 1.0), (int(tok[5]), 0.5)]
+    r1 = [(r.id, r.score) for r in i1.search(q, 50)]
+    assert r1 == [(r.id, r.score) for r in i2.search(q, 50)] == [(r.id, r.score) for r in i3.search(q, 50)] and r1
+    assert S.HipSpladeIndex.load(p2, 8, rows.ids) is not None and S.HipSpladeIndex.load(p2, 7, rows.ids) is None   # atomic replace
+    for x in (a, i1, i2, i3):
+        x.close()
