@@ -430,3 +430,69 @@ def test_persistence_round_trip_and_rejections(S, oracle, tmp_path):
     assert S.HipSpladeIndex.load(p2, 8, rows.ids) is not None and S.HipSpladeIndex.load(p2, 7, rows.ids) is None   # atomic replace
     for x in (a, i1, i2, i3):
         x.close()
+
+
+def _forge_sparse_file(path, chunks, tok, off, post, rank=None, generation=1, fix_checksum=True):
+    """A file in the library's sparse-index format with a VALID checksum (the multiply-rotate hash of persist_util.h restated
+    here), whatever its sections hold - to reach the loader's structure checks behind the checksum."""
+    import struct
+    M = (1 << 64) - 1
+    P1, P2 = 0x9E3779B185EBCA87, 0xC2B2AE3D27D4EB4F
+
+    def pad8(b):
+        return b + b"\0" * (-len(b) % 8)
+
+    secs = [pad8(np.asarray(tok, np.uint32).tobytes()), pad8(np.asarray(off, np.uint64).tobytes()),
+            pad8(np.asarray(post, np.uint32).reshape(-1, 2).tobytes() if len(post) else b""),
+            pad8(np.asarray(rank, np.uint32).tobytes()) if rank is not None else b""]
+    body = b"".join(secs)
+    h = 0x27D4EB2F165667C5 ^ len(body)
+    for (w,) in struct.iter_unpack("<Q", body):
+        h ^= (w * P1) & M
+        h = ((((h << 31) | (h >> 33)) & M) * P2) & M
+    h ^= h >> 29; h = (h * P2) & M; h ^= h >> 32
+    if not fix_checksum:
+        h ^= 1
+    header = struct.pack("<8sIIQQQQQ8s", b"CQSHIPS1", 1, 1 if rank is not None else 0, chunks, len(tok), len(post), generation, h, b"\0" * 8)
+    assert len(header) == 64
+    open(path, "wb").write(header + body)
+
+
+def test_loader_rejects_forged_structure(S, tmp_path):
+    """The loader is handed a file from disk: behind a matching checksum it still re-checks everything the kernels rely on
+    (they index LDS by posting position).  A well-formed forged file loads and answers; each single defect - a position past
+    the end, a descending list, offsets that do not tile the postings, a repeated token, an id order that is not a
+    permutation, the reserved weight pattern - makes the load answer "rebuild", never a handle."""
+    one = np.float32(1.0).view(np.uint32).item()
+    good = dict(chunks=6, tok=[3, 9], off=[0, 3, 5], post=[(0, one), (2, one), (5, one), (1, one), (2, one)])
+    p = tmp_path / "ok.bin"
+    _forge_sparse_file(p, **good)
+    h = S.HipSpladeIndex.load(p, 1)
+    assert h is not None and len(h) == 6 and h.unique_tokens() == 2 and h.postings() == 5
+    c, s_, rc = h.search_raw([3, 9], [1.0, 2.0], 10)
+    assert rc == 0 and list(c) == [2, 1, 0, 5] and list(s_) == [3.0, 2.0, 1.0, 1.0]
+    h.close()
+    _forge_sparse_file(p, **good, rank=[5, 4, 3, 2, 1, 0])
+    h = S.HipSpladeIndex.load(p, 1)
+    assert h is not None and list(h.search_raw([3], [1.0], 10)[0]) == [5, 3, 0]     # positions 0, 2, 5 are chunks 5, 3, 0; ties by position
+    h.close()
+    bad = {
+        "position past the end": dict(good, post=[(0, one), (2, one), (6, one), (1, one), (2, one)]),
+        "descending list": dict(good, post=[(2, one), (0, one), (5, one), (1, one), (2, one)]),
+        "offsets do not tile": dict(good, off=[0, 4, 4]),
+        "offsets run past the postings": dict(good, off=[0, 6, 5]),
+        "repeated token": dict(good, tok=[3, 3]),
+        "descending tokens": dict(good, tok=[9, 3]),
+        "reserved weight pattern": dict(good, post=[(0, one), (2, 0xFFFFFFFF), (5, one), (1, one), (2, one)]),
+    }
+    for name, spec in bad.items():
+        _forge_sparse_file(p, **spec)
+        assert S.HipSpladeIndex.load(p, 1) is None, name
+    _forge_sparse_file(p, **good, rank=[0, 1, 2, 3, 4, 4])
+    assert S.HipSpladeIndex.load(p, 1) is None                                       # not a permutation
+    _forge_sparse_file(p, **good, rank=[0, 1, 2, 3, 4, 9])
+    assert S.HipSpladeIndex.load(p, 1) is None
+    _forge_sparse_file(p, **good, fix_checksum=False)
+    assert S.HipSpladeIndex.load(p, 1) is None                                       # and the checksum itself
+    _forge_sparse_file(p, **good)
+    assert S.HipSpladeIndex.load(p, 1) is not None                                   # (the forger is sound)
