@@ -80,10 +80,10 @@ extern "C" {
     fn cqs_hip_sparse_index_last_error(idx: *const CqsHipSparseIndex, buf: *mut c_char, cap: usize) -> usize;
 }
 
-/// In-HBM inverted index for SPLADE sparse vectors.
+/// The sparse retrieval leg with its postings resident on the GPU (`SpladeIndex`'s surface).
 pub struct HipSpladeIndex {
     raw: *mut CqsHipSparseIndex,
-    /// Sequential chunk ID map (chunk_index -> chunk_id), as `SpladeIndex::id_map`.
+    /// chunk id of every position of the build order - the library answers in positions.
     id_map: Vec<Box<str>>,
 }
 
@@ -186,7 +186,7 @@ impl HipSpladeIndex {
         Some(Self { raw, id_map })
     }
 
-    /// Search the inverted index (unfiltered).
+    /// `SpladeIndex::search` (index.rs:214-216): every chunk is a candidate.
     pub fn search(&self, query: &SparseVector, k: usize) -> Vec<IndexResult> {
         self.search_with_filter(query, k, &|_: &str| true)
     }
@@ -276,17 +276,17 @@ impl HipSpladeIndex {
         all
     }
 
-    /// Number of chunks in the index.
+    /// `SpladeIndex::len` (index.rs:294-296).
     pub fn len(&self) -> usize {
         unsafe { cqs_hip_sparse_index_len(self.raw) as usize }
     }
 
-    /// Whether the index is empty.
+    /// `SpladeIndex::is_empty` (index.rs:299-301).
     pub fn is_empty(&self) -> bool {
         self.len() == 0
     }
 
-    /// Number of unique tokens in the vocabulary.
+    /// `SpladeIndex::unique_tokens` (index.rs:304-306): tokens that own a posting list.
     pub fn unique_tokens(&self) -> usize {
         unsafe { cqs_hip_sparse_index_unique_tokens(self.raw) as usize }
     }
