@@ -67,3 +67,57 @@ def test_single_gpu_line_carries_the_same_keys(hip):
     assert p.returncode == 0, p.stderr[-3000:]
     d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
     assert d["config"]["ranks_seen"] == 1 and d["prewarm_steps"] == 200 and "rehearsal" not in d and d["n_gpus"] == 1
+
+
+DRIVER_CMD = ["--gpus", "1", "--steps", "20", "--warmup", "5"]       # what the driver runs at round end, verbatim
+TOP_LEVEL = ["roofline", "cpu_baseline", "latency_host_api", "concurrent_clients", "other_configs", "abi_sharded",
+             "strong_scaling_n1", "embed", "e2e", "aux_models", "sparse_index"]
+
+
+def _errors_in(x, path=""):
+    """Every {"error": ...} / {"skipped": ...} anywhere under a leg's key."""
+    out = []
+    if isinstance(x, dict):
+        for key in ("error", "skipped"):
+            if key in x:
+                out.append((path, key, x[key]))
+        for k, v in x.items():
+            out += _errors_in(v, path + "/" + str(k))
+    return out
+
+
+def test_the_drivers_command_with_every_leg_on(hip):
+    """VERDICT r04 #1c: `bench.py --gpus 1 --steps 20 --warmup 5` with extras ON (round 4's line died in a leg that no test
+    ran at the driver's --steps).  Sizes are scaled by flags only; every top-level key must be there, non-null, error-free."""
+    scale = ["--rows", "200000", "--sparse-chunks", "200000", "--e2e-chunks", "2000", "--embed-steps", "2", "--cpu-seconds", "0.5",
+             "--strict", "1"]
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + DRIVER_CMD + scale, cwd=ROOT, env=dict(os.environ),
+                       capture_output=True, text=True, timeout=900)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, (p.returncode, p.stdout[-1500:], p.stderr[-3000:])
+    d = json.loads(lines[0])
+    assert d["leg_errors"] is None and p.returncode == 0, (d["leg_errors"], p.stderr[-3000:])
+    assert d["steps"] == 20 and d["warmup"] == 5 and d["n_gpus"] == 1 and d["value"] > 0
+    for key in TOP_LEVEL:
+        assert d.get(key), key
+        assert not _errors_in(d[key]), (key, _errors_in(d[key]))
+    assert d["sparse_index"]["hybrid"]["two_threads_ms_per_query"] > 0            # the sub-leg that crashed round 4
+    assert d["roofline"]["frac"] > 0 and d["cpu_baseline"]["value"] > 0
+    assert d["embed"]["cpu_baseline"]["chunks_per_sec"] > 0 and d["e2e"]["recall_vs_cpu_oracle"]["R@5"] > 0.9
+
+
+def test_a_failing_leg_does_not_cost_the_line(hip):
+    """VERDICT r04 #1b: an exception inside a leg becomes {"error": ...} under that leg's key; headline, roofline and
+    cpu_baseline still print; `--strict 1` turns it into exit status 3 AFTER the line."""
+    env = dict(os.environ)
+    env["CQS_BENCH_FAIL_LEG"] = "concurrent_clients"          # test hook of Legs.run: that leg raises before it starts
+    args = ["--rows", "100000", "--embed-steps", "0", "--e2e-chunks", "0", "--sparse-chunks", "0", "--cpu-seconds", "0.3",
+            "--abi-devices", ""]
+    for strict, rc in (("0", 0), ("1", 3)):
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + DRIVER_CMD + args + ["--strict", strict], cwd=ROOT, env=env,
+                           capture_output=True, text=True, timeout=600)
+        lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+        assert p.returncode == rc and len(lines) == 1, (p.returncode, p.stderr[-2000:])
+        d = json.loads(lines[0])
+        assert "concurrent_clients" in d["leg_errors"] and "error" in d["concurrent_clients"]
+        assert d["value"] > 0 and d["roofline"]["frac"] > 0 and d["cpu_baseline"]["value"] > 0 and d["other_configs"]["k500_1M"]["checked"]

@@ -3,12 +3,12 @@
 import argparse, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
-import bench
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--embed-steps", type=int, default=8)
 a = ap.parse_args()
-out = bench.aux_models_leg(a, np)
+from bench_legs.aux_models import aux_models_leg
+out = aux_models_leg(a, np)
 for k, v in out.items():
     if isinstance(v, dict):
         print(k, json.dumps({kk: vv for kk, vv in v.items() if "per_sec" in kk or kk in ("ms_per_batch", "sync_api", "tflops")}))
