@@ -34,14 +34,45 @@ def abi_sharded_leg(a, torch, np, rows, queries, k, dim):
             assert np.array_equal(r1, res[i][0])
     info = sh.shards()
     single.close()
+    clients = None
+    if getattr(a, "extras", 1):
+        clients = sharded_clients(np, sh, qh[:48], [r[0][0] for r in res[:48]], [r[1][0] for r in res[:48]], k, dim)
     sh.close()
     return {"devices": devs, "shards": [{"device": d, "rows": r, "rccl": rc} for d, _f, r, rc in info],
             "queries_per_sec_host_api": round(nq / el, 1), "ms_per_query": round(el / nq * 1e3, 4),
             "single_device_same_queries": {"queries_per_sec_host_api": round(nq / el1, 1), "ms_per_query": round(el1 / nq * 1e3, 4)},
             "vs_single_device": round(el1 / el, 4), "queries": nq,
-            "build_s": round(t_build, 2), "checked_vs_single_device": True, "checked": True,
+            "build_s": round(t_build, 2), "checked_vs_single_device": True, "checked": True, "concurrent_clients": clients,
             "what": "cqs_hip_index_create_sharded -> per-shard scan + select -> gather -> host merge, blocking host API, "
                     "one query per call; a device named more than once gathers without RCCL (one-GPU form)"}
+
+
+def sharded_clients(np, sh, q, want_rows, want_scores, k, dim):
+    """Concurrent single-query callers on the SHARDED handle (round 5: its own combining queue): N native
+    threads, each one blocking cqs_hip_index_search(b = 1) at a time; every answer compared bit for bit with the lone call's."""
+    import ctypes as C
+    storm = sh._lib.cqs_hip_debug_client_storm
+    storm.restype = C.c_double
+    storm.argtypes = [C.c_void_p, C.c_void_p] + [C.c_uint32] * 5 + [C.c_void_p] * 3
+    q = np.ascontiguousarray(q, dtype=np.float32)
+    nq = q.shape[0]
+    want_r, want_s = np.stack(want_rows), np.stack(want_scores)
+    out = {"what": "N native threads on the sharded handle, one blocking cqs_hip_index_search(b = 1) each at a time; every answer "
+                   "bit-identical to the lone call's (checked)", "native_threads": {}}
+    for T in (1, 4, 8, 16):
+        per = max(40, 960 // T)
+        rows = np.zeros((nq, k), np.uint64)
+        scores = np.zeros((nq, k), np.float32)
+        counts = np.zeros((nq,), np.uint32)
+        storm(sh._h, q.ctypes.data, nq, dim, k, T, 16, rows.ctypes.data, scores.ctypes.data, counts.ctypes.data)   # warm
+        p0, q0 = sh.combine_stats()
+        el = storm(sh._h, q.ctypes.data, nq, dim, k, T, per, rows.ctypes.data, scores.ctypes.data, counts.ctypes.data)
+        p1, q1 = sh.combine_stats()
+        assert el > 0, "a client call failed"
+        assert np.all(counts == k) and np.array_equal(rows, want_r) and np.array_equal(scores, want_s), "combined sharded answers differ from the lone call's"
+        out["native_threads"][str(T)] = {"queries_per_sec": round(T * per / el, 1), "ms_per_call": round(el / per * 1e3, 4),
+                                          "mean_callers_per_pass": round((q1 - q0) / max(p1 - p0, 1), 2), "checked": True}
+    return out
 
 
 def abi_after_group_leg(a, torch, np, world, k, dim, rows_per_device=250_000, budget_s=150.0):

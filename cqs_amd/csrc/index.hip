@@ -52,8 +52,8 @@ int32_t fail(cqs_hip_index* idx, int32_t code, const char* what, hipError_t e) {
 }
 
 void free_scratch(cqs_hip_index* x) {
-    hipFree(x->d_q); hipFree(x->d_scores); hipFree(x->d_gmax); hipFree(x->d_work);
-    x->d_work = nullptr;
+    hipFree(x->d_q); hipFree(x->d_scores); hipFree(x->d_gmax); hipFree(x->d_work); hipFree(x->d_gaux);
+    x->d_work = nullptr; x->d_gaux = nullptr;
     hipFree(x->d_out_keys); hipFree(x->d_out_counts);
     hipHostFree(x->h_q); hipHostFree(x->h_out_keys); hipHostFree(x->h_out_counts);
     x->d_q = x->d_scores = nullptr; x->d_gmax = nullptr;
@@ -78,6 +78,9 @@ int32_t ensure_scratch(cqs_hip_index* x, uint32_t b, uint32_t k) {
     // work-queue heads must be zero on entry; every search re-zeroes them
     HIP_TRY(x, hipMemset(x->d_work, 0, cqs::kWorkWords * sizeof(uint32_t)));
     HIP_TRY(x, hipMalloc(&x->d_gmax, (size_t)qc * (n_pad / cqs::kTaskRowsSmall) * sizeof(float)));
+    // (argmax, runner-up) per task: gemv blocks only (<= kGauxQueries queries; larger blocks run on the matrix cores or,
+    // gemv_only, without it)
+    HIP_TRY(x, hipMalloc(&x->d_gaux, (size_t)(qc < kGauxQueries ? qc : kGauxQueries) * (n_pad / cqs::kTaskRowsSmall) * sizeof(uint64_t)));
     HIP_TRY(x, hipMalloc(&x->d_out_keys, (size_t)qc * kc * sizeof(uint64_t)));
     HIP_TRY(x, hipMalloc(&x->d_out_counts, (size_t)qc * sizeof(uint32_t)));
     HIP_TRY(x, hipHostMalloc(&x->h_q, (size_t)qc * x->dim * sizeof(float), hipHostMallocDefault));
@@ -132,6 +135,7 @@ int32_t enqueue_search(cqs_hip_index* x, const float* d_q, uint32_t b, uint32_t 
     a.linear_bins = (x->metric == CQS_HIP_METRIC_COSINE) || (mode == CQS_HIP_MODE_PIPELINE);
     a.k = k;
     a.gmax = x->d_gmax;
+    a.gaux = b <= kGauxQueries ? x->d_gaux : nullptr;
     a.work = x->d_work;
     a.n_cu = x->n_cu;
     a.dbg = x->d_dbg;
@@ -179,6 +183,11 @@ int32_t stage_keep(cqs_hip_index* x, const uint32_t* host_words, uint64_t words)
     return CQS_HIP_OK;
 }
 
+void read_combine_env(cqs_hip_index* x) {                                              // read once per handle
+    if (const char* ce = getenv("CQS_HIP_COMBINE")) x->combine = ce[0] != '0';
+    if (const char* cw = getenv("CQS_HIP_COMBINE_WAIT_US")) x->combine_wait_us = (uint32_t)atoi(cw);
+}
+
 int32_t create_common(uint64_t n, uint32_t dim, uint32_t metric, int32_t device, uint64_t row_base,
                       cqs_hip_index** out, cqs_hip_index** made) {
     if (!out) return CQS_HIP_ERR_INVALID;
@@ -197,8 +206,7 @@ int32_t create_common(uint64_t n, uint32_t dim, uint32_t metric, int32_t device,
         delete x;
         return CQS_HIP_ERR_DEVICE;
     }
-    if (const char* ce = getenv("CQS_HIP_COMBINE")) x->combine = ce[0] != '0';          // read once per handle
-    if (const char* cw = getenv("CQS_HIP_COMBINE_WAIT_US")) x->combine_wait_us = (uint32_t)atoi(cw);
+    read_combine_env(x);
     if (getenv("CQS_HIP_DEBUG_STAMPS")) {
         const size_t bytes = (16 + 2 * cqs::kDbgWaves) * sizeof(unsigned long long);
         if (hipMalloc(&x->d_dbg, bytes) == hipSuccess) (void)hipMemset(x->d_dbg, 0, bytes);
@@ -728,22 +736,31 @@ static uint32_t count_like_front(const cqs_hip_index* x) {
     return n;
 }
 
+// One sealed block on a single-device handle: the device mutex is taken here, for the pass alone.
+static int32_t combine_run_single(cqs_hip_index* x, cqs_combine_req* const* batch, uint32_t nb) {
+    std::lock_guard<std::mutex> dev(x->mu);       // (other entry points - device API searches, extend, save - order with the pass here)
+    if (x->poisoned.load(std::memory_order_acquire)) return CQS_HIP_ERR_POISONED;
+    HostQuery hq[kCombineCap];
+    for (uint32_t i = 0; i < nb; ++i) hq[i] = HostQuery{batch[i]->q, batch[i]->out_rows, batch[i]->out_scores, batch[i]->out_count};
+    return search_host_locked(x, hq, nb, batch[0]->k, nullptr, batch[0]->mode, batch[0]->thr, /*gemv_only=*/true);
+}
+
 // Lead one pass.  `lk` holds cmu on entry and on exit; x->leader is set by the caller.
 static void combine_lead(cqs_hip_index* x, std::unique_lock<std::mutex>& lk) {
-    lk.unlock();
-    std::unique_lock<std::mutex> dev(x->mu);       // the device is ours: the previous pass (or any other entry point) is over
-    lk.lock();
     // Stragglers: if recent passes carried more callers than are parked now, their threads are on their way back (a
-    // caller needs some tens of microseconds between getting its answer and asking again).  Waiting for them costs up to
-    // combine_wait_us once; scanning without them costs them a whole pass.  A lone caller never waits: expect is 1.
+    // caller needs some tens of microseconds between getting its answer and asking again).  Waiting for them costs a
+    // little once; scanning without them costs them a whole pass.  The window is anchored at the END OF THE PREVIOUS
+    // PASS (round 5), not at this leader's arrival: a caller that comes alone combine_wait_us or more after a burst does
+    // not wait at all (round 4: it paid the full wait once), and a lone caller never waits (expect is 1).  No device
+    // mutex is held meanwhile (round 4 spun inside x->mu): there is one leader at a time, so the device is only ever
+    // contended by the other entry points, and those must not queue behind a spin.
     const uint32_t target = x->expect < kCombineCap ? x->expect : kCombineCap;
     if (x->combine_wait_us && count_like_front(x) < target) {
-        const auto t_end = std::chrono::steady_clock::now() + std::chrono::microseconds(x->combine_wait_us);
-        for (;;) {
+        const auto t_end = x->last_pass_end + std::chrono::microseconds(x->combine_wait_us);
+        while (count_like_front(x) < target && std::chrono::steady_clock::now() < t_end) {
             lk.unlock();
             for (int i = 0; i < 64; ++i) __builtin_ia32_pause();
             lk.lock();
-            if (count_like_front(x) >= target || std::chrono::steady_clock::now() >= t_end) break;
         }
     }
     // seal the block: the oldest request and everything parked with its parameters, oldest first
@@ -766,25 +783,19 @@ static void combine_lead(cqs_hip_index* x, std::unique_lock<std::mutex>& lk) {
     lk.unlock();
 
     int32_t rc = CQS_HIP_OK;
-    bool poisoned = x->poisoned.load(std::memory_order_acquire);
-    if (poisoned) rc = CQS_HIP_ERR_POISONED;
-    else {
-        try {
-            HostQuery hq[kCombineCap];
-            for (uint32_t i = 0; i < nb; ++i) hq[i] = HostQuery{batch[i]->q, batch[i]->out_rows, batch[i]->out_scores, batch[i]->out_count};
-            rc = search_host_locked(x, hq, nb, batch[0]->k, nullptr, batch[0]->mode, batch[0]->thr, /*gemv_only=*/true);
-        } catch (const std::bad_alloc&) {
-            rc = fail(x, CQS_HIP_ERR_NOMEM, "search: out of host memory");
-        } catch (...) {
-            rc = fail(x, CQS_HIP_ERR_INVALID, "search: unexpected C++ exception");
-        }
-        x->stat_passes.fetch_add(1, std::memory_order_relaxed);
-        x->stat_queries.fetch_add(nb, std::memory_order_relaxed);
-        poisoned = x->poisoned.load(std::memory_order_acquire);
+    try {
+        rc = x->sh ? cqs_sharded::search_combined(x, batch, nb) : combine_run_single(x, batch, nb);
+    } catch (const std::bad_alloc&) {
+        rc = fail(x, CQS_HIP_ERR_NOMEM, "search: out of host memory");
+    } catch (...) {
+        rc = fail(x, CQS_HIP_ERR_INVALID, "search: unexpected C++ exception");
     }
-    dev.unlock();
+    x->stat_passes.fetch_add(1, std::memory_order_relaxed);
+    x->stat_queries.fetch_add(nb, std::memory_order_relaxed);
+    const bool poisoned = x->sh ? cqs_sharded::poisoned(x) != 0 : x->poisoned.load(std::memory_order_acquire);
 
     lk.lock();
+    x->last_pass_end = std::chrono::steady_clock::now();
     for (uint32_t i = 0; i < nb; ++i) {
         // the call that met the failure reports it; whoever rode along on a handle that is now poisoned gets what
         // any later call gets (src/cagra.rs:486-490)
@@ -831,12 +842,13 @@ int32_t cqs_hip_index_search(cqs_hip_index* x, const float* queries, uint32_t b,
                              float* out_scores, uint32_t* out_counts) CQS_ABI_TRY {
     CQS_ROCTX_RANGE("cqs_hip_index_search");
     if (!x) return CQS_HIP_ERR_INVALID;
-    if (x->sh) return cqs_sharded::search(x, queries, b, query_dim, k, keep_bitset, mode, threshold, out_rows, out_scores, out_counts);
     // One query, no filter, arguments in order: the combining queue (dim is immutable; everything else the locked
-    // path would check is checked here or inside the pass).
+    // path would check is checked here or inside the pass).  Round 5: a row-sharded parent takes it too - what a
+    // multi-GPU daemon binds - its block runs through every shard and the host merge (cqs_sharded::search_combined).
     if (x->combine && b == 1 && !keep_bitset && queries && out_counts && out_rows && out_scores && query_dim == x->dim &&
         k >= 1 && k <= kMaxK && mode <= CQS_HIP_MODE_PIPELINE) {
-        if (x->poisoned.load(std::memory_order_acquire)) return CQS_HIP_ERR_POISONED;  // src/cagra.rs:486-490
+        if (x->sh ? cqs_sharded::poisoned(x) != 0 : x->poisoned.load(std::memory_order_acquire))
+            return CQS_HIP_ERR_POISONED;                                               // src/cagra.rs:486-490
         out_counts[0] = 0;
         bool finite = true;
         for (uint32_t d = 0; d < query_dim; ++d) finite &= std::isfinite(queries[d]);
@@ -844,6 +856,7 @@ int32_t cqs_hip_index_search(cqs_hip_index* x, const float* queries, uint32_t b,
         cqs_combine_req r{queries, k, mode, threshold, out_rows, out_scores, out_counts};
         return combine_search(x, r);
     }
+    if (x->sh) return cqs_sharded::search(x, queries, b, query_dim, k, keep_bitset, mode, threshold, out_rows, out_scores, out_counts);
     std::lock_guard<std::mutex> g(x->mu);
     if (x->poisoned.load(std::memory_order_acquire)) return CQS_HIP_ERR_POISONED;  // src/cagra.rs:486-490
     if (b == 0) return CQS_HIP_OK;

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <deque>
 #include <mutex>
@@ -49,6 +50,7 @@ struct cqs_hip_index {
     unsigned long long* d_dbg = nullptr;  // CQS_HIP_DEBUG_STAMPS=1: select_finish phase stamps
     uint32_t n_cu = 256;
     float* d_gmax = nullptr;      // [q_cap, <= n_pad/16] per-task maxima (stride = tiers.total())
+    uint64_t* d_gaux = nullptr;   // [min(q_cap, kGauxQueries), <= n_pad/16] (argmax lane, runner-up) of each task (gemv blocks)
     uint64_t* d_out_keys = nullptr;
     uint32_t* d_out_counts = nullptr;
     uint32_t* d_keep = nullptr;
@@ -90,7 +92,8 @@ struct cqs_hip_index {
     bool leader = false;                  // somebody is collecting / running a combined pass
     uint32_t expect = 1;                  // callers the next pass should expect (what recent passes saw); guarded by cmu
     bool combine = true;                  // CQS_HIP_COMBINE=0: every caller takes the serial path
-    uint32_t combine_wait_us = 100;       // CQS_HIP_COMBINE_WAIT_US: longest a leader waits for expected stragglers
+    uint32_t combine_wait_us = 100;       // CQS_HIP_COMBINE_WAIT_US: how long after the END of a pass the next leader waits for the callers that pass carried
+    std::chrono::steady_clock::time_point last_pass_end{};   // guarded by cmu (epoch until the first pass: nobody waits)
     std::atomic<uint64_t> stat_passes{0}, stat_queries{0};   // combined passes run / queries they carried
     std::atomic<int32_t> inject_fail{0};  // test hook (cqs_hip_debug_index_fail_next): the next host search fails as a device error
 };
@@ -99,6 +102,7 @@ namespace cqs_idx {
 
 constexpr size_t kMaxTimingEvents = 8192;
 constexpr uint64_t kNtBytes = 200ull << 20;  // corpus larger than this streams past L2/MALL
+constexpr uint32_t kGauxQueries = 32;        // query blocks up to this size (every gemv block the host paths form) carry the select's (argmax, runner-up) index
 constexpr size_t kDirectOutKeys = 8192;      // host searches of up to this many result keys have them written straight to pinned host memory
 
 uint64_t pad_rows(uint64_t n);
@@ -114,6 +118,7 @@ hipError_t quiesce(cqs_hip_index* x);
 int32_t stage_keep(cqs_hip_index* x, const uint32_t* host_words, uint64_t words);
 int32_t create_common(uint64_t n, uint32_t dim, uint32_t metric, int32_t device, uint64_t row_base,
                       cqs_hip_index** out, cqs_hip_index** made);
+void read_combine_env(cqs_hip_index* x);
 
 // persistence over one or more device segments in row order (index.hip)
 struct Segment { int device; float* d_rows; uint64_t rows; hipStream_t stream; };
@@ -131,6 +136,10 @@ void destroy(cqs_hip_index* parent);
 int32_t search(cqs_hip_index* parent, const float* queries, uint32_t b, uint32_t query_dim, uint32_t k,
                const uint32_t* keep_bitset, uint32_t mode, float threshold, uint64_t* out_rows, float* out_scores,
                uint32_t* out_counts);
+// One sealed block of the combining queue (index.hip): nb single-query callers with the same (k, mode, threshold), every
+// query finite and of the parent's dimension; takes the parent mutex for the block.  gemv passes only, so each caller gets
+// the bits its lone call gets.
+int32_t search_combined(cqs_hip_index* parent, cqs_combine_req* const* batch, uint32_t nb);
 int32_t neighbors(cqs_hip_index* parent, uint64_t target_row, uint32_t limit, uint64_t* out_rows, float* out_scores,
                   uint32_t* out_count);
 int32_t extend(cqs_hip_index* parent, const float* rows, uint64_t n_new);

@@ -49,6 +49,9 @@ struct ScanArgs {
     bool range_bins = false;// select only: linear bins over the range of the row's own group maxima (the sparse index)
     uint32_t k;
     float* gmax;            // [b, tiers.total()] per-task maxima (written by the scan)
+    uint64_t* gaux = nullptr;// nullable, [b, tiers.total()]: (lane of the task's maximum << 32) | f32 bits of its runner-up
+                            // (written by the gemv scan and the sparse index; the matrix-core scan does not: its select
+                            // launch ignores the field)
     TaskTiers tiers;        // plan_tiers(n_pad, n_cu, uniform_groups(b, dim))
     uint32_t* work;         // [kWorkWords] work-queue heads (zero on entry)
     uint32_t n_cu;          // compute units of the device

@@ -160,6 +160,7 @@ struct ScanParams {
     TaskTiers tiers;    // task t -> (first row, 64 / 32 / 16 rows)
     uint32_t n_tasks;   // tiers.total()
     float* gmax;        // [BQ][n_tasks] maximum valid score of each task's rows (-inf if none)
+    uint64_t* gaux;     // nullable, [BQ][n_tasks]: (lane of that maximum << 32) | bits of the largest score of the task's OTHER rows
     unsigned long long* dbg;  // CQS_HIP_DEBUG_STAMPS: [16 + 2*wave] = start / end realtime of each wave
 };
 
@@ -292,6 +293,17 @@ __global__ __launch_bounds__(256, OCC) void scan_gemv_kernel(const ScanParams p)
 #pragma unroll
             for (int off = 32; off >= 1; off >>= 1) gm = fmaxf(gm, __shfl_xor(gm, off, 64));
             if (lane == 0) p.gmax[(size_t)b * n_tasks + cur] = gm;
+            if (p.gaux) {
+                // Round 5: WHERE the maximum sits and the best score among the task's other rows.  A task whose runner-up
+                // is below the select's threshold contributes exactly one candidate - (gm, base + arg) - without its score
+                // row being read back (select_finish_kernel: 500 x 256 B of gather through ONE CU were 11 of its 28 us).
+                // Rows tied at the maximum: only lane `arg` is masked, so the runner-up equals gm and the task is read.
+                const uint32_t arg = (uint32_t)__builtin_ctzll(__ballot(s == gm));   // (no valid row: gm = -inf, every lane matches)
+                float sec = ((uint32_t)lane == arg) ? -INFINITY : s;
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) sec = fmaxf(sec, __shfl_xor(sec, off, 64));
+                if (lane == 0) p.gaux[(size_t)b * n_tasks + cur] = ((uint64_t)arg << 32) | (uint64_t)__float_as_uint(sec);
+            }
         }
     };
     // ticket -> task index
@@ -424,34 +436,9 @@ __device__ uint32_t slow_select(const float* __restrict__ s, uint32_t n_pad, uin
 constexpr uint32_t kGroupCap = 8192;
 constexpr int kGB = 16;  // independent loads in flight per thread
 
-// Append the flagged items of a wave to a list with ONE counter atomic per wave:
-// returns in slot[u] the list position of item u of this thread (valid where take[u]).
-template <int N>
-__device__ __forceinline__ void wave_slots(const bool (&take)[N], uint32_t* counter, int lane, uint32_t (&slot)[N]) {
-    uint32_t c = 0;
-#pragma unroll
-    for (int u = 0; u < N; ++u) c += take[u] ? 1u : 0u;
-    uint32_t incl = c;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t v = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += v;
-    }
-    const uint32_t total = __shfl(incl, 63, 64);
-    uint32_t base = 0;
-    if (total) {
-        if (lane == 0) base = atomicAdd(counter, total);
-        base = __shfl(base, 0, 64);
-    }
-    uint32_t o = base + incl - c;
-#pragma unroll
-    for (int u = 0; u < N; ++u) {
-        slot[u] = o;
-        o += take[u] ? 1u : 0u;
-    }
-}
 __global__ __launch_bounds__(1024) void select_finish_kernel(const float* __restrict__ scores,
-                                                             const float* __restrict__ gmax, uint32_t n_pad,
+                                                             const float* __restrict__ gmax,
+                                                             const uint64_t* __restrict__ gaux, uint32_t n_pad,
                                                              const TaskTiers tiers, uint32_t slot_log2, uint32_t k,
                                                              uint32_t row_base, uint32_t linear,
                                                              uint64_t* __restrict__ out_keys,
@@ -460,10 +447,10 @@ __global__ __launch_bounds__(1024) void select_finish_kernel(const float* __rest
                                                              unsigned long long* __restrict__ dbg) {
     __shared__ uint64_t s_keys[kCandCap];
     __shared__ uint32_t s_groups[kGroupCap];
-    __shared__ uint32_t s_hist[kHistBins];
+    __shared__ __attribute__((aligned(16))) uint32_t s_hist[kHistBins];
     __shared__ uint32_t s_part[1024];
     __shared__ uint32_t s_res[4];
-    __shared__ uint32_t s_cnt, s_ng;
+    __shared__ uint32_t s_cnt, s_ng, s_ng2;
     const uint32_t qi = blockIdx.x;
     const uint32_t n_tasks = tiers.total();
     const float* s = scores + (size_t)qi * n_pad;
@@ -474,7 +461,7 @@ __global__ __launch_bounds__(1024) void select_finish_kernel(const float* __rest
 #define CQS_STAMP(i) do { if (dbg && threadIdx.x == 0 && blockIdx.x == 0) dbg[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
     CQS_STAMP(0);
     for (uint32_t i = threadIdx.x; i < kHistBins; i += 1024u) s_hist[i] = 0u;
-    if (threadIdx.x == 0) { s_cnt = 0; s_ng = 0; }
+    if (threadIdx.x == 0) { s_cnt = 0; s_ng = 0; s_ng2 = 0; }
     __syncthreads();
     if (linear == 2u) {                                    // phase 0: smallest and largest finite group maximum
         float lo = INFINITY, hi = -INFINITY;
@@ -536,54 +523,120 @@ __global__ __launch_bounds__(1024) void select_finish_kernel(const float* __rest
                 m[u] = t < n_tasks ? v : -INFINITY;
             }
         }
+        // list positions by ballot + mbcnt, one LDS atomic per wave (round 5; until then a 6-step shuffle scan over 16 flags)
         bool take[kGB];
-        uint32_t slot[kGB];
+        uint64_t mk[kGB];
+        uint32_t pre[kGB], tot = 0;
 #pragma unroll
-        for (int u = 0; u < kGB; ++u) take[u] = (m[u] != -INFINITY) && (bin_any(m[u], linear, r_lo, r_scale) >= T);
-        wave_slots<kGB>(take, &s_ng, lane, slot);
+        for (int u = 0; u < kGB; ++u) {
+            take[u] = (m[u] != -INFINITY) && (bin_any(m[u], linear, r_lo, r_scale) >= T);
+            mk[u] = __ballot(take[u]);
+            pre[u] = tot;
+            tot += (uint32_t)__popcll(mk[u]);
+        }
+        uint32_t base = 0;
+        if (tot) {                                       // wave-uniform
+            if (lane == 0) base = atomicAdd(&s_ng, tot);
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        }
 #pragma unroll
-        for (int u = 0; u < kGB; ++u)
-            if (take[u] && slot[u] < kGroupCap) s_groups[slot[u]] = t0 + (uint32_t)u * 1024u + threadIdx.x;
+        for (int u = 0; u < kGB; ++u) {
+            const uint32_t slot = base + pre[u] + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk[u] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk[u], 0u));
+            if (take[u] && slot < kGroupCap) s_groups[slot] = t0 + (uint32_t)u * 1024u + threadIdx.x;
+        }
     }
     __syncthreads();
     CQS_STAMP(3);
     const uint32_t ng = s_ng;
     uint32_t count = kCandCap + 1u;
     if (ng <= kGroupCap) {
-        // phase 3: their scores (L2 / Infinity Cache hits: the scan just wrote them)
-        // every selected group gets 2^slot_log2 element slots (the widest tier in use); the slots
-        // past a narrower group's rows stay empty
-        const uint32_t slots = 1u << slot_log2;
-        const uint32_t total = ng << slot_log2;
-        for (uint32_t e0 = 0; e0 < total; e0 += 1024u * kGB) {
-            // straight-line on purpose: addresses first, then all kGB loads back to back, then the masks.  (Until round 4 a
-            // block-uniform `continue` for the slices past `total` sat inside this unrolled loop; with it hipcc put an
-            // `s_waitcnt vmcnt(0)` behind every single load - 32 serial round trips, 18 of the kernel's 38 us at k = 500.)
-            float v[kGB];
-            uint32_t idx[kGB];
-            bool in[kGB];
+        // phase 3: their scores (L2 / Infinity Cache hits: the scan just wrote them).  Round 5: ONE WAVE PER GROUP -
+        // lane <-> row of the group, so a group is one coalesced load at a wave-uniform base (no per-element
+        // slot -> (group, offset) arithmetic), kGU groups in flight per wave, and the survivors are appended with
+        // ballot + mbcnt ranks and ONE LDS atomic per kGU groups.  (Round 4 spread group x slot over all threads:
+        // 2 rounds of 16 loads per thread with a 6-step shuffle scan each - 11 us of one CU's issue slots at k = 500.)
+        // Round 5, producers that also left `gaux` (the gemv scan, the sparse index): a selected group whose runner-up
+        // misses the threshold bin IS its maximum - the candidate (gm, base + arg) goes straight to the list and the
+        // group's rows are never read; only groups with a second entry at or above the threshold (a few per cent at
+        // k = 500, all of them under heavy ties) are gathered.
+        const uint32_t* glist = s_groups;
+        uint32_t n2 = ng;
+        if (gaux) {
+            uint32_t* const s_list2 = s_hist;              // the histogram is dead (T lives in a register)
+            const uint64_t* const ga = gaux + (size_t)qi * n_tasks;
+            for (uint32_t i0 = 0; i0 < ng; i0 += 1024u) {
+                const uint32_t i = i0 + threadIdx.x;
+                const bool valid = i < ng;
+                const uint32_t t = s_groups[valid ? i : ng - 1u];
+                const uint64_t ax = ga[t];
+                const float mx = gm[t];
+                const float sec = __uint_as_float((uint32_t)ax);
+                const bool need = valid && (sec != -INFINITY) && (bin_any(sec, linear, r_lo, r_scale) >= T);
+                const bool direct = valid && !need;
+                const uint64_t mn = __ballot(need), md = __ballot(direct);
+                uint32_t bn = 0, bd = 0;
+                if (lane == 0) {
+                    if (mn) bn = atomicAdd(&s_ng2, (uint32_t)__popcll(mn));
+                    if (md) bd = atomicAdd(&s_cnt, (uint32_t)__popcll(md));
+                }
+                bn = (uint32_t)__builtin_amdgcn_readfirstlane((int)bn);
+                bd = (uint32_t)__builtin_amdgcn_readfirstlane((int)bd);
+                if (need) {
+                    const uint32_t slot = bn + __builtin_amdgcn_mbcnt_hi((uint32_t)(mn >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mn, 0u));
+                    if (slot < kHistBins) s_list2[slot] = t;
+                }
+                if (direct) {
+                    const uint32_t slot = bd + __builtin_amdgcn_mbcnt_hi((uint32_t)(md >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)md, 0u));
+                    uint32_t grows;
+                    const uint32_t gbase = tiers.locate(t, grows);
+                    if (slot < kCandCap) s_keys[slot] = pack_key(okey(mx), row_base + gbase + (uint32_t)(ax >> 32));
+                }
+            }
+            __syncthreads();
+            if (s_ng2 <= kHistBins) { glist = s_list2; n2 = s_ng2; }
+            else {                                         // more groups to read than the second list holds: read them all
+                __syncthreads();
+                if (threadIdx.x == 0) s_cnt = 0;
+                __syncthreads();
+            }
+        }
+        constexpr int kGU = 8;
+        const uint32_t wv = threadIdx.x >> 6;
+        for (uint32_t g0 = wv * kGU; g0 < n2; g0 += 16u * kGU) {
+            float v[kGU];
+            uint32_t idx[kGU];
+            bool in[kGU];
 #pragma unroll
-            for (int u = 0; u < kGB; ++u) {
-                const uint32_t e = e0 + (uint32_t)u * 1024u + threadIdx.x;
-                const uint32_t ec = e < total ? e : total - 1u;
+            for (int u = 0; u < kGU; ++u) {
+                const uint32_t g = g0 + (uint32_t)u;
                 uint32_t grows;
-                const uint32_t gbase = tiers.locate(s_groups[ec >> slot_log2], grows);
-                const uint32_t off = ec & (slots - 1u);
-                in[u] = e < total && off < grows;
-                idx[u] = gbase + (in[u] ? off : 0u);
+                const uint32_t gbase = tiers.locate((uint32_t)__builtin_amdgcn_readfirstlane((int)glist[g < n2 ? g : n2 - 1u]), grows);
+                in[u] = g < n2 && (uint32_t)lane < grows;
+                idx[u] = gbase + (in[u] ? (uint32_t)lane : 0u);
             }
 #pragma unroll
-            for (int u = 0; u < kGB; ++u) v[u] = s[idx[u]];
+            for (int u = 0; u < kGU; ++u) v[u] = s[idx[u]];
+            uint64_t mask[kGU];
+            uint32_t pre[kGU], tot = 0;
+            bool take[kGU];
 #pragma unroll
-            for (int u = 0; u < kGB; ++u) v[u] = in[u] ? v[u] : -INFINITY;
-            bool take[kGB];
-            uint32_t slot[kGB];
+            for (int u = 0; u < kGU; ++u) {
+                take[u] = in[u] && (v[u] != -INFINITY) && (bin_any(v[u], linear, r_lo, r_scale) >= T);
+                mask[u] = __ballot(take[u]);
+                pre[u] = tot;
+                tot += (uint32_t)__popcll(mask[u]);
+            }
+            uint32_t base = 0;
+            if (tot) {                                   // wave-uniform
+                if (lane == 0) base = atomicAdd(&s_cnt, tot);
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            }
 #pragma unroll
-            for (int u = 0; u < kGB; ++u) take[u] = (v[u] != -INFINITY) && (bin_any(v[u], linear, r_lo, r_scale) >= T);
-            wave_slots<kGB>(take, &s_cnt, lane, slot);
-#pragma unroll
-            for (int u = 0; u < kGB; ++u)
-                if (take[u] && slot[u] < kCandCap) s_keys[slot[u]] = pack_key(okey(v[u]), row_base + idx[u]);
+            for (int u = 0; u < kGU; ++u) {
+                const uint32_t slot = base + pre[u] +
+                    __builtin_amdgcn_mbcnt_hi((uint32_t)(mask[u] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask[u], 0u));
+                if (take[u] && slot < kCandCap) s_keys[slot] = pack_key(okey(v[u]), row_base + idx[u]);
+            }
         }
         __syncthreads();
         count = s_cnt;
@@ -597,24 +650,44 @@ __global__ __launch_bounds__(1024) void select_finish_kernel(const float* __rest
     if (count <= 1024u) {
         // Rank sort: the keys are distinct, so rank(i) = #{j : key[j] > key[i]} is a permutation.
         // One key per thread, count broadcast LDS reads, no barriers inside the loop.
+        // Round 5: the ranks are taken on the keys' TOP HALVES (the ordered score bits), four per 16-byte LDS read:
+        // 1 read + 4 compares + 4 adds per four keys instead of 4 reads + 4 64-bit compares + 8 (7 -> ~3 us at 510 keys).
+        // Two equal scores among the candidates get the same rank and leave a hole in the output - detected below, and
+        // only then are the ranks retaken on the full keys (exact: scores equal in all 32 bits are duplicates or ties).
         uint64_t* s_sorted = reinterpret_cast<uint64_t*>(s_groups);  // group list is dead by now
+        uint32_t* s_ok = s_hist;                                      // histogram is dead by now (slow_select included)
         __syncthreads();
-        // (Two threads per key, each over half of the list, took as long: the loop is bound by LDS broadcast reads,
-        // waves x keys of them either way - 7 us at 510 keys.)
+        const uint32_t cpad = (count + 3u) & ~3u;
+        if (threadIdx.x < cpad) s_ok[threadIdx.x] = threadIdx.x < count ? (uint32_t)(s_keys[threadIdx.x] >> 32) : 0u;
+        if (threadIdx.x < count) s_sorted[threadIdx.x] = 0ull;       // (no valid key is 0)
+        if (threadIdx.x == 0) s_res[0] = 0u;
+        __syncthreads();
         if (threadIdx.x < count) {
             const uint64_t mine = s_keys[threadIdx.x];
+            const uint32_t mh = (uint32_t)(mine >> 32);
             uint32_t rank = 0;
-            uint32_t j = 0;
-            for (; j + 4u <= count; j += 4u) {
-                rank += (s_keys[j] > mine) ? 1u : 0u;
-                rank += (s_keys[j + 1] > mine) ? 1u : 0u;
-                rank += (s_keys[j + 2] > mine) ? 1u : 0u;
-                rank += (s_keys[j + 3] > mine) ? 1u : 0u;
+#pragma unroll 8
+            for (uint32_t j = 0; j < cpad; j += 4u) {                 // (unrolled: eight 16-byte reads in flight, not one)
+                const uint4 o = *reinterpret_cast<const uint4*>(&s_ok[j]);
+                rank += (o.x > mh) ? 1u : 0u;
+                rank += (o.y > mh) ? 1u : 0u;
+                rank += (o.z > mh) ? 1u : 0u;
+                rank += (o.w > mh) ? 1u : 0u;
             }
-            for (; j < count; ++j) rank += (s_keys[j] > mine) ? 1u : 0u;
             s_sorted[rank] = mine;
         }
         __syncthreads();
+        if (threadIdx.x < count && s_sorted[threadIdx.x] == 0ull) s_res[0] = 1u;   // a hole: two candidates share their score bits
+        __syncthreads();
+        if (s_res[0] != 0u) {
+            if (threadIdx.x < count) {
+                const uint64_t mine = s_keys[threadIdx.x];
+                uint32_t rank = 0;
+                for (uint32_t j = 0; j < count; ++j) rank += (s_keys[j] > mine) ? 1u : 0u;
+                s_sorted[rank] = mine;
+            }
+            __syncthreads();
+        }
         sorted = s_sorted;
     } else {
         // Bitonic sort, descending (slow path sizes: up to kCandCap).
@@ -709,6 +782,7 @@ static hipError_t launch_gemv(const ScanArgs& a, uint32_t q0, uint32_t nq, uint3
     p.tiers = a.tiers;
     p.n_tasks = a.tiers.total();
     p.gmax = a.gmax + (size_t)q0 * p.n_tasks;
+    p.gaux = a.gaux ? a.gaux + (size_t)q0 * p.n_tasks : nullptr;
     p.dbg = (unsigned long long*)a.dbg;
     // One-shot grid (one task per wave, the hardware dispatcher schedules: beats a persistent grid up to
     // ~1.5M rows) or, for huge corpora, a persistent grid that continues from the work queue (beats the
@@ -824,7 +898,8 @@ hipError_t launch_scan(const ScanArgs& a, hipStream_t st) {
 hipError_t launch_select(const ScanArgs& a, uint32_t row_base, uint64_t* out_keys, uint32_t* out_counts,
                          hipStream_t st) {
     if (a.b == 0 || a.k == 0) return hipSuccess;
-    hipLaunchKernelGGL(select_finish_kernel, dim3(a.b), dim3(1024), 0, st, a.scores, a.gmax, a.n_pad,
+    hipLaunchKernelGGL(select_finish_kernel, dim3(a.b), dim3(1024), 0, st, a.scores, a.gmax,
+                       (!a.gemv_only && use_mfma(a.b, a.dim)) ? nullptr : a.gaux, a.n_pad,
                        a.tiers, tier_slot_log2(a.tiers), a.k, row_base,
                        a.range_bins ? 2u : (a.linear_bins ? 1u : 0u), out_keys, out_counts, a.work,
                        (unsigned long long*)a.dbg);

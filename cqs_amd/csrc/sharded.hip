@@ -193,7 +193,8 @@ int32_t ensure_hq(cqs_hip_index* p, size_t floats) {
 // One block of `nb` staged queries (p->sh->h_q) through every shard, gathered and merged on the host.
 // keep_host: nullable GLOBAL bitset (bit i = parent row i); bad[q] != 0: query q had a non-finite component.
 int32_t search_block(cqs_hip_index* p, uint32_t nb, uint32_t k_eff, const uint32_t* keep_host, uint32_t mode, float thr,
-                     const uint8_t* bad, uint64_t* out_rows, float* out_scores, uint32_t* out_counts, uint32_t k_out) {
+                     const uint8_t* bad, uint64_t* out_rows, float* out_scores, uint32_t* out_counts, uint32_t k_out,
+                     bool gemv_only = false) {
     ShardSet* ss = p->sh;
     const size_t G = ss->shard.size();
     const size_t keys = (size_t)nb * k_eff;
@@ -228,7 +229,7 @@ int32_t search_block(cqs_hip_index* p, uint32_t nb, uint32_t k_eff, const uint32
             P_TRY(p, hipMemsetAsync(keys_out, 0, keys * sizeof(uint64_t), c->stream));
         } else {
             P_TRY(p, hipMemcpyAsync(c->d_q, ss->h_q, qbytes, hipMemcpyHostToDevice, c->stream));   // the query broadcast
-            if ((rc = enqueue_search(c, c->d_q, nb, k_eff, d_keep, mode, thr, keys_out, counts_out, c->stream)) != CQS_HIP_OK)
+            if ((rc = enqueue_search(c, c->d_q, nb, k_eff, d_keep, mode, thr, keys_out, counts_out, c->stream, gemv_only)) != CQS_HIP_OK)
                 return child_fail(p, s, rc);
         }
     }
@@ -413,6 +414,42 @@ int32_t search(cqs_hip_index* p, const float* queries, uint32_t b, uint32_t quer
     return CQS_HIP_OK;
 }
 
+// The combining queue's block on a sharded parent (index.hip, combine_lead): the callers' queries become ONE block
+// through every shard (gemv passes only: a shard's scores do not depend on how many queries share its pass), one
+// gather, one host merge per query; answers go back to each caller's own buffers.
+int32_t search_combined(cqs_hip_index* p, cqs_combine_req* const* batch, uint32_t nb) {
+    std::lock_guard<std::mutex> g(p->mu);
+    if (poisoned(p)) return CQS_HIP_ERR_POISONED;
+    if (p->inject_fail.exchange(0, std::memory_order_acq_rel) != 0)
+        return pfail(p, CQS_HIP_ERR_DEVICE, "search: injected device failure (test hook)");
+    const uint32_t k = batch[0]->k;
+    for (uint32_t i = 0; i < nb; ++i) *batch[i]->out_count = 0;
+    if (len(p) == 0) return CQS_HIP_OK;                              // src/cagra.rs:445-447
+    uint32_t blk = 1024;
+    for (const cqs_hip_index* c : p->sh->shard) blk = std::min(blk, max_query_block(c));
+    static thread_local std::vector<uint64_t> rows;
+    static thread_local std::vector<float> scores;
+    static thread_local std::vector<uint32_t> counts;
+    static thread_local std::vector<uint8_t> bad;
+    rows.resize((size_t)nb * k); scores.resize((size_t)nb * k); counts.assign(nb, 0u); bad.assign(nb, 0);
+    for (uint32_t done = 0; done < nb;) {
+        const uint32_t b = std::min(nb - done, blk);
+        int32_t rc = ensure_hq(p, (size_t)b * p->dim);
+        if (rc != CQS_HIP_OK) return rc;
+        for (uint32_t i = 0; i < b; ++i) memcpy(p->sh->h_q + (size_t)i * p->dim, batch[done + i]->q, (size_t)p->dim * sizeof(float));
+        rc = search_block(p, b, k, nullptr, batch[0]->mode, batch[0]->thr, bad.data() + done, rows.data() + (size_t)done * k,
+                          scores.data() + (size_t)done * k, counts.data() + done, k, /*gemv_only=*/true);
+        if (rc != CQS_HIP_OK) return rc;
+        done += b;
+    }
+    for (uint32_t i = 0; i < nb; ++i) {
+        memcpy(batch[i]->out_rows, rows.data() + (size_t)i * k, (size_t)counts[i] * sizeof(uint64_t));
+        memcpy(batch[i]->out_scores, scores.data() + (size_t)i * k, (size_t)counts[i] * sizeof(float));
+        *batch[i]->out_count = counts[i];
+    }
+    return CQS_HIP_OK;
+}
+
 // src/cli/commands/search/neighbors.rs:86-132 across shards: the target row comes back to the host from the
 // shard that holds it (3 KB) and is searched like any query with k = limit + 1; the target is then dropped.
 int32_t neighbors(cqs_hip_index* p, uint64_t target_row, uint32_t limit, uint64_t* out_rows, float* out_scores,
@@ -539,6 +576,7 @@ int32_t cqs_hip_index_create_sharded(const float* rows, uint64_t n, uint32_t dim
     cqs_hip_index* p = new (std::nothrow) cqs_hip_index();
     if (!p) return CQS_HIP_ERR_NOMEM;
     p->dim = dim; p->metric = metric; p->row_base = row_base; p->device = devices[0];
+    cqs_idx::read_combine_env(p);
     p->sh = new (std::nothrow) cqs_sharded::ShardSet();
     if (!p->sh) { delete p; return CQS_HIP_ERR_NOMEM; }
     const std::vector<uint64_t> lo = cqs_sharded::plan(n, n_devices);
@@ -573,6 +611,7 @@ int32_t cqs_hip_index_load_sharded(const char* path, uint32_t expected_dim, uint
     cqs_hip_index* p = new (std::nothrow) cqs_hip_index();
     if (!p) { close(fd); return CQS_HIP_ERR_NOMEM; }
     p->dim = expected_dim; p->metric = metric; p->row_base = row_base; p->device = devices[0];
+    cqs_idx::read_combine_env(p);
     p->sh = new (std::nothrow) cqs_sharded::ShardSet();
     if (!p->sh) { close(fd); delete p; return CQS_HIP_ERR_NOMEM; }
     const std::vector<uint64_t> lo = cqs_sharded::plan(rows, n_devices);

@@ -87,13 +87,15 @@ __global__ __launch_bounds__(256) void sparse_accumulate_kernel(const uint2* __r
                                                                 const uint32_t* __restrict__ q_term_off /*[queries + 1]*/, const uint32_t* __restrict__ dir,
                                                                 uint32_t n, uint32_t n_pad, uint32_t sh,
                                                                 const uint32_t* __restrict__ keep, const uint32_t* __restrict__ chunk_of_rank,
-                                                                float* __restrict__ scores, float* __restrict__ gmax, uint32_t group16) {
+                                                                float* __restrict__ scores, float* __restrict__ gmax,
+                                                                uint64_t* __restrict__ gaux, uint32_t group16) {
     extern __shared__ uint32_t sp_lds[];
     // blockIdx.y = the query of a batch: its terms, its score row, its maxima
     const SparseTerm* const terms = terms_all + q_term_off[blockIdx.y];
     const uint32_t n_terms = q_term_off[blockIdx.y + 1u] - q_term_off[blockIdx.y];
     scores += (size_t)blockIdx.y * n_pad;
     gmax += (size_t)blockIdx.y * (group16 ? n_pad >> 4 : n_pad >> 6);
+    gaux += (size_t)blockIdx.y * (group16 ? n_pad >> 4 : n_pad >> 6);
     const uint32_t rw = 1u << sh;
     const int lane = threadIdx.x & 63;
     const uint32_t wid = threadIdx.x >> 6;
@@ -212,12 +214,25 @@ __global__ __launch_bounds__(256) void sparse_accumulate_kernel(const uint2* __r
         float m = v;
 #pragma unroll
         for (int off = 8; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+        // beside each maximum: the lane it sits in and the group's runner-up (select_finish_kernel, round 5: a group whose
+        // runner-up misses the threshold contributes its maximum without its scores being read back)
         if (group16) {                                    // small indexes: maxima of 16 chunks (fewer than k groups of 64 would
             if ((lane & 15) == 0) gmax[r >> 4] = m;       // make every score a candidate and send the select down its radix path)
+            const uint32_t seg = (uint32_t)(__ballot(v == m) >> (lane & 48)) & 0xFFFFu;   // my 16 lanes (no scored chunk: m = -inf, all match)
+            const uint32_t arg = (uint32_t)__builtin_ctz(seg);
+            float sec = ((uint32_t)(lane & 15) == arg) ? -INFINITY : v;
+#pragma unroll
+            for (int off = 8; off >= 1; off >>= 1) sec = fmaxf(sec, __shfl_xor(sec, off, 64));
+            if ((lane & 15) == 0) gaux[r >> 4] = ((uint64_t)arg << 32) | (uint64_t)__builtin_bit_cast(uint32_t, sec);
         } else {
             m = fmaxf(m, __shfl_xor(m, 16, 64));
             m = fmaxf(m, __shfl_xor(m, 32, 64));
             if (lane == 0) gmax[r >> 6] = m;
+            const uint32_t arg = (uint32_t)__builtin_ctzll(__ballot(v == m));
+            float sec = ((uint32_t)lane == arg) ? -INFINITY : v;
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) sec = fmaxf(sec, __shfl_xor(sec, off, 64));
+            if (lane == 0) gaux[r >> 6] = ((uint64_t)arg << 32) | (uint64_t)__builtin_bit_cast(uint32_t, sec);
         }
     }
 }
@@ -344,7 +359,7 @@ int32_t ensure_batch(cqs_hip_sparse_index* s, uint32_t b) {
     s->b_cap = 0;
     const size_t groups = s->n_pad / (s->group16 ? 16u : 64u);
     S_TRY(s, hipMalloc((void**)&s->d_scores, (size_t)b * s->n_pad * 4));
-    S_TRY(s, hipMalloc((void**)&s->d_gmax, (size_t)b * groups * 4));
+    S_TRY(s, hipMalloc((void**)&s->d_gmax, (size_t)b * groups * 12));   // maxima, then (argmax, runner-up) pairs (groups % 4 == 0: 8-byte aligned)
     S_TRY(s, hipMalloc((void**)&s->d_out_keys, (size_t)b * cqs::kMaxK * 8));
     S_TRY(s, hipMalloc((void**)&s->d_out_count, (size_t)b * 4));
     // keys [b][k] then the b counts, in one pinned + device-visible block: the select writes there
@@ -839,7 +854,8 @@ int32_t search_locked(cqs_hip_sparse_index* s, const uint64_t* q_off, const uint
     S_TRY(s, hipEventRecord(s->ev0, st));
     hipLaunchKernelGGL(sparse_accumulate_kernel, dim3((waves + 3u) / 4u, b), dim3(256), (size_t)4 * sparse_wave_lds_words(s->rw) * 4, st,
                        s->d_post, s->d_terms, s->d_qoff, s->d_dir, (uint32_t)s->n, s->n_pad, s->sh, d_keep,
-                       s->ranked ? s->d_chunk_of_rank : nullptr, s->d_scores, s->d_gmax, s->group16 ? 1u : 0u);
+                       s->ranked ? s->d_chunk_of_rank : nullptr, s->d_scores, s->d_gmax,
+                       (uint64_t*)(s->d_gmax + (size_t)s->b_cap * (s->n_pad / (s->group16 ? 16u : 64u))), s->group16 ? 1u : 0u);
     S_TRY(s, hipGetLastError());
     S_TRY(s, hipEventRecord(s->ev1, st));
     cqs::ScanArgs a{};
@@ -848,6 +864,8 @@ int32_t search_locked(cqs_hip_sparse_index* s, const uint64_t* q_off, const uint
     a.b = b;
     a.scores = s->d_scores;
     a.gmax = s->d_gmax;
+    a.gaux = (uint64_t*)(s->d_gmax + (size_t)s->b_cap * (s->n_pad / (s->group16 ? 16u : 64u)));
+    a.gemv_only = true;                                   // (not the matrix-core scan: the select reads gaux)
     a.tiers = s->group16 ? cqs::TaskTiers{0u, 0u, s->n_pad / 16u} : cqs::TaskTiers{s->n_pad / 64u, 0u, 0u};
     a.k = k;
     a.linear_bins = false;

@@ -137,6 +137,110 @@ def test_poisoned_handle_wakes_every_parked_caller(hip):
     idx.close()
 
 
+def test_sharded_handle_takes_the_combining_queue(hip):
+    """the row-sharded parent (what a multi-GPU daemon binds; one-GPU form: device 0 named three times)
+    combines concurrent single-query callers too.  Every answer equals the lone call's bit for bit, the queue really
+    combined, and mixed parameters / a multi-query block / a bitset still get their own answers."""
+    rows = synth.gaussian_unit(200_000, seed=45)
+    qs = synth.gaussian_unit(48, seed=46)
+    sh = HipIndex.build_sharded(None, rows, [0, 0, 0])
+    single = HipIndex.build_from_flat(None, rows)
+    want = [sh.search_batch(qs[i], 20) for i in range(len(qs))]
+    want50 = [sh.search_batch(qs[i], 50) for i in range(len(qs))]
+    for i in range(len(qs)):                                 # the sharded answer is the single-device answer (scores: same kernels per row)
+        r1, s1, c1 = single.search_batch(qs[i], 20)
+        assert np.array_equal(c1, want[i][2]) and np.max(np.abs(s1 - want[i][1])) <= 2e-6
+    keep = np.random.default_rng(47).integers(0, 2**32, size=(len(rows) + 31) // 32, dtype=np.uint64).astype(np.uint32)
+    want_keep = sh.search_batch(qs[3], 10, keep_bitset=keep)
+    want_blk = sh.search_batch(qs[:12], 20)
+    p0, q0 = sh.combine_stats()
+    assert p0 == q0 == 2 * len(qs)                          # lone callers: one query per pass
+
+    def work(t):
+        for rep in range(8):
+            for i in range(t, len(qs), 8):
+                w = want50 if t % 4 == 3 else want
+                r, s, c = sh.search_batch(qs[i], 50 if t % 4 == 3 else 20)
+                assert np.array_equal(r, w[i][0]) and np.array_equal(s, w[i][1]) and np.array_equal(c, w[i][2]), (t, rep, i)
+            if t == 0:
+                r, s, c = sh.search_batch(qs[:12], 20)
+                assert np.array_equal(r, want_blk[0]) and np.array_equal(s, want_blk[1])
+            if t == 1:
+                r, s, c = sh.search_batch(qs[3], 10, keep_bitset=keep)
+                assert np.array_equal(r, want_keep[0]) and np.array_equal(s, want_keep[1])
+
+    _run_threads(work, 8)
+    p1, q1 = sh.combine_stats()
+    assert q1 - q0 == 8 * len(qs)
+    assert (q1 - q0) > 1.5 * (p1 - p0), f"the sharded queue did not combine: {q1 - q0} queries in {p1 - p0} passes"
+    single.close()
+    sh.close()
+
+
+def test_poisoned_sharded_handle_wakes_every_parked_caller(hip):
+    """The poisoned case on the sharded parent: the leading call reports the device error, everybody parked behind it and
+    every later call gets CQS_HIP_ERR_POISONED; nobody hangs."""
+    import ctypes as C
+    from cqs_amd import _lib
+    rows = synth.gaussian_unit(200_000, seed=55)
+    qs = synth.gaussian_unit(16, seed=56)
+    sh = HipIndex.build_sharded(None, rows, [0, 0])
+    lib = _lib.load()
+    lib.cqs_hip_debug_index_fail_next.argtypes = [C.c_void_p]
+    lib.cqs_hip_debug_index_fail_next.restype = None
+    codes = []
+    lock = threading.Lock()
+    start = threading.Barrier(9)
+
+    def work(t):
+        start.wait()
+        for rep in range(40):
+            try:
+                sh.search_batch(qs[(t + rep) % len(qs)], 20)
+            except HipError as e:
+                with lock:
+                    codes.append(e.code)
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(8)]
+    [x.start() for x in th]
+    start.wait()
+    lib.cqs_hip_debug_index_fail_next(sh._h)
+    [x.join(timeout=60) for x in th]
+    assert not any(x.is_alive() for x in th), "a caller is still parked on a poisoned sharded handle"
+    assert sh.is_poisoned()
+    assert codes.count(_lib.ERR_DEVICE) == 1, codes
+    assert codes.count(_lib.ERR_POISONED) == len(codes) - 1 and len(codes) >= 8, codes
+    sh.close()
+
+
+def test_a_lone_caller_after_a_burst_does_not_wait_for_stragglers(hip, monkeypatch):
+    """The leader's straggler window is anchored at the end of the previous pass (round 5): with a 50 ms window, a caller
+    that comes alone 200 ms after an 8-thread burst must not pay it (round 4: it paid the whole window once)."""
+    import time
+    monkeypatch.setenv("CQS_HIP_COMBINE_WAIT_US", "50000")
+    rows = synth.gaussian_unit(100_000, seed=65)
+    qs = synth.gaussian_unit(8, seed=66)
+    idx = HipIndex.build_from_flat(None, rows)
+    monkeypatch.delenv("CQS_HIP_COMBINE_WAIT_US")
+    for i in range(8):
+        idx.search_batch(qs[i], 20)
+
+    def work(t):
+        for rep in range(10):
+            idx.search_batch(qs[t], 20)
+
+    _run_threads(work, 8)
+    p0, q0 = idx.combine_stats()
+    time.sleep(0.2)
+    t0 = time.perf_counter()
+    idx.search_batch(qs[0], 20)
+    dt = time.perf_counter() - t0
+    p1, q1 = idx.combine_stats()
+    assert (p1 - p0, q1 - q0) == (1, 1)
+    assert dt < 0.025, f"a lone caller waited {dt * 1e3:.1f} ms behind a burst that ended 200 ms earlier"
+    idx.close()
+
+
 def test_embed_engine_from_two_threads(hip):
     from test_embed_gpu import SMALL, batch, make
     eng, _ = make(SMALL, seed=91)
