@@ -65,6 +65,7 @@ struct cqs_hip_embedder {
     bool single_ctx = false;              // CQS_HIP_EMBED_CONTEXTS=1: one execution context (A/B hook for the two-chain overlap)
     // o_proj / down fused with the residual add + both norms (gemm_rowfuse.hip).  Read ONCE, at finalize
     // (CQS_HIP_GEMM_FUSE_NORM / _MIN_ROWS); tests flip it through cqs_hip_debug_embedder_set_fuse_norm.
+    uint32_t fuse_fallbacks = 0;          // times a pair-exchange timeout sent this engine back to the two-launch chain (0 or 1)
     int fuse_norm = 2;                    // 0 = two launches, 1 = the 64-row kernel of round 3, 2 = the pair-split kernel (128 rows x 384 columns)
     uint32_t fuse_min_rows = 4096;        // token count from which the fused kernel runs (pair-split kernel, ragged 10k-token batches, tickets in
                                           // flight: 9.6 k chunks/s at 1024-4096, 9.4 k at 2048 / 8192, 8.3 k at 12288; round 3's 64-row kernel needed 12288)
@@ -137,6 +138,8 @@ struct cqs_hip_embedder {
         int ctx = 0;               // execution context the ticket runs on
         bool direct = false;       // the result is in the context's q_out_pin, not in `out`
         bool collecting = false;   // a collect is waiting on this ticket: a second collector of the same ticket is refused
+        bool batch_chain = false;  // the ticket ran the batch path (whose fused projections exchange row sums across workgroups)
+        bool rerun = false;        // a pair exchange timed out while this ticket was in flight: recompute it at its collect
     };
     static constexpr int kSlots = 3;
     Slot slot[kSlots];
@@ -801,6 +804,22 @@ size_t cqs_hip_embedder_last_error(const cqs_hip_embedder* e, char* buf, size_t 
 // channel pipeline (src/cli/pipeline/mod.rs:61-244), moved under the `session.run` seam.
 namespace {
 
+// The batch path of one packed slot: H2D of its tables, the layers, pool + Dense head, D2H, the slot's events.
+int32_t enqueue_batch_chain(cqs_hip_embedder* e, Ctx& c, cqs_hip_embedder::Slot& sl) {
+    hipStream_t st = c.stream;
+    const uint32_t H = e->g.hidden, B = sl.B;
+    int32_t rc = run_layers(e, c, sl);
+    if (rc != CQS_HIP_OK) return rc;
+    const cqs::EmbedGeom& g = e->g;
+    E_TRY(e, cqs::launch_mean_pool(c.hidden, c.d_seq_start, c.d_seq_len, c.pooled, B, H, st));
+    E_TRY(e, cqs::launch_gemm_skinny(c.pooled, e->dense1, c.d1, B, g.dense_hidden, H, g.dense_hidden, cqs::GEMM_OUT_BF16, st));
+    E_TRY(e, cqs::launch_gemm_skinny(c.d1, e->dense2, c.out, B, H, g.dense_hidden, H, cqs::GEMM_OUT_F32, st));
+    E_TRY(e, hipEventRecord(sl.ev1, st));
+    E_TRY(e, hipMemcpyAsync(sl.out, c.out, (size_t)B * H * sizeof(float), hipMemcpyDeviceToHost, st));
+    E_TRY(e, hipEventRecord(sl.done, st));
+    return CQS_HIP_OK;
+}
+
 int32_t submit_locked(cqs_hip_embedder* e, uint32_t B, const std::function<int32_t(cqs_hip_embedder::Slot&)>& pack,
                       uint64_t* ticket) {
     if (e->poisoned.load(std::memory_order_acquire)) return CQS_HIP_ERR_POISONED;
@@ -815,6 +834,8 @@ int32_t submit_locked(cqs_hip_embedder* e, uint32_t B, const std::function<int32
     E_TRY(e, hipSetDevice(e->device));
     int32_t rc = pack(*sl);
     if (rc != CQS_HIP_OK) return rc;
+    sl->batch_chain = false;
+    sl->rerun = false;
     // The context with fewer tickets in flight; ties alternate - so pipelined callers interleave two kernel chains on the
     // device as before, while ONE blocking call at a time always lands on context 0: the same 0.3 GB of activation scratch
     // (and the same captured query graphs) call after call instead of two sets taking turns in L2 / the Infinity Cache.
@@ -827,7 +848,18 @@ int32_t submit_locked(cqs_hip_embedder* e, uint32_t B, const std::function<int32
     // calls (tools/r04_ctx_sweep.py, same box): 12 288 tokens 6 370 | 5 480 | 5 510; 14 336: 6 530 | 6 175 | 6 130; 16 384: 6 220-6 450 |
     // 6 400 | 6 440; 18 432: 5 975-6 300 | 4 845 | 4 820; 24 576: 6 050 | 5 690 | 5 740; 32 768: 6 340 | 6 530 | 6 600; 49 152: 6 220 | 6 110 |
     // 6 200; 65 536: 6 100 | 5 970 | 6 060.  So: those two sizes stay on context 0, everything else alternates.
-    if (sl->M == 16384u || sl->M == 32768u) ci = 0;
+    // The rule is the geometry, not the two bench shapes: the fused projections launch two workgroups per 128 token
+    // rows; a batch is "exact rounds" when the last round of those workgroups is full or within 1/32 of full (16 384 - 500
+    // tokens still is; 14 336 and 18 432 - 7/8 and 9/8 of a round - are not, and measured faster on two contexts above).
+    {
+        static const uint32_t n_cu = [] {
+            int dev = 0, v = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+            return (uint32_t)v;
+        }();
+        const uint32_t wgs = (sl->M + 127u) / 128u * 2u, last = wgs % n_cu;
+        if (wgs >= n_cu && (last == 0u || last * 32u >= n_cu * 31u)) ci = 0;
+    }
     if (e->single_ctx) ci = 0;            // CQS_HIP_EMBED_CONTEXTS=1: every ticket on one stream (tickets still overlap host packing / copies)
     e->last_ctx = ci;
     sl->ctx = ci;
@@ -848,15 +880,9 @@ int32_t submit_locked(cqs_hip_embedder* e, uint32_t B, const std::function<int32
         if (!sl->direct) E_TRY(e, hipMemcpyAsync(sl->out, c.q_out, (size_t)H * sizeof(float), hipMemcpyDeviceToHost, st));
         E_TRY(e, hipEventRecord(sl->done, st));
     } else {
-        rc = run_layers(e, c, *sl);
+        rc = enqueue_batch_chain(e, c, *sl);
         if (rc != CQS_HIP_OK) return rc;
-        const cqs::EmbedGeom& g = e->g;
-        E_TRY(e, cqs::launch_mean_pool(c.hidden, c.d_seq_start, c.d_seq_len, c.pooled, B, H, st));
-        E_TRY(e, cqs::launch_gemm_skinny(c.pooled, e->dense1, c.d1, B, g.dense_hidden, H, g.dense_hidden, cqs::GEMM_OUT_BF16, st));
-        E_TRY(e, cqs::launch_gemm_skinny(c.d1, e->dense2, c.out, B, H, g.dense_hidden, H, cqs::GEMM_OUT_F32, st));
-        E_TRY(e, hipEventRecord(sl->ev1, st));
-        E_TRY(e, hipMemcpyAsync(sl->out, c.out, (size_t)B * H * sizeof(float), hipMemcpyDeviceToHost, st));
-        E_TRY(e, hipEventRecord(sl->done, st));
+        sl->batch_chain = true;
     }
     sl->ticket = e->next_ticket++;
     *ticket = sl->ticket;
@@ -902,9 +928,24 @@ int32_t cqs_hip_embed_collect(cqs_hip_embedder* e, uint64_t ticket, float* out) 
     std::lock_guard<std::mutex> lk(e->mu);
     sl->collecting = false;
     if (he != hipSuccess) { sl->ticket = 0; return efail(e, CQS_HIP_ERR_DEVICE, "collect: device failure", he); }
-    if (e->fuse_err && *(volatile unsigned*)e->fuse_err != 0u) {   // a pair of the fused projection kernel never met: the rows are garbage
-        sl->ticket = 0;
-        return efail(e, CQS_HIP_ERR_DEVICE, "collect: fused projection pair exchange timed out");
+    if (e->fuse_err && *(volatile unsigned*)e->fuse_err != 0u) {
+        // A pair of the fused projection kernel never met (gemm_rowfuse.hip: workgroup b waits for granules of workgroup
+        // b ^ 8 of the same launch, which needs both resident - true on an otherwise idle device, not promised by HIP):
+        // rows of EVERY batch-chain ticket in flight may be garbage.  Round 5: the engine drops to the
+        // two-launch chain (no cross-workgroup exchange, the same bits) for good and recomputes those tickets - this
+        // one here, the others at their own collect - instead of poisoning itself.
+        (void)hipDeviceSynchronize();
+        *(volatile unsigned*)e->fuse_err = 0u;
+        e->fuse_norm = 0;
+        e->fuse_fallbacks++;
+        for (cqs_hip_embedder::Slot& c2 : e->slot)
+            if (c2.ticket != 0 && c2.batch_chain) c2.rerun = true;
+    }
+    if (sl->rerun) {
+        sl->rerun = false;
+        int32_t rc = enqueue_batch_chain(e, e->ctx[sl->ctx], *sl);
+        if (rc == CQS_HIP_OK && hipEventSynchronize(sl->done) != hipSuccess) rc = efail(e, CQS_HIP_ERR_DEVICE, "collect: device failure in the recomputed batch");
+        if (rc != CQS_HIP_OK) { sl->ticket = 0; return rc; }
     }
     const uint32_t H = e->g.hidden, B = sl->B;
     if (out) {                         // out == NULL: abandon the ticket (wait, release the slot, drop the rows)
@@ -1043,6 +1084,19 @@ void cqs_hip_debug_embedder_set_fuse_norm(cqs_hip_embedder* e, int32_t on, uint3
     e->fuse_norm = on < 0 ? 0 : (on > 2 ? 2 : on);     // 0 = two launches, 1 = the 64-row kernel, 2 = the pair-split kernel
     if (min_rows) e->fuse_min_rows = min_rows;
 } CQS_ABI_CATCH_VOID
+
+// Test hook (not part of the public header): pretend a pair exchange of the fused projection kernel timed out (what the
+// kernel's bounded spin reports through the pinned error word), and read how often the engine has fallen back.
+void cqs_hip_debug_embedder_fake_fuse_timeout(cqs_hip_embedder* e) CQS_ABI_TRY {
+    if (!e || !e->fuse_err) return;
+    std::lock_guard<std::mutex> lk(e->mu);
+    *(volatile unsigned*)e->fuse_err = 1u;
+} CQS_ABI_CATCH_VOID
+uint32_t cqs_hip_debug_embedder_fuse_fallbacks(cqs_hip_embedder* e) CQS_ABI_TRY {
+    if (!e) return 0;
+    std::lock_guard<std::mutex> lk(e->mu);
+    return e->fuse_fallbacks;
+} CQS_ABI_CATCH_VAL(0)
 
 // Test hook (not part of the public header): the 256-row kernel's in-register GeGLU pairing on / off for THIS engine.
 void cqs_hip_debug_embedder_set_geglu4(cqs_hip_embedder* e, int32_t on) CQS_ABI_TRY {

@@ -387,12 +387,14 @@ int32_t finish_create(cqs_hip_sparse_index* s, const std::vector<uint2>& post, i
     while ((1u << s->sh) < s->rw) ++s->sh;
     // Range directories: dir[r] = how many postings of the list sit below position r * rw, r = 0 .. n_pad / rw - what a wave
     // needs to find its slice of the list with two adjacent loads.  Longest lists first, within a budget of entries equal
-    // to the postings' own bytes (never less than 256 MB): every list of a real vocabulary gets one (30 522 tokens x 3 907
-    // ranges = 0.48 GB at 1M chunks); lists left without (shorter than kDirMinLen, or past the budget) are bisected.
+    // to the postings' own bytes (2 P entries x 4 B = P x 8 B; never less than 64 MB.  Round 4's floor was 256 MB: a 100k-chunk
+    // index with a 30k-token vocabulary paid 192 MB of directories - and the same again as a host staging vector - for
+    // 80 MB of postings): at 1M chunks rw = 128, so a list's directory is 7 813 + 1 entries and the ~25 k longest
+    // lists of a 96 M-posting index get one; lists left without (shorter than kDirMinLen, or past the budget) are bisected.
     {
         constexpr uint64_t kDirMinLen = 32;
         const uint64_t R1 = (uint64_t)(s->n_pad / s->rw) + 1;
-        const uint64_t budget = std::max<uint64_t>(64ull << 20, 2ull * P);
+        const uint64_t budget = std::max<uint64_t>(16ull << 20, 2ull * P);
         s->dir_off.assign(s->tok.size(), kNoDir);
         std::vector<uint32_t> order;
         for (size_t t = 0; t < s->tok.size(); ++t)

@@ -186,21 +186,44 @@ impl HipSpladeIndex {
         Some(Self { raw, id_map })
     }
 
-    /// `SpladeIndex::search` (index.rs:214-216): every chunk is a candidate.
+    /// Largest `k` one call serves (the library's top-k capacity).  The reference asks the sparse leg for
+    /// `candidate_count_for(limit) = max(500, 5 * limit)` with no cap (query.rs:858, 896-897; limits.rs:315-320), i.e. more
+    /// than this for `limit > 204`: the caller caps to it the way `cap_k_to_backend` caps the dense leg (query.rs:232-245),
+    /// or keeps the in-memory `SpladeIndex` for such limits.  `search*` below clamp and SAY SO.
+    pub fn max_k(&self) -> usize {
+        MAX_K
+    }
+
+    fn clamp_k(&self, k: usize) -> usize {
+        if k > MAX_K {
+            tracing::warn!(requested = k, served = MAX_K, "HIP SPLADE index: k above max_k, sparse pool is shorter than SpladeIndex::search would return");
+        }
+        k.min(MAX_K)
+    }
+
+    /// `SpladeIndex::search` (index.rs:214-216): every chunk is a candidate.  No bitset is built or uploaded (round 4 went
+    /// through `search_with_filter(|_| true)`: one closure call per chunk and a 125 KB upload in front of a 50 us search).
     pub fn search(&self, query: &SparseVector, k: usize) -> Vec<IndexResult> {
-        self.search_with_filter(query, k, &|_: &str| true)
+        self.search_keep(query, k, None)
     }
 
     /// `SpladeIndex::search_with_filter` (index.rs:223-290).  The predicate is evaluated once per chunk id on the host
     /// and handed over as a bitset; a device failure logs and returns no results (the caller's dense leg still answers).
+    /// A caller that searches repeatedly under one filter builds the bitset once (`keep_bitset`) and calls
+    /// `search_with_keep`: the reference evaluates its predicate on touched postings only, this path cannot.
     pub fn search_with_filter(&self, query: &SparseVector, k: usize, filter: &dyn Fn(&str) -> bool) -> Vec<IndexResult> {
-        let _span = tracing::debug_span!("hip_splade_index_search", k, query_terms = query.len(), index_size = self.id_map.len()).entered();
         if query.is_empty() || self.id_map.is_empty() || k == 0 {
             return Vec::new();
         }
-        let k = k.min(MAX_K);
-        let q_tokens: Vec<u32> = query.iter().map(|&(t, _)| t).collect();
-        let q_weights: Vec<f32> = query.iter().map(|&(_, w)| w).collect();
+        match self.keep_bitset(filter) {
+            Some(keep) => self.search_keep(query, k, Some(&keep)),
+            None => self.search_keep(query, k, None),          // the predicate kept everything
+        }
+    }
+
+    /// The keep-bitset of a predicate over this index's chunk ids (bit i = chunk i kept); `None` when it keeps every
+    /// chunk.  Cache it per filter key: it costs one predicate call per chunk.
+    pub fn keep_bitset(&self, filter: &dyn Fn(&str) -> bool) -> Option<Vec<u32>> {
         let mut keep = vec![0u32; (self.id_map.len() + 31) / 32];
         let mut all = true;
         for (i, id) in self.id_map.iter().enumerate() {
@@ -210,6 +233,26 @@ impl HipSpladeIndex {
                 all = false;
             }
         }
+        if all { None } else { Some(keep) }
+    }
+
+    /// `search_with_filter` with a bitset from `keep_bitset`.
+    pub fn search_with_keep(&self, query: &SparseVector, k: usize, keep: &[u32]) -> Vec<IndexResult> {
+        if keep.len() != (self.id_map.len() + 31) / 32 {
+            tracing::warn!(words = keep.len(), "HIP SPLADE index: keep bitset of the wrong length, no results");
+            return Vec::new();
+        }
+        self.search_keep(query, k, Some(keep))
+    }
+
+    fn search_keep(&self, query: &SparseVector, k: usize, keep: Option<&[u32]>) -> Vec<IndexResult> {
+        let _span = tracing::debug_span!("hip_splade_index_search", k, query_terms = query.len(), index_size = self.id_map.len()).entered();
+        if query.is_empty() || self.id_map.is_empty() || k == 0 {
+            return Vec::new();
+        }
+        let k = self.clamp_k(k);
+        let q_tokens: Vec<u32> = query.iter().map(|&(t, _)| t).collect();
+        let q_weights: Vec<f32> = query.iter().map(|&(_, w)| w).collect();
         let mut chunks = vec![0u64; k];
         let mut scores = vec![0f32; k];
         let mut count = 0u32;
@@ -220,7 +263,7 @@ impl HipSpladeIndex {
                 q_weights.as_ptr(),
                 q_tokens.len() as u32,
                 k as u32,
-                if all { std::ptr::null() } else { keep.as_ptr() },
+                keep.map_or(std::ptr::null(), |w| w.as_ptr()),
                 chunks.as_mut_ptr(),
                 scores.as_mut_ptr(),
                 &mut count,
@@ -238,7 +281,7 @@ impl HipSpladeIndex {
     /// Several queries in one pair of launches (`cqs eval`, or a daemon that gathers its clients' queries): each answer is the
     /// one `search` gives for that query alone.  At most 64 queries per call; more are served in slices.
     pub fn search_batch(&self, queries: &[&SparseVector], k: usize) -> Vec<Vec<IndexResult>> {
-        let k = k.min(MAX_K);
+        let k = self.clamp_k(k);
         let mut all = Vec::with_capacity(queries.len());
         for slice in queries.chunks(64) {
             let mut q_off: Vec<u64> = Vec::with_capacity(slice.len() + 1);

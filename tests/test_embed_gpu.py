@@ -544,6 +544,37 @@ def test_fused_projection_addnorm_is_bit_identical_to_the_two_launch_chain(hip):
     eng.close()
 
 
+def test_a_pair_exchange_timeout_falls_back_instead_of_poisoning(hip):
+    """the pair-split projection kernel makes workgroup b wait (bounded) for granules of workgroup b ^ 8 of the
+    same launch; a timeout used to leave garbage rows and poison the engine at collect.  Now the engine drops to the
+    two-launch chain (same bits, no cross-workgroup exchange) and recomputes every batch-chain ticket that was in flight:
+    three tickets in flight, the timeout word set by the debug hook, every collect returns the rows of an undisturbed run,
+    the engine stays usable and has fallen back exactly once."""
+    import ctypes as C
+    cfg = G.GemmaConfig(vocab_size=4096, hidden=768, layers=4, heads=3, kv_heads=1, head_dim=256, intermediate=1152,
+                        dense_hidden=3072, sliding_window=512, sliding_pattern=2, max_seq=2048)
+    eng, _w = make(cfg, seed=45)
+    fake = eng._lib.cqs_hip_debug_embedder_fake_fuse_timeout
+    fake.restype = None
+    fake.argtypes = [C.c_void_p]
+    nfb = eng._lib.cqs_hip_debug_embedder_fuse_fallbacks
+    nfb.restype = C.c_uint32
+    nfb.argtypes = [C.c_void_p]
+    set_fuse_norm(eng, 2, 64)
+    batches = [batch(cfg, lens, seed=sum(lens)) for lens in ([700, 650, 33, 517], [300] * 6, [1000, 3])]
+    want = [eng.run(i, m) for i, m in batches]
+    assert nfb(eng._h) == 0
+    t = [eng.submit(i, m) for i, m in batches]
+    fake(eng._h)
+    for tk, w_, (i, _m) in zip(t, want, batches):
+        assert np.array_equal(eng.collect(tk, i.shape[0]), w_)
+    assert nfb(eng._h) == 1 and eng._lib.cqs_hip_embedder_poisoned(eng._h) == 0
+    for (i, m), w_ in zip(batches, want):                      # the engine keeps serving, now on the two-launch chain
+        assert np.array_equal(eng.run(i, m), w_)
+    assert nfb(eng._h) == 1
+    eng.close()
+
+
 def set_fuse_qkv(eng, on):
     import ctypes as C
     f = eng._lib.cqs_hip_debug_embedder_set_fuse_qkv
