@@ -439,6 +439,191 @@ __global__ __launch_bounds__(256, OCC) void scan_mfma16_kernel(const MfmaParams 
     }
 }
 
+// ---- blocks of <= 64 queries: K split over the waves, the query tile resident in registers (round 5) --------------------
+// What a small block wants is the one-query scan's access pattern (whole row pieces, contiguous, each fetched once) with the
+// matrix cores' arithmetic.  The two kernels above stage EVERY operand through shared LDS tiles: a stage is 64 B (16 floats) of
+// each of 256 rows plus the same 64 B of every query again, one workgroup barrier per stage, and HBM sees sector-sized pieces
+// of 10^5 rows at once (4.5 TB/s at 32 queries against the 6.8 the one-query scan reads).  Here:
+//   * a workgroup = 4 waves, 2 workgroups per CU; wave w owns the K quarter [w KQ, (w + 1) KQ) of EVERY row of the tile and of
+//     every query: its 32 queries' fragments for that quarter live in registers for the whole launch (KG float4 = 96 VGPRs at
+//     768 dimensions) - the query tile is read once per workgroup, not once per stage;
+//   * the wave streams its quarter of the tile's rows in CHUNKS of 32 rows x 64 floats: per row 256 contiguous bytes, the three
+//     chunks of a quarter 768 contiguous bytes fetched back to back; a chunk is loaded (8 x 16 B per lane, coalesced in 256-B
+//     pieces) while the previous one multiplies, transposed through a wave-PRIVATE padded LDS image ([32][68] floats:
+//     conflict-free ds_write_b128 / ds_read_b128) - no workgroup barrier anywhere in the K loop;
+//   * per chunk: 8 fragment reads (one ds_read_b128 per 4 MFMAs; the A operand needs none) and 32 v_mfma_f32_32x32x2_f32;
+//   * the four partial sums of a 32 q x 64 row tile meet once per tile through LDS (32 KB, over the chunk images), summed in
+//     wave order; then the usual epilogue (lane & 31 <-> corpus row: 128-B score stores; one maximum per 64 rows).
+// Blocks of 33-64 queries run as two query blocks of 32 on alternate workgroup octets (blocks b and b + 8 share an XCD's L2
+// under round-robin placement, speed only) with a work queue each; the second reader of a row tile finds it in L2 / the
+// Infinity Cache (default-policy loads).  dim % 256 == 0 and <= 1024 (the query registers); everything else keeps the
+// kernels above.  Scores differ from theirs in summation order only (parity tolerance 1e-5, tests/test_scan_gpu.py).
+constexpr int kKsRows = 64;        // corpus rows per tile (two MFMA row tiles)
+constexpr int kKsLdr = 68;         // padded chunk row stride in floats (272 B: 16 rows -> 16 distinct 4-bank slots)
+
+template <int KG, int WQ, bool NT>
+__global__ __launch_bounds__(256 * WQ, 2) void scan_mfma_ks_kernel(const MfmaParams p) {
+    constexpr int NCH = KG / 8;                  // 64-float chunks per row tile and wave
+    static_assert(KG % 8 == 0, "a wave's K share is whole 64-float chunks");
+    static_assert(WQ == 1 || WQ == 2, "one or two query tiles of 32");
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // [4 WQ][32][kKsLdr] chunk images; the combine reuses it as [WQ][4][32][64]
+    __shared__ uint32_t s_task;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wq = wid >> 2, wk = wid & 3;       // query tile, K quarter of this wave
+    const int l31 = lane & 31, lh = lane >> 5;
+    const uint32_t dim = p.dim, n = p.n, last_row = n - 1u;
+    float* const my = smem + (size_t)wid * 32 * kKsLdr;
+
+    // this wave's query fragments: lane l feeds A[i = l & 31][k = wk KQ + 8 kg + 4 (l >> 5) + c] to the c-th MFMA of k-group kg
+    f4 qa[KG];
+    {
+        // (K labelling: chunk ch of wave wk = floats [256 ch + 64 wk, + 64) - at every step the four waves' pieces of a row
+        // are ADJACENT, 1 KB together, the one-query scan's request size; a contiguous quarter per wave read 256-B islands)
+        const float* qp = p.q + ((size_t)wq * 32u + (uint32_t)l31) * dim + (uint32_t)wk * 64u + 4u * (uint32_t)lh;
+#pragma unroll
+        for (int kg = 0; kg < KG; ++kg) qa[kg] = *(const f4*)(qp + (kg / 8) * 256 + (kg % 8) * 8);
+    }
+    // chunk staging: float4 f = 64 u + lane of a chunk -> row f >> 4, 16-byte column f & 15 (a wave-load = 4 rows x 256 B)
+    const uint32_t st_row0 = (uint32_t)lane >> 4, st_c4 = (uint32_t)lane & 15u;
+    uint32_t task = blockIdx.x;                  // first tile = the workgroup's index, later ones from the queue
+    const uint32_t n_tiles = p.n_tasks;
+
+    auto chunk_load = [&](uint32_t row0, int st, f4 (&reg)[8]) {     // st = row tile (0, 1) * NCH + chunk
+        const uint32_t rt = (uint32_t)st / NCH, ch = (uint32_t)st % NCH;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            uint32_t r = row0 + rt * 32u + 4u * (uint32_t)u + st_row0;
+            r = r > last_row ? last_row : r;
+            const f4* a = (const f4*)(p.rows + (size_t)r * dim + ch * 256u + (uint32_t)wk * 64u + st_c4 * 4u);
+            reg[u] = NT ? __builtin_nontemporal_load(a) : *a;
+        }
+    };
+    // Two chunks in flight per wave (16 KB; 128 KB per CU at two workgroups): chunk st + 2 is requested as soon as chunk st has
+    // moved from its registers to the LDS image.  The last two requests of a tile belong to the NEXT tile, so a workgroup
+    // knows its next tile one tile ahead: the first two are static, the queue hands out the one after next.
+    uint32_t task_next = task + gridDim.x;
+    f4 reg[2][8];
+    if (task < n_tiles) {
+        chunk_load(task * (uint32_t)kKsRows, 0, reg[0]);
+        chunk_load(task * (uint32_t)kKsRows, 1, reg[1]);
+    }
+    while (task < n_tiles) {
+        const uint32_t row0 = task * (uint32_t)kKsRows;
+        // (past the end: request this tile's rows again - unconditional loads keep hipcc's wait counts those of the loop)
+        const uint32_t row0_next = (task_next < n_tiles ? task_next : task) * (uint32_t)kKsRows;
+        uint32_t claimed = 0;
+        if (tid == 0) claimed = 2u * gridDim.x + atomicAdd(p.work, 1u);
+        f16v acc[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+#pragma unroll
+        for (int st = 0; st < 2 * NCH; ++st) {
+            // the chunk requested two steps ago: registers -> this wave's LDS image (its reads of the previous chunk are
+            // complete: their MFMAs have been issued), then the request for chunk st + 2 goes out under this one's MFMAs
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                *(f4*)(my + (4 * u + (int)st_row0) * kKsLdr + (int)st_c4 * 4) = reg[st & 1][u];
+            if (st + 2 < 2 * NCH) chunk_load(row0, st + 2, reg[st & 1]);
+            else chunk_load(row0_next, st + 2 - 2 * NCH, reg[st & 1]);
+            const float* fr = my + l31 * kKsLdr + 4 * lh;
+#pragma unroll
+            for (int kg = 0; kg < 8; ++kg) {
+                const f4 bf = *(const f4*)(fr + kg * 8);
+                const f4 af = qa[(st % NCH) * 8 + kg];
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    acc[st / NCH] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c], bf[c], acc[st / NCH], 0, 0, 0);
+            }
+        }
+        if (tid == 0) s_task = claimed;
+        __syncthreads();                              // every wave is done with its chunk image; s_task is visible
+        const uint32_t task_after = s_task;
+        // ---- the four K quarters of a query tile meet: partial[wq][wk][t * 16 + r][lane], summed in wave order by the wave
+        // that owns registers 4 wk .. 4 wk + 3 of both row tiles (it holds both halves of every 64-row group for the maximum) ----
+        float* const part = smem + (size_t)wq * 4 * 32 * 64;      // 32 KB per query tile <= its four chunk images (34 816 B)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) part[((size_t)wk * 32 + t * 16 + r) * 64 + lane] = acc[t][r];
+        __syncthreads();
+        float sum[2][4];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = 4 * wk + j;
+                float v = part[((size_t)0 * 32 + t * 16 + r) * 64 + lane];
+                v += part[((size_t)1 * 32 + t * 16 + r) * 64 + lane];
+                v += part[((size_t)2 * 32 + t * 16 + r) * 64 + lane];
+                v += part[((size_t)3 * 32 + t * 16 + r) * 64 + lane];
+                sum[t][j] = v;
+            }
+        __syncthreads();                              // the images are free for the next tile's chunks
+        // ---- epilogue: lane & 31 <-> corpus row, register r <-> query (r & 3) + 8 (r >> 2) + 4 (lane >> 5) ----
+        const uint32_t nwords = (n + 31u) / 32u;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const uint32_t row = row0 + (uint32_t)(t * 32 + l31);
+            bool live = row < n;
+            if (p.keep && live) {
+                const uint32_t w = row >> 5;
+                live = w < nwords && ((p.keep[w] >> (row & 31u)) & 1u);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t qi = (uint32_t)(wq * 32 + j + 8 * wk + 4 * lh);       // r = 4 wk + j: (r & 3) = j, (r >> 2) = wk
+                float sv = sum[t][j];
+                if (!live || !(__builtin_fabsf(sv) <= 3.4028234664e38f)) sv = -INFINITY;
+                else if (p.mode == 1u) {
+                    sv = sv < 0.f ? 0.f : (sv > 1.f ? 1.f : sv);
+                    if (!(sv >= p.thr)) sv = -INFINITY;
+                }
+                sum[t][j] = sv;
+                if (qi < p.b) p.scores[(size_t)qi * p.n_pad + row] = sv;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float m = half_wave_max(fmaxf(sum[0][j], sum[1][j]));
+            const uint32_t qi = (uint32_t)(wq * 32 + j + 8 * wk + 4 * lh);
+            if (l31 == 0 && qi < p.b) p.gmax[(size_t)qi * (p.n_pad / 64u) + task] = m;
+        }
+        task = task_next;
+        task_next = task_after;
+    }
+}
+
+template <int KG>
+static hipError_t launch_mfma_ks(const ScanArgs& a, uint32_t q0, uint32_t nq, uint32_t slot, hipStream_t st) {
+    MfmaParams p;
+    p.rows = a.rows; p.n = a.n; p.n_pad = a.n_pad; p.dim = a.dim;
+    p.q = a.q + (size_t)q0 * a.dim;
+    p.b = nq;
+    p.scores = a.scores + (size_t)q0 * a.n_pad;
+    p.gmax = a.gmax + (size_t)q0 * (a.n_pad / kTaskRows);
+    p.keep = a.keep; p.mode = a.mode; p.thr = a.threshold;
+    p.work = a.work + slot;
+    p.q_blocks = 1;
+    p.n_tasks = a.n_pad / (uint32_t)kKsRows;
+    // 33-64 queries: eight waves per workgroup, waves 4-7 hold the second query tile and stream the same row pieces as
+    // waves 0-3 (the second fetch of a piece is an L1 / L2 hit: default-policy loads), one workgroup per CU; else two of four
+    const bool two = nq > 32u;
+    const size_t lds = (size_t)(two ? 8 : 4) * 32 * kKsLdr * sizeof(float);
+    const uint32_t want = (two ? 1u : 2u) * a.n_cu;
+    const uint32_t blocks = want < p.n_tasks ? want : p.n_tasks;
+    const bool nt = a.nontemporal && !two;
+    const void* kern;
+    if (two) kern = (const void*)scan_mfma_ks_kernel<KG, 2, false>;
+    else kern = nt ? (const void*)scan_mfma_ks_kernel<KG, 1, true> : (const void*)scan_mfma_ks_kernel<KG, 1, false>;
+    static DynLdsOnce once[3];
+    hipError_t e = once[two ? 2 : (nt ? 1 : 0)].ensure(kern, lds);
+    if (e != hipSuccess) return e;
+    void* args[] = {(void*)&p};
+    return hipLaunchKernel(kern, dim3(blocks), dim3(two ? 512 : 256), args, lds, st);
+}
+
 // (Round 4 built and removed a STREAMING kernel for blocks of <= 32 queries - queries resident in LDS, every wave feeding
 // v_mfma_f32_16x16x4_f32 with corpus rows loaded straight from global memory, 128 KB in flight per CU, no barrier in the
 // loop: bit-correct, 0.70 ms at 32 queries x 1M rows with default-policy loads (0.80 streaming-policy; a 32x32x2 form with
@@ -496,6 +681,16 @@ static hipError_t launch_mfma_cfg(const ScanArgs& a, uint32_t q0, uint32_t nq, u
 // padded) up to the next multiple of the chosen query tile.
 hipError_t launch_scan_mfma(const ScanArgs& a, uint32_t q0, uint32_t nq, uint32_t slot, hipStream_t st) {
     static const int waves = [] { const char* e = getenv("CQS_HIP_SCAN_MFMA_WAVES"); return e ? atoi(e) : 16; }();   // A/B hook: 4 = round-2 kernels, 8 = one 8-wave workgroup per CU
+    static const int ksplit = [] { const char* e = getenv("CQS_HIP_SCAN_MFMA_KSPLIT"); return e ? atoi(e) : 1; }();  // A/B hook: 0 = the LDS-tiled kernels for every block size
+    // blocks of <= 64 queries at 768 / 1024 dimensions: the K-split kernel (query tile in registers, 256-B row pieces)
+    // (33-64 queries keep the LDS-tiled kernel: measured at 64 queries x 1M rows 1.02-1.05 ms on eight K-split waves per CU and
+    // 1.13 ms with two query tiles per wave at one wave per SIMD, against 0.93 ms; CQS_HIP_SCAN_MFMA_KSPLIT=2 runs them anyway)
+    if (ksplit && waves == 16 && nq <= (uint32_t)(ksplit == 2 ? 64 : 32)) {
+        if (a.dim == 768u) return launch_mfma_ks<24>(a, q0, nq, slot, st);
+        if (a.dim == 1024u) return launch_mfma_ks<32>(a, q0, nq, slot, st);
+        if (a.dim == 512u) return launch_mfma_ks<16>(a, q0, nq, slot, st);
+        if (a.dim == 256u) return launch_mfma_ks<8>(a, q0, nq, slot, st);
+    }
     if (waves == 16) {                                       // 2 workgroups of 4 waves per CU, K staged 16 at a time
         if (nq > 64) return launch_mfma16_cfg<2, 2, 2, 2>(a, q0, nq, slot, st);   // 128 q x 128 rows (x 2 query blocks for 129-256)
         // Measured (1M x 768, scan + select, round 4): three workgroups per CU need <= 168 VGPRs - the 64-query tile then spills

@@ -229,6 +229,47 @@ def test_query_blocks_match_single(hip, oracle, b):
     idx.close()
 
 
+KSPLIT_CASE = """
+import sys
+sys.path.insert(0, %r)
+sys.path.insert(0, %r)
+import numpy as np
+from cqs_amd import HipIndex, synth
+from oracle import oracle
+from parity import assert_topk_parity
+for b, n, dim, k in [(9, 700, 768, 20), (32, 20000, 768, 20), (33, 9000, 768, 50), (64, 40000, 768, 20), (48, 5000, 1024, 10),
+                     (20, 3000, 512, 10), (64, 2000, 256, 10)]:
+    rows = synth.gaussian_unit(n, seed=300 + b, dim=dim)
+    qs = synth.gaussian_unit(b, seed=400 + b, dim=dim)
+    keep = np.random.default_rng(b).integers(0, 2**32, size=(n + 31) // 32, dtype=np.uint64).astype(np.uint32)
+    idx = HipIndex.build_from_flat(None, rows)
+    for kb in (None, keep):
+        r, s, c = idx.search_batch(qs, k, keep_bitset=kb)
+        for i in range(b):
+            ids, sc = oracle.index_search(rows, qs[i], k + 64, kb)
+            assert_topk_parity(r[i, :c[i]], s[i, :c[i]], ids, sc, k)
+    idx.close()
+print("ok")
+"""
+
+
+@pytest.mark.parametrize("ksplit", ["1", "2", "0"])
+def test_k_split_matrix_core_kernel_all_forms(hip, ksplit):
+    """Round 5: query blocks of 9-32 at 256 / 512 / 768 / 1024 dimensions run `scan_mfma_ks_kernel` (K split over the waves,
+    the query tile resident in registers, 256-byte row pieces through wave-private LDS images).  Its eight-wave form for
+    33-64 queries is measured slower than the LDS-tiled kernel and stays behind CQS_HIP_SCAN_MFMA_KSPLIT=2; =0 disables
+    the kernel.  The switch is read once per process, so each setting runs in a process of its own: every form against the
+    oracle, with and without a bitset, tiles that end inside the last row tile, the work queue (40 000 rows = 625 tiles)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CQS_HIP_SCAN_MFMA_KSPLIT=ksplit)
+    p = subprocess.run([sys.executable, "-c", KSPLIT_CASE % (root, os.path.join(root, "tests"))], env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert p.returncode == 0 and p.stdout.strip().endswith("ok"), p.stderr[-3000:]
+
+
 @pytest.mark.parametrize("b,n,dim,k", [(16, 5000, 768, 20), (64, 9000, 768, 20), (100, 4097, 768, 50),
                                        (256, 20000, 768, 20), (300, 3000, 768, 20), (40, 2000, 384, 10),
                                        (32, 2500, 1024, 10), (24, 1500, 100, 10)])
