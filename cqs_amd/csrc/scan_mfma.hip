@@ -525,8 +525,12 @@ __global__ __launch_bounds__(256 * WQ, 2) void scan_mfma_ks_kernel(const MfmaPar
 #pragma unroll
             for (int u = 0; u < 8; ++u)
                 *(f4*)(my + (4 * u + (int)st_row0) * kKsLdr + (int)st_c4 * 4) = reg[st & 1][u];
+            // (sched_barriers: left alone, hipcc sinks these loads to their first use two steps later and waits for them there
+            // with vmcnt(0) - the whole HBM round trip exposed every other step; seen in the ISA, round 5)
+            __builtin_amdgcn_sched_barrier(0);
             if (st + 2 < 2 * NCH) chunk_load(row0, st + 2, reg[st & 1]);
             else chunk_load(row0_next, st + 2 - 2 * NCH, reg[st & 1]);
+            __builtin_amdgcn_sched_barrier(0);
             const float* fr = my + l31 * kKsLdr + 4 * lh;
 #pragma unroll
             for (int kg = 0; kg < 8; ++kg) {
@@ -536,6 +540,7 @@ __global__ __launch_bounds__(256 * WQ, 2) void scan_mfma_ks_kernel(const MfmaPar
                 for (int c = 0; c < 4; ++c)
                     acc[st / NCH] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c], bf[c], acc[st / NCH], 0, 0, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (tid == 0) s_task = claimed;
         __syncthreads();                              // every wave is done with its chunk image; s_task is visible
