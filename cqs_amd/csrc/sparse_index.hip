@@ -270,6 +270,7 @@ struct cqs_hip_sparse_index {
     bool leader = false;
     bool combine = true;                     // CQS_HIP_COMBINE=0 turns it off (read at create)
     uint32_t combine_wait_us = 100;          // CQS_HIP_COMBINE_WAIT_US
+    std::chrono::steady_clock::time_point last_pass_end{};   // guarded by cmu
     uint32_t expect = 1;                     // like-parameter callers recent passes saw
     std::atomic<uint64_t> stat_passes{0}, stat_queries{0};
     std::string last_error;
@@ -922,17 +923,15 @@ uint32_t count_like_front(const cqs_hip_sparse_index* s) {
 
 // Lead one batch.  `lk` holds cmu on entry and on exit; s->leader is set by the caller.
 void sparse_combine_lead(cqs_hip_sparse_index* s, std::unique_lock<std::mutex>& lk) {
-    lk.unlock();
-    std::unique_lock<std::mutex> dev(s->mu);
-    lk.lock();
+    // stragglers of the last pass are on their way back: wait for them until combine_wait_us after that pass ENDED (a caller
+    // that comes alone later than that does not wait), without the device mutex (round 5, as index.hip's combine_lead)
     const uint32_t target = s->expect < kSparseMaxBatch ? s->expect : kSparseMaxBatch;
-    if (s->combine_wait_us && count_like_front(s) < target) {     // stragglers of the last pass are on their way back
-        const auto t_end = std::chrono::steady_clock::now() + std::chrono::microseconds(s->combine_wait_us);
-        for (;;) {
+    if (s->combine_wait_us && count_like_front(s) < target) {
+        const auto t_end = s->last_pass_end + std::chrono::microseconds(s->combine_wait_us);
+        while (count_like_front(s) < target && std::chrono::steady_clock::now() < t_end) {
             lk.unlock();
             for (int i = 0; i < 64; ++i) __builtin_ia32_pause();
             lk.lock();
-            if (count_like_front(s) >= target || std::chrono::steady_clock::now() >= t_end) break;
         }
     }
     cqs_sparse_req* batch[kSparseMaxBatch];
@@ -951,6 +950,7 @@ void sparse_combine_lead(cqs_hip_sparse_index* s, std::unique_lock<std::mutex>& 
     }
     s->expect = nb + left_like;
     lk.unlock();
+    std::unique_lock<std::mutex> dev(s->mu);               // the device, for the batch alone
 
     int32_t rc = CQS_HIP_OK;
     const uint32_t k = batch[0]->k;
@@ -987,6 +987,7 @@ void sparse_combine_lead(cqs_hip_sparse_index* s, std::unique_lock<std::mutex>& 
     dev.unlock();
 
     lk.lock();
+    s->last_pass_end = std::chrono::steady_clock::now();
     for (uint32_t i = 0; i < nb; ++i) {
         batch[i]->rc = (rc != CQS_HIP_OK && i > 0 && poisoned) ? CQS_HIP_ERR_POISONED : rc;
         batch[i]->done = true;
