@@ -135,7 +135,10 @@ int32_t enqueue_search(cqs_hip_index* x, const float* d_q, uint32_t b, uint32_t 
     a.linear_bins = (x->metric == CQS_HIP_METRIC_COSINE) || (mode == CQS_HIP_MODE_PIPELINE);
     a.k = k;
     a.gmax = x->d_gmax;
-    a.gaux = b <= kGauxQueries ? x->d_gaux : nullptr;
+    static const bool use_gaux = [] { const char* e = getenv("CQS_HIP_SELECT_AUX"); return !(e && e[0] == '0'); }();   // A/B hook
+    // Only where the gather it replaces is long: at k = 20 the index costs what it saves (same-box A/B, 1M x 768, scan + select per
+    // step: k = 20 0.4698 with / 0.4667 ms without; k = 500 0.4783 / 0.4825 - tools/ab_select_aux.sh), so small k keeps round 4's path.
+    a.gaux = (use_gaux && b <= kGauxQueries && k >= kGauxMinK) ? x->d_gaux : nullptr;
     a.work = x->d_work;
     a.n_cu = x->n_cu;
     a.dbg = x->d_dbg;

@@ -103,6 +103,7 @@ namespace cqs_idx {
 constexpr size_t kMaxTimingEvents = 8192;
 constexpr uint64_t kNtBytes = 200ull << 20;  // corpus larger than this streams past L2/MALL
 constexpr uint32_t kGauxQueries = 32;        // query blocks up to this size (every gemv block the host paths form) carry the select's (argmax, runner-up) index
+constexpr uint32_t kGauxMinK = 100;          // ... and only from this k on (below it the gather it replaces is a few groups)
 constexpr size_t kDirectOutKeys = 8192;      // host searches of up to this many result keys have them written straight to pinned host memory
 
 uint64_t pad_rows(uint64_t n);
