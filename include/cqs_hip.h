@@ -171,7 +171,9 @@ size_t cqs_hip_index_last_error(const cqs_hip_index* idx, char* buf, size_t cap)
  * pass over the corpus (up to 8 queries share the HBM stream; more run as consecutive
  * passes inside the same hold of the device).  Each caller receives exactly the bytes a
  * lone call would have produced.  A lone caller pays two uncontended mutex operations.
- * Calls with a bitset, b > 1, or on a sharded handle run one after the other as before.
+ * A handle made by cqs_hip_index_create_sharded / _load_sharded combines the same way
+ * (round 5): the block goes to every shard at once, one gather, one host merge per query.
+ * Calls with a bitset or b > 1 run one after the other as before.
  * If a pass fails, the call that led it returns the device error and every parked caller
  * returns CQS_HIP_ERR_POISONED.  CQS_HIP_COMBINE=0 (read at create) turns the queue off. */
 int32_t cqs_hip_index_search(cqs_hip_index* idx, const float* queries, uint32_t b, uint32_t query_dim,
