@@ -502,10 +502,14 @@ __global__ __launch_bounds__(256 * WQ, 2) void scan_mfma_ks_kernel(const MfmaPar
     // moved from its registers to the LDS image.  The last two requests of a tile belong to the NEXT tile, so a workgroup
     // knows its next tile one tile ahead: the first two are static, the queue hands out the one after next.
     uint32_t task_next = task + gridDim.x;
-    f4 reg[2][8];
+#ifndef CQS_KS_DEPTH
+#define CQS_KS_DEPTH 2
+#endif
+    constexpr int D = ((2 * NCH) % CQS_KS_DEPTH == 0 && 2 * NCH >= CQS_KS_DEPTH) ? CQS_KS_DEPTH : 2;   // chunks in flight per wave
+    f4 reg[D][8];
     if (task < n_tiles) {
-        chunk_load(task * (uint32_t)kKsRows, 0, reg[0]);
-        chunk_load(task * (uint32_t)kKsRows, 1, reg[1]);
+#pragma unroll
+        for (int d = 0; d < D; ++d) chunk_load(task * (uint32_t)kKsRows, d, reg[d]);
     }
     while (task < n_tiles) {
         const uint32_t row0 = task * (uint32_t)kKsRows;
@@ -524,12 +528,12 @@ __global__ __launch_bounds__(256 * WQ, 2) void scan_mfma_ks_kernel(const MfmaPar
             // complete: their MFMAs have been issued), then the request for chunk st + 2 goes out under this one's MFMAs
 #pragma unroll
             for (int u = 0; u < 8; ++u)
-                *(f4*)(my + (4 * u + (int)st_row0) * kKsLdr + (int)st_c4 * 4) = reg[st & 1][u];
+                *(f4*)(my + (4 * u + (int)st_row0) * kKsLdr + (int)st_c4 * 4) = reg[st % D][u];
             // (sched_barriers: left alone, hipcc sinks these loads to their first use two steps later and waits for them there
             // with vmcnt(0) - the whole HBM round trip exposed every other step; seen in the ISA, round 5)
             __builtin_amdgcn_sched_barrier(0);
-            if (st + 2 < 2 * NCH) chunk_load(row0, st + 2, reg[st & 1]);
-            else chunk_load(row0_next, st + 2 - 2 * NCH, reg[st & 1]);
+            if (st + D < 2 * NCH) chunk_load(row0, st + D, reg[st % D]);
+            else chunk_load(row0_next, st + D - 2 * NCH, reg[st % D]);
             __builtin_amdgcn_sched_barrier(0);
             const float* fr = my + l31 * kKsLdr + 4 * lh;
 #pragma unroll
