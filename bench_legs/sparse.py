@@ -26,13 +26,12 @@ def sparse_index_leg(a, np, dense_idx=None):
         qs = synth.sparse_queries(40, terms, vocab, seed=0x5BA2DF + terms)
         for qt, qw in qs[:5]:
             h.search_raw(qt, qw, k)
-        res, acc, touched = [], [], []
+        # the timed calls are what a caller pays; the accumulate launch's own time comes from a second pass (asking for it
+        # makes the library bracket the launch with two events from then on, ~4 us per call)
+        res = []
         t0 = time.perf_counter()
         for qt, qw in qs:
             res.append(h.search_raw(qt, qw, k))
-            ms, tp = h.last_search()
-            acc.append(ms)
-            touched.append(tp)
         el = time.perf_counter() - t0
         t0 = time.perf_counter()
         ncpu = 0
@@ -43,6 +42,13 @@ def sparse_index_leg(a, np, dense_idx=None):
             if time.perf_counter() - t0 > max(2.0, a.cpu_seconds / 2):
                 break
         cpu_el = time.perf_counter() - t0
+        acc, touched = [], []
+        h.last_search()
+        for qt, qw in qs:
+            h.search_raw(qt, qw, k)
+            ms, tp = h.last_search()
+            acc.append(ms)
+            touched.append(tp)
         acc = np.asarray(acc, dtype=np.float64) * 1e-3
         alg = np.asarray(touched, dtype=np.float64) * 8.0 + n * 4.0 + (n / 64.0) * 4.0
         gbs = float(np.mean(alg / acc)) / 1e9

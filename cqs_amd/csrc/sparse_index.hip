@@ -53,6 +53,7 @@ struct SparseTerm {            // one query term, resolved on the host
     float w;                   // query weight
 };
 constexpr unsigned long long kNoDir = ~0ull;
+constexpr size_t kQoffBytes = ((kSparseMaxBatch + 1) * 4 + 15) / 16 * 16;   // the offsets' share of the query block (terms follow, 16-byte aligned)
 
 __device__ __forceinline__ uint32_t lower_bound_chunk(const uint2* __restrict__ p, uint32_t a, uint32_t b, uint32_t c) {
     while (a < b) {
@@ -241,6 +242,7 @@ __global__ __launch_bounds__(256) void sparse_accumulate_kernel(const uint2* __r
 
 using cqs::kMaxTerms;
 using cqs::kSparseMaxBatch;
+using cqs::kQoffBytes;
 using cqs::kNoDir;
 using cqs::kSparsePad;
 using cqs::kUnscored;
@@ -307,6 +309,7 @@ struct cqs_hip_sparse_index {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     unsigned long long* d_dbg = nullptr;     // CQS_HIP_DEBUG_STAMPS=1: select_finish phase stamps of the last search (printed to stderr)
     float last_ms = 0.f;
+    std::atomic<bool> want_timing{false};    // set by the first last_search that asks for the time: searches are timed from then on
     uint64_t last_touched = 0;
 };
 
@@ -329,9 +332,9 @@ void release(cqs_hip_sparse_index* s) {
     (void)hipSetDevice(s->device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     for (void* p : {(void*)s->d_post, (void*)s->d_chunk_of_rank, (void*)s->d_scores, (void*)s->d_gmax, (void*)s->d_work,
-                    (void*)s->d_keep, (void*)s->d_terms, (void*)s->d_qoff, (void*)s->d_dir, (void*)s->d_out_keys, (void*)s->d_out_count, (void*)s->d_dbg})
+                    (void*)s->d_keep, (void*)s->d_qoff, (void*)s->d_dir, (void*)s->d_out_keys, (void*)s->d_out_count, (void*)s->d_dbg})
         if (p) (void)hipFree(p);
-    for (void* p : {(void*)s->h_terms, (void*)s->h_keep, (void*)s->h_out_keys, (void*)s->h_qoff})
+    for (void* p : {(void*)s->h_keep, (void*)s->h_out_keys, (void*)s->h_qoff})      // (d_terms / h_terms point into the qoff blocks)
         if (p) (void)hipHostFree(p);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
@@ -342,11 +345,15 @@ void release(cqs_hip_sparse_index* s) {
 int32_t ensure_terms(cqs_hip_sparse_index* s, uint32_t t) {
     if (t <= s->terms_cap) return CQS_HIP_OK;
     const uint32_t cap = std::max(256u, t + t / 2u);
-    if (s->d_terms) { (void)hipFree(s->d_terms); s->d_terms = nullptr; }
-    if (s->h_terms) { (void)hipHostFree(s->h_terms); s->h_terms = nullptr; }
+    // ONE block per side: [first-term offsets of the batch's queries: kQoffBytes][terms] - a search is one H2D copy
+    // (round 4 sent the offsets and the terms in two)
+    if (s->d_qoff) { (void)hipFree(s->d_qoff); s->d_qoff = nullptr; s->d_terms = nullptr; }
+    if (s->h_qoff) { (void)hipHostFree(s->h_qoff); s->h_qoff = nullptr; s->h_terms = nullptr; }
     s->terms_cap = 0;
-    S_TRY(s, hipMalloc((void**)&s->d_terms, (size_t)cap * sizeof(SparseTerm)));
-    S_TRY(s, hipHostMalloc((void**)&s->h_terms, (size_t)cap * sizeof(SparseTerm), hipHostMallocDefault));
+    S_TRY(s, hipMalloc((void**)&s->d_qoff, kQoffBytes + (size_t)cap * sizeof(SparseTerm)));
+    S_TRY(s, hipHostMalloc((void**)&s->h_qoff, kQoffBytes + (size_t)cap * sizeof(SparseTerm), hipHostMallocDefault));
+    s->d_terms = (SparseTerm*)((char*)s->d_qoff + kQoffBytes);
+    s->h_terms = (SparseTerm*)((char*)s->h_qoff + kQoffBytes);
     s->terms_cap = cap;
     return CQS_HIP_OK;
 }
@@ -438,8 +445,6 @@ int32_t finish_create(cqs_hip_sparse_index* s, const std::vector<uint2>& post, i
     // measured (select at k = 500): 20k chunks 40 -> 24 us, 100k 29 -> 23, 1M 29 -> 45: 16-chunk groups while their maxima fit
     // one pass of the select's workgroup (1024 threads x 16 registers)
     s->group16 = s->n_pad / 16u <= 16384u;
-    if ((he = hipMalloc((void**)&s->d_qoff, (kSparseMaxBatch + 1) * 4)) != hipSuccess) return dfail(he);
-    if ((he = hipHostMalloc((void**)&s->h_qoff, (kSparseMaxBatch + 1) * 4, hipHostMallocDefault)) != hipSuccess) return dfail(he);
     if ((he = hipMalloc((void**)&s->d_work, cqs::kWorkWords * 4)) != hipSuccess) return dfail(he);
     if ((he = hipMemset(s->d_work, 0, cqs::kWorkWords * 4)) != hipSuccess) return dfail(he);
     if ((he = hipMalloc((void**)&s->d_keep, (size_t)(s->n_pad / 32u) * 4)) != hipSuccess) return dfail(he);
@@ -844,8 +849,7 @@ int32_t search_locked(cqs_hip_sparse_index* s, const uint64_t* q_off, const uint
     if (nt == 0) return CQS_HIP_OK;
     s->last_touched = touched;
     hipStream_t st = s->stream;
-    S_TRY(s, hipMemcpyAsync(s->d_terms, s->h_terms, (size_t)nt * sizeof(SparseTerm), hipMemcpyHostToDevice, st));
-    S_TRY(s, hipMemcpyAsync(s->d_qoff, s->h_qoff, (size_t)(b + 1) * 4, hipMemcpyHostToDevice, st));
+    S_TRY(s, hipMemcpyAsync(s->d_qoff, s->h_qoff, kQoffBytes + (size_t)nt * sizeof(SparseTerm), hipMemcpyHostToDevice, st));
     const uint32_t* d_keep = nullptr;
     if (keep_bitset) {
         const size_t words = (size_t)((s->n + 31) / 32);
@@ -854,13 +858,16 @@ int32_t search_locked(cqs_hip_sparse_index* s, const uint64_t* q_off, const uint
         d_keep = s->d_keep;
     }
     const uint32_t waves = s->n_pad / s->rw;
-    S_TRY(s, hipEventRecord(s->ev0, st));
+    // the scoring launch is bracketed by events only once somebody has asked for its time (cqs_hip_sparse_index_last_search
+    // with a non-NULL accumulate_ms): two event records are ~4 us of an 80 us call
+    const bool timed = s->want_timing.load(std::memory_order_relaxed);
+    if (timed) S_TRY(s, hipEventRecord(s->ev0, st));
     hipLaunchKernelGGL(sparse_accumulate_kernel, dim3((waves + 3u) / 4u, b), dim3(256), (size_t)4 * sparse_wave_lds_words(s->rw) * 4, st,
                        s->d_post, s->d_terms, s->d_qoff, s->d_dir, (uint32_t)s->n, s->n_pad, s->sh, d_keep,
                        s->ranked ? s->d_chunk_of_rank : nullptr, s->d_scores, s->d_gmax,
                        (uint64_t*)(s->d_gmax + (size_t)s->b_cap * (s->n_pad / (s->group16 ? 16u : 64u))), s->group16 ? 1u : 0u);
     S_TRY(s, hipGetLastError());
-    S_TRY(s, hipEventRecord(s->ev1, st));
+    if (timed) S_TRY(s, hipEventRecord(s->ev1, st));
     cqs::ScanArgs a{};
     a.n = (uint32_t)s->n;
     a.n_pad = s->n_pad;
@@ -885,7 +892,7 @@ int32_t search_locked(cqs_hip_sparse_index* s, const uint64_t* q_off, const uint
         S_TRY(s, hipMemcpyAsync(h_counts, s->d_out_count, (size_t)b * 4, hipMemcpyDeviceToHost, st));
     }
     S_TRY(s, hipStreamSynchronize(st));
-    (void)hipEventElapsedTime(&s->last_ms, s->ev0, s->ev1);
+    if (timed) (void)hipEventElapsedTime(&s->last_ms, s->ev0, s->ev1);
     if (s->d_dbg) {
         unsigned long long h[16];
         if (hipMemcpy(h, s->d_dbg, sizeof h, hipMemcpyDeviceToHost) == hipSuccess)
@@ -1067,7 +1074,10 @@ void cqs_hip_sparse_index_combine_stats(const cqs_hip_sparse_index* s, uint64_t*
 int32_t cqs_hip_sparse_index_last_search(const cqs_hip_sparse_index* s, float* accumulate_ms, uint64_t* touched_postings) CQS_ABI_TRY {
     if (!s) return CQS_HIP_ERR_INVALID;
     std::lock_guard<std::mutex> g(const_cast<cqs_hip_sparse_index*>(s)->mu);
-    if (accumulate_ms) *accumulate_ms = s->last_ms;
+    if (accumulate_ms) {
+        *accumulate_ms = s->last_ms;             // 0 for a search that ran before the first request
+        const_cast<cqs_hip_sparse_index*>(s)->want_timing.store(true, std::memory_order_relaxed);
+    }
     if (touched_postings) *touched_postings = s->last_touched;
     return CQS_HIP_OK;
 } CQS_ABI_CATCH_VAL(CQS_HIP_ERR_INVALID)

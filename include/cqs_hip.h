@@ -482,7 +482,9 @@ int32_t cqs_hip_sparse_index_search_batch(cqs_hip_sparse_index* idx, const uint6
  * carried.  Either pointer may be NULL.  Diagnostic. */
 void cqs_hip_sparse_index_combine_stats(const cqs_hip_sparse_index* idx, uint64_t* passes, uint64_t* queries);
 /* Profiling aid: device time of the last search's accumulate launch (HIP events on its stream) and the postings it read
- * (the sum of its terms' list lengths: 8 bytes each = the launch's algorithmic bytes, with 4 bytes per chunk of score row). */
+ * (the sum of its terms' list lengths: 8 bytes each = the launch's algorithmic bytes, with 4 bytes per chunk of score row).
+ * Searches are bracketed by the two events only from the first call with a non-NULL accumulate_ms on (round 5: a caller
+ * that never asks does not pay for them); that first call reports 0 ms for the search before it. */
 int32_t cqs_hip_sparse_index_last_search(const cqs_hip_sparse_index* idx, float* accumulate_ms, uint64_t* touched_postings);
 int32_t cqs_hip_sparse_index_poisoned(const cqs_hip_sparse_index* idx);
 size_t  cqs_hip_sparse_index_last_error(const cqs_hip_sparse_index* idx, char* buf, size_t cap);
