@@ -639,7 +639,10 @@ static hipError_t launch_mfma_ks(const ScanArgs& a, uint32_t q0, uint32_t nq, ui
 // arithmetic, 164 VGPRs, three workgroups per CU).  Bit-correct, and exactly as fast: 0.5912 against 0.5889 ms at 32 queries,
 // 0.5586 against 0.5598 at 16, 0.5502 against 0.5485 at 12 (same box, scan + select).  Neither the shape of the requests nor
 // half the matrix work nor a third wave per SIMD moves this kernel: timing builds put it at 0.424 ms with no corpus loads
-// after the first chunks, 0.545 with no score stores, 0.590 as built - profiles/r05_ksplit_ab.txt.)
+// after the first chunks, 0.545 with no score stores, 0.590 as built - profiles/r05_ksplit_ab.txt.  A third form staged the
+// chunks by LDS-DMA (global_load_lds_dwordx4 from inline asm into two unpadded XOR-swizzled images per wave, counted
+// vmcnt(8), the combine's partials in each wave's second image; 204 VGPRs): bit-correct, 0.5627 / 0.5598 against 0.5584 / 0.5661 ms
+// at 32 queries, 0.5484 against 0.5262 at 16 - the register round trip is not what holds the stream back either; removed.)
 // (Round 4 built and removed a STREAMING kernel for blocks of <= 32 queries - queries resident in LDS, every wave feeding
 // v_mfma_f32_16x16x4_f32 with corpus rows loaded straight from global memory, 128 KB in flight per CU, no barrier in the
 // loop: bit-correct, 0.70 ms at 32 queries x 1M rows with default-policy loads (0.80 streaming-policy; a 32x32x2 form with
