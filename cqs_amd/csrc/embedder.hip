@@ -845,7 +845,7 @@ int32_t submit_locked(cqs_hip_embedder* e, uint32_t B, const std::function<int32
     int ci = load[0] == load[1] ? (load[0] == 0 ? 0 : 1 - e->last_ctx) : (load[0] < load[1] ? 0 : 1);
     // A batch whose kernels are EXACT rounds of the 256 CUs (16 384 or 32 768 tokens: 128 / 256 row blocks x 2 workgroups) leaves a
     // second chain nothing to fill - side by side the two only contend.  Tickets in flight, chunks/s, two contexts | one | blocking
-    // calls (tools/r04_ctx_sweep.py, same box): 12 288 tokens 6 370 | 5 480 | 5 510; 14 336: 6 530 | 6 175 | 6 130; 16 384: 6 220-6 450 |
+    // calls (a round-4 sweep script, since deleted, same box): 12 288 tokens 6 370 | 5 480 | 5 510; 14 336: 6 530 | 6 175 | 6 130; 16 384: 6 220-6 450 |
     // 6 400 | 6 440; 18 432: 5 975-6 300 | 4 845 | 4 820; 24 576: 6 050 | 5 690 | 5 740; 32 768: 6 340 | 6 530 | 6 600; 49 152: 6 220 | 6 110 |
     // 6 200; 65 536: 6 100 | 5 970 | 6 060.  So: those two sizes stay on context 0, everything else alternates.
     // The rule is the geometry, not the two bench shapes: the fused projections launch two workgroups per 128 token

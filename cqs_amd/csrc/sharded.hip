@@ -252,7 +252,7 @@ int32_t search_block(cqs_hip_index* p, uint32_t nb, uint32_t k_eff, const uint32
         // device 0's stream, so the host waits for each shard's stream in turn - the first wait is the scan, the others
         // return at once.  (Until round 4 device 0's stream waited on one event per shard and the host on that stream:
         // G - 1 cross-stream barrier packets in front of the wake-up, 64 us between a query's last kernel and the next
-        // query's first one against 28 us on a single-device handle - rocprofv3 kernel trace, tools/r04_shard_trace.sh.)
+        // query's first one against 28 us on a single-device handle - rocprofv3 kernel trace, a round-4 one-off script, since deleted.)
         for (size_t s = 0; s < G; ++s) {
             cqs_hip_index* c = ss->shard[s];
             P_TRY(p, hipSetDevice(c->device));
