@@ -109,6 +109,41 @@ def test_all_rows_identical_heavy_ties(hip, oracle):
     idx.close()
 
 
+@pytest.mark.parametrize("n", [9000, 150_000, 420_000])
+def test_select_index_direct_and_gathered_groups(hip, oracle, n):
+    """Round 5: from k = 100 on the gemv scan leaves (lane of the maximum, runner-up) beside each task maximum and the select
+    takes a selected group's maximum WITHOUT reading its scores when the runner-up misses the threshold bin; groups with a
+    second entry at or above it are still gathered.  Both kinds at once, in every task tier (16-row tasks at 9 000 rows,
+    64-row tasks at 150 000, 64- then 32-row tasks at 420 000): a random corpus (mostly direct groups) with planted
+    near-duplicates of the query - pairs inside one group, exact duplicates (ties at the maximum: runner-up = maximum), a
+    run of 40 consecutive rows - against the oracle, ids exact; k = 100 (the first k that uses the index), 150, 500, 1000,
+    with a bitset (maxima over kept rows only) and in PIPELINE mode (clamped scores tie at 1.0 / 0.0)."""
+    from cqs_amd import _lib
+    rows = synth.gaussian_unit(n, seed=91 + n % 7)
+    q = synth.gaussian_unit(1, seed=92)[0]
+    rng = np.random.default_rng(93)
+
+    def near(eps):
+        v = q + eps * rng.standard_normal(768).astype(np.float32)
+        return (v / np.linalg.norm(v)).astype(np.float32)
+
+    for base in (64 * 11, 64 * 57 + 3, n - 70):           # two strong rows inside one group, twice an exact duplicate
+        rows[base] = near(0.3); rows[base + 5] = near(0.3)
+        rows[base + 9] = rows[base]
+    run0 = (n // 2) // 64 * 64 + 20
+    for i in range(40):                                     # a run of strong rows across a group boundary
+        rows[run0 + i] = near(0.5)
+    rows[7] = q; rows[n - 1] = q                            # exact score ties far apart
+    idx = HipIndex.build_from_flat(None, rows)
+    keep = rng.integers(0, 2**32, size=(n + 31) // 32, dtype=np.uint64).astype(np.uint32)
+    for k in (100, 150, 500, 1000):
+        check(oracle, idx, rows, q, k)
+    check(oracle, idx, rows, q, 500, keep=keep)
+    check(oracle, idx, rows, q, 300, mode=_lib.MODE_PIPELINE, thr=0.0)
+    check(oracle, idx, rows, q, 300, keep=keep, mode=_lib.MODE_PIPELINE, thr=0.05)
+    idx.close()
+
+
 def test_crowded_bin_forces_level2(hip, oracle):
     """Scores packed inside one 12-bit radix bin (near-duplicate corpus) exercise the second histogram level."""
     rng = np.random.default_rng(5)
