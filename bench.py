@@ -396,7 +396,7 @@ def main():
     if n1 and a.extras:
         from bench_legs.clients import concurrent_clients_leg
         clients = legs.run("concurrent_clients", lambda: concurrent_clients_leg(
-            np, idx, make_unit_rows(torch, 48, dim, 0xC950031, dev).cpu().numpy(), k, dim))
+            np, idx, make_unit_rows(torch, 96, dim, 0xC950031, dev).cpu().numpy(), k, dim, rows_ptr=rows.data_ptr()))
 
     # The CPU baseline runs LAST (after every GPU leg; only its inputs are taken here, while the corpus is still resident):
     # 10-20 s of one AVX-512 worker per physical core, pinned, over a first-touched 3 GB copy leave the host in a state in

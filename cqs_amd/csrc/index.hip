@@ -189,6 +189,7 @@ int32_t stage_keep(cqs_hip_index* x, const uint32_t* host_words, uint64_t words)
 void read_combine_env(cqs_hip_index* x) {                                              // read once per handle
     if (const char* ce = getenv("CQS_HIP_COMBINE")) x->combine = ce[0] != '0';
     if (const char* cw = getenv("CQS_HIP_COMBINE_WAIT_US")) x->combine_wait_us = (uint32_t)atoi(cw);
+    if (const char* cb = getenv("CQS_HIP_COMBINE_BITS")) x->combine_relaxed = cb[0] == 'r';
 }
 
 int32_t create_common(uint64_t n, uint32_t dim, uint32_t metric, int32_t device, uint64_t row_base,
@@ -745,7 +746,12 @@ static int32_t combine_run_single(cqs_hip_index* x, cqs_combine_req* const* batc
     if (x->poisoned.load(std::memory_order_acquire)) return CQS_HIP_ERR_POISONED;
     HostQuery hq[kCombineCap];
     for (uint32_t i = 0; i < nb; ++i) hq[i] = HostQuery{batch[i]->q, batch[i]->out_rows, batch[i]->out_scores, batch[i]->out_count};
-    return search_host_locked(x, hq, nb, batch[0]->k, nullptr, batch[0]->mode, batch[0]->thr, /*gemv_only=*/true);
+    // gemv passes only: each caller gets its lone call's bits.  CQS_HIP_COMBINE_BITS=relaxed (opt-in, read at create) lets a
+    // block of >= 9 callers take the matrix-core kernel instead - 32 queries per corpus sweep instead of 8, scores in another
+    // summation order (|delta| <= 2e-6 on unit vectors, inside the parity tolerance; the reference's GPU backend promises no
+    // bit-reproducibility across calls either, src/cagra.rs:443-492)
+    const bool gemv_only = !(x->combine_relaxed && nb >= cqs::kMfmaMinQueries);
+    return search_host_locked(x, hq, nb, batch[0]->k, nullptr, batch[0]->mode, batch[0]->thr, gemv_only);
 }
 
 // Lead one pass.  `lk` holds cmu on entry and on exit; x->leader is set by the caller.

@@ -92,6 +92,8 @@ struct cqs_hip_index {
     bool leader = false;                  // somebody is collecting / running a combined pass
     uint32_t expect = 1;                  // callers the next pass should expect (what recent passes saw); guarded by cmu
     bool combine = true;                  // CQS_HIP_COMBINE=0: every caller takes the serial path
+    bool combine_relaxed = false;         // CQS_HIP_COMBINE_BITS=relaxed: blocks of >= 9 callers may run on the matrix cores (32 queries per
+                                          // sweep instead of 8): answers within the parity tolerance of the lone call's, not its bits
     uint32_t combine_wait_us = 100;       // CQS_HIP_COMBINE_WAIT_US: how long after the END of a pass the next leader waits for the callers that pass carried
     std::chrono::steady_clock::time_point last_pass_end{};   // guarded by cmu (epoch until the first pass: nobody waits)
     std::atomic<uint64_t> stat_passes{0}, stat_queries{0};   // combined passes run / queries they carried

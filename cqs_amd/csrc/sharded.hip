@@ -438,7 +438,8 @@ int32_t search_combined(cqs_hip_index* p, cqs_combine_req* const* batch, uint32_
         if (rc != CQS_HIP_OK) return rc;
         for (uint32_t i = 0; i < b; ++i) memcpy(p->sh->h_q + (size_t)i * p->dim, batch[done + i]->q, (size_t)p->dim * sizeof(float));
         rc = search_block(p, b, k, nullptr, batch[0]->mode, batch[0]->thr, bad.data() + done, rows.data() + (size_t)done * k,
-                          scores.data() + (size_t)done * k, counts.data() + done, k, /*gemv_only=*/true);
+                          scores.data() + (size_t)done * k, counts.data() + done, k,
+                          /*gemv_only=*/!(p->combine_relaxed && b >= cqs::kMfmaMinQueries));
         if (rc != CQS_HIP_OK) return rc;
         done += b;
     }

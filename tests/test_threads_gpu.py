@@ -241,6 +241,43 @@ def test_a_lone_caller_after_a_burst_does_not_wait_for_stragglers(hip, monkeypat
     idx.close()
 
 
+@pytest.mark.parametrize("sharded", [False, True])
+def test_relaxed_combining_mode_stays_inside_the_parity_tolerance(hip, monkeypatch, sharded):
+    """CQS_HIP_COMBINE_BITS=relaxed (opt-in, read at create): a combined block of >= 9 callers may run on the matrix cores -
+    32 queries per corpus sweep instead of 8.  Answers are then NOT the lone call's bits (another summation order) but must
+    stay inside the parity tolerance: scores within 2e-6, ids equal wherever neighbouring scores are further apart than
+    that, and the queue must really have formed blocks of > 8.  The default mode on the same corpus stays bit-identical
+    (the tests above)."""
+    rows = synth.gaussian_unit(200_000, seed=75)
+    qs = synth.gaussian_unit(64, seed=76)
+    strict = HipIndex.build_from_flat(None, rows)
+    want = [strict.search_batch(qs[i], 20) for i in range(len(qs))]
+    strict.close()
+    monkeypatch.setenv("CQS_HIP_COMBINE_BITS", "relaxed")
+    idx = HipIndex.build_sharded(None, rows, [0, 0]) if sharded else HipIndex.build_from_flat(None, rows)
+    monkeypatch.delenv("CQS_HIP_COMBINE_BITS")
+    # native threads (the interpreter lock keeps Python threads from ever parking more than a few callers at once)
+    import ctypes as C
+    storm = idx._lib.cqs_hip_debug_client_storm
+    storm.restype = C.c_double
+    storm.argtypes = [C.c_void_p, C.c_void_p] + [C.c_uint32] * 5 + [C.c_void_p] * 3
+    nq, k, dim = len(qs), 20, rows.shape[1]
+    q = np.ascontiguousarray(qs, dtype=np.float32)
+    got_r = np.zeros((nq, k), np.uint64); got_s = np.zeros((nq, k), np.float32); got_c = np.zeros((nq,), np.uint32)
+    p0, q0 = idx.combine_stats()
+    el = storm(idx._h, q.ctypes.data, nq, dim, k, 16, 40, got_r.ctypes.data, got_s.ctypes.data, got_c.ctypes.data)
+    p1, q1 = idx.combine_stats()
+    assert el > 0 and q1 - q0 == 16 * 40
+    for i in range(nq):
+        wr, ws, wc = want[i]
+        assert got_c[i] == wc[0] and np.max(np.abs(got_s[i] - ws[0])) <= 2e-6, i
+        gap = np.abs(np.diff(ws[0])) <= 4e-6
+        far = np.ones(k, bool); far[:-1] &= ~gap; far[1:] &= ~gap
+        assert np.array_equal(got_r[i][far], wr[0][far]), i
+    assert (q1 - q0) > 8.5 * (p1 - p0), f"no block of more than 8 callers formed: {q1 - q0} queries in {p1 - p0} passes"
+    idx.close()
+
+
 def test_embed_engine_from_two_threads(hip):
     from test_embed_gpu import SMALL, batch, make
     eng, _ = make(SMALL, seed=91)

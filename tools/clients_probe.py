@@ -13,6 +13,7 @@ dev = torch.device("cuda", 0)
 n, dim, k = int(os.environ.get("ROWS", 1_000_000)), 768, 20
 rows = make_unit_rows(torch, n, dim, 0xC950001, dev)
 idx = HipIndex.build_from_device(None, rows.data_ptr(), n, dim, borrow=True, keepalive=rows)
-q = make_unit_rows(torch, 48, dim, 0xC950031, dev).cpu().numpy()
-out = concurrent_clients_leg(np, idx, q, k, dim)
+q = make_unit_rows(torch, 96, dim, 0xC950031, dev).cpu().numpy()
+out = concurrent_clients_leg(np, idx, q, k, dim, rows_ptr=rows.data_ptr())
 print(json.dumps({t: (v["queries_per_sec"], v["ms_per_call"]) for t, v in out["native_threads"].items()}))
+print("relaxed", json.dumps({t: (v["queries_per_sec"], v["ms_per_call"]) for t, v in out.get("native_threads_relaxed_bits", {}).items() if t != "what"}))
