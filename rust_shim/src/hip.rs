@@ -395,6 +395,11 @@ impl HipIndex {
 }
 
 impl VectorIndex for HipIndex {
+    /// Called concurrently from the daemon's client threads (src/cli/watch/daemon.rs:273) on one `Arc<dyn VectorIndex>`:
+    /// the library combines single-query, unfiltered calls that meet on the handle - single-device or sharded - into shared
+    /// passes over the corpus (include/cqs_hip.h, "Concurrent callers"), each caller still getting the bytes its lone call
+    /// would.  `CQS_HIP_COMBINE_BITS=relaxed` in the daemon's environment (read when the index is opened) trades that
+    /// bit-reproducibility for throughput past 8 callers (blocks of >= 9 on the matrix cores; scores within 2e-6).
     fn search(&self, query: &Embedding, k: usize) -> Vec<IndexResult> {
         let _span = tracing::debug_span!("hip_search", k).entered();
         if self.id_map.is_empty() || k == 0 {
