@@ -31,6 +31,7 @@ import traceback
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+_T_PROCESS = time.perf_counter()       # (before `import torch`: the driver's clock runs from process start)
 
 
 
@@ -63,6 +64,9 @@ def parse():
     ap.add_argument("--budget-s", type=float, default=400.0, help="N=1: an auxiliary leg that would START later than this many seconds "
                     "into the run is skipped (recorded as such), so that the line prints inside the driver's limit; the two "
                     "cpu_baseline legs are not subject to it (they are bounded by --cpu-seconds)")
+    ap.add_argument("--hard-limit-s", type=float, default=540.0, help="N=1: if the process is still running this many seconds after it "
+                    "started (a leg that hangs rather than raises), a watchdog thread prints the line with what has been measured so far "
+                    "(`incomplete` names the leg that was running) and ends the process - the driver's limit is 600 s; 0 = no watchdog")
     ap.add_argument("--strict", type=int, default=0, help="1: exit with status 3 AFTER printing the line when any leg errored "
                     "(what tests/test_bench_modes_gpu.py runs); default 0 keeps status 0 so that a measured headline is never "
                     "discarded over an auxiliary leg - the errors are in the line (`leg_errors`) either way")
@@ -79,6 +83,7 @@ class Legs:
         self.budget_s = budget_s
         self.errors = {}
         self.seconds = {}
+        self.running = None
 
     def run(self, name, fn, *args, budgeted=True, **kw):
         now = time.perf_counter() - self.t0
@@ -86,9 +91,13 @@ class Legs:
             self.seconds[name] = 0.0
             return {"skipped": "leg would start %.0f s into the run, past --budget-s %.0f" % (now, self.budget_s)}
         t = time.perf_counter()
+        self.running = name
         try:
             if os.environ.get("CQS_BENCH_FAIL_LEG") == name:       # test hook (tests/test_bench_modes_gpu.py)
                 raise RuntimeError("CQS_BENCH_FAIL_LEG")
+            if os.environ.get("CQS_BENCH_HANG_LEG") == name:       # test hook: a leg that never returns
+                while True:
+                    time.sleep(1.0)
             return fn(*args, **kw)
         except KeyboardInterrupt:
             raise
@@ -99,6 +108,7 @@ class Legs:
             return {"error": msg}
         finally:
             self.seconds[name] = round(time.perf_counter() - t, 1)
+            self.running = None
 
 
 def host_api_latency(idx, torch, k, dim, dev):
@@ -391,6 +401,90 @@ def main():
     # ---- the auxiliary legs: N = 1 only, each in its own module, each under legs.run ----
     n1 = rank == 0 and world == 1 and mode == "single"
     latency = clients = other = abi = strong_n1 = sparse = aux = e2e = cpu = None
+    embed = eng = ecfg = eweights = None
+
+    def build_line():
+        """The one JSON line from what has been measured SO FAR (called at the end - and by the watchdog below if a leg hangs)."""
+        if mode == "weak":
+            total_q = K * bq * world
+            workload = ("weak scaling (round-1 variant): %d x %d fp32 unit vectors per GPU, %d quer%s per rank per step, "
+                        "brute-force cosine top-%d" % (n, dim, bq, "y" if bq == 1 else "ies", k))
+        elif mode == "strong":
+            total_q = K * bq
+            workload = ("BASELINE configs[4]: %d x %d fp32 unit vectors row-sharded over %d GPU%s, %d quer%s per step scanned "
+                        "by every shard, one RCCL all-gather of per-shard top-%d, host merge"
+                        % (total_rows, dim, world, "" if world == 1 else "s", bq, "y" if bq == 1 else "ies", k))
+        else:
+            total_q = K * bq
+            workload = ("BASELINE configs[1]: %d x %d fp32 unit vectors, %d quer%s per step, brute-force cosine top-%d"
+                        % (n, dim, bq, "y" if bq == 1 else "ies", k))
+        line = {
+            "metric": "queries/sec @k=%d (brute-force cosine scan + top-k, 768-d fp32)" % k,
+            "value": round(total_q / elapsed, 2),
+            "unit": "queries/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": W,
+            "prewarm_steps": prewarm_steps,          # untimed repeats of step 0 before the W warm-ups (clocks, caches)
+            "ms_per_step": round(elapsed / K * 1e3, 5),
+            "higher_is_better": True,
+            "scaling": "weak" if mode in ("weak", "single") else "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": workload, "mode": mode, "rows_per_gpu": n, "total_rows": total_rows, "dim": dim, "k": k,
+                       "queries_per_step": bq * (world if mode == "weak" else 1),
+                       "parallelism": ("row-sharded x%d, %s all-gather of per-shard candidates, host merge"
+                                       % (world, "gloo (host-staged, REHEARSAL)" if rehearsal else "RCCL")) if world > 1 else "single GPU",
+                       "ranks_seen": ranks_seen if ranks_seen is not None else 1,     # group size as the collective's all-reduce saw it
+                       "rank_devices": rank_devices if rank_devices is not None else [{"rank": 0, "device": local_rank}],
+                       "collective": collective},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+            "latency_host_api": latency,
+            "concurrent_clients": clients,
+            "other_configs": other,
+            "abi_sharded": abi,
+            "strong_scaling_n1": strong_n1,
+            "embed": embed if not isinstance(embed, tuple) else None,
+            "e2e": e2e,
+            "aux_models": aux,
+            "sparse_index": sparse,
+            "leg_errors": dict(legs.errors) or None,      # leg name -> message; the same message sits under that leg's own key
+            "leg_seconds": dict(legs.seconds),
+            "wall_s": round(time.perf_counter() - legs.t0, 1),
+        }
+        if rehearsal or (force_dist and world == 1):
+            # all ranks on one GPU over gloo, or a 1-rank RCCL group: the N > 1 LOGIC ran, nothing here measures N GPUs
+            line["rehearsal"] = True
+            line["metric"] = "REHEARSAL (logic check, not a measurement): " + line["metric"]
+            line["vs_baseline"] = None
+        return line
+
+    # A leg that HANGS (rather than raises) must not cost the line either: past --hard-limit-s a watchdog prints what has been
+    # measured (the headline and the roofline exist from here on) and ends the process.
+    import threading
+    print_lock = threading.Lock()
+    printed = [False]
+    if n1 and a.hard_limit_s > 0:
+        def watchdog():
+            while time.perf_counter() - _T_PROCESS < a.hard_limit_s:
+                time.sleep(0.5)
+                if printed[0]:
+                    return
+            with print_lock:
+                if printed[0]:
+                    return
+                printed[0] = True
+                line = build_line()
+                hung = legs.running or "between legs"
+                line["incomplete"] = "hard limit of %.0f s reached while `%s` was running; later legs did not run" % (a.hard_limit_s, hung)
+                errs = dict(line["leg_errors"] or {})
+                errs[hung] = "did not return within the run's hard limit"
+                line["leg_errors"] = errs
+                print(json.dumps(line), flush=True)
+            os._exit(3 if a.strict else 0)
+        threading.Thread(target=watchdog, daemon=True).start()
     if n1:
         latency = legs.run("latency_host_api", host_api_latency, idx, torch, k, dim, dev)
     if n1 and a.extras:
@@ -428,7 +522,6 @@ def main():
         from bench_legs.sparse import sparse_index_leg
         sparse = legs.run("sparse_index", sparse_index_leg, a, np, idx)
 
-    embed = eng = ecfg = eweights = None
     if a.embed_steps > 0:
         from bench_legs.embed import embed_cpu_baseline, embed_leg
         idx.close()
@@ -478,61 +571,10 @@ def main():
             if mode == "strong" and not (abi or {}).get("_hung"):
                 strong_n1 = strong_n1_leg(a, torch, k, dim, total_rows)
     if rank == 0:
-        if mode == "weak":
-            total_q = K * bq * world
-            workload = ("weak scaling (round-1 variant): %d x %d fp32 unit vectors per GPU, %d quer%s per rank per step, "
-                        "brute-force cosine top-%d" % (n, dim, bq, "y" if bq == 1 else "ies", k))
-        elif mode == "strong":
-            total_q = K * bq
-            workload = ("BASELINE configs[4]: %d x %d fp32 unit vectors row-sharded over %d GPU%s, %d quer%s per step scanned "
-                        "by every shard, one RCCL all-gather of per-shard top-%d, host merge"
-                        % (total_rows, dim, world, "" if world == 1 else "s", bq, "y" if bq == 1 else "ies", k))
-        else:
-            total_q = K * bq
-            workload = ("BASELINE configs[1]: %d x %d fp32 unit vectors, %d quer%s per step, brute-force cosine top-%d"
-                        % (n, dim, bq, "y" if bq == 1 else "ies", k))
-        line = {
-            "metric": "queries/sec @k=%d (brute-force cosine scan + top-k, 768-d fp32)" % k,
-            "value": round(total_q / elapsed, 2),
-            "unit": "queries/s",
-            "n_gpus": world,
-            "steps": K,
-            "warmup": W,
-            "prewarm_steps": prewarm_steps,          # untimed repeats of step 0 before the W warm-ups (clocks, caches)
-            "ms_per_step": round(elapsed / K * 1e3, 5),
-            "higher_is_better": True,
-            "scaling": "weak" if mode in ("weak", "single") else "strong",
-            "vs_baseline": None,
-            "dtype": "f32",
-            "data": "synthetic",
-            "config": {"workload": workload, "mode": mode, "rows_per_gpu": n, "total_rows": total_rows, "dim": dim, "k": k,
-                       "queries_per_step": bq * (world if mode == "weak" else 1),
-                       "parallelism": ("row-sharded x%d, %s all-gather of per-shard candidates, host merge"
-                                       % (world, "gloo (host-staged, REHEARSAL)" if rehearsal else "RCCL")) if world > 1 else "single GPU",
-                       "ranks_seen": ranks_seen if ranks_seen is not None else 1,     # group size as the collective's all-reduce saw it
-                       "rank_devices": rank_devices if rank_devices is not None else [{"rank": 0, "device": local_rank}],
-                       "collective": collective},
-            "roofline": roofline,
-            "cpu_baseline": cpu,
-            "latency_host_api": latency,
-            "concurrent_clients": clients,
-            "other_configs": other,
-            "abi_sharded": abi,
-            "strong_scaling_n1": strong_n1,
-            "embed": embed,
-            "e2e": e2e,
-            "aux_models": aux,
-            "sparse_index": sparse,
-            "leg_errors": legs.errors or None,      # leg name -> message; the same message sits under that leg's own key
-            "leg_seconds": legs.seconds,
-            "wall_s": round(time.perf_counter() - legs.t0, 1),
-        }
-        if rehearsal or (force_dist and world == 1):
-            # all ranks on one GPU over gloo, or a 1-rank RCCL group: the N > 1 LOGIC ran, nothing here measures N GPUs
-            line["rehearsal"] = True
-            line["metric"] = "REHEARSAL (logic check, not a measurement): " + line["metric"]
-            line["vs_baseline"] = None
-        print(json.dumps(line), flush=True)
+        with print_lock:
+            if not printed[0]:
+                printed[0] = True
+                print(json.dumps(build_line()), flush=True)
     if a.embed_steps <= 0 and not abi_after_group:
         idx.close()
     if dist is not None:

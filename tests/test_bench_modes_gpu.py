@@ -121,3 +121,21 @@ def test_a_failing_leg_does_not_cost_the_line(hip):
         d = json.loads(lines[0])
         assert "concurrent_clients" in d["leg_errors"] and "error" in d["concurrent_clients"]
         assert d["value"] > 0 and d["roofline"]["frac"] > 0 and d["cpu_baseline"]["value"] > 0 and d["other_configs"]["k500_1M"]["checked"]
+
+
+def test_a_hanging_leg_does_not_cost_the_line_either(hip):
+    """A leg that never returns (a hung kernel, a deadlocked collective) cannot be caught as an exception: past --hard-limit-s
+    (540 s by default, the driver's limit being 600) a watchdog thread prints the line with everything measured so far,
+    names the leg in `incomplete` / `leg_errors`, and ends the process."""
+    env = dict(os.environ)
+    env["CQS_BENCH_HANG_LEG"] = "other_configs"              # test hook of Legs.run: that leg sleeps forever
+    args = ["--rows", "100000", "--embed-steps", "0", "--e2e-chunks", "0", "--sparse-chunks", "0", "--cpu-seconds", "0.3",
+            "--abi-devices", "", "--hard-limit-s", "45"]
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + DRIVER_CMD + args, cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=300)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert p.returncode == 0 and len(lines) == 1, (p.returncode, p.stderr[-2000:])
+    d = json.loads(lines[0])
+    assert "other_configs" in d["incomplete"] and "other_configs" in d["leg_errors"]
+    assert d["value"] > 0 and d["roofline"]["frac"] > 0 and d["latency_host_api"]["ms_per_query"] > 0
+    assert d["concurrent_clients"]["native_threads"]["8"]["checked"] and d["other_configs"] is None
