@@ -64,6 +64,9 @@ def parse():
     ap.add_argument("--budget-s", type=float, default=400.0, help="N=1: an auxiliary leg that would START later than this many seconds "
                     "into the run is skipped (recorded as such), so that the line prints inside the driver's limit; the two "
                     "cpu_baseline legs are not subject to it (they are bounded by --cpu-seconds)")
+    ap.add_argument("--child", type=str, default="", help="internal: `after_group` = run the N > 1 line's after-the-group legs (the "
+                    "single-process sharded handle over devices 0..N-1, the N = 1 point of the strong-scaling curve) in THIS process and "
+                    "print their results as one JSON object - rank 0 starts it as a child so that a crash in there cannot cost the line")
     ap.add_argument("--hard-limit-s", type=float, default=540.0, help="N=1: if the process is still running this many seconds after it "
                     "started (a leg that hangs rather than raises), a watchdog thread prints the line with what has been measured so far "
                     "(`incomplete` names the leg that was running) and ends the process - the driver's limit is 600 s; 0 = no watchdog")
@@ -125,8 +128,44 @@ def host_api_latency(idx, torch, k, dim, dev):
             "what": "cqs_hip_index_search, host query in / host results out, one call at a time"}
 
 
+def after_group_child(a):
+    """`--child after_group`: the two legs rank 0 of an N > 1 run wants after its process group is gone, in a process of their
+    own (an RCCL clique over N distinct devices inside the library has never run on hardware: an abort in there must not
+    take the N > 1 line with it).  Prints {"abi": ..., "strong_n1": ...}."""
+    import numpy as np
+    import torch
+    from bench_legs.sharded import abi_after_group_leg, strong_n1_leg
+    out = {"abi": None, "strong_n1": None}
+    out["abi"] = abi_after_group_leg(a, torch, np, a.gpus, a.k, a.dim)
+    if a.mode == "strong" and not (out["abi"] or {}).get("_hung"):
+        out["strong_n1"] = strong_n1_leg(a, torch, a.k, a.dim, a.total_rows)
+    print(json.dumps(out), flush=True)
+    os._exit(0)            # (a leg left running in its watchdog thread must not keep the child alive)
+
+
+def run_after_group_child(a, world, k, dim, total_rows, mode, budget_s=330.0):
+    """Rank 0: start `--child after_group` and read its one JSON object; whatever happens to the child becomes an `error`."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--child", "after_group", "--gpus", str(world), "--k", str(k), "--dim", str(dim),
+           "--total-rows", str(total_rows), "--mode", mode, "--extras", str(a.extras)]
+    try:
+        p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=budget_s)
+    except subprocess.TimeoutExpired:
+        return {"error": "after-group child exceeded its %.0f s budget and was killed" % budget_s, "_hung": True}, None
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    if p.returncode != 0 or not lines:
+        return {"error": "after-group child ended with status %d: %s" % (p.returncode, (p.stderr or "")[-400:].replace("\n", " | "))}, None
+    try:
+        d = json.loads(lines[-1])
+    except ValueError as e:
+        return {"error": "after-group child printed no JSON: %s" % e}, None
+    return d.get("abi"), d.get("strong_n1")
+
+
 def main():
     a = parse()
+    if a.child == "after_group":
+        return after_group_child(a)
     import numpy as np
     import torch
     from cqs_amd import HipIndex, unpack_keys
@@ -566,10 +605,9 @@ def main():
         dist.destroy_process_group()
         dist = None
         if rank == 0:
-            from bench_legs.sharded import abi_after_group_leg, strong_n1_leg
-            abi = abi_after_group_leg(a, torch, np, world, k, dim)
-            if mode == "strong" and not (abi or {}).get("_hung"):
-                strong_n1 = strong_n1_leg(a, torch, k, dim, total_rows)
+            # in a CHILD process (round 5): the in-library RCCL clique over N distinct devices has never run on hardware - an
+            # abort in there would have taken this rank, and the N > 1 line with it, down
+            abi, strong_n1 = run_after_group_child(a, world, k, dim, total_rows, mode)
     if rank == 0:
         with print_lock:
             if not printed[0]:
