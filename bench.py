@@ -67,7 +67,7 @@ def parse():
     ap.add_argument("--child", type=str, default="", help="internal: `after_group` = run the N > 1 line's after-the-group legs (the "
                     "single-process sharded handle over devices 0..N-1, the N = 1 point of the strong-scaling curve) in THIS process and "
                     "print their results as one JSON object - rank 0 starts it as a child so that a crash in there cannot cost the line")
-    ap.add_argument("--hard-limit-s", type=float, default=540.0, help="N=1: if the process is still running this many seconds after it "
+    ap.add_argument("--hard-limit-s", type=float, default=540.0, help="rank 0: if the process is still running this many seconds after it "
                     "started (a leg that hangs rather than raises), a watchdog thread prints the line with what has been measured so far "
                     "(`incomplete` names the leg that was running) and ends the process - the driver's limit is 600 s; 0 = no watchdog")
     ap.add_argument("--strict", type=int, default=0, help="1: exit with status 3 AFTER printing the line when any leg errored "
@@ -505,7 +505,7 @@ def main():
     import threading
     print_lock = threading.Lock()
     printed = [False]
-    if n1 and a.hard_limit_s > 0:
+    if rank == 0 and a.hard_limit_s > 0:                 # (N > 1 too: rank 0 stuck in a collective still prints what it measured)
         def watchdog():
             while time.perf_counter() - _T_PROCESS < a.hard_limit_s:
                 time.sleep(0.5)
