@@ -128,6 +128,7 @@ def test_a_hanging_leg_does_not_cost_the_line_either(hip):
     (540 s by default, the driver's limit being 600) a watchdog thread prints the line with everything measured so far,
     names the leg in `incomplete` / `leg_errors`, and ends the process."""
     env = dict(os.environ)
+    subprocess.run([sys.executable, "-c", "import torch"], env=env, timeout=600)      # (the limit counts from process start: page torch in first)
     env["CQS_BENCH_HANG_LEG"] = "other_configs"              # test hook of Legs.run: that leg sleeps forever
     args = ["--rows", "100000", "--embed-steps", "0", "--e2e-chunks", "0", "--sparse-chunks", "0", "--cpu-seconds", "0.3",
             "--abi-devices", "", "--hard-limit-s", "45"]
