@@ -713,10 +713,26 @@ def test_full_size_against_the_oracle_1m(hip, oracle):
         r, s = unpack_keys(hk[qi])
         ext_ids, ext_scores = oracle.index_search(rows, qs[qi], k + MARGIN)
         assert_topk_parity(r, s, ext_ids, ext_scores, k)
+    # round 5: blocks of 9-32 queries run the K-split kernel (15 625 row tiles over 512 workgroups: its work queue, the
+    # two-tiles-ahead hand-over) and blocks of 33-64 the LDS-tiled one - both against the oracle at full size, k = 20 and the
+    # production k = 500 (at 500 the gemv-only select index does not apply: matrix-core producers do not write it)
+    for bb, kk, picks in ((32, 20, (0, 13, 31)), (17, 500, (0, 16)), (64, 20, (5, 63))):
+        keys = torch.zeros((bb, kk), dtype=torch.int64, device="cuda"); cnt = torch.zeros((bb,), dtype=torch.int32, device="cuda")
+        idx.search_device(d_qs.data_ptr(), bb, kk, keys.data_ptr(), cnt.data_ptr(), stream=st)
+        torch.cuda.synchronize()
+        hk = keys.cpu().numpy().view(np.uint64)
+        for qi in picks:
+            assert int(cnt[qi].item()) == kk
+            r, s = unpack_keys(hk[qi])
+            ext_ids, ext_scores = oracle.index_search(rows, qs[qi], kk + MARGIN)
+            assert_topk_parity(r, s, ext_ids, ext_scores, kk)
     # and through the blocking host API (what VectorIndex::search calls: host query in, host results out)
     got_rows, got_scores, counts = idx.search_batch(qs[9], 20)
     ext_ids, ext_scores = oracle.index_search(rows, qs[9], 20 + MARGIN)
     assert_topk_parity(got_rows[0, :counts[0]], got_scores[0, :counts[0]], ext_ids, ext_scores, 20)
+    got_rows, got_scores, counts = idx.search_batch(qs[9], 500)                # (k >= 100: the select index on the gemv path)
+    ext_ids, ext_scores = oracle.index_search(rows, qs[9], 500 + MARGIN)
+    assert_topk_parity(got_rows[0, :counts[0]], got_scores[0, :counts[0]], ext_ids, ext_scores, 500)
     idx.close()
 
 
