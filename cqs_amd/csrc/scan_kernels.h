@@ -81,4 +81,30 @@ inline bool uniform_groups(uint32_t b, uint32_t dim) { return use_mfma(b, dim); 
 
 bool scan_dim_supported(uint32_t dim);
 
+#if defined(__HIPCC__)
+// Maximum over the 64 lanes of a wave, in every lane, without the LDS: four DPP steps inside the 16-lane rows (quad_perm
+// xor 1, xor 2, row_half_mirror, row_mirror), then v_permlane16_swap and v_permlane32_swap between the rows.  (`__shfl_xor`
+// compiles to ds_bpermute_b32 on gfx950: six dependent trips through the LDS queue per maximum.)  max16: the first four
+// steps alone = the maximum of each aligned group of 16 lanes.
+template <int CTRL>
+__device__ __forceinline__ float wave_dpp(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float wave_max16(float m) {
+    m = fmaxf(m, wave_dpp<0xB1>(m));
+    m = fmaxf(m, wave_dpp<0x4E>(m));
+    m = fmaxf(m, wave_dpp<0x141>(m));
+    m = fmaxf(m, wave_dpp<0x140>(m));
+    return m;
+}
+__device__ __forceinline__ float wave_max64(float m) {
+    typedef unsigned wm_u2 __attribute__((ext_vector_type(2)));
+    m = wave_max16(m);
+    const wm_u2 a = __builtin_amdgcn_permlane16_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+    m = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    const wm_u2 b = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+#endif
+
 }  // namespace cqs

@@ -289,9 +289,7 @@ __global__ __launch_bounds__(256, OCC) void scan_gemv_kernel(const ScanParams p)
             }
             if ((uint32_t)b >= p.nq) continue;  // padding slot of a 5..7-query pass
             if ((uint32_t)lane < trows && row < p.n_pad) p.scores[(size_t)b * p.n_pad + row] = s;
-            float gm = s;
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) gm = fmaxf(gm, __shfl_xor(gm, off, 64));
+            const float gm = wave_max64(s);
             if (lane == 0) p.gmax[(size_t)b * n_tasks + cur] = gm;
             if (p.gaux) {
                 // Round 5: WHERE the maximum sits and the best score among the task's other rows.  A task whose runner-up
@@ -299,9 +297,7 @@ __global__ __launch_bounds__(256, OCC) void scan_gemv_kernel(const ScanParams p)
                 // row being read back (select_finish_kernel: 500 x 256 B of gather through ONE CU were 11 of its 28 us).
                 // Rows tied at the maximum: only lane `arg` is masked, so the runner-up equals gm and the task is read.
                 const uint32_t arg = (uint32_t)__builtin_ctzll(__ballot(s == gm));   // (no valid row: gm = -inf, every lane matches)
-                float sec = ((uint32_t)lane == arg) ? -INFINITY : s;
-#pragma unroll
-                for (int off = 32; off >= 1; off >>= 1) sec = fmaxf(sec, __shfl_xor(sec, off, 64));
+                const float sec = wave_max64(((uint32_t)lane == arg) ? -INFINITY : s);
                 if (lane == 0) p.gaux[(size_t)b * n_tasks + cur] = ((uint64_t)arg << 32) | (uint64_t)__float_as_uint(sec);
             }
         }

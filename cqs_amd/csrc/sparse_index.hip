@@ -212,27 +212,20 @@ __global__ __launch_bounds__(256) void sparse_accumulate_kernel(const uint2* __r
         }
         v = ok ? v : -INFINITY;
         scores[r] = v;
-        float m = v;
-#pragma unroll
-        for (int off = 8; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+        float m = cqs::wave_max16(v);                     // (DPP: `__shfl_xor` is a ds_bpermute round trip per step on gfx950)
         // beside each maximum: the lane it sits in and the group's runner-up (select_finish_kernel, round 5: a group whose
         // runner-up misses the threshold contributes its maximum without its scores being read back)
         if (group16) {                                    // small indexes: maxima of 16 chunks (fewer than k groups of 64 would
             if ((lane & 15) == 0) gmax[r >> 4] = m;       // make every score a candidate and send the select down its radix path)
             const uint32_t seg = (uint32_t)(__ballot(v == m) >> (lane & 48)) & 0xFFFFu;   // my 16 lanes (no scored chunk: m = -inf, all match)
             const uint32_t arg = (uint32_t)__builtin_ctz(seg);
-            float sec = ((uint32_t)(lane & 15) == arg) ? -INFINITY : v;
-#pragma unroll
-            for (int off = 8; off >= 1; off >>= 1) sec = fmaxf(sec, __shfl_xor(sec, off, 64));
+            const float sec = cqs::wave_max16(((uint32_t)(lane & 15) == arg) ? -INFINITY : v);
             if ((lane & 15) == 0) gaux[r >> 4] = ((uint64_t)arg << 32) | (uint64_t)__builtin_bit_cast(uint32_t, sec);
         } else {
-            m = fmaxf(m, __shfl_xor(m, 16, 64));
-            m = fmaxf(m, __shfl_xor(m, 32, 64));
+            m = cqs::wave_max64(v);
             if (lane == 0) gmax[r >> 6] = m;
             const uint32_t arg = (uint32_t)__builtin_ctzll(__ballot(v == m));
-            float sec = ((uint32_t)lane == arg) ? -INFINITY : v;
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) sec = fmaxf(sec, __shfl_xor(sec, off, 64));
+            const float sec = cqs::wave_max64(((uint32_t)lane == arg) ? -INFINITY : v);
             if (lane == 0) gaux[r >> 6] = ((uint64_t)arg << 32) | (uint64_t)__builtin_bit_cast(uint32_t, sec);
         }
     }
