@@ -1333,6 +1333,25 @@ hipError_t qf_launch_attn_oproj_h(const QfAttnParams& a, hipStream_t st) {
                          qf_attn_lds<MTV>(NH) + (size_t)NWV * MTV * 64 * 16 +                                               \
                              (MTV < 3 ? (size_t)NC * (NH * kQfHD + 8) * sizeof(bf16_t) : 0), st, 64u * NWV);                \
     }()
+    static const bool mt5_off = [] { const char* e = getenv("CQS_HIP_QUERY_ATTN80"); return e && e[0] == '0'; }();   // A/B hook
+    if (a.T > 64u && a.T <= 80u && !mt5_off && a.H % 16u == 0) {
+        // 65-80 tokens (round 5): five key tiles still fit the one-shot kernel's LDS next to a 16-query block (154 of 160 KiB
+        // with three heads) - no qk_norm_rope launch, no second key half, 4 launches per layer like every shorter query:
+        // 0.90 -> 0.78-0.84 ms device.  (Six tiles fit too - 162 304 of 163 840 bytes - but 81-96 tokens are 6 query blocks x 48
+        // column tiles = 288 workgroups, two rounds on 256 CUs: 1.09 ms against 0.91 for the two-halves kernel; measured, not kept.)
+#define QF_AOS56(MTV)                                                                                                        \
+    [&]() -> hipError_t {                                                                                                   \
+        static DynLdsOnce once;                                                                                             \
+        const size_t lds = ((size_t)(NH * 16 + 16 * MTV) * kQfKRow + (size_t)kQfHD * qf_vrow<MTV>()) * sizeof(bf16_t) +     \
+                           (size_t)8 * 64 * 16 + (size_t)16 * (NH * kQfHD + 8) * sizeof(bf16_t);                            \
+        if (lds > 160u * 1024u) return hipErrorNotSupported;                                                                \
+        return qf_launch(qf_attn_oproj_kernel<MTV, 4, NH, 16, 8, 1, 16>, once, a, a.H / 16u, lds, st, 512u,                 \
+                         (a.T + 15u) / 16u);                                                                                \
+    }()
+        const hipError_t e56 = QF_AOS56(5);
+#undef QF_AOS56
+        if (e56 != hipErrorNotSupported) return e56;
+    }
     if (a.T > 64u) {                                               // 65-128 tokens: the keys in two halves (online softmax across them)
         if (a.H % 32u || a.T > 128u || !a.pos) return hipErrorNotSupported;
         // q / k heads normalised + rotated (q scaled) once, in place on the qkv rows: the workgroups below only copy them
